@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""PDHG inner-loop benchmark (BASELINE.json metric: PDHG iterations/s and
+achieved GB/s of the CSR SpMV vs the HBM roofline).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one ``take_step`` of the adaptive policy (pdhg.jl:653-731): one
+accepted PDHG iteration including any rejected trials, from the zero start,
+no restarts/rescaling (the reference's "basic algorithm" timer,
+pdhg.jl:1025-1047).  Workload at N=1: BASELINE configs[4], synthetic random LP
+m = n = 10M, nnz = 100M, fp64.  With N > 1 the same LP is row-partitioned
+(strong scaling), one process per GPU over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--m", type=int, default=10_000_000)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--nnz-per-row", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--profile-steps", type=int, default=30)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import folp_loader
+    pkg = folp_loader.load()
+    from firstorderlp_jl_amd.generators import random_lp
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
+        AdaptiveStepsizeParams, PdhgSolverState, take_step)
+    from firstorderlp_jl_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    t0 = time.time()
+    problem = random_lp(args.m, args.n, args.nnz_per_row, args.seed)
+    A = problem.constraint_matrix
+    nnz = int(A.nnz)
+    t_gen = time.time() - t0
+
+    t0 = time.time()
+    if world > 1:
+        from firstorderlp_jl_amd.distributed import make_row_partitioned_hip_engine
+        eng = make_row_partitioned_hip_engine(problem, device_id=local_rank)
+        local = eng.local
+    else:
+        eng = pkg.HipPdhgEngine.from_problem(problem, device_id=local_rank)
+        local = eng
+    t_create = time.time() - t0
+
+    step0 = 1.0 / float(np.abs(A.data).max())                      # pdhg.jl:823
+    cn = float(np.sqrt(np.sum(problem.objective_vector ** 2)))
+    bn = float(np.sqrt(np.sum(problem.right_hand_side ** 2)))
+    pw0 = cn / bn if cn > 0 and bn > 0 else 1.0                    # saddle_point.jl:1049
+    state = PdhgSolverState(eng, step_size=step0, primal_weight=pw0)
+    policy = AdaptiveStepsizeParams(0.3, 0.6)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        take_step(policy, state)
+    barrier()
+    trials0 = state.total_number_iterations
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        take_step(policy, state)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    trials = state.total_number_iterations - trials0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: HIP events on the engine's stream
+    roofline = None
+    kernels = {}
+    local.profile_enable(True)
+    for _ in range(args.profile_steps):
+        take_step(policy, state)
+    for kid in range(_lib.K_COUNT):
+        cnt, ms = local.profile_read(kid)
+        if cnt:
+            byts = local.kernel_algorithmic_bytes(kid)
+            avg_ms = ms / cnt
+            kernels[local.kernel_name(kid)] = {
+                "launches": cnt, "avg_ms": round(avg_ms, 5),
+                "algorithmic_bytes": byts,
+                "achieved_GBps": round(byts / (avg_ms * 1e-3) / 1e9, 1)}
+    local.profile_enable(False)
+    dom = max((_lib.K_SPMV_DUAL, _lib.K_SPMV_ATY),
+              key=lambda k: local.profile_read(k)[1])
+    dk = kernels[local.kernel_name(dom)]
+    roofline = {"bound": "hbm", "kernel": local.kernel_name(dom),
+                "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(dk["achieved_GBps"] / HBM_PEAK_GBS, 4),
+                "traffic": None, "avg_launch_ms": dk["avg_ms"],
+                "algorithmic_bytes_per_launch": dk["algorithmic_bytes"]}
+
+    # ---- CPU baseline: the literal single-thread restatement, bounded sample
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.oracle import OracleState
+        Q = problem.objective_matrix
+        st = OracleState(A.shape[0], A.shape[1], A.indptr, A.indices, A.data,
+                         problem.objective_vector, problem.right_hand_side,
+                         problem.variable_lower_bound, problem.variable_upper_bound,
+                         problem.num_equalities)
+        st.step_size, st.primal_weight = step0, pw0
+        t0 = time.perf_counter()
+        its = 0
+        while its < 3 or (time.perf_counter() - t0 < args.cpu_baseline_seconds and its < 1000):
+            st.take_step_adaptive(0.3, 0.6)
+            its += 1
+        dt = time.perf_counter() - t0
+        cpu_baseline = {"value": round(its / dt, 4), "unit": "iterations/s",
+                        "cores": 1, "kind": "port",
+                        "sample": f"first {its} adaptive take_step calls on the same LP "
+                                  f"({st.total_number_iterations} trials), oracle/pdhg_oracle.c, "
+                                  f"1 thread of {os.cpu_count()} host cores"}
+        st.close()
+
+    if rank == 0:
+        m, n = A.shape
+        b_pair = 24 * nnz + 16 * (m + n) + 4 * (m + n + 2)
+        b_iter = b_pair + 8 * (13 * n + 6 * m)
+        out = {
+            "metric": "pdhg_iterations_per_sec", "value": round(value, 3),
+            "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"random LP m={m} n={n} nnz={nnz} seed={args.seed} "
+                                   "(BASELINE configs[4]), adaptive step, zero start, "
+                                   "no restarts/rescaling",
+                       "m": m, "n": n, "nnz": nnz,
+                       "parallelism": "single GPU" if world == 1 else f"row-partition x{world} + RCCL all-reduce"},
+            "trials_per_step": round(trials / args.steps, 4),
+            "whole_iteration_GBps": round(b_iter * (trials / args.steps) / (ms_per_step * 1e-3) / 1e9, 1),
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "kernels": kernels,
+            "setup_sec": {"generate": round(t_gen, 1), "create_upload": round(t_create, 1)},
+        }
+        if cpu_baseline:
+            out["speedup_vs_cpu_port"] = round(value / cpu_baseline["value"], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""ctypes loader for csrc/libpdhg_hip.so (the C ABI in include/pdhg_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or cannot be
+loaded the product path raises.  (The CPU oracle under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIB_PATH = os.path.join(CSRC, "libpdhg_hip.so")
+SRC_PATH = os.path.join(CSRC, "pdhg_hip.hip")
+
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off",
+               "-std=c++17", "-shared", "-fPIC"]
+
+# every symbol include/pdhg_hip.h declares
+EXPORTS = [
+    "pdhg_last_error", "pdhg_abi_version", "pdhg_create",
+    "pdhg_set_objective_matrix", "pdhg_destroy", "pdhg_trial_step",
+    "pdhg_trial_primal", "pdhg_trial_dual", "pdhg_accept",
+    "pdhg_add_current_primal_to_average", "pdhg_get_average_info",
+    "pdhg_get_average", "pdhg_reset_average", "pdhg_restart_to_average",
+    "pdhg_get_current", "pdhg_set_current", "pdhg_get_trial", "pdhg_spmv",
+    "pdhg_spmv_t", "pdhg_dist_trial_begin", "pdhg_dist_trial_end",
+    "pdhg_dist_exchange_ptr", "pdhg_dist_dual_product_begin",
+    "pdhg_dist_dual_product_end", "pdhg_profile_enable", "pdhg_profile_read",
+    "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info",
+]
+
+K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_COUNT = range(6)
+
+
+def build(force=False, verbose=False):
+    """Cross-compile the HIP library for gfx950 with hipcc (no GPU needed)."""
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    if not force and os.path.exists(LIB_PATH) and \
+            os.path.getmtime(LIB_PATH) >= max(
+                os.path.getmtime(SRC_PATH),
+                os.path.getmtime(os.path.join(INCLUDE, "pdhg_hip.h"))):
+        return LIB_PATH
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", LIB_PATH, SRC_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+
+
+def lib():
+    """Load the library and declare every prototype.  Raises if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    d, i64, i32 = ctypes.c_double, ctypes.c_int64, ctypes.c_int
+    L.pdhg_last_error.restype = ctypes.c_char_p
+    L.pdhg_last_error.argtypes = []
+    L.pdhg_abi_version.restype = i32
+    L.pdhg_create.restype = i32
+    L.pdhg_create.argtypes = [ctypes.POINTER(_vp), i64, i64, i64, _ip, _ip,
+                              _dp, i32, _dp, _dp, _dp, _dp, i64, i32, _vp]
+    L.pdhg_set_objective_matrix.restype = i32
+    L.pdhg_set_objective_matrix.argtypes = [_vp, i64, _ip, _ip, _dp, i32]
+    L.pdhg_destroy.restype = None
+    L.pdhg_destroy.argtypes = [_vp]
+    L.pdhg_trial_step.restype = i32
+    L.pdhg_trial_step.argtypes = [_vp, d, d, d, _dp]
+    L.pdhg_trial_primal.restype = i32
+    L.pdhg_trial_primal.argtypes = [_vp, d, d]
+    L.pdhg_trial_dual.restype = i32
+    L.pdhg_trial_dual.argtypes = [_vp, d, d, d, _dp]
+    L.pdhg_accept.restype = i32
+    L.pdhg_accept.argtypes = [_vp, d]
+    L.pdhg_add_current_primal_to_average.restype = i32
+    L.pdhg_add_current_primal_to_average.argtypes = [_vp, d]
+    L.pdhg_get_average_info.restype = i32
+    L.pdhg_get_average_info.argtypes = [_vp, _ip, _dp]
+    L.pdhg_get_average.restype = i32
+    L.pdhg_get_average.argtypes = [_vp, _dp, _dp]
+    L.pdhg_reset_average.restype = i32
+    L.pdhg_reset_average.argtypes = [_vp]
+    L.pdhg_restart_to_average.restype = i32
+    L.pdhg_restart_to_average.argtypes = [_vp]
+    L.pdhg_get_current.restype = i32
+    L.pdhg_get_current.argtypes = [_vp, _dp, _dp, _dp]
+    L.pdhg_set_current.restype = i32
+    L.pdhg_set_current.argtypes = [_vp, _dp, _dp]
+    L.pdhg_get_trial.restype = i32
+    L.pdhg_get_trial.argtypes = [_vp, _dp, _dp, _dp]
+    L.pdhg_spmv.restype = i32
+    L.pdhg_spmv.argtypes = [_vp, _dp, _dp]
+    L.pdhg_spmv_t.restype = i32
+    L.pdhg_spmv_t.argtypes = [_vp, _dp, _dp]
+    L.pdhg_dist_trial_begin.restype = i32
+    L.pdhg_dist_trial_begin.argtypes = [_vp, d, d, d]
+    L.pdhg_dist_trial_end.restype = i32
+    L.pdhg_dist_trial_end.argtypes = [_vp, _dp]
+    L.pdhg_dist_exchange_ptr.restype = _vp
+    L.pdhg_dist_exchange_ptr.argtypes = [_vp]
+    L.pdhg_dist_dual_product_begin.restype = i32
+    L.pdhg_dist_dual_product_begin.argtypes = [_vp]
+    L.pdhg_dist_dual_product_end.restype = i32
+    L.pdhg_dist_dual_product_end.argtypes = [_vp]
+    L.pdhg_profile_enable.restype = i32
+    L.pdhg_profile_enable.argtypes = [_vp, i32]
+    L.pdhg_profile_read.restype = i32
+    L.pdhg_profile_read.argtypes = [_vp, i32, _ip, _dp]
+    L.pdhg_kernel_algorithmic_bytes.restype = i64
+    L.pdhg_kernel_algorithmic_bytes.argtypes = [_vp, i32]
+    L.pdhg_kernel_name.restype = ctypes.c_char_p
+    L.pdhg_kernel_name.argtypes = [i32]
+    L.pdhg_layout_info.restype = i32
+    L.pdhg_layout_info.argtypes = [_vp, _ip]
+    _lib = L
+    return L
+
+
+class PdhgHipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().pdhg_last_error().decode("utf-8", "replace")
+        raise PdhgHipError(f"pdhg_hip error {rc}: {msg}")

@@ -1,0 +1,200 @@
+"""Device-backed PDHG solver state: the Python binding over the C ABI
+(include/pdhg_hip.h).  One ``HipPdhgEngine`` == one ``pdhg_handle``.
+
+The engine owns the n-/m-length vectors of ``PdhgSolverState``
+(primal_dual_hybrid_gradient.jl:205-258) and ``SolutionWeightedAverage``
+(saddle_point.jl:215-222) on the GPU; the scalars (step_size, primal_weight,
+counters) stay with the host driver in primal_dual_hybrid_gradient.py.
+
+No fallback: constructing an engine without the HIP library or without a GPU
+raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int64)
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _pd(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_ip)
+
+
+class HipPdhgEngine:
+    """All arguments describe the *rescaled* problem the iterations run on."""
+
+    def __init__(self, constraint_matrix, objective_vector, right_hand_side,
+                 variable_lower_bound, variable_upper_bound, num_equalities,
+                 objective_matrix=None, device_id=-1, stream=None):
+        self._L = _lib.lib()
+        A = constraint_matrix
+        self.m, self.n = int(A.shape[0]), int(A.shape[1])
+        colptr, rowval, nzval = _i(A.indptr), _i(A.indices), _d(A.data)
+        c, b = _d(objective_vector), _d(right_hand_side)
+        lb, ub = _d(variable_lower_bound), _d(variable_upper_bound)
+        if c.shape != (self.n,) or lb.shape != (self.n,) or ub.shape != (self.n,) \
+                or b.shape != (self.m,):
+            raise ValueError("vector lengths do not match the constraint matrix")
+        h = ctypes.c_void_p()
+        _lib.check(self._L.pdhg_create(
+            ctypes.byref(h), self.m, self.n, len(nzval), _pi(colptr),
+            _pi(rowval), _pd(nzval), 0, _pd(c), _pd(b), _pd(lb), _pd(ub),
+            int(num_equalities), int(device_id),
+            ctypes.c_void_p(stream) if stream else None))
+        self._h = h
+        if objective_matrix is not None and objective_matrix.nnz > 0:
+            Q = objective_matrix
+            qc, qr, qv = _i(Q.indptr), _i(Q.indices), _d(Q.data)
+            _lib.check(self._L.pdhg_set_objective_matrix(
+                self._h, len(qv), _pi(qc), _pi(qr), _pd(qv), 0))
+
+    @classmethod
+    def from_problem(cls, problem, **kw):
+        return cls(problem.constraint_matrix, problem.objective_vector,
+                   problem.right_hand_side, problem.variable_lower_bound,
+                   problem.variable_upper_bound, problem.num_equalities,
+                   objective_matrix=problem.objective_matrix, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pdhg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the hot path -------------------------------------------------------
+    def trial_step(self, step_size, primal_weight, theta=1.0):
+        out = np.empty(5)
+        _lib.check(self._L.pdhg_trial_step(self._h, step_size, primal_weight,
+                                           theta, _pd(out)))
+        return out
+
+    def trial_primal(self, step_size, primal_weight):
+        _lib.check(self._L.pdhg_trial_primal(self._h, step_size, primal_weight))
+
+    def trial_dual(self, step_size, primal_weight, theta):
+        out = np.empty(5)
+        _lib.check(self._L.pdhg_trial_dual(self._h, step_size, primal_weight,
+                                           theta, _pd(out)))
+        return out
+
+    def accept(self, avg_weight):
+        _lib.check(self._L.pdhg_accept(self._h, avg_weight))
+
+    def add_current_primal_to_average(self, weight):
+        _lib.check(self._L.pdhg_add_current_primal_to_average(self._h, weight))
+
+    # ---- weighted average / restarts ---------------------------------------
+    def average_info(self):
+        counts = np.zeros(2, dtype=np.int64)
+        weights = np.zeros(2)
+        _lib.check(self._L.pdhg_get_average_info(self._h, _pi(counts),
+                                                 _pd(weights)))
+        return int(counts[0]), int(counts[1]), float(weights[0]), float(weights[1])
+
+    def get_average(self):
+        xa, ya = np.empty(self.n), np.empty(self.m)
+        _lib.check(self._L.pdhg_get_average(self._h, _pd(xa), _pd(ya)))
+        return xa, ya
+
+    def reset_average(self):
+        _lib.check(self._L.pdhg_reset_average(self._h))
+
+    def restart_to_average(self):
+        _lib.check(self._L.pdhg_restart_to_average(self._h))
+
+    # ---- iterate I/O ---------------------------------------------------------
+    def get_current(self):
+        x, y = np.empty(self.n), np.empty(self.m)
+        _lib.check(self._L.pdhg_get_current(self._h, _pd(x), _pd(y), None))
+        return x, y
+
+    def get_dual_product(self):
+        aty = np.empty(self.n)
+        _lib.check(self._L.pdhg_get_current(self._h, None, None, _pd(aty)))
+        return aty
+
+    def set_current(self, x=None, y=None):
+        x = None if x is None else _d(x)
+        y = None if y is None else _d(y)
+        _lib.check(self._L.pdhg_set_current(self._h, _pd(x), _pd(y)))
+
+    def get_trial(self):
+        x, y, a = np.empty(self.n), np.empty(self.m), np.empty(self.n)
+        _lib.check(self._L.pdhg_get_trial(self._h, _pd(x), _pd(y), _pd(a)))
+        return x, y, a
+
+    # ---- standalone primitives ------------------------------------------------
+    def spmv(self, x):
+        x = _d(x)
+        out = np.empty(self.m)
+        _lib.check(self._L.pdhg_spmv(self._h, _pd(x), _pd(out)))
+        return out
+
+    def spmv_t(self, y):
+        y = _d(y)
+        out = np.empty(self.n)
+        _lib.check(self._L.pdhg_spmv_t(self._h, _pd(y), _pd(out)))
+        return out
+
+    # ---- row-partitioned form --------------------------------------------------
+    def dist_trial_begin(self, step_size, primal_weight, theta=1.0):
+        _lib.check(self._L.pdhg_dist_trial_begin(self._h, step_size,
+                                                 primal_weight, theta))
+
+    def dist_trial_end(self):
+        out = np.empty(5)
+        _lib.check(self._L.pdhg_dist_trial_end(self._h, _pd(out)))
+        return out
+
+    def dist_exchange_ptr(self):
+        return int(self._L.pdhg_dist_exchange_ptr(self._h))
+
+    def dist_dual_product_begin(self):
+        _lib.check(self._L.pdhg_dist_dual_product_begin(self._h))
+
+    def dist_dual_product_end(self):
+        _lib.check(self._L.pdhg_dist_dual_product_end(self._h))
+
+    # ---- measurement -------------------------------------------------------------
+    def profile_enable(self, enable=True):
+        _lib.check(self._L.pdhg_profile_enable(self._h, int(bool(enable))))
+
+    def profile_read(self, kernel_id):
+        cnt = ctypes.c_int64()
+        ms = ctypes.c_double()
+        _lib.check(self._L.pdhg_profile_read(self._h, kernel_id,
+                                             ctypes.byref(cnt), ctypes.byref(ms)))
+        return cnt.value, ms.value
+
+    def kernel_algorithmic_bytes(self, kernel_id):
+        return int(self._L.pdhg_kernel_algorithmic_bytes(self._h, kernel_id))
+
+    def kernel_name(self, kernel_id):
+        return self._L.pdhg_kernel_name(kernel_id).decode()
+
+    def layout_info(self):
+        info = np.zeros(8, dtype=np.int64)
+        _lib.check(self._L.pdhg_layout_info(self._h, _pi(info)))
+        keys = ["A_blocks", "A_long_rows", "A_long_chunks", "A_max_row_nnz",
+                "At_blocks", "At_long_rows", "At_long_chunks", "At_max_row_nnz"]
+        return dict(zip(keys, info.tolist()))

@@ -1,0 +1,169 @@
+/*
+ * pdhg_hip.h -- C ABI of the MI355X (gfx950) PDHG inner-step library.
+ *
+ * This is the drop-in boundary for the one hot path of
+ * google-research/FirstOrderLp.jl: everything `take_step` does per iteration
+ * (src/primal_dual_hybrid_gradient.jl:442-549, 555-767, called from
+ * `optimize` at :1044) plus the state accessors `optimize`'s evaluation /
+ * restart branch needs (:892-1023).  The reference has no FFI of its own (it
+ * is pure Julia); each entry point below names the reference lines it
+ * replaces.  A Julia `ccall` shim and a Python `ctypes` binding over exactly
+ * these symbols are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns int: 0 = ok, <0 = invalid argument / unsupported,
+ *    >0 = hipError_t from the runtime.  `pdhg_last_error()` gives the text.
+ *  - the library owns all device memory.  Host arrays passed in are read
+ *    during the call only; output arrays are caller-allocated host memory.
+ *  - one host thread per handle; calls return after the handle's stream has
+ *    drained whenever they produce host-visible results.
+ *  - fp64 throughout; kernels are built with -ffp-contract=off so elementwise
+ *    updates round exactly like the reference's unfused Julia broadcasts.
+ */
+#ifndef PDHG_HIP_H_
+#define PDHG_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pdhg_handle pdhg_handle;
+
+/* Text of the most recent error on this thread ("" if none). */
+const char *pdhg_last_error(void);
+
+/* Library/ABI version (bumped on any signature change). */
+int pdhg_abi_version(void);
+
+/*
+ * Ingest the (already rescaled) LP exactly as Julia stores it:
+ * `constraint_matrix::SparseMatrixCSC{Float64,Int64}` = (colptr[n+1],
+ * rowval[nnz], nzval[nnz]) with `index_base` 1 (Julia) or 0 (scipy), plus
+ * objective_vector c[n], right_hand_side b[m], variable bounds lb/ub[n]
+ * (+-Inf allowed) and num_equalities (rows 0..num_equalities-1 are
+ * equalities).  Builds device CSR(A) and CSR(A') with 32-bit indices and
+ * zero-initialises x, y, A'y and the weighted-average sums.
+ * Replaces: QuadraticProgrammingProblem (src/quadratic_programming.jl:34-76)
+ * as the data contract, and the PdhgSolverState zeros(...) construction
+ * (src/primal_dual_hybrid_gradient.jl:805-819).
+ * `stream`: a hipStream_t to run on (e.g. the caller's torch stream), or NULL
+ * for a private stream.  `device_id` < 0 keeps the current device.
+ */
+int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
+                const int64_t *colptr, const int64_t *rowval,
+                const double *nzval, int index_base, const double *c,
+                const double *b, const double *lb, const double *ub,
+                int64_t num_equalities, int device_id, void *stream);
+
+/*
+ * Attach objective_matrix (QP term, CSC n x n) -- src/quadratic_programming.jl:49.
+ * Without this call the problem is an LP (objective_matrix == 0).
+ */
+int pdhg_set_objective_matrix(pdhg_handle *h, int64_t q_nnz,
+                              const int64_t *q_colptr, const int64_t *q_rowval,
+                              const double *q_nzval, int index_base);
+
+void pdhg_destroy(pdhg_handle *h);
+
+/*
+ * One trial step into shadow buffers x', y', A'y' (nothing is committed):
+ *   x'  = proj_[lb,ub](x - (step/pw) * (Qx + c - A'y))   compute_next_primal_solution  pdhg.jl:442-470
+ *   xb  = x' + theta*(x' - x)                                                           pdhg.jl:486-487
+ *   y'  = proj(y + (pw*step) * (b - A*xb))                compute_next_dual_solution    pdhg.jl:472-494
+ *   A'y'                                                                                pdhg.jl:492
+ * out[0] = dx . (A'y' - A'y)   out[1] = sum dx^2   out[2] = sum dy^2
+ * out[3] = sum (A'y' - A'y)^2  out[4] = 0.5 * dx' Q dx (0 for an LP)
+ * -- the raw sums compute_interaction_and_movement (pdhg.jl:527-549) and the
+ * Malitsky-Pock test (pdhg.jl:615-616) are built from; the host applies
+ * abs / sqrt / primal_weight.
+ */
+int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight,
+                    double theta, double out[5]);
+
+/* Malitsky-Pock split (pdhg.jl:572-616): x' once, then repeated dual trials. */
+int pdhg_trial_primal(pdhg_handle *h, double step_size, double primal_weight);
+int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight,
+                    double theta, double out[5]);
+
+/*
+ * Commit the last trial: x<-x', y<-y', A'y<-A'y' (buffer swap) and
+ * sum_x += w*x, sum_y += w*y, counts += 1, weights += w.
+ * Replaces update_solution_in_solver_state (pdhg.jl:500-519) +
+ * add_to_solution_weighted_average (saddle_point.jl:252-294).  The caller
+ * passes the weight (reference quirk: it is solver_state.step_size on entry to
+ * take_step, pdhg.jl:512).
+ */
+int pdhg_accept(pdhg_handle *h, double avg_weight);
+
+/* add_to_primal_solution_weighted_average on the CURRENT x (pdhg.jl:621-627). */
+int pdhg_add_current_primal_to_average(pdhg_handle *h, double weight);
+
+/* SolutionWeightedAverage bookkeeping (saddle_point.jl:215-222). */
+int pdhg_get_average_info(pdhg_handle *h, int64_t counts[2], double weights[2]);
+/* compute_average (saddle_point.jl:296-301): sum / weight.  NULL skips one. */
+int pdhg_get_average(pdhg_handle *h, double *x_avg, double *y_avg);
+/* reset_solution_weighted_average (saddle_point.jl:238-250). */
+int pdhg_reset_average(pdhg_handle *h);
+/* current .= avg (saddle_point.jl:808-809) + A'y recompute (pdhg.jl:1018-1022). */
+int pdhg_restart_to_average(pdhg_handle *h);
+
+/* Iterate I/O for the host-side evaluation / restart branch (pdhg.jl:892-1023). */
+int pdhg_get_current(pdhg_handle *h, double *x, double *y, double *aty);
+/* Overwrite x,y (NULL keeps one) and recompute the cached A'y. */
+int pdhg_set_current(pdhg_handle *h, const double *x, const double *y);
+/* Shadow (trial) buffers; after pdhg_accept they hold the PREVIOUS iterate. */
+int pdhg_get_trial(pdhg_handle *h, double *x_next, double *y_next,
+                   double *aty_next);
+
+/* Standalone primitives on host vectors: out = A*x (saddle_point.jl:1106),
+ * out = A'*y (pdhg.jl:492), for the evaluation branch
+ * (iteration_stats_utils.jl:34,162). */
+int pdhg_spmv(pdhg_handle *h, const double *x, double *out);
+int pdhg_spmv_t(pdhg_handle *h, const double *y, double *out);
+
+/*
+ * Row-partitioned multi-GPU form (one process per GPU; this handle holds the
+ * row block A_p, its slice of y/b, and a full replica of the n-vectors).
+ *   begin : x', xb, y'_p, and the LOCAL partial A_p' y'_p written to the
+ *           exchange buffer; slot [n] of that buffer = local sum dy_p^2.
+ *   (caller all-reduces(sum) the n+1 doubles at pdhg_dist_exchange_ptr over
+ *    RCCL, e.g. torch.distributed.all_reduce on the same stream)
+ *   end   : reductions on the replicated n-vectors; out[] as pdhg_trial_step.
+ * No reference counterpart (the reference is single-process).
+ */
+int pdhg_dist_trial_begin(pdhg_handle *h, double step_size,
+                          double primal_weight, double theta);
+int pdhg_dist_trial_end(pdhg_handle *h, double out[5]);
+/* Device pointer to the current exchange buffer (n+1 doubles). */
+void *pdhg_dist_exchange_ptr(pdhg_handle *h);
+/* Same split for A'y recompute after set_current/restart: partial then finish. */
+int pdhg_dist_dual_product_begin(pdhg_handle *h);
+int pdhg_dist_dual_product_end(pdhg_handle *h);
+
+/* ---- measurement ---------------------------------------------------------- */
+enum {
+  PDHG_K_PRIMAL = 0,     /* x', xb elementwise                         */
+  PDHG_K_SPMV_DUAL = 1,  /* CSR(A)  SpMV + dual update epilogue        */
+  PDHG_K_SPMV_ATY = 2,   /* CSR(A') SpMV + interaction epilogue        */
+  PDHG_K_FINAL = 3,      /* second-stage reduction of block partials   */
+  PDHG_K_ACCEPT = 4,     /* weighted-average AXPY                      */
+  PDHG_K_COUNT = 5
+};
+/* Bracket every launch of the hot kernels with hipEvents on the handle's
+ * stream and accumulate per-kernel time (profiling mode serialises launches;
+ * do not enable inside a throughput-timed region). */
+int pdhg_profile_enable(pdhg_handle *h, int enable);
+int pdhg_profile_read(pdhg_handle *h, int kernel_id, int64_t *launches,
+                      double *total_ms);
+/* Algorithmic HBM bytes one launch of `kernel_id` must move. */
+int64_t pdhg_kernel_algorithmic_bytes(pdhg_handle *h, int kernel_id);
+const char *pdhg_kernel_name(int kernel_id);
+/* Row-block statistics of the two CSR-adaptive layouts (diagnostics). */
+int pdhg_layout_info(pdhg_handle *h, int64_t info[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDHG_HIP_H_ */

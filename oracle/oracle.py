@@ -1,0 +1,234 @@
+"""ctypes wrapper over oracle/libpdhg_oracle.so (the CPU restatement).
+
+TEST INFRASTRUCTURE ONLY -- see the header of pdhg_oracle.c.  Nothing under
+``firstorderlp.jl_amd/`` imports this module; it is loaded by ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpdhg_oracle.so")
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_i64_p = ctypes.POINTER(ctypes.c_int64)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+    src = os.path.join(_HERE, "pdhg_oracle.c")
+    if (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpdhg_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_create.restype = ctypes.c_void_p
+        for name in ("step_size", "primal_weight", "ratio_step_sizes",
+                     "cumulative_kkt_passes"):
+            getattr(_lib, "oracle_get_" + name).restype = ctypes.c_double
+            getattr(_lib, "oracle_get_" + name).argtypes = [ctypes.c_void_p]
+            getattr(_lib, "oracle_set_" + name).argtypes = [ctypes.c_void_p,
+                                                            ctypes.c_double]
+        _lib.oracle_get_numerical_error.restype = ctypes.c_int
+        _lib.oracle_get_numerical_error.argtypes = [ctypes.c_void_p]
+        _lib.oracle_set_numerical_error.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.oracle_get_total_number_iterations.restype = ctypes.c_int64
+        _lib.oracle_get_total_number_iterations.argtypes = [ctypes.c_void_p]
+        _lib.oracle_take_step_adaptive.argtypes = [ctypes.c_void_p,
+                                                   ctypes.c_double,
+                                                   ctypes.c_double]
+        _lib.oracle_take_step_constant.argtypes = [ctypes.c_void_p]
+        _lib.oracle_take_step_malitsky_pock.argtypes = [ctypes.c_void_p] + \
+            [ctypes.c_double] * 3
+    return _lib
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_c_i64_p)
+
+
+def spmv(m, n, colptr, rowval, nzval, x):
+    """A*x, Julia SparseMatrixCSC order (0-based CSC arrays)."""
+    colptr, rowval, nzval, x = _i(colptr), _i(rowval), _d(nzval), _d(x)
+    out = np.empty(m, dtype=np.float64)
+    lib().oracle_spmv(ctypes.c_int64(m), ctypes.c_int64(n), _ip(colptr),
+                      _ip(rowval), _dp(nzval), _dp(x), _dp(out))
+    return out
+
+
+def spmv_t(m, n, colptr, rowval, nzval, y):
+    """A'*y, Julia Adjoint{SparseMatrixCSC} order (0-based CSC arrays)."""
+    colptr, rowval, nzval, y = _i(colptr), _i(rowval), _d(nzval), _d(y)
+    out = np.empty(n, dtype=np.float64)
+    lib().oracle_spmv_t(ctypes.c_int64(m), ctypes.c_int64(n), _ip(colptr),
+                        _ip(rowval), _dp(nzval), _dp(y), _dp(out))
+    return out
+
+
+class OracleState:
+    """PdhgSolverState + problem held by the C oracle.
+
+    Arguments are the *already rescaled* problem, CSC 0-based: the same data
+    the product's C-ABI ``pdhg_create`` ingests.
+    """
+
+    def __init__(self, m, n, colptr, rowval, nzval, c, b, lb, ub,
+                 num_equalities, q_colptr=None, q_rowval=None, q_nzval=None):
+        L = lib()
+        self.m, self.n = int(m), int(n)
+        colptr, rowval, nzval = _i(colptr), _i(rowval), _d(nzval)
+        c, b, lb, ub = _d(c), _d(b), _d(lb), _d(ub)
+        assert colptr.shape == (n + 1,) and c.shape == (n,) and b.shape == (m,)
+        if q_colptr is None:
+            q_colptr = np.zeros(n + 1, dtype=np.int64)
+            q_rowval = np.zeros(0, dtype=np.int64)
+            q_nzval = np.zeros(0, dtype=np.float64)
+        q_colptr, q_rowval, q_nzval = _i(q_colptr), _i(q_rowval), _d(q_nzval)
+        self._h = ctypes.c_void_p(L.oracle_create(
+            ctypes.c_int64(m), ctypes.c_int64(n), _ip(colptr), _ip(rowval),
+            _dp(nzval), ctypes.c_int64(len(q_nzval)), _ip(q_colptr),
+            _ip(q_rowval), _dp(q_nzval), _dp(c), _dp(b), _dp(lb), _dp(ub),
+            ctypes.c_int64(num_equalities)))
+        self._L = L
+
+    def close(self):
+        if self._h:
+            self._L.oracle_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- vectors ------------------------------------------------------------
+    def _get(self, name, length):
+        out = np.empty(length, dtype=np.float64)
+        getattr(self._L, "oracle_get_" + name)(self._h, _dp(out))
+        return out
+
+    def _set(self, name, arr, length):
+        arr = _d(arr)
+        assert arr.shape == (length,)
+        getattr(self._L, "oracle_set_" + name)(self._h, _dp(arr))
+
+    x = property(lambda s: s._get("x", s.n), lambda s, v: s._set("x", v, s.n))
+    y = property(lambda s: s._get("y", s.m), lambda s, v: s._set("y", v, s.m))
+    aty = property(lambda s: s._get("aty", s.n),
+                   lambda s, v: s._set("aty", v, s.n))
+    delta_x = property(lambda s: s._get("delta_x", s.n))
+    delta_y = property(lambda s: s._get("delta_y", s.m))
+    sum_x = property(lambda s: s._get("sum_x", s.n))
+    sum_y = property(lambda s: s._get("sum_y", s.m))
+    x_next = property(lambda s: s._get("x_next", s.n))
+    y_next = property(lambda s: s._get("y_next", s.m))
+    aty_next = property(lambda s: s._get("aty_next", s.n))
+
+    # -- scalars ------------------------------------------------------------
+    step_size = property(lambda s: s._L.oracle_get_step_size(s._h),
+                         lambda s, v: s._L.oracle_set_step_size(s._h, float(v)))
+    primal_weight = property(
+        lambda s: s._L.oracle_get_primal_weight(s._h),
+        lambda s, v: s._L.oracle_set_primal_weight(s._h, float(v)))
+    ratio_step_sizes = property(
+        lambda s: s._L.oracle_get_ratio_step_sizes(s._h),
+        lambda s, v: s._L.oracle_set_ratio_step_sizes(s._h, float(v)))
+    cumulative_kkt_passes = property(
+        lambda s: s._L.oracle_get_cumulative_kkt_passes(s._h),
+        lambda s, v: s._L.oracle_set_cumulative_kkt_passes(s._h, float(v)))
+    numerical_error = property(
+        lambda s: bool(s._L.oracle_get_numerical_error(s._h)),
+        lambda s, v: s._L.oracle_set_numerical_error(s._h, int(bool(v))))
+    total_number_iterations = property(
+        lambda s: int(s._L.oracle_get_total_number_iterations(s._h)))
+
+    def average_counts(self):
+        counts = np.zeros(2, dtype=np.int64)
+        weights = np.zeros(2, dtype=np.float64)
+        self._L.oracle_get_average_counts(self._h, _ip(counts), _dp(weights))
+        return int(counts[0]), int(counts[1]), float(weights[0]), float(weights[1])
+
+    # -- hot path pieces ------------------------------------------------------
+    def trial_step(self, step_size, primal_weight, theta=1.0):
+        """One trial: returns raw (dx.dAty, sum dx^2, sum dy^2) like the C-ABI."""
+        L, h = self._L, self._h
+        xn = np.empty(self.n)
+        yn = np.empty(self.m)
+        an = np.empty(self.n)
+        L.oracle_compute_next_primal(h, ctypes.c_double(step_size),
+                                     ctypes.c_double(primal_weight), _dp(xn))
+        L.oracle_compute_next_dual(h, _dp(xn), ctypes.c_double(step_size),
+                                   ctypes.c_double(primal_weight),
+                                   ctypes.c_double(theta), _dp(yn), _dp(an))
+        inter = ctypes.c_double()
+        move = ctypes.c_double()
+        raw = np.empty(3)
+        L.oracle_interaction_and_movement(h, _dp(xn), _dp(yn), _dp(an),
+                                          ctypes.byref(inter),
+                                          ctypes.byref(move), _dp(raw))
+        self._set("x_next", xn, self.n)
+        self._set("y_next", yn, self.m)
+        self._set("aty_next", an, self.n)
+        return raw, xn, yn, an
+
+    def accept(self, xn, yn, an):
+        self._L.oracle_update_solution(self._h, _dp(_d(xn)), _dp(_d(yn)),
+                                       _dp(_d(an)))
+
+    def take_step_adaptive(self, reduction_exponent=0.3, growth_exponent=0.6):
+        return self._L.oracle_take_step_adaptive(self._h, reduction_exponent,
+                                                 growth_exponent)
+
+    def take_step_constant(self):
+        return self._L.oracle_take_step_constant(self._h)
+
+    def take_step_malitsky_pock(self, downscaling_factor, breaking_factor,
+                                interpolation_coefficient):
+        return self._L.oracle_take_step_malitsky_pock(
+            self._h, downscaling_factor, breaking_factor,
+            interpolation_coefficient)
+
+    def add_to_primal_average(self, x, weight):
+        self._L.oracle_add_to_primal_average(self._h, _dp(_d(x)),
+                                             ctypes.c_double(weight))
+
+    def reset_average(self):
+        self._L.oracle_reset_average(self._h)
+
+    def compute_average(self):
+        xa = np.empty(self.n)
+        ya = np.empty(self.m)
+        self._L.oracle_compute_average(self._h, _dp(xa), _dp(ya))
+        return xa, ya
+
+    def recompute_dual_product(self):
+        self._L.oracle_recompute_dual_product(self._h)

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import folp_loader  # noqa: E402
+
+folp_loader.load()
+
+
+def pytest_configure(config):
+    config.addinivalue_line(
+        "markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu_required():
+    """GPU tests must fail loudly (not skip) when selected without a GPU."""
+    if not has_gpu():
+        pytest.fail("test marked gpu but no GPU is visible")
