@@ -1,0 +1,178 @@
+"""One-shot host setup before the loop: validation and diagonal rescaling,
+mirroring src/preprocess.jl (validate :18-84, l2_norm :99-113, l2_norm_rescaling
+:358-372, ruiz_rescaling :412-477, pock_chambolle_rescaling :508-539,
+scale_problem :555-573, rescale_problem :631-687)."""
+import numpy as np
+import scipy.sparse as sp
+
+from .quadratic_programming import (QuadraticProgrammingProblem,
+                                    ScaledQpProblem, as_csc)
+
+
+def validate(p):
+    """preprocess.jl:18-84: raises on a malformed problem."""
+    errors = []
+    n = len(p.objective_vector)
+    if len(p.variable_lower_bound) != len(p.variable_upper_bound):
+        errors.append("length(variable_lower_bound) != length(variable_upper_bound)")
+    if len(p.variable_lower_bound) != n:
+        errors.append("length(variable_lower_bound) != length(objective_vector)")
+    if p.constraint_matrix.shape[0] != len(p.right_hand_side):
+        errors.append("size(constraint_matrix, 1) != length(right_hand_side)")
+    if p.constraint_matrix.shape[1] != n:
+        errors.append("size(constraint_matrix, 2) != length(objective_vector)")
+    if p.objective_matrix.shape != (n, n):
+        errors.append("objective_matrix is not square with length(objective_vector)")
+    if np.any(p.variable_lower_bound == np.inf):
+        errors.append("variable_lower_bound contains +Inf")
+    if np.any(p.variable_upper_bound == -np.inf):
+        errors.append("variable_upper_bound contains -Inf")
+    if np.any(np.isnan(p.variable_lower_bound)) or np.any(np.isnan(p.variable_upper_bound)):
+        errors.append("NaN found in variable bounds")
+    if not np.all(np.isfinite(p.right_hand_side)):
+        errors.append("NaN or Inf found in right hand side")
+    if not np.all(np.isfinite(p.objective_vector)):
+        errors.append("NaN or Inf found in objective vector")
+    if not np.all(np.isfinite(p.constraint_matrix.data)):
+        errors.append("NaN or Inf found in constraint matrix")
+    if not np.all(np.isfinite(p.objective_matrix.data)):
+        errors.append("NaN or Inf found in objective matrix")
+    if errors:
+        raise ValueError("Error found when validating QuadraticProgrammingProblem: "
+                         + "; ".join(errors))
+    return True
+
+
+def _max_abs(matrix, dims):
+    """vec(maximum(abs, matrix, dims=dims)) with Julia's dims (1: per column,
+    2: per row); structural zeros count as 0."""
+    a = abs(matrix)
+    if dims == 1:
+        return np.asarray(a.max(axis=0).todense()).reshape(-1) if a.nnz else np.zeros(matrix.shape[1])
+    return np.asarray(a.max(axis=1).todense()).reshape(-1) if a.nnz else np.zeros(matrix.shape[0])
+
+
+def _sum_f(matrix, dims, f):
+    """vec(sum(f, matrix, dims=dims)) over stored entries (f(0) = 0 here)."""
+    m = matrix.copy()
+    m.data = f(m.data)
+    axis = 0 if dims == 1 else 1
+    return np.asarray(m.sum(axis=axis)).reshape(-1)
+
+
+def l2_norm(matrix, dimension):
+    """preprocess.jl:99-113: scaled sum of squares to avoid overflow."""
+    scale_factor = _max_abs(matrix, dimension)
+    scale_factor[scale_factor == 0.0] = 1.0
+    if dimension == 1:
+        scaled = matrix @ sp.diags(1.0 / scale_factor)
+    else:
+        scaled = sp.diags(1.0 / scale_factor) @ matrix
+    return scale_factor * np.sqrt(_sum_f(sp.csc_matrix(scaled), dimension, np.square))
+
+
+def scale_problem(problem, constraint_rescaling, variable_rescaling):
+    """preprocess.jl:555-573 (in place)."""
+    assert np.all(constraint_rescaling > 0) and np.all(variable_rescaling > 0)
+    problem.objective_vector = problem.objective_vector / variable_rescaling
+    dinv = sp.diags(1.0 / variable_rescaling)
+    problem.objective_matrix = as_csc((dinv @ problem.objective_matrix) @ dinv)
+    problem.variable_upper_bound = problem.variable_upper_bound * variable_rescaling
+    problem.variable_lower_bound = problem.variable_lower_bound * variable_rescaling
+    problem.right_hand_side = problem.right_hand_side / constraint_rescaling
+    einv = sp.diags(1.0 / constraint_rescaling) if len(constraint_rescaling) else sp.csc_matrix((0, 0))
+    problem.constraint_matrix = as_csc((einv @ problem.constraint_matrix) @ dinv)
+
+
+def unscale_problem(problem, constraint_rescaling, variable_rescaling):
+    """preprocess.jl:580-587"""
+    scale_problem(problem, 1.0 / constraint_rescaling, 1.0 / variable_rescaling)
+
+
+def l2_norm_rescaling(problem):
+    """preprocess.jl:358-372"""
+    norm_of_rows = l2_norm(problem.constraint_matrix, 2)
+    norm_of_columns = l2_norm(problem.constraint_matrix, 1)
+    norm_of_rows[norm_of_rows == 0.0] = 1.0
+    norm_of_columns[norm_of_columns == 0.0] = 1.0
+    column_rescale_factor = np.sqrt(norm_of_columns)
+    row_rescale_factor = np.sqrt(norm_of_rows)
+    scale_problem(problem, row_rescale_factor, column_rescale_factor)
+    return row_rescale_factor, column_rescale_factor
+
+
+def ruiz_rescaling(problem, num_iterations, p=np.inf):
+    """preprocess.jl:412-477"""
+    num_constraints, num_variables = problem.constraint_matrix.shape
+    cum_constraint_rescaling = np.ones(num_constraints)
+    cum_variable_rescaling = np.ones(num_variables)
+    for _ in range(num_iterations):
+        constraint_matrix = problem.constraint_matrix
+        objective_matrix = problem.objective_matrix
+        if p == np.inf:
+            variable_rescaling = np.sqrt(np.maximum(_max_abs(constraint_matrix, 1),
+                                                    _max_abs(objective_matrix, 1)))
+        else:
+            assert p == 2
+            variable_rescaling = np.sqrt(np.sqrt(l2_norm(constraint_matrix, 1) ** 2 +
+                                                 l2_norm(objective_matrix, 1) ** 2))
+        variable_rescaling[variable_rescaling == 0.0] = 1.0
+        if num_constraints == 0:
+            constraint_rescaling = np.zeros(0)
+        else:
+            if p == np.inf:
+                constraint_rescaling = np.sqrt(_max_abs(constraint_matrix, 2))
+            else:
+                norm_of_rows = l2_norm(problem.constraint_matrix, 2)
+                if problem.objective_matrix.nnz == 0 or not np.any(problem.objective_matrix.data):
+                    target_row_norm = np.sqrt(num_variables / num_constraints)
+                else:
+                    target_row_norm = np.sqrt(num_variables / (num_constraints + num_variables))
+                constraint_rescaling = np.sqrt(norm_of_rows / target_row_norm)
+            constraint_rescaling[constraint_rescaling == 0.0] = 1.0
+        scale_problem(problem, constraint_rescaling, variable_rescaling)
+        cum_constraint_rescaling *= constraint_rescaling
+        cum_variable_rescaling *= variable_rescaling
+    return cum_constraint_rescaling, cum_variable_rescaling
+
+
+def pock_chambolle_rescaling(problem, alpha):
+    """preprocess.jl:508-539"""
+    assert 0 <= alpha <= 2
+    constraint_matrix = problem.constraint_matrix
+    variable_rescaling = np.sqrt(_sum_f(constraint_matrix, 1, lambda t: np.abs(t) ** (2 - alpha)))
+    constraint_rescaling = np.sqrt(_sum_f(constraint_matrix, 2, lambda t: np.abs(t) ** alpha))
+    variable_rescaling[variable_rescaling == 0.0] = 1.0
+    constraint_rescaling[constraint_rescaling == 0.0] = 1.0
+    scale_problem(problem, constraint_rescaling, variable_rescaling)
+    return constraint_rescaling, variable_rescaling
+
+
+def rescale_problem(l_inf_ruiz_iterations, l2_norm_rescaling_flag,
+                    pock_chambolle_alpha, verbosity, original_problem):
+    """preprocess.jl:631-687: returns a ScaledQpProblem; original untouched."""
+    problem = original_problem.copy()
+    num_constraints, num_variables = problem.constraint_matrix.shape
+    constraint_rescaling = np.ones(num_constraints)
+    variable_rescaling = np.ones(num_variables)
+    if l_inf_ruiz_iterations > 0:
+        con_rescale, var_rescale = ruiz_rescaling(problem, l_inf_ruiz_iterations, np.inf)
+        constraint_rescaling *= con_rescale
+        variable_rescaling *= var_rescale
+    if l2_norm_rescaling_flag:
+        con_rescale, var_rescale = l2_norm_rescaling(problem)
+        constraint_rescaling *= con_rescale
+        variable_rescaling *= var_rescale
+    if pock_chambolle_alpha is not None:
+        con_rescale, var_rescale = pock_chambolle_rescaling(problem, pock_chambolle_alpha)
+        constraint_rescaling *= con_rescale
+        variable_rescaling *= var_rescale
+    scaled_problem = ScaledQpProblem(original_problem, problem, constraint_rescaling,
+                                     variable_rescaling)
+    if verbosity >= 3:
+        if l_inf_ruiz_iterations == 0 and not l2_norm_rescaling_flag:
+            print("No rescaling.")
+        else:
+            print(f"Problem after rescaling (Ruiz iterations = {l_inf_ruiz_iterations}, "
+                  f"l2_norm_rescaling = {l2_norm_rescaling_flag}):")
+    return scaled_problem

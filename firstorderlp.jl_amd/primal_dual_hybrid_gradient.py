@@ -162,3 +162,275 @@ def take_step(step_params, solver_state, is_lp=True):
     if isinstance(step_params, ConstantStepsizeParams):
         return take_step_constant(step_params, solver_state)
     raise TypeError(f"unknown step size policy {type(step_params)}")
+
+
+# ==============================================================================
+# optimize(): the reference's outer loop (pdhg.jl:782-1049) on the host, with
+# every n-/m-length vector operation behind ``engine``.
+# ==============================================================================
+import time as _time
+
+from .iteration_stats_utils import evaluate_unscaled_iteration_stats
+from .preprocess import rescale_problem, validate
+from .quadratic_programming import is_linear_programming_problem
+from .saddle_point import (RestartParameters, compute_new_primal_weight,
+                           create_last_restart_info, run_restart_scheme,
+                           select_initial_primal_weight,
+                           unscaled_saddle_point_output,
+                           update_objective_bound_estimates)
+from .solve_log import PointType, RestartChoice, TerminationReason
+from .termination import (TerminationCriteria, cached_quadratic_program_info,
+                          check_termination_criteria)
+
+
+@dataclass
+class PdhgParameters:
+    """pdhg.jl:128-199 (same field names and order)."""
+    l_inf_ruiz_iterations: int
+    l2_norm_rescaling: bool
+    pock_chambolle_alpha: Optional[float]
+    primal_importance: float
+    scale_invariant_initial_primal_weight: bool
+    verbosity: int
+    record_iteration_stats: bool
+    termination_evaluation_frequency: int
+    termination_criteria: TerminationCriteria
+    restart_params: RestartParameters
+    step_size_policy_params: object
+
+
+class EngineOps:
+    """A*x, A'*y of the SCALED problem on the device (pdhg_spmv / pdhg_spmv_t);
+    Q*x on the host (Q is LP-empty or tiny in the reference's QPs)."""
+
+    def __init__(self, engine, problem):
+        self._eng = engine
+        self._Q = problem.objective_matrix
+        self._n = problem.num_variables
+
+    def Ax(self, x):
+        return self._eng.spmv(x)
+
+    def ATy(self, y):
+        return self._eng.spmv_t(y)
+
+    def Qx(self, x):
+        if self._Q.nnz == 0:
+            return np.zeros(self._n)
+        return self._Q @ x
+
+
+class UnscaledEngineOps:
+    """The ORIGINAL problem's mat-vecs through the scaled device matrix:
+    A = E A_s D  =>  A x = E .* (A_s (D .* x)),  A'y = D .* (A_s' (E .* y))."""
+
+    def __init__(self, engine, scaled_problem):
+        self._eng = engine
+        self._E = scaled_problem.constraint_rescaling
+        self._D = scaled_problem.variable_rescaling
+        self._Q = scaled_problem.original_qp.objective_matrix
+        self._n = scaled_problem.original_qp.num_variables
+
+    def Ax(self, x):
+        return self._E * self._eng.spmv(self._D * x)
+
+    def ATy(self, y):
+        return self._D * self._eng.spmv_t(self._E * y)
+
+    def Qx(self, x):
+        if self._Q.nnz == 0:
+            return np.zeros(self._n)
+        return self._Q @ x
+
+
+def power_method_failure_probability(dimension, epsilon, k):
+    """pdhg.jl:378-390"""
+    if k < 2 or epsilon <= 0.0:
+        return 1.0
+    return min(0.824, 0.354 / math.sqrt(epsilon * (k - 1))) * \
+        math.sqrt(dimension) * (1.0 - epsilon) ** (k - 1 / 2)
+
+
+def estimate_maximum_singular_value(ops, num_cols, probability_of_failure=0.01,
+                                    desired_relative_error=0.1, seed=1):
+    """pdhg.jl:414-440.  The reference draws randn(MersenneTwister(seed)); that
+    stream cannot be replayed outside Julia, so parity of the constant-step
+    policy is at the tolerance of the power method, not bitwise."""
+    epsilon = 1.0 - (1.0 - desired_relative_error) ** 2
+    x = np.random.default_rng(seed).standard_normal(num_cols)
+    number_of_power_iterations = 0
+    while power_method_failure_probability(num_cols, epsilon,
+                                           number_of_power_iterations) > probability_of_failure:
+        x = x / math.sqrt(float(x @ x))
+        x = ops.ATy(ops.Ax(x))
+        number_of_power_iterations += 1
+    return (math.sqrt(float(x @ ops.ATy(ops.Ax(x))) / float(x @ x)),
+            number_of_power_iterations)
+
+
+def define_norms(primal_size, dual_size, step_size, primal_weight):
+    """pdhg.jl:265-277"""
+    with np.errstate(divide="ignore"):
+        primal_norm_params = np.float64(1) / step_size * primal_weight * np.ones(primal_size)
+        dual_norm_params = np.float64(1) / step_size / primal_weight * np.ones(dual_size)
+    return primal_norm_params, dual_norm_params
+
+
+def _default_engine_factory(problem):
+    from .engine import HipPdhgEngine
+    return HipPdhgEngine.from_problem(problem)
+
+
+def optimize(params, original_problem, engine_factory=None):
+    """``optimize(params::PdhgParameters, original_problem)`` -- pdhg.jl:782-1049.
+
+    ``engine_factory(scaled_qp) -> engine`` builds the device state; the
+    default is the HIP engine on the current GPU and there is no CPU fallback.
+    Returns a ``SaddlePointOutput``."""
+    validate(original_problem)
+    qp_cache = cached_quadratic_program_info(original_problem)
+    scaled_problem = rescale_problem(params.l_inf_ruiz_iterations,
+                                     params.l2_norm_rescaling,
+                                     params.pock_chambolle_alpha,
+                                     params.verbosity, original_problem)
+    problem = scaled_problem.scaled_qp
+    primal_size = problem.num_variables
+    dual_size = problem.num_constraints
+    if params.primal_importance <= 0 or not math.isfinite(params.primal_importance):
+        raise ValueError("primal_importance must be positive and finite")
+
+    engine = (engine_factory or _default_engine_factory)(problem)
+    ops = EngineOps(engine, problem)
+    original_ops = UnscaledEngineOps(engine, scaled_problem)
+    is_lp = is_linear_programming_problem(problem)
+    solver_state = PdhgSolverState(engine)   # zeros(...) state, pdhg.jl:805-819
+    policy = params.step_size_policy_params
+
+    def inv_max_abs():
+        data = problem.constraint_matrix.data
+        mx = float(np.max(np.abs(data))) if len(data) else 0.0   # norm(A, Inf) on a sparse matrix
+        return math.inf if mx == 0.0 else 1.0 / mx
+
+    if isinstance(policy, AdaptiveStepsizeParams):
+        solver_state.cumulative_kkt_passes += 0.5
+        solver_state.step_size = inv_max_abs()
+    elif isinstance(policy, MalitskyPockStepsizeParameters):
+        solver_state.cumulative_kkt_passes += 0.5
+        solver_state.step_size = inv_max_abs()
+        solver_state.ratio_step_sizes = 1.0
+    else:
+        desired_relative_error = 0.2
+        maximum_singular_value, number_of_power_iterations = \
+            estimate_maximum_singular_value(ops, primal_size,
+                                            probability_of_failure=0.001,
+                                            desired_relative_error=desired_relative_error)
+        solver_state.step_size = (1 - desired_relative_error) / maximum_singular_value
+        solver_state.cumulative_kkt_passes += number_of_power_iterations
+
+    KKT_PASSES_PER_TERMINATION_EVALUATION = 2.0
+
+    if params.scale_invariant_initial_primal_weight:
+        solver_state.primal_weight = select_initial_primal_weight(
+            problem, np.ones(primal_size), np.ones(dual_size),
+            params.primal_importance, params.verbosity)
+    else:
+        solver_state.primal_weight = params.primal_importance
+
+    primal_weight_update_smoothing = params.restart_params.primal_weight_update_smoothing
+    iteration_stats = []
+    start_time = _time.time()
+    time_spent_doing_basic_algorithm = 0.0
+
+    x0, y0 = engine.get_current()
+    last_restart_info = create_last_restart_info(problem, x0, y0)
+
+    termination_criteria = params.termination_criteria
+    iteration_limit = termination_criteria.iteration_limit
+    termination_evaluation_frequency = params.termination_evaluation_frequency
+    solver_state.numerical_error = False
+
+    iteration = 0
+    while True:
+        iteration += 1
+        if ((iteration - 1) % termination_evaluation_frequency == 0 or
+                iteration == iteration_limit + 1 or iteration <= 10 or
+                solver_state.numerical_error):
+            solver_state.cumulative_kkt_passes += KKT_PASSES_PER_TERMINATION_EVALUATION
+            count_x, count_y, _, _ = engine.average_info()
+            if solver_state.numerical_error or count_x == 0 or count_y == 0:
+                avg_primal_solution, avg_dual_solution = engine.get_current()
+            else:
+                avg_primal_solution, avg_dual_solution = engine.get_average()
+
+            current_iteration_stats = evaluate_unscaled_iteration_stats(
+                scaled_problem, qp_cache, params.termination_criteria,
+                params.record_iteration_stats, avg_primal_solution,
+                avg_dual_solution, iteration, _time.time() - start_time,
+                solver_state.cumulative_kkt_passes,
+                termination_criteria.eps_optimal_absolute,
+                termination_criteria.eps_optimal_relative,
+                solver_state.step_size, solver_state.primal_weight,
+                PointType.POINT_TYPE_AVERAGE_ITERATE, original_ops)
+            method_specific_stats = current_iteration_stats.method_specific_stats
+            method_specific_stats["time_spent_doing_basic_algorithm"] = \
+                time_spent_doing_basic_algorithm
+
+            primal_norm_params, dual_norm_params = define_norms(
+                primal_size, dual_size, solver_state.step_size,
+                solver_state.primal_weight)
+            update_objective_bound_estimates(
+                current_iteration_stats.method_specific_stats, problem,
+                avg_primal_solution, avg_dual_solution, primal_norm_params,
+                dual_norm_params, ops)
+            termination_reason = check_termination_criteria(
+                termination_criteria, qp_cache, current_iteration_stats)
+            if solver_state.numerical_error and termination_reason is False:
+                termination_reason = TerminationReason.TERMINATION_REASON_NUMERICAL_ERROR
+
+            if params.record_iteration_stats or termination_reason is not False:
+                iteration_stats.append(current_iteration_stats)
+
+            if params.verbosity >= 4 or (params.verbosity >= 2 and termination_reason is not False):
+                _display_iteration_stats(current_iteration_stats)
+
+            if termination_reason is not False:
+                # ** Terminate the algorithm ** (the only exit, pdhg.jl:973-992)
+                if params.verbosity >= 2:
+                    print(f"Terminated after {iteration - 1} iterations: "
+                          f"{termination_reason.name}")
+                out = unscaled_saddle_point_output(
+                    scaled_problem, avg_primal_solution, avg_dual_solution,
+                    termination_reason, iteration - 1, iteration_stats)
+                if hasattr(engine, "close"):
+                    engine.close()
+                return out
+
+            current_iteration_stats.restart_used = run_restart_scheme(
+                problem, engine, last_restart_info, iteration - 1,
+                primal_norm_params, dual_norm_params,
+                solver_state.primal_weight, params.verbosity,
+                params.restart_params, ops)
+
+            if current_iteration_stats.restart_used != RestartChoice.RESTART_CHOICE_NO_RESTART:
+                solver_state.primal_weight = compute_new_primal_weight(
+                    last_restart_info, solver_state.primal_weight,
+                    primal_weight_update_smoothing, params.verbosity)
+                solver_state.ratio_step_sizes = 1.0
+            # RESTART_TO_AVERAGE: A'y was recomputed inside
+            # engine.restart_to_average() (pdhg.jl:1018-1022).
+
+        time_spent_doing_basic_algorithm_checkpoint = _time.time()
+        take_step(policy, solver_state, is_lp)
+        time_spent_doing_basic_algorithm += \
+            _time.time() - time_spent_doing_basic_algorithm_checkpoint
+
+
+def _display_iteration_stats(stats):
+    """Condensed form of display_iteration_stats (iteration_stats_utils.jl:559-619)."""
+    ci = stats.convergence_information[0]
+    print("  %6d %9.1f %8.2f | %9.2e %9.2e %9.2e | %12.5e %12.5e | %9.2e %9.2e" % (
+        stats.iteration_number, stats.cumulative_kkt_matrix_passes,
+        stats.cumulative_time_sec, ci.relative_l2_primal_residual,
+        ci.relative_l2_dual_residual, ci.relative_optimality_gap,
+        ci.primal_objective, ci.dual_objective, stats.step_size,
+        stats.primal_weight))

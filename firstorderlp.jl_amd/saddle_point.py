@@ -1,0 +1,398 @@
+"""Restart scheme, primal-weight update and output un-scaling: host control
+logic mirroring src/saddle_point.jl (the parts that are NOT on the per-iteration
+hot path; the hot-path parts -- projections, weighted average, gradients --
+live in csrc/pdhg_hip.hip)."""
+import enum
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from .solve_log import IterationStats, RestartChoice, TerminationReason
+from .termination import termination_reason_to_string
+from .trust_region_utils import (EUCLIDEAN_NORM, MAX_NORM,
+                                 OptimalObjectiveBoundResult,
+                                 bound_optimal_objective, get_gap,
+                                 weighted_norm)
+
+EPS = float(np.finfo(np.float64).eps)
+
+
+@dataclass
+class SaddlePointOutput:
+    """saddle_point.jl:22-53"""
+    primal_solution: np.ndarray
+    dual_solution: np.ndarray
+    termination_reason: TerminationReason
+    termination_string: str
+    iteration_count: int
+    iteration_stats: List[IterationStats]
+
+
+def unscaled_saddle_point_output(scaled_problem, primal_solution, dual_solution,
+                                 termination_reason, iterations_completed,
+                                 iteration_stats):
+    """saddle_point.jl:55-77"""
+    return SaddlePointOutput(
+        primal_solution / scaled_problem.variable_rescaling,
+        dual_solution / scaled_problem.constraint_rescaling,
+        termination_reason, termination_reason_to_string(termination_reason),
+        int(iterations_completed), iteration_stats)
+
+
+class RestartScheme(enum.Enum):
+    """saddle_point.jl:322"""
+    NO_RESTARTS = 0
+    FIXED_FREQUENCY = 1
+    ADAPTIVE_NORMALIZED = 2
+    ADAPTIVE_LOCALIZED = 3
+    ADAPTIVE_DISTANCE = 4
+
+
+class RestartToCurrentMetric(enum.Enum):
+    """saddle_point.jl:337"""
+    NO_RESTART_TO_CURRENT = 0
+    GAP_OVER_DISTANCE = 1
+    GAP_OVER_DISTANCE_SQUARED = 2
+
+
+for _e in (RestartScheme, RestartToCurrentMetric):
+    for _m in _e:
+        globals()[_m.name] = _m
+
+
+@dataclass
+class RestartParameters:
+    """saddle_point.jl:339-400"""
+    restart_scheme: RestartScheme
+    restart_to_current_metric: RestartToCurrentMetric
+    restart_frequency_if_fixed: int
+    artificial_restart_threshold: float
+    sufficient_reduction_for_restart: float
+    necessary_reduction_for_restart: float
+    primal_weight_update_smoothing: float
+    use_approximate_localized_duality_gap: bool
+
+
+def construct_restart_parameters(restart_scheme, restart_to_current_metric,
+                                 restart_frequency_if_fixed,
+                                 artificial_restart_threshold,
+                                 sufficient_reduction_for_restart,
+                                 necessary_reduction_for_restart,
+                                 primal_weight_update_smoothing,
+                                 use_approximate_localized_duality_gap):
+    """saddle_point.jl:402-430"""
+    assert restart_frequency_if_fixed > 1
+    assert 0.0 < artificial_restart_threshold <= 1.0
+    assert 0.0 < sufficient_reduction_for_restart <= necessary_reduction_for_restart <= 1.0
+    assert 0.0 <= primal_weight_update_smoothing <= 1.0
+    return RestartParameters(restart_scheme, restart_to_current_metric,
+                             restart_frequency_if_fixed,
+                             artificial_restart_threshold,
+                             sufficient_reduction_for_restart,
+                             necessary_reduction_for_restart,
+                             primal_weight_update_smoothing,
+                             use_approximate_localized_duality_gap)
+
+
+@dataclass
+class RestartInfo:
+    """saddle_point.jl:158-198"""
+    primal_solution: np.ndarray
+    dual_solution: np.ndarray
+    last_restart_localized_duality_gap: Optional[OptimalObjectiveBoundResult]
+    last_restart_length: int
+    primal_distance_moved_last_restart_period: float
+    dual_distance_moved_last_restart_period: float
+    gap_reduction_ratio_last_trial: float
+
+
+def create_last_restart_info(problem, primal_solution, dual_solution):
+    """saddle_point.jl:200-213"""
+    return RestartInfo(primal_solution.copy(), dual_solution.copy(), None, 1,
+                       0.0, 0.0, 1.0)
+
+
+def compute_localized_duality_gap(problem, primal_solution, dual_solution,
+                                  primal_norm_params, dual_norm_params,
+                                  distance_to_optimality, norm,
+                                  use_approximate_localized_duality_gap, ops):
+    """saddle_point.jl:134-156"""
+    return bound_optimal_objective(
+        problem, primal_solution, dual_solution, primal_norm_params,
+        dual_norm_params, distance_to_optimality, norm, ops,
+        solve_approximately=use_approximate_localized_duality_gap)
+
+
+def _div(a, b):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(np.float64(a) / np.float64(b))
+
+
+def compute_localized_duality_gaps(problem, current_primal_solution,
+                                   current_dual_solution, avg_primal_solution,
+                                   avg_dual_solution, primal_norm_params,
+                                   dual_norm_params, last_restart_info,
+                                   use_approximate_localized_duality_gap, ops):
+    """saddle_point.jl:432-496"""
+    lri = last_restart_info
+    distance_traveled_by_average = math.sqrt(
+        weighted_norm(avg_primal_solution - lri.primal_solution, primal_norm_params) ** 2 +
+        weighted_norm(avg_dual_solution - lri.dual_solution, dual_norm_params) ** 2)
+    gap_at_average = compute_localized_duality_gap(
+        problem, avg_primal_solution, avg_dual_solution, primal_norm_params,
+        dual_norm_params, distance_traveled_by_average, EUCLIDEAN_NORM,
+        use_approximate_localized_duality_gap, ops)
+    distance_traveled_by_current = math.sqrt(
+        weighted_norm(current_primal_solution - lri.primal_solution, primal_norm_params) ** 2 +
+        weighted_norm(current_dual_solution - lri.dual_solution, dual_norm_params) ** 2)
+    gap_at_current = compute_localized_duality_gap(
+        problem, current_primal_solution, current_dual_solution,
+        primal_norm_params, dual_norm_params, distance_traveled_by_current,
+        EUCLIDEAN_NORM, use_approximate_localized_duality_gap, ops)
+    return dict(gap_at_average=gap_at_average,
+                distance_traveled_by_average=distance_traveled_by_average,
+                gap_at_current=gap_at_current,
+                distance_traveled_by_current=distance_traveled_by_current)
+
+
+def should_reset_to_average(current, distance_traveled_by_current, average,
+                            distance_traveled_by_average,
+                            restart_to_current_metric):
+    """saddle_point.jl:530-549"""
+    current_normalized_gap = _div(get_gap(current), distance_traveled_by_current)
+    average_normalized_gap = _div(get_gap(average), distance_traveled_by_average)
+    if restart_to_current_metric == RestartToCurrentMetric.GAP_OVER_DISTANCE_SQUARED:
+        return _div(current_normalized_gap, distance_traveled_by_current) >= \
+            _div(average_normalized_gap, distance_traveled_by_average)
+    elif restart_to_current_metric == RestartToCurrentMetric.GAP_OVER_DISTANCE:
+        return current_normalized_gap >= average_normalized_gap
+    return True
+
+
+def should_do_adaptive_restart_normalized_duality_gap(
+        problem, primal_norm_params, dual_norm_params, candidate_localized_gap,
+        candidate_distance_traveled, restart_params, last_restart_info,
+        use_approximate_localized_duality_gap, primal_weight, ops):
+    """saddle_point.jl:551-596"""
+    lri = last_restart_info
+    distance_traveled_last_restart = math.sqrt(
+        lri.primal_distance_moved_last_restart_period ** 2 * primal_weight +
+        lri.dual_distance_moved_last_restart_period ** 2 / primal_weight)
+    last_restart = compute_localized_duality_gap(
+        problem, lri.primal_solution, lri.dual_solution, primal_norm_params,
+        dual_norm_params, distance_traveled_last_restart, EUCLIDEAN_NORM,
+        use_approximate_localized_duality_gap, ops)
+    do_restart = False
+    normalized_candidate_gap = _div(get_gap(candidate_localized_gap), candidate_distance_traveled)
+    normalized_last_restart_gap = _div(get_gap(last_restart), distance_traveled_last_restart)
+    gap_reduction_ratio = _div(normalized_candidate_gap, normalized_last_restart_gap)
+    if gap_reduction_ratio < restart_params.necessary_reduction_for_restart:
+        if gap_reduction_ratio < restart_params.sufficient_reduction_for_restart:
+            do_restart = True
+        elif gap_reduction_ratio > lri.gap_reduction_ratio_last_trial:
+            do_restart = True
+    lri.gap_reduction_ratio_last_trial = gap_reduction_ratio
+    return do_restart
+
+
+def should_do_localized_adaptive_restart(candidate_localized_gap,
+                                         candidate_restart_length,
+                                         restart_params, last_restart_info):
+    """saddle_point.jl:600-624"""
+    lri = last_restart_info
+    if candidate_localized_gap is None or lri.last_restart_localized_duality_gap is None:
+        return True
+    new_potential = _div(get_gap(candidate_localized_gap), candidate_restart_length)
+    old_potential = _div(get_gap(lri.last_restart_localized_duality_gap), lri.last_restart_length)
+    return _div(new_potential, old_potential) < restart_params.necessary_reduction_for_restart
+
+
+def should_do_distance_based_adaptive_restart(candidate_localized_gap,
+                                              candidate_distance_traveled,
+                                              candidate_restart_length,
+                                              restart_params, last_restart_info,
+                                              primal_weight):
+    """saddle_point.jl:627-653"""
+    lri = last_restart_info
+    distance_traveled_last_restart = math.sqrt(
+        lri.primal_distance_moved_last_restart_period ** 2 * primal_weight +
+        lri.dual_distance_moved_last_restart_period ** 2 / primal_weight)
+    new_potential = _div(candidate_distance_traveled, candidate_restart_length)
+    old_potential = _div(distance_traveled_last_restart, lri.last_restart_length)
+    return _div(new_potential, old_potential) < restart_params.necessary_reduction_for_restart
+
+
+def run_restart_scheme(problem, engine, last_restart_info, iterations_completed,
+                       primal_norm_params, dual_norm_params, primal_weight,
+                       verbosity, restart_params, ops):
+    """saddle_point.jl:688-846.  ``engine`` holds solution_weighted_avg and the
+    current iterate on the device; a restart to the average is performed
+    there (pdhg_restart_to_average, which also recomputes A'y as
+    pdhg.jl:1018-1022 does).  Returns a RestartChoice."""
+    count_x, count_y, _, _ = engine.average_info()
+    if count_x > 0 and count_y > 0:
+        avg_primal_solution, avg_dual_solution = engine.get_average()
+    else:
+        return RestartChoice.RESTART_CHOICE_NO_RESTART
+
+    restart_length = count_x
+    artificial_restart = False
+    do_restart = False
+    if restart_length >= restart_params.artificial_restart_threshold * iterations_completed:
+        do_restart = True
+        artificial_restart = True
+
+    current_primal_solution = current_dual_solution = None
+    if restart_params.restart_scheme == RestartScheme.NO_RESTARTS:
+        reset_to_average = False
+        candidate_localized_gap = None
+        candidate_distance_traveled = None
+    else:
+        current_primal_solution, current_dual_solution = engine.get_current()
+        gaps = compute_localized_duality_gaps(
+            problem, current_primal_solution, current_dual_solution,
+            avg_primal_solution, avg_dual_solution, primal_norm_params,
+            dual_norm_params, last_restart_info,
+            restart_params.use_approximate_localized_duality_gap, ops)
+        reset_to_average = should_reset_to_average(
+            gaps["gap_at_current"], gaps["distance_traveled_by_current"],
+            gaps["gap_at_average"], gaps["distance_traveled_by_average"],
+            restart_params.restart_to_current_metric)
+        if reset_to_average:
+            candidate_localized_gap = gaps["gap_at_average"]
+            candidate_distance_traveled = gaps["distance_traveled_by_average"]
+        else:
+            candidate_localized_gap = gaps["gap_at_current"]
+            candidate_distance_traveled = gaps["distance_traveled_by_current"]
+
+    if not do_restart:
+        scheme = restart_params.restart_scheme
+        if scheme == RestartScheme.ADAPTIVE_NORMALIZED:
+            do_restart = should_do_adaptive_restart_normalized_duality_gap(
+                problem, primal_norm_params, dual_norm_params,
+                candidate_localized_gap, candidate_distance_traveled,
+                restart_params, last_restart_info,
+                restart_params.use_approximate_localized_duality_gap,
+                primal_weight, ops)
+        elif scheme in (RestartScheme.ADAPTIVE_LOCALIZED, RestartScheme.ADAPTIVE_DISTANCE) and \
+                last_restart_info.last_restart_localized_duality_gap is None:
+            do_restart = True
+        elif scheme == RestartScheme.ADAPTIVE_LOCALIZED:
+            do_restart = should_do_localized_adaptive_restart(
+                candidate_localized_gap, restart_length, restart_params, last_restart_info)
+        elif scheme == RestartScheme.ADAPTIVE_DISTANCE:
+            do_restart = should_do_distance_based_adaptive_restart(
+                candidate_localized_gap, candidate_distance_traveled,
+                restart_length, restart_params, last_restart_info, primal_weight)
+        elif scheme == RestartScheme.FIXED_FREQUENCY and \
+                restart_params.restart_frequency_if_fixed <= restart_length:
+            do_restart = True
+
+    if not do_restart:
+        return RestartChoice.RESTART_CHOICE_NO_RESTART
+
+    if reset_to_average:
+        if verbosity >= 4:
+            print("  Restarted to average", end="")
+        engine.restart_to_average()          # current .= avg ; A'y recomputed
+        current_primal_solution = avg_primal_solution
+        current_dual_solution = avg_dual_solution
+    else:
+        if verbosity >= 4:
+            print("  Restarted to current", end="")
+        if current_primal_solution is None:
+            current_primal_solution, current_dual_solution = engine.get_current()
+    if verbosity >= 4:
+        print(" after ", str(restart_length).ljust(4), " iterations",
+              "*" if artificial_restart else "", sep="")
+    engine.reset_average()                   # reset_solution_weighted_average
+
+    update_last_restart_info(last_restart_info, current_primal_solution,
+                             current_dual_solution, avg_primal_solution,
+                             avg_dual_solution, primal_norm_params,
+                             dual_norm_params, primal_weight,
+                             candidate_localized_gap, restart_length)
+    if reset_to_average:
+        return RestartChoice.RESTART_CHOICE_RESTART_TO_AVERAGE
+    return RestartChoice.RESTART_CHOICE_WEIGHTED_AVERAGE_RESET
+
+
+def compute_new_primal_weight(last_restart_info, primal_weight,
+                              primal_weight_update_smoothing, verbosity):
+    """saddle_point.jl:862-891"""
+    primal_distance = last_restart_info.primal_distance_moved_last_restart_period
+    dual_distance = last_restart_info.dual_distance_moved_last_restart_period
+    if primal_distance > EPS and dual_distance > EPS:
+        new_primal_weight_estimate = dual_distance / primal_distance
+        log_primal_weight = (
+            primal_weight_update_smoothing * math.log(new_primal_weight_estimate) +
+            (1 - primal_weight_update_smoothing) * math.log(primal_weight))
+        primal_weight = math.exp(log_primal_weight)
+        if verbosity >= 4:
+            print("  New computed primal weight is %.2e" % primal_weight)
+        return primal_weight
+    return primal_weight
+
+
+def update_last_restart_info(last_restart_info, current_primal_solution,
+                             current_dual_solution, avg_primal_solution,
+                             avg_dual_solution, primal_norm_params,
+                             dual_norm_params, primal_weight,
+                             candidate_localized_gap, restart_length):
+    """saddle_point.jl:893-927"""
+    lri = last_restart_info
+    lri.primal_distance_moved_last_restart_period = weighted_norm(
+        avg_primal_solution - lri.primal_solution, primal_norm_params) / math.sqrt(primal_weight)
+    lri.dual_distance_moved_last_restart_period = weighted_norm(
+        avg_dual_solution - lri.dual_solution, dual_norm_params) * math.sqrt(primal_weight)
+    lri.primal_solution = np.array(current_primal_solution, dtype=np.float64, copy=True)
+    lri.dual_solution = np.array(current_dual_solution, dtype=np.float64, copy=True)
+    lri.last_restart_length = restart_length
+    lri.last_restart_localized_duality_gap = candidate_localized_gap
+
+
+def update_objective_bound_estimates(method_specific_stats, problem,
+                                     current_primal_solution,
+                                     current_dual_solution,
+                                     primal_norm_weights, dual_norm_weights, ops):
+    """saddle_point.jl:1015-1047"""
+    estimated_primal_distance_to_optimality = max(
+        1e-8, weighted_norm(current_primal_solution, primal_norm_weights))
+    estimated_dual_distance_to_optimality = max(
+        1e-8, weighted_norm(current_dual_solution, dual_norm_weights))
+    gap = compute_localized_duality_gap(
+        problem, current_primal_solution, current_dual_solution,
+        primal_norm_weights / estimated_primal_distance_to_optimality ** 2,
+        dual_norm_weights / estimated_dual_distance_to_optimality ** 2,
+        1.0, MAX_NORM, False, ops)
+    method_specific_stats["lagrangian_value"] = gap.lagrangian_value
+    method_specific_stats["estimated_lower_bound"] = gap.lower_bound_value
+    method_specific_stats["estimated_upper_bound"] = gap.upper_bound_value
+
+
+def select_initial_primal_weight(problem, primal_norm_params, dual_norm_params,
+                                 primal_importance, verbosity):
+    """saddle_point.jl:1049-1075"""
+    rhs_vec_norm = weighted_norm(problem.right_hand_side, dual_norm_params)
+    obj_vec_norm = weighted_norm(problem.objective_vector, primal_norm_params)
+    if obj_vec_norm > 0.0 and rhs_vec_norm > 0.0:
+        primal_weight = primal_importance * (obj_vec_norm / rhs_vec_norm)
+    else:
+        primal_weight = primal_importance
+    if verbosity >= 6:
+        print(f"Initial primal weight = {primal_weight}")
+    return primal_weight
+
+
+def compute_lagrangian_value(problem, primal_solution, dual_solution, ops=None):
+    """saddle_point.jl:1109-1120"""
+    if ops is None:
+        from .iteration_stats_utils import HostOps
+        ops = HostOps(problem)
+    return (0.5 * float(primal_solution @ ops.Qx(primal_solution)) +
+            float(primal_solution @ problem.objective_vector) -
+            float(primal_solution @ ops.ATy(dual_solution)) +
+            float(dual_solution @ problem.right_hand_side) +
+            problem.objective_constant)

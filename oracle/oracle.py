@@ -178,27 +178,38 @@ class OracleState:
         return int(counts[0]), int(counts[1]), float(weights[0]), float(weights[1])
 
     # -- hot path pieces ------------------------------------------------------
-    def trial_step(self, step_size, primal_weight, theta=1.0):
-        """One trial: returns raw (dx.dAty, sum dx^2, sum dy^2) like the C-ABI."""
-        L, h = self._L, self._h
+    def trial_primal(self, step_size, primal_weight):
+        """compute_next_primal_solution into the state's x_next."""
         xn = np.empty(self.n)
+        self._L.oracle_compute_next_primal(self._h, ctypes.c_double(step_size),
+                                           ctypes.c_double(primal_weight), _dp(xn))
+        self._set("x_next", xn, self.n)
+        return xn
+
+    def trial_dual(self, step_size, primal_weight, theta):
+        """compute_next_dual_solution from the stored x_next; returns the raw
+        sums (same 5 entries as the C-ABI's out[5]) and the trial vectors."""
+        L, h = self._L, self._h
+        xn = self.x_next
         yn = np.empty(self.m)
         an = np.empty(self.n)
-        L.oracle_compute_next_primal(h, ctypes.c_double(step_size),
-                                     ctypes.c_double(primal_weight), _dp(xn))
         L.oracle_compute_next_dual(h, _dp(xn), ctypes.c_double(step_size),
                                    ctypes.c_double(primal_weight),
                                    ctypes.c_double(theta), _dp(yn), _dp(an))
         inter = ctypes.c_double()
         move = ctypes.c_double()
-        raw = np.empty(3)
+        raw = np.empty(5)
         L.oracle_interaction_and_movement(h, _dp(xn), _dp(yn), _dp(an),
                                           ctypes.byref(inter),
                                           ctypes.byref(move), _dp(raw))
-        self._set("x_next", xn, self.n)
         self._set("y_next", yn, self.m)
         self._set("aty_next", an, self.n)
         return raw, xn, yn, an
+
+    def trial_step(self, step_size, primal_weight, theta=1.0):
+        """One full trial (primal then dual)."""
+        self.trial_primal(step_size, primal_weight)
+        return self.trial_dual(step_size, primal_weight, theta)
 
     def accept(self, xn, yn, an):
         self._L.oracle_update_solution(self._h, _dp(_d(xn)), _dp(_d(yn)),

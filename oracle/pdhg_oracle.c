@@ -341,7 +341,9 @@ void oracle_compute_next_dual(oracle_state *s, const double *x_next,
 
 /* compute_interaction_and_movement (pdhg.jl:527-549).
  * raw[0] = delta_primal' * (next_dual_product - current_dual_product)
- * raw[1] = sum delta_primal^2, raw[2] = sum delta_dual^2 (before sqrt/square) */
+ * raw[1] = sum delta_primal^2, raw[2] = sum delta_dual^2 (before sqrt/square)
+ * raw[3] = sum (next_dual_product - current_dual_product)^2
+ * raw[4] = 0.5 * delta_primal' * Q * delta_primal  -- the C-ABI's out[5] */
 void oracle_interaction_and_movement(oracle_state *s, const double *x_next,
                                      const double *y_next,
                                      const double *aty_next,
@@ -369,7 +371,17 @@ void oracle_interaction_and_movement(oracle_state *s, const double *x_next,
   *interaction = fabs(pdi) + fabs(primal_objective_interaction);
   *movement = 0.5 * s->primal_weight * (nx * nx) +
               (0.5 / s->primal_weight) * (ny * ny);
-  if (raw) { raw[0] = pdi; raw[1] = ssx; raw[2] = ssy; }
+  if (raw) {
+    /* raw[3] = sum (A'y' - A'y)^2 (Malitsky-Pock test, pdhg.jl:615) */
+    double ssd = 0.0;
+    for (int64_t j = 0; j < s->n; ++j) {
+      const double dd = aty_next[j] - s->aty[j];
+      const double p = dd * dd;
+      ssd = ssd + p;
+    }
+    raw[0] = pdi; raw[1] = ssx; raw[2] = ssy; raw[3] = ssd;
+    raw[4] = primal_objective_interaction;
+  }
 }
 
 /* update_solution_in_solver_state (pdhg.jl:500-519).  Note quirk Q1: the

@@ -123,7 +123,8 @@ def test_trial_step_matches_oracle(gpu_required, maker, seed):
             np.testing.assert_allclose(ga, an, rtol=1e-11, atol=1e-11)
         scale = np.array([np.abs(raw_o[1] * raw_o[2]) ** 0.5 + abs(raw_o[0]),
                           raw_o[1], raw_o[2]])
-        assert np.all(np.abs(raw[:3] - raw_o) <= 1e-12 * scale + 1e-300)
+        assert np.all(np.abs(raw[:3] - raw_o[:3]) <= 1e-12 * scale + 1e-300)
+        assert abs(raw[3] - raw_o[3]) <= 1e-12 * raw_o[3] + 1e-300
         assert raw[4] == 0.0
 
 
