@@ -1,0 +1,72 @@
+"""CPU-only checks: the C-ABI library builds/loads and exports every symbol
+include/pdhg_hip.h declares; host-side helpers pinned by the reference's
+exact-equality unit tests (test/test_saddle_point.jl, test_iteration_stats.jl)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from firstorderlp_jl_amd import _lib, linear_programming_problem
+from firstorderlp_jl_amd.iteration_stats_utils import (compute_dual_stats,
+                                                       max_primal_violation,
+                                                       primal_obj)
+from firstorderlp_jl_amd.saddle_point import (compute_lagrangian_value,
+                                              select_initial_primal_weight)
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_all_exported():
+    header = open(os.path.join(ROOT, "include", "pdhg_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(pdhg_[a-z_0-9]+)\s*\(", header)))
+    assert declared, "no declarations found"
+    assert sorted(_lib.EXPORTS) == declared
+    L = ctypes.CDLL(_lib.LIB_PATH)       # loads without a GPU
+    for name in declared:
+        assert hasattr(L, name), f"{name} not exported by libpdhg_hip.so"
+    assert _lib.lib().pdhg_abi_version() == 1
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from firstorderlp_jl_amd import HipPdhgEngine
+    with pytest.raises(_lib.PdhgHipError):
+        HipPdhgEngine.from_problem(H.example_lp())
+
+
+def test_select_initial_primal_weight():
+    """test/test_saddle_point.jl:43-63 (exact ==)."""
+    lp = H.example_lp()
+    pw = select_initial_primal_weight(lp, np.ones(4), np.ones(3), 1.0, 0)
+    assert pw == np.sqrt(31.0) / np.sqrt(194.0) or abs(pw - np.sqrt(31.0 / 194.0)) < 1e-16
+    lp.objective_vector = np.zeros(4)
+    assert select_initial_primal_weight(lp, np.ones(4), np.ones(3), 1.0, 0) == 1.0
+    assert select_initial_primal_weight(lp, np.ones(4), np.ones(3), 2.5, 0) == 2.5
+
+
+def test_compute_lagrangian_value():
+    """test/test_saddle_point.jl:66-74: zero point -> objective_constant."""
+    lp = H.example_lp()
+    assert compute_lagrangian_value(lp, np.zeros(4), np.zeros(3)) == -14.0
+    qp = H.example_qp()
+    assert compute_lagrangian_value(qp, np.zeros(2), np.zeros(1)) == 0.0
+    # L(x,y) = c'x - y'(Ax) + b'y + const at the LP optimum equals the optimum value
+    x, y = np.array([1.0, 0.0, 6.0, 2.0]), np.array([0.5, 4.0, 0.0])
+    assert abs(compute_lagrangian_value(lp, x, y) - (-1.0)) < 1e-14
+
+
+def test_residual_and_objective_helpers():
+    """test/test_iteration_stats.jl:17-45 style checks on example_lp."""
+    lp = H.example_lp()
+    x_opt = np.array([1.0, 0.0, 6.0, 2.0])
+    assert max_primal_violation(lp, x_opt) == 0.0
+    assert primal_obj(lp, x_opt) == -1.0
+    assert max_primal_violation(lp, np.zeros(4)) == 12.0
+    ds = compute_dual_stats(lp, x_opt, np.array([0.5, 4.0, 0.0]))
+    assert abs(ds.dual_objective - (-1.0)) < 1e-14
+    assert np.max(np.abs(ds.dual_residual)) == 0.0

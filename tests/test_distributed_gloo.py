@@ -1,0 +1,115 @@
+"""The row-partitioned (multi-GPU) host path on CPU: 2 processes, gloo, with
+the CPU oracle injected as each rank's local engine.  Checks that the sharded
+run reproduces the unsharded oracle: same accept/reject decisions, iterates
+equal to 1e-12 (the only difference is the order of the 2-term all-reduce sum
+and the numpy dot in dist_trial_end)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import folp_loader
+    folp_loader.load()
+    import torch.distributed as dist
+    from firstorderlp_jl_amd.distributed import (RowPartitionedEngine, TorchComm,
+                                                 partition_rows, shard_rows)
+    from firstorderlp_jl_amd.generators import random_lp
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
+        AdaptiveStepsizeParams, PdhgSolverState, take_step)
+    from tests.oracle_engine import OracleEngine
+    from tests import helpers as H
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = random_lp(600, 500, 6, seed=5)
+        ranges = partition_rows(p.constraint_matrix, world)
+        lo, hi = ranges[rank]
+        local = OracleEngine(**shard_rows(p, lo, hi))
+        eng = RowPartitionedEngine(local, TorchComm(), ranges)
+        step, pw = H.initial_step_and_weight(p)
+        state = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+        for _ in range(40):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), state)
+        x, y = eng.get_current()
+        xa, ya = eng.get_average()
+        # restart to the average exercises the A'y refresh all-reduce
+        eng.restart_to_average()
+        aty = eng.get_dual_product()
+        for _ in range(5):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), state)
+        x2, y2 = eng.get_current()
+        q.put((rank, ranges, x, y, xa, ya, aty, x2, y2, state.step_size,
+               state.total_number_iterations))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_row_partition_matches_unsharded_oracle():
+    sys.path.insert(0, ROOT)
+    from firstorderlp_jl_amd.generators import random_lp
+    from tests.oracle_engine import OracleEngine
+    from tests import helpers as H
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
+        AdaptiveStepsizeParams, PdhgSolverState, take_step)
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+
+    p = random_lp(600, 500, 6, seed=5)
+    ref = OracleEngine.from_problem(p)
+    step, pw = H.initial_step_and_weight(p)
+    state = PdhgSolverState(ref, step_size=step, primal_weight=pw)
+    for _ in range(40):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), state)
+    x, y = ref.get_current()
+    xa, ya = ref.get_average()
+    ref.restart_to_average()
+    aty = ref.get_dual_product()
+    for _ in range(5):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), state)
+    x2, y2 = ref.get_current()
+
+    ranges = results[0][1]
+    assert ranges[0][0] == 0 and ranges[-1][1] == 600 and ranges[0][1] == ranges[1][0]
+    for (rank, _, rx, ry, rxa, rya, raty, rx2, ry2, rstep, rtot) in results:
+        assert rtot == state.total_number_iterations
+        assert abs(rstep - state.step_size) <= 1e-12 * state.step_size
+        for got, want in ((rx, x), (ry, y), (rxa, xa), (rya, ya), (raty, aty), (rx2, x2), (ry2, y2)):
+            np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-11)
+    # replicas are bitwise identical across ranks
+    for a, b in zip(results[0][2:9], results[1][2:9]):
+        assert np.array_equal(a, b)
+
+
+def test_partition_rows_balances_nnz():
+    sys.path.insert(0, ROOT)
+    from firstorderlp_jl_amd.distributed import partition_rows, shard_rows
+    from tests import helpers as H
+    p = H.skewed_lp(400, 300, seed=3, dense_rows=2, dense_cols=1)
+    for world in (1, 2, 3, 8):
+        ranges = partition_rows(p.constraint_matrix, world)
+        assert len(ranges) == world and ranges[0][0] == 0 and ranges[-1][1] == 400
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        tot = 0
+        for lo, hi in ranges:
+            sh = shard_rows(p, lo, hi)
+            tot += sh["constraint_matrix"].nnz
+            assert sh["num_equalities"] == min(max(p.num_equalities - lo, 0), hi - lo)
+        assert tot == p.constraint_matrix.nnz
