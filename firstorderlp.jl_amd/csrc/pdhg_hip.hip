@@ -39,6 +39,12 @@ constexpr int LONG_CHUNK = 8192;     // nnz per workgroup for rows longer than B
 constexpr int NUM_XCD = 8;
 constexpr int EW_MAX_BLOCKS = 256 * 8;  // elementwise kernels: grid-stride above this
 constexpr int FINAL_TPB = 1024;
+// tiled-sweep layout (SpMV v2)
+constexpr int TW_ROWS = 256;          // rows owned by one wave (2 KiB of LDS accumulators)
+constexpr int TW_COL_BITS = 24;       // packed entry = row_local << 24 | col
+constexpr unsigned TW_COL_MASK = (1u << TW_COL_BITS) - 1u;
+constexpr unsigned TW_PAD = 0xFFFFFFFFu;
+constexpr int TW_U = 4;               // 64-entry chunks in flight per wave
 
 thread_local std::string g_last_error;
 
@@ -221,6 +227,84 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) e.partials[q * e.stride + b] = acc[q];
+    }
+  }
+}
+
+// CSR "tiled sweep" kernel (SpMV v2) for matrices whose gathered vector is far
+// larger than the 4 MiB per-XCD L2 (a uniformly random 8-byte gather tops out
+// at ~56 G/s on MI355X; L2-resident gathers reach ~190-245 G/s).
+// Layout: every wave owns TW_ROWS consecutive rows and streams ITS nonzeros,
+// pre-sorted on the host by (column tile, row, column), packed as
+// {row_local:8 | col:24} + value.  All resident waves therefore walk the
+// column tiles of the gathered vector in the same order and at about the same
+// pace, so at any moment the chip gathers from a ~1 MiB slice that sits in
+// every XCD's L2.  Accumulators live in the wave's private 2 KiB of LDS; DS
+// operations of one wave execute in order, so no barrier is needed, and each
+// row still receives its products in ascending column order (tile-major order
+// preserves it) => bit-identical to the sequential CPU loops.  Entries of one
+// row that fall into the same 64-entry chunk are adjacent; the run head adds
+// them left to right via lane shuffles.
+template <int MODE>
+__global__ __launch_bounds__(TPB) void spmv_tiled_kernel(
+    const int2 *__restrict__ wave_rows, const int *__restrict__ wave_ent, int nwaves,
+    const unsigned *__restrict__ pk, const double *__restrict__ tv,
+    const double *__restrict__ xin, EpiArgs e) {
+  __shared__ double acc_all[(TPB / WAVE) * TW_ROWS];
+  __shared__ double red[3][TPB / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x / WAVE;
+  const int w = blockIdx.x * (TPB / WAVE) + wid;
+  double acc3[3] = {0.0, 0.0, 0.0};
+  double *acc = acc_all + wid * TW_ROWS;
+  if (w < nwaves) {
+    const int2 rr = wave_rows[w];
+    const int nrows = rr.y - rr.x;
+#pragma unroll
+    for (int r = lane; r < TW_ROWS; r += WAVE) acc[r] = 0.0;
+    const int e0 = wave_ent[w];
+    const int e1 = wave_ent[w + 1];
+    for (int base = e0; base < e1; base += WAVE * TW_U) {
+      unsigned p[TW_U];
+      double v[TW_U];
+      double xv[TW_U];
+#pragma unroll
+      for (int i = 0; i < TW_U; ++i) {
+        const int k = base + i * WAVE + lane;
+        const bool ok = k < e1;
+        p[i] = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
+        v[i] = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < TW_U; ++i) xv[i] = (p[i] != TW_PAD) ? xin[p[i] & TW_COL_MASK] : 0.0;
+#pragma unroll
+      for (int i = 0; i < TW_U; ++i) {
+        if (base + i * WAVE < e1) {  // wave-uniform
+          const bool valid = p[i] != TW_PAD;
+          const unsigned row = valid ? (p[i] >> TW_COL_BITS) : 0x1FFu;
+          const double prod = v[i] * xv[i];
+          const unsigned rowp = __shfl_up(row, 1, WAVE);
+          const bool head = valid && (lane == 0 || rowp != row);
+          double s = head ? acc[row] : 0.0;
+          for (int j = 0; j < WAVE; ++j) {
+            const double pj = __shfl_down(prod, j, WAVE);
+            const unsigned rj = __shfl_down(row, j, WAVE);
+            const bool take = head && (lane + j < WAVE) && (rj == row);
+            if (!__any(take)) break;
+            if (take) s = s + pj;
+          }
+          if (head) acc[row] = s;
+        }
+      }
+    }
+    for (int r = lane; r < nrows; r += WAVE) row_epilogue<MODE>(e, rr.x + r, acc[r], acc3);
+  }
+  constexpr int NQ = ModeNQ<MODE>::value;
+  if (NQ > 0) {
+    block_sum<NQ, TPB>(acc3, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) e.partials[q * e.stride + blockIdx.x] = acc3[q];
     }
   }
 }
@@ -465,6 +549,13 @@ struct CsrDev {
   int *long_row = nullptr, *long_chunk_ptr = nullptr, *chunk_row = nullptr, *chunk_off = nullptr;
   double *chunk_partial = nullptr;
   int64_t max_row_nnz = 0;
+  // tiled-sweep layout (optional)
+  bool tiled = false;
+  int tile_shift = 0, nwaves = 0;
+  int2 *wave_rows = nullptr;
+  int *wave_ent = nullptr;
+  unsigned *pk = nullptr;
+  double *tv = nullptr;
   int slots() const { return grid + long_grid; }
   CsrView view() const { return CsrView{rows, rowptr, col, val}; }
 };
@@ -484,9 +575,57 @@ int alloc_zero(double **dst, int64_t len) {
   return 0;
 }
 
+// Host-side construction of the tiled-sweep layout: wave row blocks (runs of
+// <= TW_ROWS consecutive non-long rows) and their entries counting-sorted by
+// column tile (stable, so (row, col) order is kept inside a tile).
+int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::vector<int> &col,
+                const std::vector<double> &val, int tile_shift) {
+  const int ntiles = (int)((((int64_t)D.cols) + (1LL << tile_shift) - 1) >> tile_shift);
+  std::vector<int2> wave_rows;
+  std::vector<int> wave_ent(1, 0);
+  std::vector<unsigned> pk;
+  std::vector<double> tv;
+  pk.reserve((size_t)D.nnz);
+  tv.reserve((size_t)D.nnz);
+  std::vector<int> cnt((size_t)ntiles + 1);
+  int r = 0;
+  while (r < rows) {
+    if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) { ++r; continue; }  // long row: separate path
+    const int r0 = r;
+    while (r < rows && (r - r0) < TW_ROWS && rowptr[r + 1] - rowptr[r] <= BLOCK_NNZ) ++r;
+    const int k0 = rowptr[r0], k1 = rowptr[r];
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int k = k0; k < k1; ++k) cnt[(col[k] >> tile_shift) + 1] += 1;
+    for (int t = 0; t < ntiles; ++t) cnt[t + 1] += cnt[t];
+    const size_t base = pk.size();
+    pk.resize(base + (size_t)(k1 - k0));
+    tv.resize(base + (size_t)(k1 - k0));
+    for (int rr = r0; rr < r; ++rr) {
+      const unsigned rl = (unsigned)(rr - r0) << TW_COL_BITS;
+      for (int k = rowptr[rr]; k < rowptr[rr + 1]; ++k) {
+        const int pos = cnt[col[k] >> tile_shift]++;
+        pk[base + pos] = rl | (unsigned)col[k];
+        tv[base + pos] = val[k];
+      }
+    }
+    wave_rows.push_back(make_int2(r0, r));
+    wave_ent.push_back((int)pk.size());
+  }
+  D.tiled = true;
+  D.tile_shift = tile_shift;
+  D.nwaves = (int)wave_rows.size();
+  D.grid = (D.nwaves + (TPB / WAVE) - 1) / (TPB / WAVE);
+  int rc;
+  if ((rc = upload(&D.wave_rows, wave_rows))) return rc;
+  if ((rc = upload(&D.wave_ent, wave_ent))) return rc;
+  if ((rc = upload(&D.pk, pk))) return rc;
+  if ((rc = upload(&D.tv, tv))) return rc;
+  return 0;
+}
+
 int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
                   const std::vector<int> &col, const std::vector<double> &val,
-                  bool remap) {
+                  bool remap, int tile_shift = 0) {
   D.rows = rows;
   D.cols = cols;
   D.nnz = rowptr[rows];
@@ -535,12 +674,15 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
   if ((rc = upload(&D.chunk_row, chunk_row))) return rc;
   if ((rc = upload(&D.chunk_off, chunk_off))) return rc;
   if ((rc = alloc_zero(&D.chunk_partial, D.nchunks))) return rc;
+  if (tile_shift > 0) {
+    if ((rc = build_tiled(D, rows, rowptr, col, val, tile_shift))) return rc;
+  }
   return 0;
 }
 
 void free_csr_dev(CsrDev &D) {
   void *ptrs[] = {D.rowptr, D.col, D.val, D.blks, D.long_row, D.long_chunk_ptr,
-                  D.chunk_row, D.chunk_off, D.chunk_partial};
+                  D.chunk_row, D.chunk_off, D.chunk_partial, D.wave_rows, D.wave_ent, D.pk, D.tv};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   D = CsrDev();
 }
@@ -612,7 +754,11 @@ struct ProfScope {
 
 template <int MODE>
 int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
-  if (D.grid > 0) {
+  if (D.tiled) {
+    if (D.grid > 0)
+      hipLaunchKernelGGL(spmv_tiled_kernel<MODE>, dim3(D.grid), dim3(TPB), 0, h->stream,
+                         D.wave_rows, D.wave_ent, D.nwaves, D.pk, D.tv, xin, e);
+  } else if (D.grid > 0) {
     hipLaunchKernelGGL(spmv_stream_kernel<MODE>, dim3(D.grid), dim3(TPB), 0, h->stream,
                        D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, e);
   }
@@ -712,6 +858,23 @@ int check_handle(pdhg_handle *h) {
   return 0;
 }
 
+// Layout choice for one CSR: the tiled sweep pays off when the gathered vector
+// (cols doubles) is far larger than an XCD's 4 MiB L2 and rows are short.
+// PDHG_SPMV=stream|tiled forces a layout; PDHG_TILE_SHIFT sets log2(tile cols).
+int choose_tile_shift(int64_t cols, int64_t nnz, int64_t rows) {
+  const char *mode = getenv("PDHG_SPMV");
+  const char *ts = getenv("PDHG_TILE_SHIFT");
+  int shift = ts ? atoi(ts) : 17;
+  if (shift < 8) shift = 8;
+  if (shift > 23) shift = 23;
+  if (cols >= (int64_t)TW_COL_MASK) return 0;           // col must fit 24 bits (0xFFFFFF reserved)
+  if (mode && !strcmp(mode, "stream")) return 0;
+  if (mode && !strcmp(mode, "tiled")) return shift;
+  const bool big_vector = cols * 8 > (16LL << 20);       // > 16 MiB: 4x an XCD L2
+  const bool short_rows = rows > 0 && nnz / rows <= 64;
+  return (big_vector && short_rows) ? shift : 0;
+}
+
 // CSC (any int64 base) -> int32 CSR of the transpose (direct) and CSR (counting sort).
 int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
                 const int64_t *rowval, const double *nzval, int base,
@@ -758,7 +921,7 @@ int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
 extern "C" {
 
 const char *pdhg_last_error(void) { return g_last_error.c_str(); }
-int pdhg_abi_version(void) { return 1; }
+int pdhg_abi_version(void) { return 2; }
 
 const char *pdhg_kernel_name(int kernel_id) {
   switch (kernel_id) {
@@ -806,8 +969,8 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     h->own_stream = true;
   }
 #define CK(expr) do { int _rc = (expr); if (_rc) { pdhg_destroy(h); return _rc; } } while (0)
-  CK(build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap));
-  CK(build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap));
+  CK(build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, choose_tile_shift(n, nnz, m)));
+  CK(build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, choose_tile_shift(m, nnz, n)));
   auto up = [&](double **dst, const double *src, int64_t len) -> int {
     int r2 = alloc_zero(dst, len);
     if (r2) return r2;
@@ -1106,10 +1269,12 @@ int64_t pdhg_kernel_algorithmic_bytes(pdhg_handle *h, int kernel_id) {
   }
 }
 
-int pdhg_layout_info(pdhg_handle *h, int64_t info[8]) {
+int pdhg_layout_info(pdhg_handle *h, int64_t info[12]) {
   if (!h) return fail(-1, "null handle");
   info[0] = h->A.nblk; info[1] = h->A.nlong; info[2] = h->A.nchunks; info[3] = h->A.max_row_nnz;
   info[4] = h->At.nblk; info[5] = h->At.nlong; info[6] = h->At.nchunks; info[7] = h->At.max_row_nnz;
+  info[8] = h->A.tiled ? h->A.nwaves : 0; info[9] = h->At.tiled ? h->At.nwaves : 0;
+  info[10] = h->A.tiled ? h->A.tile_shift : 0; info[11] = h->At.tiled ? h->At.tile_shift : 0;
   return 0;
 }
 

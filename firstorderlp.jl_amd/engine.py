@@ -190,11 +190,17 @@ class HipPdhgEngine:
         return int(self._L.pdhg_kernel_algorithmic_bytes(self._h, kernel_id))
 
     def kernel_name(self, kernel_id):
-        return self._L.pdhg_kernel_name(kernel_id).decode()
+        name = self._L.pdhg_kernel_name(kernel_id).decode()
+        info = self.layout_info()
+        if (kernel_id == _lib.K_SPMV_DUAL and info["A_tiled_waves"]) or \
+                (kernel_id == _lib.K_SPMV_ATY and info["At_tiled_waves"]):
+            name = name.replace("spmv_stream_kernel", "spmv_tiled_kernel")
+        return name
 
     def layout_info(self):
-        info = np.zeros(8, dtype=np.int64)
+        info = np.zeros(12, dtype=np.int64)
         _lib.check(self._L.pdhg_layout_info(self._h, _pi(info)))
         keys = ["A_blocks", "A_long_rows", "A_long_chunks", "A_max_row_nnz",
-                "At_blocks", "At_long_rows", "At_long_chunks", "At_max_row_nnz"]
+                "At_blocks", "At_long_rows", "At_long_chunks", "At_max_row_nnz",
+                "A_tiled_waves", "At_tiled_waves", "A_tile_shift", "At_tile_shift"]
         return dict(zip(keys, info.tolist()))

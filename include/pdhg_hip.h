@@ -160,8 +160,10 @@ int pdhg_profile_read(pdhg_handle *h, int kernel_id, int64_t *launches,
 /* Algorithmic HBM bytes one launch of `kernel_id` must move. */
 int64_t pdhg_kernel_algorithmic_bytes(pdhg_handle *h, int kernel_id);
 const char *pdhg_kernel_name(int kernel_id);
-/* Row-block statistics of the two CSR-adaptive layouts (diagnostics). */
-int pdhg_layout_info(pdhg_handle *h, int64_t info[8]);
+/* Layout statistics (diagnostics): [0..3] CSR(A) {row blocks, long rows, long
+ * chunks, max row nnz}, [4..7] same for CSR(A'), [8],[9] tiled-sweep waves of
+ * A / A' (0 = stream layout), [10],[11] their log2(tile columns). */
+int pdhg_layout_info(pdhg_handle *h, int64_t info[12]);
 
 #ifdef __cplusplus
 }
