@@ -40,11 +40,10 @@ constexpr int NUM_XCD = 8;
 constexpr int EW_MAX_BLOCKS = 256 * 8;  // elementwise kernels: grid-stride above this
 constexpr int FINAL_TPB = 1024;
 // tiled-sweep layout (SpMV v2)
-constexpr int TW_ROWS = 256;          // rows owned by one wave (2 KiB of LDS accumulators)
-constexpr int TW_COL_BITS = 24;       // packed entry = row_local << 24 | col
-constexpr unsigned TW_COL_MASK = (1u << TW_COL_BITS) - 1u;
+constexpr int TW_WPB = 8;              // waves per workgroup (512 threads), 2 workgroups per CU
+constexpr int TW_MAX_ROWS = 1272;      // rows owned by one wave: 2 x 8 x 1272 x 8 B fits the 160 KiB LDS
 constexpr unsigned TW_PAD = 0xFFFFFFFFu;
-constexpr int TW_U = 4;               // 64-entry chunks in flight per wave
+constexpr int TW_U = 3;               // 64-entry chunks prefetched per wave per tile
 
 thread_local std::string g_last_error;
 
@@ -232,76 +231,138 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
 }
 
 // CSR "tiled sweep" kernel (SpMV v2) for matrices whose gathered vector is far
-// larger than the 4 MiB per-XCD L2 (a uniformly random 8-byte gather tops out
-// at ~56 G/s on MI355X; L2-resident gathers reach ~190-245 G/s).
-// Layout: every wave owns TW_ROWS consecutive rows and streams ITS nonzeros,
-// pre-sorted on the host by (column tile, row, column), packed as
-// {row_local:8 | col:24} + value.  All resident waves therefore walk the
-// column tiles of the gathered vector in the same order and at about the same
-// pace, so at any moment the chip gathers from a ~1 MiB slice that sits in
-// every XCD's L2.  Accumulators live in the wave's private 2 KiB of LDS; DS
-// operations of one wave execute in order, so no barrier is needed, and each
-// row still receives its products in ascending column order (tile-major order
-// preserves it) => bit-identical to the sequential CPU loops.  Entries of one
-// row that fall into the same 64-entry chunk are adjacent; the run head adds
+// larger than the 4 MiB per-XCD L2.  Measured on MI355X (tools/gather_probe):
+// a uniformly random 8-byte gather tops out at ~56 G/s over an 80 MB vector but
+// reaches ~190-245 G/s when the window fits L2.
+// Layout: every wave owns up to TW_ROWS consecutive rows and streams ITS
+// nonzeros, pre-sorted on the host by (column tile, row, column) and packed
+// tile-locally as {row_local << tile_shift | col_local} + value, with one
+// offset per (wave, tile).  A workgroup is 8 such waves; all of them process
+// tile t, then meet at a barrier -- the barrier is pacing, not correctness: it
+// keeps the 16 waves of a CU (and, statistically, the CUs of an XCD) inside
+// the same ~1 MiB slice of the gathered vector, which therefore stays in L2.
+// The next tile's entries are prefetched into registers before the barrier.
+// Accumulators live in the wave's private LDS slice; one wave's DS operations
+// execute in order, each row receives its products in ascending column order
+// (tile-major order preserves it) => bit-identical to the sequential CPU
+// loops.  Entries of one row inside a tile are adjacent; the run head adds
 // them left to right via lane shuffles.
+__device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, double xv,
+                                            int tile_shift, int lane) {
+  const bool valid = p != TW_PAD;
+  const unsigned row = valid ? (p >> tile_shift) : 0xFFFFFFFFu;
+  const double prod = v * xv;
+  const unsigned rowp = __shfl_up(row, 1, WAVE);
+  const bool head = valid && (lane == 0 || rowp != row);
+  double s = head ? acc[row] : 0.0;
+  for (int j = 0; j < WAVE; ++j) {
+    const double pj = __shfl_down(prod, j, WAVE);
+    const unsigned rj = __shfl_down(row, j, WAVE);
+    const bool take = head && (lane + j < WAVE) && (rj == row);
+    if (!__any(take)) break;
+    if (take) s = s + pj;
+  }
+  if (head) acc[row] = s;
+}
+
 template <int MODE>
-__global__ __launch_bounds__(TPB) void spmv_tiled_kernel(
-    const int2 *__restrict__ wave_rows, const int *__restrict__ wave_ent, int nwaves,
-    const unsigned *__restrict__ pk, const double *__restrict__ tv,
-    const double *__restrict__ xin, EpiArgs e) {
-  __shared__ double acc_all[(TPB / WAVE) * TW_ROWS];
-  __shared__ double red[3][TPB / WAVE];
+__global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
+    const int2 *__restrict__ wave_rows, const int *__restrict__ tile_ptr, int nwaves,
+    int ntiles, int tile_shift, int TW_ROWS, const unsigned *__restrict__ pk,
+    const double *__restrict__ tv, const double *__restrict__ xin, EpiArgs e) {
+  constexpr int TW_THREADS = TW_WPB * WAVE;
+  constexpr int U = TW_U;   // 64-entry chunks held in registers per (wave, tile)
+  constexpr int D = 3;      // entry loads run D tiles ahead of the accumulate
+  constexpr int R = D + 1;  // register ring (statically indexed: the tile loop is unrolled R times)
+  extern __shared__ double tw_lds[];  // [TW_WPB][TW_ROWS] accumulators, then red[3][TW_WPB]
+  double(*red)[TW_WPB] = reinterpret_cast<double(*)[TW_WPB]>(tw_lds + TW_WPB * TW_ROWS);
   const int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x / WAVE;
-  const int w = blockIdx.x * (TPB / WAVE) + wid;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * TW_WPB + wid);
+  const bool live = w < nwaves;
   double acc3[3] = {0.0, 0.0, 0.0};
-  double *acc = acc_all + wid * TW_ROWS;
-  if (w < nwaves) {
-    const int2 rr = wave_rows[w];
-    const int nrows = rr.y - rr.x;
+  double *acc = tw_lds + wid * TW_ROWS;
+  int2 rr = make_int2(0, 0);
+  if (live) rr = wave_rows[w];
+  for (int r = lane; r < TW_ROWS; r += WAVE) acc[r] = 0.0;
+  const int *tp = tile_ptr + (size_t)(live ? w : 0) * (size_t)(ntiles + 1);
+  const unsigned cmask = (1u << tile_shift) - 1u;
+
+  unsigned p[R][U];
+  double v[R][U];
+  double xv[U];
+  int ks[R], ke[R];
+
+  auto load_set = [&](unsigned(&pp)[U], double(&vv)[U], int kbeg, int kend) {
 #pragma unroll
-    for (int r = lane; r < TW_ROWS; r += WAVE) acc[r] = 0.0;
-    const int e0 = wave_ent[w];
-    const int e1 = wave_ent[w + 1];
-    for (int base = e0; base < e1; base += WAVE * TW_U) {
-      unsigned p[TW_U];
-      double v[TW_U];
-      double xv[TW_U];
+    for (int i = 0; i < U; ++i) {
+      const int k = kbeg + i * WAVE + lane;
+      const bool ok = k < kend;
+      pp[i] = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
+      vv[i] = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
+    }
+  };
+
+  // prologue: entries of tiles 0..D-1
+  int kprev = live ? tp[0] : 0;
 #pragma unroll
-      for (int i = 0; i < TW_U; ++i) {
-        const int k = base + i * WAVE + lane;
-        const bool ok = k < e1;
-        p[i] = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
-        v[i] = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
-      }
+  for (int s = 0; s < D; ++s) {
+    ks[s] = kprev;
+    ke[s] = (live && s < ntiles) ? tp[s + 1] : kprev;
+    kprev = ke[s];
+    load_set(p[s], v[s], ks[s], ke[s]);
+  }
+  ks[D] = ke[D] = kprev;
 #pragma unroll
-      for (int i = 0; i < TW_U; ++i) xv[i] = (p[i] != TW_PAD) ? xin[p[i] & TW_COL_MASK] : 0.0;
+  for (int i = 0; i < U; ++i) { p[D][i] = TW_PAD; v[D][i] = 0.0; }
+  int ke_ahead = (live && D < ntiles) ? tp[D + 1] : kprev;  // end of tile D
+
+  for (int t0 = 0; t0 < ntiles; t0 += R) {
 #pragma unroll
-      for (int i = 0; i < TW_U; ++i) {
-        if (base + i * WAVE < e1) {  // wave-uniform
-          const bool valid = p[i] != TW_PAD;
-          const unsigned row = valid ? (p[i] >> TW_COL_BITS) : 0x1FFu;
-          const double prod = v[i] * xv[i];
-          const unsigned rowp = __shfl_up(row, 1, WAVE);
-          const bool head = valid && (lane == 0 || rowp != row);
-          double s = head ? acc[row] : 0.0;
-          for (int j = 0; j < WAVE; ++j) {
-            const double pj = __shfl_down(prod, j, WAVE);
-            const unsigned rj = __shfl_down(row, j, WAVE);
-            const bool take = head && (lane + j < WAVE) && (rj == row);
-            if (!__any(take)) break;
-            if (take) s = s + pj;
+    for (int s = 0; s < R; ++s) {
+      const int t = t0 + s;
+      if (t < ntiles) {  // workgroup-uniform
+        const int f = (s + D) % R;       // ring slot being refilled (held tile t-1)
+        const double *xt = xin + ((size_t)t << tile_shift);
+        // 1. gathers for tile t (entries requested D steps ago).  Issued BEFORE
+        //    the prefetch: a wave's loads return in order, so the L2-latency
+        //    gathers must not queue behind HBM-latency streaming loads.
+        //    (Gathering one tile ahead was measured slower: it widens the L2
+        //    working window of the sweep.)
+#pragma unroll
+        for (int i = 0; i < U; ++i) xv[i] = (p[s][i] != TW_PAD) ? xt[p[s][i] & cmask] : 0.0;
+        // 2. entry loads for tile t+D
+        ks[f] = ke[(s + D - 1) % R];
+        ke[f] = ke_ahead;
+        load_set(p[f], v[f], ks[f], ke[f]);
+        ke_ahead = (live && t + D + 1 < ntiles) ? tp[t + D + 2] : ke_ahead;  // end of tile t+D+1
+        // 3. accumulate tile t
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+          if (ks[s] + i * WAVE < ke[s]) {  // wave-uniform
+            tiled_chunk(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
           }
-          if (head) acc[row] = s;
         }
+        for (int kb = ks[s] + U * WAVE; kb < ke[s]; kb += WAVE) {  // cells beyond the register window
+          const int k = kb + lane;
+          const bool ok = k < ke[s];
+          const unsigned pp = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
+          const double vv = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
+          const double xx = ok ? xt[pp & cmask] : 0.0;
+          tiled_chunk(acc, pp, vv, xx, tile_shift, lane);
+        }
+        // 4. pacing barrier: keep the workgroup inside one column tile
+        //    (without it the kernel is 1.7x slower: waves drift apart and the
+        //    gathers stop hitting L2)
+        __syncthreads();
       }
     }
-    for (int r = lane; r < nrows; r += WAVE) row_epilogue<MODE>(e, rr.x + r, acc[r], acc3);
   }
+  const int nrows = rr.y - rr.x;
+  for (int r = lane; r < nrows; r += WAVE) row_epilogue<MODE>(e, rr.x + r, acc[r], acc3);
   constexpr int NQ = ModeNQ<MODE>::value;
   if (NQ > 0) {
-    block_sum<NQ, TPB>(acc3, red);
+    block_sum<NQ, TW_THREADS>(acc3, red);
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) e.partials[q * e.stride + blockIdx.x] = acc3[q];
@@ -551,9 +612,9 @@ struct CsrDev {
   int64_t max_row_nnz = 0;
   // tiled-sweep layout (optional)
   bool tiled = false;
-  int tile_shift = 0, nwaves = 0;
+  int tile_shift = 0, nwaves = 0, ntiles = 0, tw_rows = 0;
   int2 *wave_rows = nullptr;
-  int *wave_ent = nullptr;
+  int *wave_ent = nullptr;   // [nwaves][ntiles+1] entry offsets per (wave, tile)
   unsigned *pk = nullptr;
   double *tv = nullptr;
   int slots() const { return grid + long_grid; }
@@ -580,14 +641,28 @@ int alloc_zero(double **dst, int64_t len) {
 // column tile (stable, so (row, col) order is kept inside a tile).
 int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::vector<int> &col,
                 const std::vector<double> &val, int tile_shift) {
-  const int ntiles = (int)((((int64_t)D.cols) + (1LL << tile_shift) - 1) >> tile_shift);
+  // Geometry.  A CU holds 2 workgroups of 8 waves; the grid runs in rounds of
+  // 256 CUs x 16 waves.  Rows per wave is chosen so that the rounds are full
+  // (no tail round), within the LDS budget (160 KiB / 16 waves).
+  const int64_t slots = 256LL * 2 * TW_WPB;               // resident waves per round
+  const int max_rows = std::min<int>(TW_MAX_ROWS, 1 << (32 - tile_shift));
+  int TW_ROWS;
+  {
+    int64_t rounds = std::max<int64_t>(1, ((int64_t)rows + slots * max_rows - 1) / (slots * max_rows));
+    int64_t rpw = ((int64_t)rows + slots * rounds - 1) / (slots * rounds);
+    TW_ROWS = (int)std::max<int64_t>(64, std::min<int64_t>(max_rows, rpw));
+  }
+  if (const char *ev = getenv("PDHG_TW_ROWS")) TW_ROWS = std::max(1, std::min(atoi(ev), max_rows));
+  D.tw_rows = TW_ROWS;
+  const int ntiles = std::max<int>(1, (int)((((int64_t)D.cols) + (1LL << tile_shift) - 1) >> tile_shift));
   std::vector<int2> wave_rows;
-  std::vector<int> wave_ent(1, 0);
+  std::vector<int> tile_ptr;
   std::vector<unsigned> pk;
   std::vector<double> tv;
   pk.reserve((size_t)D.nnz);
   tv.reserve((size_t)D.nnz);
   std::vector<int> cnt((size_t)ntiles + 1);
+  const unsigned cmask = (1u << tile_shift) - 1u;
   int r = 0;
   while (r < rows) {
     if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) { ++r; continue; }  // long row: separate path
@@ -598,26 +673,27 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
     for (int k = k0; k < k1; ++k) cnt[(col[k] >> tile_shift) + 1] += 1;
     for (int t = 0; t < ntiles; ++t) cnt[t + 1] += cnt[t];
     const size_t base = pk.size();
+    for (int t = 0; t <= ntiles; ++t) tile_ptr.push_back((int)(base + (size_t)cnt[t]));
     pk.resize(base + (size_t)(k1 - k0));
     tv.resize(base + (size_t)(k1 - k0));
     for (int rr = r0; rr < r; ++rr) {
-      const unsigned rl = (unsigned)(rr - r0) << TW_COL_BITS;
+      const unsigned rl = (unsigned)(rr - r0) << tile_shift;
       for (int k = rowptr[rr]; k < rowptr[rr + 1]; ++k) {
         const int pos = cnt[col[k] >> tile_shift]++;
-        pk[base + pos] = rl | (unsigned)col[k];
+        pk[base + pos] = rl | ((unsigned)col[k] & cmask);
         tv[base + pos] = val[k];
       }
     }
     wave_rows.push_back(make_int2(r0, r));
-    wave_ent.push_back((int)pk.size());
   }
   D.tiled = true;
   D.tile_shift = tile_shift;
+  D.ntiles = ntiles;
   D.nwaves = (int)wave_rows.size();
-  D.grid = (D.nwaves + (TPB / WAVE) - 1) / (TPB / WAVE);
+  D.grid = (D.nwaves + TW_WPB - 1) / TW_WPB;
   int rc;
   if ((rc = upload(&D.wave_rows, wave_rows))) return rc;
-  if ((rc = upload(&D.wave_ent, wave_ent))) return rc;
+  if ((rc = upload(&D.wave_ent, tile_ptr))) return rc;
   if ((rc = upload(&D.pk, pk))) return rc;
   if ((rc = upload(&D.tv, tv))) return rc;
   return 0;
@@ -755,9 +831,18 @@ struct ProfScope {
 template <int MODE>
 int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
   if (D.tiled) {
-    if (D.grid > 0)
-      hipLaunchKernelGGL(spmv_tiled_kernel<MODE>, dim3(D.grid), dim3(TPB), 0, h->stream,
-                         D.wave_rows, D.wave_ent, D.nwaves, D.pk, D.tv, xin, e);
+    if (D.grid > 0) {
+      const size_t lds = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB);
+      static size_t attr_set[3] = {0, 0, 0};
+      if (attr_set[MODE] < lds) {
+        HIP_TRY(hipFuncSetAttribute((const void *)spmv_tiled_kernel<MODE>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[MODE] = lds;
+      }
+      hipLaunchKernelGGL(spmv_tiled_kernel<MODE>, dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
+                         D.wave_rows, D.wave_ent, D.nwaves, D.ntiles, D.tile_shift, D.tw_rows,
+                         D.pk, D.tv, xin, e);
+    }
   } else if (D.grid > 0) {
     hipLaunchKernelGGL(spmv_stream_kernel<MODE>, dim3(D.grid), dim3(TPB), 0, h->stream,
                        D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, e);
@@ -864,10 +949,10 @@ int check_handle(pdhg_handle *h) {
 int choose_tile_shift(int64_t cols, int64_t nnz, int64_t rows) {
   const char *mode = getenv("PDHG_SPMV");
   const char *ts = getenv("PDHG_TILE_SHIFT");
-  int shift = ts ? atoi(ts) : 17;
-  if (shift < 8) shift = 8;
-  if (shift > 23) shift = 23;
-  if (cols >= (int64_t)TW_COL_MASK) return 0;           // col must fit 24 bits (0xFFFFFF reserved)
+  int shift = ts ? atoi(ts) : 16;   // 64K columns = 512 KiB of the gathered vector (best of 14..19 on MI355X)
+  if (shift < 6) shift = 6;
+  if (shift > 22) shift = 22;                            // leave >= 10 bits for row_local
+  if (((cols + (1LL << shift) - 1) >> shift) > 65536) return 0;  // tile table would be huge
   if (mode && !strcmp(mode, "stream")) return 0;
   if (mode && !strcmp(mode, "tiled")) return shift;
   const bool big_vector = cols * 8 > (16LL << 20);       // > 16 MiB: 4x an XCD L2

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Dev tool: A/B the SpMV layouts/geometries on one generated problem, in one
+process, interleaved and repeated (per-kernel HIP-event averages).
+usage: tune_tiled.py [--m M --n N] "K=V K=V" "K=V" ..."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import folp_loader
+pkg = folp_loader.load()
+from firstorderlp_jl_amd.generators import random_lp
+from firstorderlp_jl_amd.primal_dual_hybrid_gradient import AdaptiveStepsizeParams, PdhgSolverState, take_step
+from firstorderlp_jl_amd import _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=10_000_000)
+ap.add_argument("--n", type=int, default=10_000_000)
+ap.add_argument("--k", type=int, default=10)
+ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("cfgs", nargs="*")
+a = ap.parse_args()
+p = random_lp(a.m, a.n, a.k, 12345)
+A = p.constraint_matrix
+step0 = 1.0 / float(np.abs(A.data).max())
+pw0 = float(np.linalg.norm(p.objective_vector) / np.linalg.norm(p.right_hand_side))
+KEYS = ["PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TW_ROWS", "PDHG_TW_WPB", "PDHG_TW_FLAGS", "PDHG_XCD_REMAP"]
+for rep in range(a.reps):
+    for cfg in a.cfgs or [""]:
+        for k in KEYS:
+            os.environ.pop(k, None)
+        for kv in cfg.split():
+            k, v = kv.split("=")
+            os.environ[k] = v
+        t0 = time.time()
+        eng = pkg.HipPdhgEngine.from_problem(p)
+        tc = time.time() - t0
+        st = PdhgSolverState(eng, step_size=step0, primal_weight=pw0)
+        for _ in range(5):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+        eng.profile_enable(True)
+        for _ in range(a.steps):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+        c1, m1 = eng.profile_read(_lib.K_SPMV_DUAL)
+        c2, m2 = eng.profile_read(_lib.K_SPMV_ATY)
+        by1 = eng.kernel_algorithmic_bytes(_lib.K_SPMV_DUAL)
+        info = eng.layout_info()
+        print(f"rep{rep} [{cfg:48s}] dual {m1/c1:.4f} ms ({by1/(m1/c1)/1e6:6.0f} GB/s)  aty {m2/c2:.4f} ms  "
+              f"waves={info['A_tiled_waves']} create={tc:.1f}s", flush=True)
+        eng.close()
