@@ -130,10 +130,17 @@ def main():
     dom = max((_lib.K_SPMV_DUAL, _lib.K_SPMV_ATY),
               key=lambda k: local.profile_read(k)[1])
     dk = kernels[local.kernel_name(dom)]
+    traffic = None
+    try:   # PMC-derived bytes/launch, measured offline with rocprofv3 on this exact workload
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            traffic = json.load(fh).get(
+                f"{local.kernel_name(dom)}@m={A.shape[0]},n={A.shape[1]},nnz={nnz}")
+    except OSError:
+        pass
     roofline = {"bound": "hbm", "kernel": local.kernel_name(dom),
                 "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(dk["achieved_GBps"] / HBM_PEAK_GBS, 4),
-                "traffic": None, "avg_launch_ms": dk["avg_ms"],
+                "traffic": traffic, "avg_launch_ms": dk["avg_ms"],
                 "algorithmic_bytes_per_launch": dk["algorithmic_bytes"]}
 
     # ---- CPU baseline: the literal single-thread restatement, bounded sample
