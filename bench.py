@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--nnz-per-row", type=int, default=10)
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--workload", choices=["random", "pagerank"], default="random",
+                    help="random: BASELINE configs[4] (default); pagerank: configs[2] (--n nodes)")
     ap.add_argument("--profile-steps", type=int, default=30)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -47,7 +49,7 @@ def main():
     import torch
     import folp_loader
     pkg = folp_loader.load()
-    from firstorderlp_jl_amd.generators import random_lp
+    from firstorderlp_jl_amd.generators import pagerank_lp, random_lp
     from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
         AdaptiveStepsizeParams, PdhgSolverState, take_step)
     from firstorderlp_jl_amd import _lib
@@ -67,7 +69,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     t0 = time.time()
-    problem = random_lp(args.m, args.n, args.nnz_per_row, args.seed)
+    if args.workload == "pagerank":
+        problem = pagerank_lp(args.n, 4 * args.n, 0.99, seed=0)
+        wl = (f"PageRank LP (generate_pagerank_lp.jl model) nodes={args.n} approx_edges={4 * args.n} "
+              "damping=0.99 (BASELINE configs[2])")
+    else:
+        problem = random_lp(args.m, args.n, args.nnz_per_row, args.seed)
+        wl = None
     A = problem.constraint_matrix
     nnz = int(A.nnz)
     t_gen = time.time() - t0
@@ -176,8 +184,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"random LP m={m} n={n} nnz={nnz} seed={args.seed} "
-                                   "(BASELINE configs[4]), adaptive step, zero start, "
+            "config": {"workload": (wl or f"random LP m={m} n={n} nnz={nnz} seed={args.seed} "
+                                    "(BASELINE configs[4])") + ", adaptive step, zero start, "
                                    "no restarts/rescaling",
                        "m": m, "n": n, "nnz": nnz,
                        "parallelism": "single GPU" if world == 1 else f"row-partition x{world} + RCCL all-reduce"},

@@ -641,6 +641,8 @@ int alloc_zero(double **dst, int64_t len) {
 // column tile (stable, so (row, col) order is kept inside a tile).
 int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::vector<int> &col,
                 const std::vector<double> &val, int tile_shift) {
+  const char *mode_env = getenv("PDHG_SPMV");
+  const bool forced = mode_env && !strcmp(mode_env, "tiled");
   // Geometry.  A CU holds 2 workgroups of 8 waves; the grid runs in rounds of
   // 256 CUs x 16 waves.  Rows per wave is chosen so that the rounds are full
   // (no tail round), within the LDS budget (160 KiB / 16 waves).
@@ -663,6 +665,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
   tv.reserve((size_t)D.nnz);
   std::vector<int> cnt((size_t)ntiles + 1);
   const unsigned cmask = (1u << tile_shift) - 1u;
+  int64_t overflow = 0;   // entries beyond the per-(wave, tile) register window
   int r = 0;
   while (r < rows) {
     if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) { ++r; continue; }  // long row: separate path
@@ -674,6 +677,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
     for (int t = 0; t < ntiles; ++t) cnt[t + 1] += cnt[t];
     const size_t base = pk.size();
     for (int t = 0; t <= ntiles; ++t) tile_ptr.push_back((int)(base + (size_t)cnt[t]));
+    for (int t = 0; t < ntiles; ++t) overflow += std::max(0, cnt[t + 1] - cnt[t] - TW_U * WAVE);
     pk.resize(base + (size_t)(k1 - k0));
     tv.resize(base + (size_t)(k1 - k0));
     for (int rr = r0; rr < r; ++rr) {
@@ -686,6 +690,11 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
     }
     wave_rows.push_back(make_int2(r0, r));
   }
+  // Skewed matrices (hub columns concentrated in a few tiles, e.g. the
+  // PageRank LP) overflow the prefetch window and serialise on the pacing
+  // barrier; they also have natural cache locality, so the stream layout
+  // serves them better.  Keep the tiled layout only when overflow is rare.
+  if (!forced && overflow * 50 > (int64_t)pk.size()) return 0;
   D.tiled = true;
   D.tile_shift = tile_shift;
   D.ntiles = ntiles;
@@ -955,7 +964,7 @@ int choose_tile_shift(int64_t cols, int64_t nnz, int64_t rows) {
   if (((cols + (1LL << shift) - 1) >> shift) > 65536) return 0;  // tile table would be huge
   if (mode && !strcmp(mode, "stream")) return 0;
   if (mode && !strcmp(mode, "tiled")) return shift;
-  const bool big_vector = cols * 8 > (16LL << 20);       // > 16 MiB: 4x an XCD L2
+  const bool big_vector = cols * 8 > (4LL << 20);        // larger than one XCD's 4 MiB L2
   const bool short_rows = rows > 0 && nnz / rows <= 64;
   return (big_vector && short_rows) ? shift : 0;
 }

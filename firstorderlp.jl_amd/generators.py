@@ -43,3 +43,62 @@ def random_lp(m, n, nnz_per_row=10, seed=12345):
     r[at_lower] = rng.random(int(at_lower.sum()))
     c = A.T @ y0 + r
     return linear_programming_problem(lb, ub, c, 0.0, A.tocsc(), b, num_eq)
+
+
+def barabasi_albert_edges(num_nodes, degree, seed=0, batch=4096):
+    """Preferential-attachment graph in the spirit of
+    LightGraphs.barabasi_albert(n, k) (generate_pagerank_lp.jl:121-125): each
+    new node attaches to `degree` distinct existing nodes with probability
+    proportional to their degree.  Batched (targets are drawn from the endpoint
+    list as of the start of the batch) so it is vectorised; not the same RNG
+    stream as LightGraphs.  Returns an (E, 2) array of undirected edges."""
+    rng = np.random.default_rng(seed)
+    k = int(degree)
+    n = int(num_nodes)
+    assert n > k >= 1
+    # seed graph: a path over the first k+1 nodes so every node has degree >= 1
+    src = [np.arange(0, k, dtype=np.int64)]
+    dst = [np.arange(1, k + 1, dtype=np.int64)]
+    endpoints = np.empty(2 * (k + k * (n - k - 1)) + 16, dtype=np.int64)
+    ne = 0
+    endpoints[ne:ne + k] = src[0]; ne += k
+    endpoints[ne:ne + k] = dst[0]; ne += k
+    t = k + 1
+    while t < n:
+        b = min(batch, n - t, max(1, t // 16))   # small batches early: keeps the attachment near-sequential
+        idx = rng.integers(0, ne, size=(b, k))
+        tgt = np.sort(endpoints[idx], axis=1)
+        keep = np.ones((b, k), dtype=bool)
+        keep[:, 1:] = tgt[:, 1:] != tgt[:, :-1]          # distinct targets per node
+        new = np.repeat(np.arange(t, t + b, dtype=np.int64), k).reshape(b, k)
+        s, d = new[keep], tgt[keep]
+        src.append(s); dst.append(d)
+        endpoints[ne:ne + len(s)] = s; ne += len(s)
+        endpoints[ne:ne + len(d)] = d; ne += len(d)
+        t += b
+    return np.stack([np.concatenate(src), np.concatenate(dst)], axis=1)
+
+
+def pagerank_lp(num_nodes, approx_num_edges=None, damping_factor=0.99, seed=0):
+    """The PageRank LP of benchmarking/generate_pagerank_lp.jl:48-73 in the
+    standard form qps_reader_to_standard_form produces (equalities first,
+    '<=' rows flipped to '>='):
+        sqrt(n) * sum_i x_i                    == sqrt(n)
+        x_i - d * sum_{j in N(i)} x_j / deg_j  >= (1 - d) / n      for every i
+        x >= 0, objective 0.
+    BASELINE configs[2]: num_nodes = 1e6, approx_num_edges = 4e6."""
+    n = int(num_nodes)
+    if approx_num_edges is None:
+        approx_num_edges = 4 * n
+    degree = int(round(approx_num_edges / n))
+    e = barabasi_albert_edges(n, degree, seed)
+    deg = np.bincount(e.reshape(-1), minlength=n).astype(np.float64)
+    i = np.concatenate([e[:, 0], e[:, 1]])
+    j = np.concatenate([e[:, 1], e[:, 0]])
+    S = sp.csr_matrix((-damping_factor / deg[j], (i, j)), shape=(n, n))
+    rows = S + sp.identity(n, format="csr")
+    top = sp.csr_matrix(np.full((1, n), np.sqrt(n)))
+    A = sp.vstack([top, rows], format="csc")
+    b = np.concatenate([[np.sqrt(n)], np.full(n, (1.0 - damping_factor) / n)])
+    return linear_programming_problem(np.zeros(n), np.full(n, np.inf), np.zeros(n), 0.0,
+                                      A, b, 1)

@@ -176,3 +176,114 @@ def rescale_problem(l_inf_ruiz_iterations, l2_norm_rescaling_flag,
             print(f"Problem after rescaling (Ruiz iterations = {l_inf_ruiz_iterations}, "
                   f"l2_norm_rescaling = {l2_norm_rescaling_flag}):")
     return scaled_problem
+
+
+# ---- presolve (preprocess.jl:122-340) ------------------------------------------
+
+from dataclasses import dataclass as _dataclass
+
+
+def remove_empty_rows(problem):
+    """preprocess.jl:122-145 (in place); returns the 0-based empty row indices."""
+    A = problem.constraint_matrix
+    seen_row = np.zeros(A.shape[0], dtype=bool)
+    seen_row[A.indices] = True
+    empty_rows = np.nonzero(~seen_row)[0]
+    for row in empty_rows:
+        if row >= problem.num_equalities and problem.right_hand_side[row] > 0.0:
+            raise ValueError("The problem is infeasible.")
+        elif row < problem.num_equalities and problem.right_hand_side[row] != 0.0:
+            raise ValueError("The problem is infeasible.")
+    if len(empty_rows):
+        problem.constraint_matrix = as_csc(sp.csr_matrix(A)[seen_row, :])
+        problem.right_hand_side = problem.right_hand_side[seen_row]
+        problem.num_equalities -= int(np.sum(empty_rows < problem.num_equalities))
+    return empty_rows
+
+
+def remove_empty_columns(problem):
+    """preprocess.jl:156-186 (in place); LP only."""
+    assert problem.objective_matrix.nnz == 0 or not np.any(problem.objective_matrix.data)
+    A = problem.constraint_matrix
+    is_empty_column = np.diff(A.indptr) == 0
+    empty_columns = np.nonzero(is_empty_column)[0]
+    if len(empty_columns) == 0:
+        return empty_columns
+    for col in empty_columns:
+        coef = problem.objective_vector[col]
+        bound = problem.variable_lower_bound[col] if coef >= 0 else problem.variable_upper_bound[col]
+        problem.objective_constant += bound * coef
+    keep = ~is_empty_column
+    problem.constraint_matrix = as_csc(A[:, keep])
+    problem.objective_vector = problem.objective_vector[keep]
+    problem.variable_lower_bound = problem.variable_lower_bound[keep]
+    problem.variable_upper_bound = problem.variable_upper_bound[keep]
+    problem.objective_matrix = as_csc(problem.objective_matrix[keep, :][:, keep])
+    return empty_columns
+
+
+def transform_bounds_into_linear_constraints(qp):
+    """preprocess.jl:191-222"""
+    lo_idx = np.nonzero(np.isfinite(qp.variable_lower_bound))[0]
+    up_idx = np.nonzero(np.isfinite(qp.variable_upper_bound))[0]
+    k = len(lo_idx) + len(up_idx)
+    block = sp.csc_matrix((np.concatenate([np.ones(len(lo_idx)), -np.ones(len(up_idx))]),
+                           (np.arange(k), np.concatenate([lo_idx, up_idx]))),
+                          shape=(k, len(qp.variable_lower_bound)))
+    qp.constraint_matrix = as_csc(sp.vstack([qp.constraint_matrix, block]))
+    qp.right_hand_side = np.concatenate([qp.right_hand_side, qp.variable_lower_bound[lo_idx],
+                                         -qp.variable_upper_bound[up_idx]])
+    qp.variable_lower_bound = np.full_like(qp.variable_lower_bound, -np.inf)
+    qp.variable_upper_bound = np.full_like(qp.variable_upper_bound, np.inf)
+
+
+@_dataclass
+class PresolveInfo:
+    """preprocess.jl:224-231"""
+    original_primal_size: int
+    original_dual_size: int
+    empty_rows: np.ndarray
+    empty_columns: np.ndarray
+    variable_lower_bound: np.ndarray
+    variable_upper_bound: np.ndarray
+
+
+def presolve(qp, verbosity=1, transform_bounds=False):
+    """preprocess.jl:236-268 (modifies qp in place)."""
+    saved_lb = qp.variable_lower_bound.copy()
+    saved_ub = qp.variable_upper_bound.copy()
+    original_dual_size, original_primal_size = qp.constraint_matrix.shape
+    empty_rows = remove_empty_rows(qp)
+    if qp.objective_matrix.nnz == 0 or not np.any(qp.objective_matrix.data):
+        empty_columns = remove_empty_columns(qp)
+    else:
+        empty_columns = np.zeros(0, dtype=np.int64)
+    if verbosity >= 1:
+        counts = np.bincount(qp.constraint_matrix.indices, minlength=qp.constraint_matrix.shape[0])
+        num_single = int(np.sum(counts == 1))
+        if num_single > 0:
+            print(f"{num_single} constraints involving exactly a single variable")
+    if transform_bounds:
+        transform_bounds_into_linear_constraints(qp)
+    return PresolveInfo(original_primal_size, original_dual_size, empty_rows, empty_columns,
+                        saved_lb, saved_ub)
+
+
+def recover_original_solution(solution, empty_indices, original_size):
+    """preprocess.jl:294-307"""
+    nonempty = np.ones(original_size, dtype=bool)
+    nonempty[empty_indices] = False
+    original = np.zeros(original_size)
+    original[nonempty] = solution[:int(nonempty.sum())]
+    return original
+
+
+def undo_presolve(presolve_info, primal_solution, dual_solution):
+    """preprocess.jl:309-332"""
+    primal = recover_original_solution(primal_solution, presolve_info.empty_columns,
+                                       presolve_info.original_primal_size)
+    primal = np.minimum(presolve_info.variable_upper_bound,
+                        np.maximum(presolve_info.variable_lower_bound, primal))
+    dual = recover_original_solution(dual_solution, presolve_info.empty_rows,
+                                     presolve_info.original_dual_size)
+    return primal, dual

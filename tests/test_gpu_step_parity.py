@@ -196,3 +196,24 @@ def test_adjoint_identity_large(gpu_required):
     A = p.constraint_matrix
     assert np.array_equal(ax, orc.spmv(eng.m, eng.n, A.indptr, A.indices, A.data, x))
     assert np.array_equal(aty, orc.spmv_t(eng.m, eng.n, A.indptr, A.indices, A.data, y))
+
+
+def test_pagerank_lp_matches_oracle(gpu_required):
+    """BASELINE configs[2] model at reduced size: one dense equality row (long
+    row in A), hub columns (long rows in A'), objective 0."""
+    from firstorderlp_jl_amd.generators import pagerank_lp
+    p = pagerank_lp(60000, seed=1)
+    eng, st = _mk(p)
+    info = eng.layout_info()
+    assert info["A_long_rows"] >= 1 and info["A_max_row_nnz"] == 60000
+    step, pw = H.initial_step_and_weight(p)
+    assert pw == 1.0                      # c == 0 -> primal_importance (saddle_point.jl:1058-1070)
+    state = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    st.step_size, st.primal_weight = step, pw
+    for _ in range(40):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), state)
+        st.take_step_adaptive(0.3, 0.6)
+    assert state.total_number_iterations == st.total_number_iterations
+    x, y = eng.get_current()
+    np.testing.assert_allclose(x, st.x, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(st.x).max()))
+    np.testing.assert_allclose(y, st.y, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(st.y).max()))
