@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--nnz-per-row", type=int, default=10)
     ap.add_argument("--seed", type=int, default=12345)
-    ap.add_argument("--workload", choices=["random", "pagerank"], default="random",
+    ap.add_argument("--workload", choices=["random", "pagerank", "l1svm"], default="random",
                     help="random: BASELINE configs[4] (default); pagerank: configs[2] (--n nodes)")
     ap.add_argument("--profile-steps", type=int, default=30)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
@@ -49,7 +49,7 @@ def main():
     import torch
     import folp_loader
     pkg = folp_loader.load()
-    from firstorderlp_jl_amd.generators import pagerank_lp, random_lp
+    from firstorderlp_jl_amd.generators import l1_svm_rcv1_like_lp, pagerank_lp, random_lp
     from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
         AdaptiveStepsizeParams, PdhgSolverState, take_step)
     from firstorderlp_jl_amd import _lib
@@ -73,6 +73,10 @@ def main():
         problem = pagerank_lp(args.n, 4 * args.n, 0.99, seed=0)
         wl = (f"PageRank LP (generate_pagerank_lp.jl model) nodes={args.n} approx_edges={4 * args.n} "
               "damping=0.99 (BASELINE configs[2])")
+    elif args.workload == "l1svm":
+        problem = l1_svm_rcv1_like_lp(seed=0)
+        wl = ("L1-SVM LP (generate_l1_svm_lp.jl model) on synthetic rcv1.binary-shaped data "
+              "20242 x 47236, ~74 nnz/row, lambda=1 (BASELINE configs[3]; rcv1 itself is not available offline)")
     else:
         problem = random_lp(args.m, args.n, args.nnz_per_row, args.seed)
         wl = None

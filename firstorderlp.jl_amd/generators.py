@@ -102,3 +102,90 @@ def pagerank_lp(num_nodes, approx_num_edges=None, damping_factor=0.99, seed=0):
     b = np.concatenate([[np.sqrt(n)], np.full(n, (1.0 - damping_factor) / n)])
     return linear_programming_problem(np.zeros(n), np.full(n, np.inf), np.zeros(n), 0.0,
                                       A, b, 1)
+
+
+def load_libsvm_file(file_name):
+    """benchmarking/generate_l1_svm_lp.jl:106-139: (feature_matrix CSC, labels);
+    label 1.0 stays 1.0, anything else becomes -1.0."""
+    labels, rows, cols, vals = [], [], [], []
+    found_label_one = False
+    with open(file_name) as fh:
+        for r, line in enumerate(fh):
+            parts = line.split()
+            if not parts:
+                continue
+            label = float(parts[0])
+            if label == 1.0:
+                found_label_one = True
+            else:
+                label = -1.0
+            labels.append(label)
+            for tok in parts[1:]:
+                c, v = tok.split(":")
+                rows.append(len(labels) - 1); cols.append(int(c) - 1); vals.append(float(v))
+    assert found_label_one
+    X = sp.csc_matrix((vals, (rows, cols)), shape=(len(labels), max(cols) + 1))
+    return X, np.array(labels)
+
+
+def preprocess_training_data(X):
+    """generate_l1_svm_lp.jl:141-167: drop empty columns, prepend the dense
+    intercept column, scale every column to unit L2 norm."""
+    X = sp.csc_matrix(X, dtype=np.float64)
+    X = X[:, np.diff(X.indptr) > 0]
+    X = sp.hstack([sp.csc_matrix(np.ones((X.shape[0], 1))), X], format="csc")
+    norms = np.sqrt(np.asarray(X.multiply(X).sum(axis=0)).reshape(-1))
+    norms[norms == 0.0] = 1.0
+    return sp.csc_matrix(X @ sp.diags(1.0 / norms))
+
+
+def l1_svm_lp(feature_matrix, labels, regularizer_weight=1.0):
+    """populate_libsvm_model (generate_l1_svm_lp.jl:54-72) in standard form.
+    Variables [beta(d) free; w(n) >= 0; z(d) free]; rows, all '>=':
+        z - beta >= 0 ; z + beta >= 0 ; w + diag(y) X beta >= 1
+    objective sum(w) + regularizer_weight * sum(z)."""
+    X = sp.csr_matrix(feature_matrix)
+    n, d = X.shape
+    y = np.asarray(labels, dtype=np.float64)
+    Id, In = sp.identity(d, format="csr"), sp.identity(n, format="csr")
+    Zdn, Znd = sp.csr_matrix((d, n)), sp.csr_matrix((n, d))
+    A = sp.bmat([[-Id, Zdn, Id], [Id, Zdn, Id], [sp.diags(y) @ X, In, Znd]], format="csc")
+    b = np.concatenate([np.zeros(2 * d), np.ones(n)])
+    c = np.concatenate([np.zeros(d), np.ones(n), np.full(d, float(regularizer_weight))])
+    lb = np.concatenate([np.full(d, -np.inf), np.zeros(n), np.full(d, -np.inf)])
+    ub = np.full(2 * d + n, np.inf)
+    return linear_programming_problem(lb, ub, c, 0.0, A, b, 0)
+
+
+def synthetic_rcv1_like(num_samples=20242, num_features=47236, nnz_per_row=74, seed=0):
+    """A LIBSVM-rcv1.binary-shaped training set (the file itself is not
+    available offline): Zipf-distributed feature frequencies, positive
+    tf-idf-like values, rows scaled to unit L2 norm, labels from a planted
+    sparse separator with 5% label noise."""
+    rng = np.random.default_rng(seed)
+    N, D, k = int(num_samples), int(num_features), int(nnz_per_row)
+    weights = 1.0 / np.arange(1, D + 1) ** 0.9
+    weights /= weights.sum()
+    counts = np.maximum(1, rng.poisson(k, size=N))
+    rows = np.repeat(np.arange(N), counts)
+    cols = rng.choice(D, size=int(counts.sum()), p=weights)
+    vals = rng.gamma(2.0, 1.0, size=len(cols))
+    X = sp.csr_matrix((vals, (rows, cols)), shape=(N, D))
+    X.sum_duplicates()
+    rn = np.sqrt(np.asarray(X.multiply(X).sum(axis=1)).reshape(-1))
+    X = sp.diags(1.0 / np.maximum(rn, 1e-300)) @ X
+    w = np.zeros(D)
+    sup = rng.choice(D, size=min(200, D), replace=False, p=weights)
+    w[sup] = rng.standard_normal(len(sup))
+    score = X @ w
+    labels = np.where(score >= np.median(score), 1.0, -1.0)
+    flip = rng.random(N) < 0.05
+    labels[flip] *= -1
+    return sp.csc_matrix(X), labels
+
+
+def l1_svm_rcv1_like_lp(num_samples=20242, num_features=47236, nnz_per_row=74,
+                        regularizer_weight=1.0, seed=0):
+    """BASELINE configs[3] on the synthetic rcv1-shaped data."""
+    X, labels = synthetic_rcv1_like(num_samples, num_features, nnz_per_row, seed)
+    return l1_svm_lp(preprocess_training_data(X), labels, regularizer_weight)

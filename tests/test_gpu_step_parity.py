@@ -217,3 +217,22 @@ def test_pagerank_lp_matches_oracle(gpu_required):
     x, y = eng.get_current()
     np.testing.assert_allclose(x, st.x, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(st.x).max()))
     np.testing.assert_allclose(y, st.y, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(st.y).max()))
+
+
+def test_l1_svm_lp_matches_oracle(gpu_required):
+    """BASELINE configs[3] model at reduced size: free variables, all-inequality
+    rows, a dense intercept column (long row in A')."""
+    from firstorderlp_jl_amd.generators import l1_svm_rcv1_like_lp
+    p = l1_svm_rcv1_like_lp(num_samples=3000, num_features=4000, nnz_per_row=30, seed=2)
+    eng, st = _mk(p)
+    assert eng.layout_info()["At_long_rows"] >= 1
+    step, pw = H.initial_step_and_weight(p)
+    state = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    st.step_size, st.primal_weight = step, pw
+    for _ in range(40):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), state)
+        st.take_step_adaptive(0.3, 0.6)
+    assert state.total_number_iterations == st.total_number_iterations
+    x, y = eng.get_current()
+    np.testing.assert_allclose(x, st.x, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(st.x).max()))
+    np.testing.assert_allclose(y, st.y, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(st.y).max()))
