@@ -29,9 +29,13 @@ EXPORTS = [
     "pdhg_dist_exchange_ptr", "pdhg_dist_dual_product_begin",
     "pdhg_dist_dual_product_end", "pdhg_profile_enable", "pdhg_profile_read",
     "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info",
+    "pdhg_set_original_problem", "pdhg_eval_point", "pdhg_save_restart_point",
+    "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound",
+    "pdhg_point_sumsq",
 ]
 
 K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_COUNT = range(6)
+POINT_CURRENT, POINT_AVERAGE, POINT_RESTART = range(3)
 
 
 def build(force=False, verbose=False):
@@ -125,6 +129,20 @@ def lib():
     L.pdhg_kernel_name.argtypes = [i32]
     L.pdhg_layout_info.restype = i32
     L.pdhg_layout_info.argtypes = [_vp, _ip]
+    L.pdhg_set_original_problem.restype = i32
+    L.pdhg_set_original_problem.argtypes = [_vp, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.pdhg_eval_point.restype = i32
+    L.pdhg_eval_point.argtypes = [_vp, i32, _dp]
+    L.pdhg_save_restart_point.restype = i32
+    L.pdhg_save_restart_point.argtypes = [_vp]
+    L.pdhg_distance_to_restart.restype = i32
+    L.pdhg_distance_to_restart.argtypes = [_vp, i32, _dp]
+    L.pdhg_point_sumsq.restype = i32
+    L.pdhg_point_sumsq.argtypes = [_vp, i32, _dp]
+    L.pdhg_get_point.restype = i32
+    L.pdhg_get_point.argtypes = [_vp, i32, _dp, _dp]
+    L.pdhg_trust_region_bound.restype = i32
+    L.pdhg_trust_region_bound.argtypes = [_vp, i32, d, d, d, i32, i32, _dp]
     _lib = L
     return L
 

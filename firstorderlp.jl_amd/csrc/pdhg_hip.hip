@@ -216,7 +216,16 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
       const int ks = A.rowptr[r] - k0;
       const int ke = A.rowptr[r + 1] - k0;
       double s = 0.0;
-      for (int k = ks; k < ke; ++k) s = s + prod[k];
+      int k = ks;
+      // 8 LDS reads in flight, adds still strictly left to right (bit-exact
+      // order); a row of ~2K products is otherwise one LDS latency per add.
+      for (; k + 8 <= ke; k += 8) {
+        const double t0 = prod[k], t1 = prod[k + 1], t2 = prod[k + 2], t3 = prod[k + 3];
+        const double t4 = prod[k + 4], t5 = prod[k + 5], t6 = prod[k + 6], t7 = prod[k + 7];
+        s = s + t0; s = s + t1; s = s + t2; s = s + t3;
+        s = s + t4; s = s + t5; s = s + t6; s = s + t7;
+      }
+      for (; k < ke; ++k) s = s + prod[k];
       row_epilogue<MODE>(e, r, s, acc);
     }
   }
@@ -588,6 +597,235 @@ __global__ __launch_bounds__(FINAL_TPB) void final_reduce_kernel(FinalSpec sp) {
   }
 }
 
+// ============================================================ evaluation branch (N1)
+// Evaluation-cadence kernels (every termination_evaluation_frequency
+// iterations): plain SpMVs into temporaries followed by elementwise kernels
+// with multi-quantity sum/max reductions.  Simplicity over fusion here: the
+// extra vector passes are noise at this cadence.
+constexpr int EV_MAXQ = 20;
+
+template <int NS, int NM>
+struct RedAcc {
+  double s[NS > 0 ? NS : 1];
+  double m[NM > 0 ? NM : 1];
+  __device__ RedAcc() {
+    for (int i = 0; i < (NS > 0 ? NS : 1); ++i) s[i] = 0.0;
+    for (int i = 0; i < (NM > 0 ? NM : 1); ++i) m[i] = 0.0;
+  }
+};
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, WAVE));
+  return v;
+}
+
+// partials[q*stride + blockIdx.x]: q < NS sums, then NM maxes (all maxes are of non-negative values)
+template <int NS, int NM>
+__device__ __forceinline__ void block_reduce_store(const RedAcc<NS, NM> &a, double *partials, int stride) {
+  __shared__ double red[NS + NM][TPB / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) { const double w = wave_sum(a.s[q]); if (lane == 0) red[q][wid] = w; }
+#pragma unroll
+  for (int q = 0; q < NM; ++q) { const double w = wave_max(a.m[q]); if (lane == 0) red[NS + q][wid] = w; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { double t = 0.0; for (int w = 0; w < TPB / WAVE; ++w) t += red[q][w]; partials[q * stride + blockIdx.x] = t; }
+#pragma unroll
+    for (int q = 0; q < NM; ++q) { double t = 0.0; for (int w = 0; w < TPB / WAVE; ++w) t = fmax(t, red[NS + q][w]); partials[(NS + q) * stride + blockIdx.x] = t; }
+  }
+}
+
+__global__ __launch_bounds__(FINAL_TPB) void multi_final_kernel(const double *__restrict__ partials, int stride,
+                                                                int count, int ns, int nm, double *__restrict__ out) {
+  __shared__ double red[3][FINAL_TPB / WAVE];
+  for (int q = 0; q < ns + nm; ++q) {
+    const double *p = partials + (size_t)q * stride;
+    const bool is_max = q >= ns;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < count; i += FINAL_TPB) v = is_max ? fmax(v, p[i]) : v + p[i];
+    v = is_max ? wave_max(v) : wave_sum(v);
+    if ((threadIdx.x & (WAVE - 1)) == 0) red[0][threadIdx.x / WAVE] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < FINAL_TPB / WAVE; ++w) t = is_max ? fmax(t, red[0][w]) : t + red[0][w];
+      out[q] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// Row side of compute_convergence_information / compute_infeasibility_information
+// (iteration_stats_utils.jl:30-63, 157-197, 228-349) on the UNSCALED point:
+//   activities A_o x_o = E .* (A_s x_s),  y_o = y_s ./ E.
+// sums: 0 sum viol^2, 1 sum y_o^2, 2 b_o.y_o, 3 sum max(-y_o,0)^2 (ineq rows)
+// maxs: 0 max|viol|, 1 max|viol_homogeneous|, 2 max|y_o|, 3 max max(-y_o,0)
+__global__ __launch_bounds__(TPB) void eval_rows_kernel(int m, int ne, const double *__restrict__ ax_s,
+                                                        const double *__restrict__ py, const double *__restrict__ E,
+                                                        const double *__restrict__ b_o, double *__restrict__ partials,
+                                                        int stride) {
+  RedAcc<4, 4> a;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < m; i += gridDim.x * TPB) {
+    const double e = E[i];
+    const double act = e * ax_s[i];
+    const double r = b_o[i] - act;
+    const double rh = 0.0 - act;
+    const bool eq = i < ne;
+    const double viol = eq ? r : fmax(r, 0.0);
+    const double violh = eq ? rh : fmax(rh, 0.0);
+    const double yo = py[i] / e;
+    const double dres = eq ? 0.0 : fmax(-yo, 0.0);
+    a.s[0] += viol * viol; a.s[1] += yo * yo; a.s[2] += b_o[i] * yo; a.s[3] += dres * dres;
+    a.m[0] = fmax(a.m[0], fabs(viol)); a.m[1] = fmax(a.m[1], fabs(violh));
+    a.m[2] = fmax(a.m[2], fabs(yo)); a.m[3] = fmax(a.m[3], dres);
+  }
+  block_reduce_store<4, 4>(a, partials, stride);
+}
+
+// Column side (LP): g = c_o - D .* (A_s' y_s), reduced costs, bound violations,
+// and the homogeneous (c = 0) dual statistics for the infeasibility certificate.
+// sums: 0 sum resid^2, 1 sum bound*rc, 2 sum x_o^2, 3 c_o.x_o, 4 sum bound-viol^2, 5 sum bound*rc_h
+// maxs: 0 max|resid|, 1 max|x_o|, 2 max bound viol, 3 max|resid_h|, 4 max|rc_h|, 5 max ray bound viol
+__global__ __launch_bounds__(TPB) void eval_cols_kernel(int n, const double *__restrict__ aty_s,
+                                                        const double *__restrict__ px, const double *__restrict__ D,
+                                                        const double *__restrict__ c_o, const double *__restrict__ lb_o,
+                                                        const double *__restrict__ ub_o, double *__restrict__ partials,
+                                                        int stride) {
+  RedAcc<6, 6> a;
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) {
+    const double d = D[j];
+    const double aty = d * aty_s[j];
+    const double xo = px[j] / d;
+    const double lb = lb_o[j], ub = ub_o[j];
+    const bool lbf = isfinite(lb), ubf = isfinite(ub);
+    // compute_reduced_costs_from_primal_gradient        iteration_stats_utils.jl:128-148
+    const double g = c_o[j] - aty;
+    const double rc = ((g > 0.0) ? lbf : ubf) ? g : 0.0;
+    const double resid = g - rc;
+    const double contrib = (rc == 0.0) ? 0.0 : ((rc > 0.0 ? lb : ub) * rc);
+    const double gh = 0.0 - aty;
+    const double rch = ((gh > 0.0) ? lbf : ubf) ? gh : 0.0;
+    const double residh = gh - rch;
+    const double contribh = (rch == 0.0) ? 0.0 : ((rch > 0.0 ? lb : ub) * rch);
+    const double lv = fmax(lb - xo, 0.0), uv = fmax(xo - ub, 0.0);
+    const double rayv = fmax(lbf ? fmax(-xo, 0.0) : 0.0, ubf ? fmax(xo, 0.0) : 0.0);
+    a.s[0] += resid * resid; a.s[1] += contrib; a.s[2] += xo * xo; a.s[3] += c_o[j] * xo;
+    a.s[4] += lv * lv + uv * uv; a.s[5] += contribh;
+    a.m[0] = fmax(a.m[0], fabs(resid)); a.m[1] = fmax(a.m[1], fabs(xo)); a.m[2] = fmax(a.m[2], fmax(lv, uv));
+    a.m[3] = fmax(a.m[3], fabs(residh)); a.m[4] = fmax(a.m[4], fabs(rch)); a.m[5] = fmax(a.m[5], rayv);
+  }
+  block_reduce_store<6, 6>(a, partials, stride);
+}
+
+// sum (a-b)^2 over two vector pairs: distances to the last restart point
+// (saddle_point.jl:445-477, 911-920; weights are uniform per block in PDHG).
+__global__ __launch_bounds__(TPB) void dist2_kernel(int n, int m, const double *__restrict__ xa,
+                                                    const double *__restrict__ xb, const double *__restrict__ ya,
+                                                    const double *__restrict__ yb, double *__restrict__ partials,
+                                                    int stride) {
+  RedAcc<2, 0> a;
+  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
+  for (int j = tid; j < n; j += st) { const double d = xb ? xa[j] - xb[j] : xa[j]; a.s[0] += d * d; }
+  for (int i = tid; i < m; i += st) { const double d = yb ? ya[i] - yb[i] : ya[i]; a.s[1] += d * d; }
+  block_reduce_store<2, 0>(a, partials, stride);
+}
+
+// bound_optimal_objective (trust_region_utils.jl:271-360) set-up on the SCALED
+// problem at point z = (x, y): gradient g = [c - A'y ; -(b - A x)], direction
+// d = -g/w (0 if the bound blocks it), breakpoint thr (trust_region_utils.jl:86-110).
+// range: 0 both blocks (EUCLIDEAN_NORM), 1 primal only, 2 dual only (MAX_NORM halves).
+// sums: 0 c.x, 1 x.(A'y), 2 y.b, 3 sum_{thr=inf} w d^2, 4 sum g^2 (in range),
+//       5 sum w d^2 (in range), 6 sum g.d primal, 7 sum g.d dual, 8 sum x^2, 9 sum y^2
+// maxs: 0 max finite thr (in range)
+__global__ __launch_bounds__(TPB) void tr_setup_kernel(int n, int m, int ne, const double *__restrict__ px,
+                                                       const double *__restrict__ py, const double *__restrict__ aty_s,
+                                                       const double *__restrict__ ax_s, const double *__restrict__ c_s,
+                                                       const double *__restrict__ b_s, const double *__restrict__ lb_s,
+                                                       const double *__restrict__ ub_s, double wp, double wd, int range,
+                                                       double *__restrict__ gvec, double *__restrict__ dir,
+                                                       double *__restrict__ thr, double *__restrict__ partials,
+                                                       int stride) {
+  RedAcc<10, 1> a;
+  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
+  for (int k = tid; k < n + m; k += st) {
+    const bool primal = k < n;
+    const int i = primal ? k : k - n;
+    double z, g, lo, hi, w;
+    if (primal) {
+      z = px[i]; g = c_s[i] - aty_s[i]; lo = lb_s[i]; hi = ub_s[i]; w = wp;
+      a.s[0] += c_s[i] * z; a.s[1] += z * aty_s[i]; a.s[8] += z * z;
+    } else {
+      z = py[i]; g = -(b_s[i] - ax_s[i]); lo = (i < ne) ? -INFINITY : 0.0; hi = INFINITY; w = wd;
+      a.s[2] += z * b_s[i]; a.s[9] += z * z;
+    }
+    const bool in_range = (range == 0) || (range == 1 && primal) || (range == 2 && !primal);
+    double d = 0.0, t = 0.0;
+    if (in_range && !((z >= hi && g <= 0.0) || (z <= lo && g >= 0.0))) {
+      d = -g / w;
+      if (d > 0.0) t = (hi - z) / d;
+      else if (d < 0.0) t = (lo - z) / d;
+      else t = 0.0;
+    }
+    gvec[k] = g; dir[k] = d; thr[k] = t;
+    if (in_range) {
+      a.s[4] += g * g;
+      a.s[5] += w * d * d;
+      if (primal) a.s[6] += g * d; else a.s[7] += g * d;
+      if (isinf(t)) a.s[3] += w * d * d; else a.m[0] = fmax(a.m[0], t);
+    }
+  }
+  block_reduce_store<10, 1>(a, partials, stride);
+}
+
+// radius^2 as a function of the step t at K probe values:
+//   low_k = sum_{thr <= t_k} w d^2 thr^2 ,  high_k = sum_{thr > t_k} w d^2
+constexpr int TR_K = 7;
+struct TrProbes { double t[TR_K]; };
+__global__ __launch_bounds__(TPB) void tr_probe_kernel(int n, int total, const double *__restrict__ dir,
+                                                       const double *__restrict__ thr, double wp, double wd,
+                                                       TrProbes pr, double *__restrict__ partials, int stride) {
+  RedAcc<2 * TR_K, 0> a;
+  for (int k = blockIdx.x * TPB + threadIdx.x; k < total; k += gridDim.x * TPB) {
+    const double d = dir[k];
+    if (d == 0.0) continue;
+    const double w = (k < n) ? wp : wd;
+    const double t = thr[k];
+    const double wd2 = w * d * d;
+    const double lowc = wd2 * t * t;   // inf for thr = inf: never selected below
+#pragma unroll
+    for (int q = 0; q < TR_K; ++q) {
+      if (t <= pr.t[q]) a.s[2 * q] += lowc; else a.s[2 * q + 1] += wd2;
+    }
+  }
+  block_reduce_store<2 * TR_K, 0>(a, partials, stride);
+}
+
+// value parts sum g_i (clamp(z_i + t d_i) - z_i), primal block and dual block
+__global__ __launch_bounds__(TPB) void tr_value_kernel(int n, int m, int ne, const double *__restrict__ px,
+                                                       const double *__restrict__ py, const double *__restrict__ lb_s,
+                                                       const double *__restrict__ ub_s, const double *__restrict__ gvec,
+                                                       const double *__restrict__ dir, double t,
+                                                       double *__restrict__ partials, int stride) {
+  RedAcc<2, 0> a;
+  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
+  for (int k = tid; k < n + m; k += st) {
+    const bool primal = k < n;
+    const int i = primal ? k : k - n;
+    const double d = dir[k];
+    if (d == 0.0) continue;
+    const double z = primal ? px[i] : py[i];
+    const double lo = primal ? lb_s[i] : ((i < ne) ? -INFINITY : 0.0);
+    const double hi = primal ? ub_s[i] : INFINITY;
+    const double cand = fmin(fmax(z + t * d, lo), hi);   // clamp.(center + t*direction, lb, ub)
+    const double v = gvec[k] * (cand - z);
+    if (primal) a.s[0] += v; else a.s[1] += v;
+  }
+  block_reduce_store<2, 0>(a, partials, stride);
+}
+
 // One-quantity variant writing to a device slot (row-partitioned form).
 __global__ __launch_bounds__(FINAL_TPB) void final_to_slot_kernel(const double *p, int cnt, double *slot) {
   __shared__ double red[3][FINAL_TPB / WAVE];
@@ -804,6 +1042,16 @@ struct pdhg_handle {
 
   double *h_out = nullptr;  // pinned, device-visible, 8 doubles
   double *d_out = nullptr;
+
+  // evaluation branch (N1), allocated on first use
+  double *E = nullptr, *Dv = nullptr, *c_o = nullptr, *b_o = nullptr, *lb_o = nullptr, *ub_o = nullptr;
+  double *x_r = nullptr, *y_r = nullptr;          // last restart point
+  double *px_avg = nullptr, *py_avg = nullptr;    // materialised average
+  double *ev_ax = nullptr, *ev_aty = nullptr;     // A*x (m), A'*y (n) at the evaluated point
+  double *tr_g = nullptr, *tr_dir = nullptr, *tr_thr = nullptr;  // n+m each
+  double *ev_partials = nullptr, *ev_out = nullptr, *ev_host = nullptr;
+  int ev_grid = 1;
+  bool has_original = false;
 
   bool profile = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1122,9 +1370,12 @@ void pdhg_destroy(pdhg_handle *h) {
   free_csr_dev(h->A); free_csr_dev(h->At); free_csr_dev(h->Q); free_csr_dev(h->Qt);
   double *bufs[] = {h->c, h->b, h->lb, h->ub, h->x, h->x_next, h->xbar, h->y, h->y_next,
                     h->aty, h->aty_next, h->sum_x, h->sum_y, h->qx, h->tmp_n, h->tmp_n2,
-                    h->tmp_m, h->pA, h->pAt, h->pQ, h->d_out};
+                    h->tmp_m, h->pA, h->pAt, h->pQ, h->d_out, h->E, h->Dv, h->c_o, h->b_o, h->lb_o,
+                    h->ub_o, h->x_r, h->y_r, h->px_avg, h->py_avg, h->ev_ax, h->ev_aty, h->tr_g,
+                    h->tr_dir, h->tr_thr, h->ev_partials, h->ev_out};
   for (double *p : bufs) if (p) (void)hipFree(p);
   if (h->h_out) (void)hipHostFree(h->h_out);
+  if (h->ev_host) (void)hipHostFree(h->ev_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1331,6 +1582,235 @@ int pdhg_dist_dual_product_end(pdhg_handle *h) {
   int rc = check_handle(h);
   if (rc) return rc;
   std::swap(h->aty, h->aty_next);
+  return 0;
+}
+
+// ---- evaluation branch on the device (N1) -----------------------------------
+
+static int ev_alloc(pdhg_handle *h) {
+  if (h->ev_partials) return 0;
+  int rc;
+  h->ev_grid = ew_grid(std::max(h->n, h->m) + 1);
+  if ((rc = alloc_zero(&h->ev_partials, (int64_t)EV_MAXQ * h->ev_grid))) return rc;
+  if ((rc = alloc_zero(&h->ev_out, EV_MAXQ))) return rc;
+  HIP_TRY(hipHostMalloc((void **)&h->ev_host, EV_MAXQ * sizeof(double), hipHostMallocDefault));
+  if ((rc = alloc_zero(&h->ev_ax, h->m))) return rc;
+  if ((rc = alloc_zero(&h->ev_aty, h->n))) return rc;
+  if ((rc = alloc_zero(&h->px_avg, h->n))) return rc;
+  if ((rc = alloc_zero(&h->py_avg, h->m))) return rc;
+  if ((rc = alloc_zero(&h->x_r, h->n))) return rc;   // zeros == the initial restart point (pdhg.jl:869)
+  if ((rc = alloc_zero(&h->y_r, h->m))) return rc;
+  return 0;
+}
+
+static int ev_finish(pdhg_handle *h, int ns, int nm, double *out) {
+  hipLaunchKernelGGL(multi_final_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->ev_partials, h->ev_grid,
+                     h->ev_grid, ns, nm, h->ev_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h->ev_host, h->ev_out, (ns + nm) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int q = 0; q < ns + nm; ++q) out[q] = h->ev_host[q];
+  return 0;
+}
+
+static int select_point(pdhg_handle *h, int point, const double **px, const double **py) {
+  int rc = ev_alloc(h);
+  if (rc) return rc;
+  if (point == PDHG_POINT_CURRENT) { *px = h->x; *py = h->y; return 0; }
+  if (point == PDHG_POINT_RESTART) { *px = h->x_r; *py = h->y_r; return 0; }
+  if (point == PDHG_POINT_AVERAGE) {
+    if (h->sum_x_count == 0 || h->sum_y_count == 0) return fail(-1, "average is empty");
+    hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->sum_x, h->sum_x_weights, h->px_avg);
+    hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, (int)h->m, h->sum_y, h->sum_y_weights, h->py_avg);
+    HIP_TRY(hipGetLastError());
+    *px = h->px_avg; *py = h->py_avg;
+    return 0;
+  }
+  return fail(-1, "unknown point selector");
+}
+
+int pdhg_set_original_problem(pdhg_handle *h, const double *constraint_rescaling,
+                              const double *variable_rescaling, const double *c_o, const double *b_o,
+                              const double *lb_o, const double *ub_o) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (h->has_q) return fail(-2, "device evaluation supports LPs only");
+  if (!constraint_rescaling || !variable_rescaling || !c_o || !lb_o || !ub_o || (h->m > 0 && !b_o))
+    return fail(-1, "null input array");
+  auto up = [&](double **dst, const double *src, int64_t len) -> int {
+    if (!*dst) { int r2 = alloc_zero(dst, len); if (r2) return r2; }
+    if (len > 0) HIP_TRY(hipMemcpy(*dst, src, sizeof(double) * (size_t)len, hipMemcpyHostToDevice));
+    return 0;
+  };
+  if ((rc = up(&h->E, constraint_rescaling, h->m))) return rc;
+  if ((rc = up(&h->Dv, variable_rescaling, h->n))) return rc;
+  if ((rc = up(&h->c_o, c_o, h->n))) return rc;
+  if ((rc = up(&h->b_o, b_o, h->m))) return rc;
+  if ((rc = up(&h->lb_o, lb_o, h->n))) return rc;
+  if ((rc = up(&h->ub_o, ub_o, h->n))) return rc;
+  h->has_original = true;
+  return ev_alloc(h);
+}
+
+int pdhg_eval_point(pdhg_handle *h, int point, double out[20]) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!h->has_original) return fail(-1, "pdhg_set_original_problem has not been called");
+  const double *px, *py;
+  if ((rc = select_point(h, point, &px, &py))) return rc;
+  EpiArgs e{};
+  e.out = h->ev_ax;
+  if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, px, e))) return rc;
+  e.out = h->ev_aty;
+  if ((rc = launch_spmv<MODE_PLAIN>(h, h->At, py, e))) return rc;
+  hipLaunchKernelGGL(eval_rows_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->m, (int)h->num_eq,
+                     h->ev_ax, py, h->E, h->b_o, h->ev_partials, h->ev_grid);
+  if ((rc = ev_finish(h, 4, 4, out))) return rc;
+  hipLaunchKernelGGL(eval_cols_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, h->ev_aty, px,
+                     h->Dv, h->c_o, h->lb_o, h->ub_o, h->ev_partials, h->ev_grid);
+  return ev_finish(h, 6, 6, out + 8);
+}
+
+int pdhg_save_restart_point(pdhg_handle *h) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if ((rc = ev_alloc(h))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->x_r, h->x, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->y_r, h->y, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+
+int pdhg_distance_to_restart(pdhg_handle *h, int point, double out[2]) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  const double *px, *py;
+  if ((rc = select_point(h, point, &px, &py))) return rc;
+  hipLaunchKernelGGL(dist2_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m, px, h->x_r,
+                     py, h->y_r, h->ev_partials, h->ev_grid);
+  return ev_finish(h, 2, 0, out);
+}
+
+int pdhg_point_sumsq(pdhg_handle *h, int point, double out[2]) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  const double *px, *py;
+  if ((rc = select_point(h, point, &px, &py))) return rc;
+  hipLaunchKernelGGL(dist2_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m, px,
+                     (const double *)nullptr, py, (const double *)nullptr, h->ev_partials, h->ev_grid);
+  return ev_finish(h, 2, 0, out);
+}
+
+int pdhg_get_point(pdhg_handle *h, int point, double *x, double *y) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  const double *px, *py;
+  if ((rc = select_point(h, point, &px, &py))) return rc;
+  if (x) HIP_TRY(hipMemcpyAsync(x, px, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  if (y) HIP_TRY(hipMemcpyAsync(y, py, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static inline uint64_t d2bits(double v) { uint64_t b; memcpy(&b, &v, 8); return b; }
+static inline double bits2d(uint64_t b) { double v; memcpy(&v, &b, 8); return v; }
+
+int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm, double dual_weight_norm,
+                            double radius, int range, int approximate, double out[8]) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (h->has_q) return fail(-2, "device trust region supports LPs only");
+  if (range < 0 || range > 2) return fail(-1, "range must be 0, 1 or 2");
+  const double *px, *py;
+  if ((rc = select_point(h, point, &px, &py))) return rc;
+  const int64_t total = h->n + h->m;
+  if (!h->tr_g) {
+    if ((rc = alloc_zero(&h->tr_g, total))) return rc;
+    if ((rc = alloc_zero(&h->tr_dir, total))) return rc;
+    if ((rc = alloc_zero(&h->tr_thr, total))) return rc;
+  }
+  const double wp = primal_weight_norm, wd = dual_weight_norm;
+  EpiArgs e{};
+  e.out = h->ev_ax;
+  if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, px, e))) return rc;
+  e.out = h->ev_aty;
+  if ((rc = launch_spmv<MODE_PLAIN>(h, h->At, py, e))) return rc;
+  hipLaunchKernelGGL(tr_setup_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m,
+                     (int)h->num_eq, px, py, h->ev_aty, h->ev_ax, h->c, h->b, h->lb, h->ub, wp, wd, range,
+                     h->tr_g, h->tr_dir, h->tr_thr, h->ev_partials, h->ev_grid);
+  double r[EV_MAXQ];
+  if ((rc = ev_finish(h, 10, 1, r))) return rc;
+  // compute_lagrangian_value (saddle_point.jl:1109-1120) without objective_constant
+  out[0] = r[0] - r[1] + r[2];
+  out[1] = out[2] = 0.0;
+  out[3] = r[8]; out[4] = r[9];
+  out[5] = 0.0; out[6] = 0.0; out[7] = 0.0;
+  const double hinf = r[3], g2 = r[4], wd2_all = r[5], tmax = r[10];
+  const double r2 = radius * radius;
+  if (approximate) {
+    // approximately_solve_bound_constrained_trust_region (trust_region_utils.jl:194-224)
+    const double dn = sqrt(wd2_all);
+    const double sc = dn > 0.0 ? radius / dn : 1.0;
+    out[1] = sc * r[6]; out[2] = sc * r[7];
+    return 0;
+  }
+  if (radius == 0.0 || g2 == 0.0) return 0;   // trust_region_utils.jl:81-83
+  // Find t* with radius^2(t*) = r2, radius^2(t) = low(t) + t^2 high(t).  The
+  // reference eliminates breakpoints by repeated medians (trust_region_utils.jl:112-165);
+  // here: TR_K-ary search over the IEEE bit patterns of t in [0, max finite
+  // breakpoint] until no breakpoint lies strictly inside the bracket, then the
+  // same closed form (trust_region_utils.jl:167-175).
+  auto probe = [&](const TrProbes &pr, double *lowhigh) -> int {
+    hipLaunchKernelGGL(tr_probe_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)total,
+                       h->tr_dir, h->tr_thr, wp, wd, pr, h->ev_partials, h->ev_grid);
+    return ev_finish(h, 2 * TR_K, 0, lowhigh);
+  };
+  double lh[2 * TR_K];
+  TrProbes pr;
+  for (int q = 0; q < TR_K; ++q) pr.t[q] = tmax;
+  if ((rc = probe(pr, lh))) return rc;
+  int passes = 1;
+  double tstar;
+  if (lh[0] + tmax * tmax * lh[1] <= r2) {
+    // every finite breakpoint is reached before the radius
+    if (hinf <= 0.0) tstar = tmax;                       // "all bounds hit" special case
+    else tstar = sqrt((r2 - lh[0]) / hinf);
+  } else {
+    uint64_t lo = 0, hi = d2bits(tmax);
+    double low_lo = 0.0, high_lo = wd2_all;              // at t = 0: nothing clamped except thr == 0 entries
+    bool have_lo = false;
+    while (hi - lo > 1) {
+      uint64_t pb[TR_K];
+      const uint64_t span = hi - lo;
+      for (int q = 0; q < TR_K; ++q) {
+        uint64_t off = (uint64_t)(((__uint128_t)span * (uint64_t)(q + 1)) / (uint64_t)(TR_K + 1));
+        if (off == 0) off = 1;
+        if (off >= span) off = span - 1;
+        pb[q] = lo + off;
+        pr.t[q] = bits2d(pb[q]);
+      }
+      if ((rc = probe(pr, lh))) return rc;
+      ++passes;
+      uint64_t nlo = lo, nhi = hi;
+      for (int q = 0; q < TR_K; ++q) {
+        const double f = lh[2 * q] + pr.t[q] * pr.t[q] * lh[2 * q + 1];
+        if (f <= r2) { if (pb[q] > nlo) { nlo = pb[q]; low_lo = lh[2 * q]; high_lo = lh[2 * q + 1]; have_lo = true; } }
+        else { if (pb[q] < nhi) nhi = pb[q]; }
+      }
+      lo = nlo; hi = nhi;
+    }
+    if (!have_lo) {  // bracket collapsed at t = 0: evaluate low/high there
+      for (int q = 0; q < TR_K; ++q) pr.t[q] = 0.0;
+      if ((rc = probe(pr, lh))) return rc;
+      ++passes;
+      low_lo = lh[0]; high_lo = lh[1];
+    }
+    tstar = high_lo > 0.0 ? sqrt(fmax(r2 - low_lo, 0.0) / high_lo) : bits2d(lo);
+  }
+  hipLaunchKernelGGL(tr_value_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m,
+                     (int)h->num_eq, px, py, h->lb, h->ub, h->tr_g, h->tr_dir, tstar, h->ev_partials, h->ev_grid);
+  double vv[2];
+  if ((rc = ev_finish(h, 2, 0, vv))) return rc;
+  out[1] = vv[0]; out[2] = vv[1]; out[5] = tstar; out[6] = (double)passes;
   return 0;
 }
 

@@ -156,6 +156,44 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_spmv_t(self._h, _pd(y), _pd(out)))
         return out
 
+    # ---- evaluation branch on the device (LP only) ---------------------------------
+    supports_device_evaluation = True
+
+    def set_original_problem(self, constraint_rescaling, variable_rescaling, c_o, b_o, lb_o, ub_o):
+        arrs = [_d(a) for a in (constraint_rescaling, variable_rescaling, c_o, b_o, lb_o, ub_o)]
+        _lib.check(self._L.pdhg_set_original_problem(self._h, *[_pd(a) for a in arrs]))
+
+    def eval_point(self, point):
+        out = np.empty(20)
+        _lib.check(self._L.pdhg_eval_point(self._h, point, _pd(out)))
+        return out
+
+    def save_restart_point(self):
+        _lib.check(self._L.pdhg_save_restart_point(self._h))
+
+    def distance_to_restart(self, point):
+        out = np.empty(2)
+        _lib.check(self._L.pdhg_distance_to_restart(self._h, point, _pd(out)))
+        return float(out[0]), float(out[1])
+
+    def point_sumsq(self, point):
+        out = np.empty(2)
+        _lib.check(self._L.pdhg_point_sumsq(self._h, point, _pd(out)))
+        return float(out[0]), float(out[1])
+
+    def get_point(self, point):
+        x, y = np.empty(self.n), np.empty(self.m)
+        _lib.check(self._L.pdhg_get_point(self._h, point, _pd(x), _pd(y)))
+        return x, y
+
+    def trust_region_bound(self, point, primal_weight_norm, dual_weight_norm, radius,
+                           norm_range, approximate=False):
+        out = np.empty(8)
+        _lib.check(self._L.pdhg_trust_region_bound(
+            self._h, point, primal_weight_norm, dual_weight_norm, radius, norm_range,
+            int(bool(approximate)), _pd(out)))
+        return out
+
     # ---- row-partitioned form --------------------------------------------------
     def dist_trial_begin(self, step_size, primal_weight, theta=1.0):
         _lib.check(self._L.pdhg_dist_trial_begin(self._h, step_size,

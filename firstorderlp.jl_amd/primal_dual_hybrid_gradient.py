@@ -170,7 +170,8 @@ def take_step(step_params, solver_state, is_lp=True):
 # ==============================================================================
 import time as _time
 
-from .iteration_stats_utils import evaluate_unscaled_iteration_stats
+from .evaluation import (POINT_AVERAGE, POINT_CURRENT, DeviceEvaluator,
+                         HostEvaluator)
 from .preprocess import rescale_problem, validate
 from .quadratic_programming import is_linear_programming_problem
 from .saddle_point import (RestartParameters, compute_new_primal_weight,
@@ -341,8 +342,11 @@ def optimize(params, original_problem, engine_factory=None):
     start_time = _time.time()
     time_spent_doing_basic_algorithm = 0.0
 
-    x0, y0 = engine.get_current()
-    last_restart_info = create_last_restart_info(problem, x0, y0)
+    if is_lp and getattr(engine, "supports_device_evaluation", False):
+        ev = DeviceEvaluator(engine, scaled_problem, qp_cache)
+    else:
+        ev = HostEvaluator(engine, scaled_problem, qp_cache, ops, original_ops)
+    last_restart_info = create_last_restart_info()
 
     termination_criteria = params.termination_criteria
     iteration_limit = termination_criteria.iteration_limit
@@ -358,30 +362,26 @@ def optimize(params, original_problem, engine_factory=None):
             solver_state.cumulative_kkt_passes += KKT_PASSES_PER_TERMINATION_EVALUATION
             count_x, count_y, _, _ = engine.average_info()
             if solver_state.numerical_error or count_x == 0 or count_y == 0:
-                avg_primal_solution, avg_dual_solution = engine.get_current()
+                avg_point = POINT_CURRENT
             else:
-                avg_primal_solution, avg_dual_solution = engine.get_average()
+                avg_point = POINT_AVERAGE
 
-            current_iteration_stats = evaluate_unscaled_iteration_stats(
-                scaled_problem, qp_cache, params.termination_criteria,
-                params.record_iteration_stats, avg_primal_solution,
-                avg_dual_solution, iteration, _time.time() - start_time,
-                solver_state.cumulative_kkt_passes,
-                termination_criteria.eps_optimal_absolute,
-                termination_criteria.eps_optimal_relative,
+            current_iteration_stats = ev.iteration_stats(
+                avg_point, termination_criteria, params.record_iteration_stats, iteration,
+                _time.time() - start_time, solver_state.cumulative_kkt_passes,
                 solver_state.step_size, solver_state.primal_weight,
-                PointType.POINT_TYPE_AVERAGE_ITERATE, original_ops)
+                PointType.POINT_TYPE_AVERAGE_ITERATE)
             method_specific_stats = current_iteration_stats.method_specific_stats
             method_specific_stats["time_spent_doing_basic_algorithm"] = \
                 time_spent_doing_basic_algorithm
 
-            primal_norm_params, dual_norm_params = define_norms(
-                primal_size, dual_size, solver_state.step_size,
-                solver_state.primal_weight)
+            # define_norms (pdhg.jl:265-277): uniform weights, kept as scalars
+            with np.errstate(divide="ignore"):
+                primal_weight_norm = float(np.float64(1) / solver_state.step_size * solver_state.primal_weight)
+                dual_weight_norm = float(np.float64(1) / solver_state.step_size / solver_state.primal_weight)
             update_objective_bound_estimates(
-                current_iteration_stats.method_specific_stats, problem,
-                avg_primal_solution, avg_dual_solution, primal_norm_params,
-                dual_norm_params, ops)
+                current_iteration_stats.method_specific_stats, ev, avg_point,
+                primal_weight_norm, dual_weight_norm)
             termination_reason = check_termination_criteria(
                 termination_criteria, qp_cache, current_iteration_stats)
             if solver_state.numerical_error and termination_reason is False:
@@ -398,6 +398,7 @@ def optimize(params, original_problem, engine_factory=None):
                 if params.verbosity >= 2:
                     print(f"Terminated after {iteration - 1} iterations: "
                           f"{termination_reason.name}")
+                avg_primal_solution, avg_dual_solution = ev.solution(avg_point)
                 out = unscaled_saddle_point_output(
                     scaled_problem, avg_primal_solution, avg_dual_solution,
                     termination_reason, iteration - 1, iteration_stats)
@@ -406,10 +407,9 @@ def optimize(params, original_problem, engine_factory=None):
                 return out
 
             current_iteration_stats.restart_used = run_restart_scheme(
-                problem, engine, last_restart_info, iteration - 1,
-                primal_norm_params, dual_norm_params,
-                solver_state.primal_weight, params.verbosity,
-                params.restart_params, ops)
+                ev, last_restart_info, iteration - 1, primal_weight_norm,
+                dual_weight_norm, solver_state.primal_weight, params.verbosity,
+                params.restart_params)
 
             if current_iteration_stats.restart_used != RestartChoice.RESTART_CHOICE_NO_RESTART:
                 solver_state.primal_weight = compute_new_primal_weight(

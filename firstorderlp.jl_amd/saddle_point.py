@@ -19,6 +19,12 @@ from .trust_region_utils import (EUCLIDEAN_NORM, MAX_NORM,
 EPS = float(np.finfo(np.float64).eps)
 
 
+def _div(a, b):
+    """Julia float division (x/0 -> Inf/NaN, no exception)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return float(np.float64(a) / np.float64(b))
+
+
 @dataclass
 class SaddlePointOutput:
     """saddle_point.jl:22-53"""
@@ -98,9 +104,9 @@ def construct_restart_parameters(restart_scheme, restart_to_current_metric,
 
 @dataclass
 class RestartInfo:
-    """saddle_point.jl:158-198"""
-    primal_solution: np.ndarray
-    dual_solution: np.ndarray
+    """saddle_point.jl:158-198.  The restart point's vectors
+    (primal_solution / dual_solution) are held by the evaluator -- on the
+    device in the product path."""
     last_restart_localized_duality_gap: Optional[OptimalObjectiveBoundResult]
     last_restart_length: int
     primal_distance_moved_last_restart_period: float
@@ -108,53 +114,32 @@ class RestartInfo:
     gap_reduction_ratio_last_trial: float
 
 
-def create_last_restart_info(problem, primal_solution, dual_solution):
-    """saddle_point.jl:200-213"""
-    return RestartInfo(primal_solution.copy(), dual_solution.copy(), None, 1,
-                       0.0, 0.0, 1.0)
+def create_last_restart_info():
+    """saddle_point.jl:200-213 (the point itself is the evaluator's restart point)."""
+    return RestartInfo(None, 1, 0.0, 0.0, 1.0)
 
 
-def compute_localized_duality_gap(problem, primal_solution, dual_solution,
-                                  primal_norm_params, dual_norm_params,
-                                  distance_to_optimality, norm,
-                                  use_approximate_localized_duality_gap, ops):
-    """saddle_point.jl:134-156"""
-    return bound_optimal_objective(
-        problem, primal_solution, dual_solution, primal_norm_params,
-        dual_norm_params, distance_to_optimality, norm, ops,
-        solve_approximately=use_approximate_localized_duality_gap)
-
-
-def _div(a, b):
-    with np.errstate(divide="ignore", invalid="ignore"):
-        return float(np.float64(a) / np.float64(b))
-
-
-def compute_localized_duality_gaps(problem, current_primal_solution,
-                                   current_dual_solution, avg_primal_solution,
-                                   avg_dual_solution, primal_norm_params,
-                                   dual_norm_params, last_restart_info,
-                                   use_approximate_localized_duality_gap, ops):
-    """saddle_point.jl:432-496"""
-    lri = last_restart_info
-    distance_traveled_by_average = math.sqrt(
-        weighted_norm(avg_primal_solution - lri.primal_solution, primal_norm_params) ** 2 +
-        weighted_norm(avg_dual_solution - lri.dual_solution, dual_norm_params) ** 2)
-    gap_at_average = compute_localized_duality_gap(
-        problem, avg_primal_solution, avg_dual_solution, primal_norm_params,
-        dual_norm_params, distance_traveled_by_average, EUCLIDEAN_NORM,
-        use_approximate_localized_duality_gap, ops)
-    distance_traveled_by_current = math.sqrt(
-        weighted_norm(current_primal_solution - lri.primal_solution, primal_norm_params) ** 2 +
-        weighted_norm(current_dual_solution - lri.dual_solution, dual_norm_params) ** 2)
-    gap_at_current = compute_localized_duality_gap(
-        problem, current_primal_solution, current_dual_solution,
-        primal_norm_params, dual_norm_params, distance_traveled_by_current,
-        EUCLIDEAN_NORM, use_approximate_localized_duality_gap, ops)
+def compute_localized_duality_gaps(ev, primal_weight_norm, dual_weight_norm,
+                                   use_approximate_localized_duality_gap):
+    """saddle_point.jl:432-496.  ``ev`` is an evaluator (evaluation.py); the norm
+    weights are uniform per block in PDHG (define_norms, pdhg.jl:265-277), so
+    weighted_norm(v, w)^2 == w * sum(v^2)."""
+    from .evaluation import POINT_AVERAGE, POINT_CURRENT
+    dx2, dy2 = ev.distance_sq_to_restart(POINT_AVERAGE)
+    distance_traveled_by_average = math.sqrt(primal_weight_norm * dx2 + dual_weight_norm * dy2)
+    gap_at_average = ev.bound(POINT_AVERAGE, primal_weight_norm, dual_weight_norm,
+                              distance_traveled_by_average, EUCLIDEAN_NORM,
+                              use_approximate_localized_duality_gap)
+    cx2, cy2 = ev.distance_sq_to_restart(POINT_CURRENT)
+    distance_traveled_by_current = math.sqrt(primal_weight_norm * cx2 + dual_weight_norm * cy2)
+    gap_at_current = ev.bound(POINT_CURRENT, primal_weight_norm, dual_weight_norm,
+                              distance_traveled_by_current, EUCLIDEAN_NORM,
+                              use_approximate_localized_duality_gap)
     return dict(gap_at_average=gap_at_average,
                 distance_traveled_by_average=distance_traveled_by_average,
                 gap_at_current=gap_at_current,
-                distance_traveled_by_current=distance_traveled_by_current)
+                distance_traveled_by_current=distance_traveled_by_current,
+                average_distance_sq=(dx2, dy2))
 
 
 def should_reset_to_average(current, distance_traveled_by_current, average,
@@ -172,18 +157,18 @@ def should_reset_to_average(current, distance_traveled_by_current, average,
 
 
 def should_do_adaptive_restart_normalized_duality_gap(
-        problem, primal_norm_params, dual_norm_params, candidate_localized_gap,
+        ev, primal_weight_norm, dual_weight_norm, candidate_localized_gap,
         candidate_distance_traveled, restart_params, last_restart_info,
-        use_approximate_localized_duality_gap, primal_weight, ops):
+        use_approximate_localized_duality_gap, primal_weight):
     """saddle_point.jl:551-596"""
+    from .evaluation import POINT_RESTART
     lri = last_restart_info
     distance_traveled_last_restart = math.sqrt(
         lri.primal_distance_moved_last_restart_period ** 2 * primal_weight +
         lri.dual_distance_moved_last_restart_period ** 2 / primal_weight)
-    last_restart = compute_localized_duality_gap(
-        problem, lri.primal_solution, lri.dual_solution, primal_norm_params,
-        dual_norm_params, distance_traveled_last_restart, EUCLIDEAN_NORM,
-        use_approximate_localized_duality_gap, ops)
+    last_restart = ev.bound(POINT_RESTART, primal_weight_norm, dual_weight_norm,
+                            distance_traveled_last_restart, EUCLIDEAN_NORM,
+                            use_approximate_localized_duality_gap)
     do_restart = False
     normalized_candidate_gap = _div(get_gap(candidate_localized_gap), candidate_distance_traveled)
     normalized_last_restart_gap = _div(get_gap(last_restart), distance_traveled_last_restart)
@@ -224,17 +209,19 @@ def should_do_distance_based_adaptive_restart(candidate_localized_gap,
     return _div(new_potential, old_potential) < restart_params.necessary_reduction_for_restart
 
 
-def run_restart_scheme(problem, engine, last_restart_info, iterations_completed,
-                       primal_norm_params, dual_norm_params, primal_weight,
-                       verbosity, restart_params, ops):
-    """saddle_point.jl:688-846.  ``engine`` holds solution_weighted_avg and the
-    current iterate on the device; a restart to the average is performed
-    there (pdhg_restart_to_average, which also recomputes A'y as
-    pdhg.jl:1018-1022 does).  Returns a RestartChoice."""
+def run_restart_scheme(ev, last_restart_info, iterations_completed,
+                       primal_weight_norm, dual_weight_norm, primal_weight,
+                       verbosity, restart_params):
+    """saddle_point.jl:688-846.  ``ev`` (evaluation.py) owns the vector work:
+    solution_weighted_avg, the current iterate and the last restart point live
+    on the device; a restart to the average is performed there
+    (pdhg_restart_to_average, which also recomputes A'y as pdhg.jl:1018-1022
+    does).  ``primal_weight_norm`` / ``dual_weight_norm`` are the uniform
+    entries of define_norms' vectors.  Returns a RestartChoice."""
+    from .evaluation import POINT_AVERAGE
+    engine = ev.engine
     count_x, count_y, _, _ = engine.average_info()
-    if count_x > 0 and count_y > 0:
-        avg_primal_solution, avg_dual_solution = engine.get_average()
-    else:
+    if not (count_x > 0 and count_y > 0):
         return RestartChoice.RESTART_CHOICE_NO_RESTART
 
     restart_length = count_x
@@ -244,18 +231,16 @@ def run_restart_scheme(problem, engine, last_restart_info, iterations_completed,
         do_restart = True
         artificial_restart = True
 
-    current_primal_solution = current_dual_solution = None
+    average_distance_sq = None
     if restart_params.restart_scheme == RestartScheme.NO_RESTARTS:
         reset_to_average = False
         candidate_localized_gap = None
         candidate_distance_traveled = None
     else:
-        current_primal_solution, current_dual_solution = engine.get_current()
         gaps = compute_localized_duality_gaps(
-            problem, current_primal_solution, current_dual_solution,
-            avg_primal_solution, avg_dual_solution, primal_norm_params,
-            dual_norm_params, last_restart_info,
-            restart_params.use_approximate_localized_duality_gap, ops)
+            ev, primal_weight_norm, dual_weight_norm,
+            restart_params.use_approximate_localized_duality_gap)
+        average_distance_sq = gaps["average_distance_sq"]
         reset_to_average = should_reset_to_average(
             gaps["gap_at_current"], gaps["distance_traveled_by_current"],
             gaps["gap_at_average"], gaps["distance_traveled_by_average"],
@@ -271,11 +256,10 @@ def run_restart_scheme(problem, engine, last_restart_info, iterations_completed,
         scheme = restart_params.restart_scheme
         if scheme == RestartScheme.ADAPTIVE_NORMALIZED:
             do_restart = should_do_adaptive_restart_normalized_duality_gap(
-                problem, primal_norm_params, dual_norm_params,
+                ev, primal_weight_norm, dual_weight_norm,
                 candidate_localized_gap, candidate_distance_traveled,
                 restart_params, last_restart_info,
-                restart_params.use_approximate_localized_duality_gap,
-                primal_weight, ops)
+                restart_params.use_approximate_localized_duality_gap, primal_weight)
         elif scheme in (RestartScheme.ADAPTIVE_LOCALIZED, RestartScheme.ADAPTIVE_DISTANCE) and \
                 last_restart_info.last_restart_localized_duality_gap is None:
             do_restart = True
@@ -293,27 +277,23 @@ def run_restart_scheme(problem, engine, last_restart_info, iterations_completed,
     if not do_restart:
         return RestartChoice.RESTART_CHOICE_NO_RESTART
 
-    if reset_to_average:
-        if verbosity >= 4:
-            print("  Restarted to average", end="")
-        engine.restart_to_average()          # current .= avg ; A'y recomputed
-        current_primal_solution = avg_primal_solution
-        current_dual_solution = avg_dual_solution
-    else:
-        if verbosity >= 4:
-            print("  Restarted to current", end="")
-        if current_primal_solution is None:
-            current_primal_solution, current_dual_solution = engine.get_current()
     if verbosity >= 4:
-        print(" after ", str(restart_length).ljust(4), " iterations",
+        print("  Restarted to average" if reset_to_average else "  Restarted to current",
+              " after ", str(restart_length).ljust(4), " iterations",
               "*" if artificial_restart else "", sep="")
-    engine.reset_average()                   # reset_solution_weighted_average
-
-    update_last_restart_info(last_restart_info, current_primal_solution,
-                             current_dual_solution, avg_primal_solution,
-                             avg_dual_solution, primal_norm_params,
-                             dual_norm_params, primal_weight,
-                             candidate_localized_gap, restart_length)
+    # update_last_restart_info (saddle_point.jl:893-927): distances use the
+    # average against the OLD restart point, so take them before restarting.
+    if average_distance_sq is None:
+        average_distance_sq = ev.distance_sq_to_restart(POINT_AVERAGE)
+    lri = last_restart_info
+    lri.primal_distance_moved_last_restart_period = \
+        math.sqrt(primal_weight_norm * average_distance_sq[0]) / math.sqrt(primal_weight)
+    lri.dual_distance_moved_last_restart_period = \
+        math.sqrt(dual_weight_norm * average_distance_sq[1]) * math.sqrt(primal_weight)
+    lri.last_restart_length = restart_length
+    lri.last_restart_localized_duality_gap = candidate_localized_gap
+    # current .= avg (if chosen) ; reset_solution_weighted_average ; restart point .= current
+    ev.restart(reset_to_average)
     if reset_to_average:
         return RestartChoice.RESTART_CHOICE_RESTART_TO_AVERAGE
     return RestartChoice.RESTART_CHOICE_WEIGHTED_AVERAGE_RESET
@@ -336,37 +316,16 @@ def compute_new_primal_weight(last_restart_info, primal_weight,
     return primal_weight
 
 
-def update_last_restart_info(last_restart_info, current_primal_solution,
-                             current_dual_solution, avg_primal_solution,
-                             avg_dual_solution, primal_norm_params,
-                             dual_norm_params, primal_weight,
-                             candidate_localized_gap, restart_length):
-    """saddle_point.jl:893-927"""
-    lri = last_restart_info
-    lri.primal_distance_moved_last_restart_period = weighted_norm(
-        avg_primal_solution - lri.primal_solution, primal_norm_params) / math.sqrt(primal_weight)
-    lri.dual_distance_moved_last_restart_period = weighted_norm(
-        avg_dual_solution - lri.dual_solution, dual_norm_params) * math.sqrt(primal_weight)
-    lri.primal_solution = np.array(current_primal_solution, dtype=np.float64, copy=True)
-    lri.dual_solution = np.array(current_dual_solution, dtype=np.float64, copy=True)
-    lri.last_restart_length = restart_length
-    lri.last_restart_localized_duality_gap = candidate_localized_gap
-
-
-def update_objective_bound_estimates(method_specific_stats, problem,
-                                     current_primal_solution,
-                                     current_dual_solution,
-                                     primal_norm_weights, dual_norm_weights, ops):
-    """saddle_point.jl:1015-1047"""
-    estimated_primal_distance_to_optimality = max(
-        1e-8, weighted_norm(current_primal_solution, primal_norm_weights))
-    estimated_dual_distance_to_optimality = max(
-        1e-8, weighted_norm(current_dual_solution, dual_norm_weights))
-    gap = compute_localized_duality_gap(
-        problem, current_primal_solution, current_dual_solution,
-        primal_norm_weights / estimated_primal_distance_to_optimality ** 2,
-        dual_norm_weights / estimated_dual_distance_to_optimality ** 2,
-        1.0, MAX_NORM, False, ops)
+def update_objective_bound_estimates(method_specific_stats, ev, point,
+                                     primal_weight_norm, dual_weight_norm):
+    """saddle_point.jl:1015-1047 (uniform norm weights)."""
+    sx2, sy2 = ev.point_sumsq(point)
+    estimated_primal_distance_to_optimality = max(1e-8, math.sqrt(primal_weight_norm * sx2))
+    estimated_dual_distance_to_optimality = max(1e-8, math.sqrt(dual_weight_norm * sy2))
+    gap = ev.bound(point,
+                   _div(primal_weight_norm, estimated_primal_distance_to_optimality ** 2),
+                   _div(dual_weight_norm, estimated_dual_distance_to_optimality ** 2),
+                   1.0, MAX_NORM, False)
     method_specific_stats["lagrangian_value"] = gap.lagrangian_value
     method_specific_stats["estimated_lower_bound"] = gap.lower_bound_value
     method_specific_stats["estimated_upper_bound"] = gap.upper_bound_value

@@ -142,6 +142,59 @@ void *pdhg_dist_exchange_ptr(pdhg_handle *h);
 int pdhg_dist_dual_product_begin(pdhg_handle *h);
 int pdhg_dist_dual_product_end(pdhg_handle *h);
 
+/*
+ * ---- evaluation branch on the device ("next" row N1) -----------------------
+ * Everything optimize()'s evaluation/restart branch (pdhg.jl:892-1023) needs,
+ * reduced to scalars on the device so that only scalars cross the boundary.
+ * LP only (a QP keeps the host-side evaluation).
+ */
+enum { PDHG_POINT_CURRENT = 0, PDHG_POINT_AVERAGE = 1, PDHG_POINT_RESTART = 2 };
+
+/* Rescaling vectors (ScaledQpProblem, quadratic_programming.jl:293-298) and the
+ * ORIGINAL problem's vectors, for statistics on the unscaled point
+ * (evaluate_unscaled_iteration_stats, iteration_stats_utils.jl:413-451). */
+int pdhg_set_original_problem(pdhg_handle *h, const double *constraint_rescaling,
+                              const double *variable_rescaling, const double *c_o,
+                              const double *b_o, const double *lb_o, const double *ub_o);
+
+/*
+ * Raw sums/maxes behind compute_convergence_information and
+ * compute_infeasibility_information (iteration_stats_utils.jl:228-349) at the
+ * unscaled point x_o = x ./ D, y_o = y ./ E:
+ *  rows  out[0] sum viol^2   out[1] sum y_o^2   out[2] b_o.y_o   out[3] sum max(-y_o,0)^2 (ineq)
+ *        out[4] max|viol|    out[5] max|viol| with b=0 (ray)      out[6] max|y_o|  out[7] max max(-y_o,0)
+ *  cols  out[8] sum (g-rc)^2 out[9] sum bound*rc  out[10] sum x_o^2  out[11] c_o.x_o
+ *        out[12] sum bound-violation^2   out[13] sum bound*rc (c=0)
+ *        out[14] max|g-rc|   out[15] max|x_o|   out[16] max bound violation
+ *        out[17] max|g-rc| (c=0)  out[18] max|rc| (c=0)  out[19] max ray bound violation
+ * with g = c_o - A_o'y_o and rc the reduced costs (iteration_stats_utils.jl:128-148).
+ */
+int pdhg_eval_point(pdhg_handle *h, int point, double out[20]);
+
+/* last_restart_info.{primal,dual}_solution .= current (saddle_point.jl:921-922). */
+int pdhg_save_restart_point(pdhg_handle *h);
+/* out[0] = sum (x - x_restart)^2, out[1] = sum (y - y_restart)^2 at `point`
+ * (weighted_norm distances, saddle_point.jl:445-477, 911-920). */
+int pdhg_distance_to_restart(pdhg_handle *h, int point, double out[2]);
+/* out[0] = sum x^2, out[1] = sum y^2 of the (scaled) point: the weighted_norm
+ * of update_objective_bound_estimates (saddle_point.jl:1024-1027). */
+int pdhg_point_sumsq(pdhg_handle *h, int point, double out[2]);
+/* Copy one of the three points to the host (NULL skips a vector). */
+int pdhg_get_point(pdhg_handle *h, int point, double *x, double *y);
+
+/*
+ * bound_optimal_objective (trust_region_utils.jl:271-360) on the scaled LP at
+ * `point`, with uniform norm weights per block (define_norms, pdhg.jl:265-277).
+ * range: 0 = joint ball (EUCLIDEAN_NORM), 1 = primal block only, 2 = dual block
+ * only (the two halves of MAX_NORM).  out[0] = Lagrangian value minus
+ * objective_constant, out[1] = sum g_x.(x_tr - x), out[2] = sum g_y.(y_tr - y)
+ * (lower bound = L + out[1], upper bound = L - out[2]), out[3] = sum x^2,
+ * out[4] = sum y^2, out[5] = t*, out[6] = reduction passes used.
+ */
+int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm,
+                            double dual_weight_norm, double radius, int range,
+                            int approximate, double out[8]);
+
 /* ---- measurement ---------------------------------------------------------- */
 enum {
   PDHG_K_PRIMAL = 0,     /* x', xb elementwise                         */

@@ -1,0 +1,109 @@
+"""N1: the device-side evaluation branch against the host (numpy) evaluation on
+the same engine state: convergence / infeasibility statistics, restart
+distances and the trust-region objective bounds.  Tolerance 1e-9 relative
+(sums are reduced in a different order; the trust-region breakpoint search is
+a different algorithm with the same closed form at the end)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from firstorderlp_jl_amd import HipPdhgEngine
+from firstorderlp_jl_amd.evaluation import (POINT_AVERAGE, POINT_CURRENT, POINT_RESTART,
+                                            DeviceEvaluator, HostEvaluator)
+from firstorderlp_jl_amd.generators import pagerank_lp, random_lp
+from firstorderlp_jl_amd.preprocess import rescale_problem
+from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
+    AdaptiveStepsizeParams, EngineOps, PdhgSolverState, UnscaledEngineOps, take_step)
+from firstorderlp_jl_amd.solve_log import PointType
+from firstorderlp_jl_amd.termination import (cached_quadratic_program_info,
+                                             construct_termination_criteria)
+from firstorderlp_jl_amd.trust_region_utils import EUCLIDEAN_NORM, MAX_NORM
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(p, ruiz=3, alpha=1.0, steps=35):
+    sp_ = rescale_problem(ruiz, False, alpha, 0, p)
+    eng = HipPdhgEngine.from_problem(sp_.scaled_qp)
+    qp_cache = cached_quadratic_program_info(p)
+    ev_h = HostEvaluator(eng, sp_, qp_cache, EngineOps(eng, sp_.scaled_qp), UnscaledEngineOps(eng, sp_))
+    ev_d = DeviceEvaluator(eng, sp_, qp_cache)
+    step, pw = H.initial_step_and_weight(sp_.scaled_qp)
+    st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    for _ in range(steps):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+    return eng, ev_h, ev_d, st
+
+
+def _close(a, b, rel=1e-9, scale=1.0):
+    if np.isinf(a) or np.isinf(b):
+        assert a == b
+    else:
+        assert abs(a - b) <= rel * max(abs(a), abs(b), scale), (a, b)
+
+
+@pytest.mark.parametrize("maker", [lambda: random_lp(3000, 4000, 8, 3),
+                                   lambda: H.skewed_lp(2500, 6000, 5),
+                                   lambda: pagerank_lp(20000, seed=2),
+                                   lambda: H.example_lp()],
+                         ids=["random", "skewed_freevars", "pagerank", "example_lp"])
+def test_device_evaluation_matches_host(gpu_required, maker):
+    eng, ev_h, ev_d, st = _setup(maker())
+    tc = construct_termination_criteria()
+    for point in (POINT_AVERAGE, POINT_CURRENT):
+        a = ev_h.iteration_stats(point, tc, True, 36, 0.0, 70.0, st.step_size, st.primal_weight,
+                                 PointType.POINT_TYPE_AVERAGE_ITERATE)
+        b = ev_d.iteration_stats(point, tc, True, 36, 0.0, 70.0, st.step_size, st.primal_weight,
+                                 PointType.POINT_TYPE_AVERAGE_ITERATE)
+        ca, cb = a.convergence_information[0], b.convergence_information[0]
+        obj_scale = abs(ca.primal_objective) + abs(ca.dual_objective) + 1.0
+        for f in dataclasses.fields(ca):
+            va, vb = getattr(ca, f.name), getattr(cb, f.name)
+            if isinstance(va, float):
+                _close(va, vb, scale=obj_scale if "objective" in f.name else 1e-6)
+        ia, ib = a.infeasibility_information[0], b.infeasibility_information[0]
+        for f in dataclasses.fields(ia):
+            va, vb = getattr(ia, f.name), getattr(ib, f.name)
+            if isinstance(va, float):
+                _close(va, vb, scale=1e-6)
+        assert a.iteration_number == b.iteration_number == 35
+
+    wp = st.primal_weight / st.step_size
+    wd = 1.0 / st.step_size / st.primal_weight
+    for point in (POINT_AVERAGE, POINT_CURRENT, POINT_RESTART):
+        dh, dd = ev_h.distance_sq_to_restart(point), ev_d.distance_sq_to_restart(point)
+        _close(dh[0], dd[0]); _close(dh[1], dd[1])
+        sh, sd = ev_h.point_sumsq(point), ev_d.point_sumsq(point)
+        _close(sh[0], sd[0]); _close(sh[1], sd[1])
+    dx2, dy2 = ev_h.distance_sq_to_restart(POINT_AVERAGE)
+    radius = float(np.sqrt(wp * dx2 + wd * dy2))
+    for point in (POINT_AVERAGE, POINT_CURRENT, POINT_RESTART):
+        for norm in (EUCLIDEAN_NORM, MAX_NORM):
+            for rad in (radius, 0.05 * radius, 30.0 * radius, 0.0):
+                for approx in (False, True):
+                    gh = ev_h.bound(point, wp, wd, rad, norm, approx)
+                    gd = ev_d.bound(point, wp, wd, rad, norm, approx)
+                    sc = abs(gh.lagrangian_value) + abs(gh.upper_bound_value - gh.lower_bound_value) + 1e-9
+                    _close(gh.lagrangian_value, gd.lagrangian_value, scale=sc)
+                    _close(gh.lower_bound_value, gd.lower_bound_value, rel=1e-8, scale=sc)
+                    _close(gh.upper_bound_value, gd.upper_bound_value, rel=1e-8, scale=sc)
+
+
+def test_device_restart_bookkeeping(gpu_required):
+    eng, ev_h, ev_d, st = _setup(random_lp(2000, 1500, 6, 9), steps=20)
+    xa, ya = eng.get_average()
+    ev_d.restart(True)                       # current .= avg ; reset ; restart point .= current
+    x, y = eng.get_current()
+    assert np.array_equal(x, xa) and np.array_equal(y, ya)
+    xr, yr = eng.get_point(POINT_RESTART)
+    assert np.array_equal(xr, xa) and np.array_equal(yr, ya)
+    assert eng.average_info()[:2] == (0, 0)
+    assert ev_d.distance_sq_to_restart(POINT_CURRENT) == (0.0, 0.0)
+    for _ in range(5):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+    dx2, dy2 = ev_d.distance_sq_to_restart(POINT_CURRENT)
+    x, y = eng.get_current()
+    assert abs(dx2 - float((x - xa) @ (x - xa))) <= 1e-12 * dx2
+    assert abs(dy2 - float((y - ya) @ (y - ya))) <= 1e-12 * dy2
