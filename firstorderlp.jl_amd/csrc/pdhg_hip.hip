@@ -1776,13 +1776,26 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
     else tstar = sqrt((r2 - lh[0]) / hinf);
   } else {
     uint64_t lo = 0, hi = d2bits(tmax);
-    double low_lo = 0.0, high_lo = wd2_all;              // at t = 0: nothing clamped except thr == 0 entries
+    double low_lo = 0.0, high_lo = 0.0;
     bool have_lo = false;
+    bool exact = false;
+    tstar = 0.0;
     while (hi - lo > 1) {
       uint64_t pb[TR_K];
       const uint64_t span = hi - lo;
-      for (int q = 0; q < TR_K; ++q) {
-        uint64_t off = (uint64_t)(((__uint128_t)span * (uint64_t)(q + 1)) / (uint64_t)(TR_K + 1));
+      int q0 = 0;
+      // Probe 0: the closed-form candidate from the current lower end,
+      // t' = sqrt((r2 - low)/high).  If no breakpoint lies in (lo, t'] the
+      // probe returns the same (low, high) and t' is the exact answer -- this
+      // fixed-point step usually lands within a few passes; the remaining
+      // probes keep a guaranteed 8-ary bracket in IEEE bit space.
+      if (have_lo && high_lo > 0.0) {
+        const double cand = sqrt(fmax(r2 - low_lo, 0.0) / high_lo);
+        const uint64_t cb = d2bits(cand);
+        if (cb > lo && cb < hi) { pb[0] = cb; pr.t[0] = cand; q0 = 1; }
+      }
+      for (int q = q0; q < TR_K; ++q) {
+        uint64_t off = (uint64_t)(((__uint128_t)span * (uint64_t)(q - q0 + 1)) / (uint64_t)(TR_K - q0 + 1));
         if (off == 0) off = 1;
         if (off >= span) off = span - 1;
         pb[q] = lo + off;
@@ -1790,6 +1803,7 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
       }
       if ((rc = probe(pr, lh))) return rc;
       ++passes;
+      if (q0 == 1 && lh[0] == low_lo && lh[1] == high_lo) { tstar = pr.t[0]; exact = true; break; }
       uint64_t nlo = lo, nhi = hi;
       for (int q = 0; q < TR_K; ++q) {
         const double f = lh[2 * q] + pr.t[q] * pr.t[q] * lh[2 * q + 1];
@@ -1798,13 +1812,15 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
       }
       lo = nlo; hi = nhi;
     }
-    if (!have_lo) {  // bracket collapsed at t = 0: evaluate low/high there
-      for (int q = 0; q < TR_K; ++q) pr.t[q] = 0.0;
-      if ((rc = probe(pr, lh))) return rc;
-      ++passes;
-      low_lo = lh[0]; high_lo = lh[1];
+    if (!exact) {
+      if (!have_lo) {  // bracket collapsed at t = 0: evaluate low/high there
+        for (int q = 0; q < TR_K; ++q) pr.t[q] = 0.0;
+        if ((rc = probe(pr, lh))) return rc;
+        ++passes;
+        low_lo = lh[0]; high_lo = lh[1];
+      }
+      tstar = high_lo > 0.0 ? sqrt(fmax(r2 - low_lo, 0.0) / high_lo) : bits2d(lo);
     }
-    tstar = high_lo > 0.0 ? sqrt(fmax(r2 - low_lo, 0.0) / high_lo) : bits2d(lo);
   }
   hipLaunchKernelGGL(tr_value_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m,
                      (int)h->num_eq, px, py, h->lb, h->ub, h->tr_g, h->tr_dir, tstar, h->ev_partials, h->ev_grid);

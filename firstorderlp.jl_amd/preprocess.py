@@ -43,45 +43,99 @@ def validate(p):
     return True
 
 
+class _CscView:
+    """Row/column reductions and diagonal scaling directly on a CSC matrix's
+    arrays (no sparse matmul, no reallocation): the stored pattern never
+    changes under diagonal rescaling."""
+
+    def __init__(self, matrix):
+        self.A = matrix
+        self.m, self.n = matrix.shape
+        self.indptr = matrix.indptr
+        self.indices = matrix.indices
+        self.col_counts = np.diff(self.indptr)
+        self._col_of_nz = None
+        self._perm = None
+        self._row_indptr = None
+
+    @property
+    def col_of_nz(self):
+        if self._col_of_nz is None:
+            self._col_of_nz = np.repeat(np.arange(self.n, dtype=np.int64), self.col_counts)
+        return self._col_of_nz
+
+    def _row_major(self):
+        if self._perm is None:
+            self._perm = np.argsort(self.indices, kind="stable")
+            counts = np.bincount(self.indices, minlength=self.m)
+            self._row_indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        return self._perm, self._row_indptr
+
+    @staticmethod
+    def _segments(values, indptr, ufunc, size):
+        out = np.zeros(size)
+        counts = np.diff(indptr)
+        nonempty = counts > 0
+        if len(values) and nonempty.any():
+            red = ufunc.reduceat(values, indptr[:-1][nonempty])
+            out[nonempty] = red
+        return out
+
+    def reduce(self, dims, values, ufunc):
+        """Julia dims: 1 -> one result per column, 2 -> one per row."""
+        if dims == 1:
+            return self._segments(values, self.indptr, ufunc, self.n)
+        perm, row_indptr = self._row_major()
+        return self._segments(values[perm], row_indptr, ufunc, self.m)
+
+    def scale(self, constraint_rescaling, variable_rescaling):
+        """(Diagonal(1 ./ E) * A) * Diagonal(1 ./ D), entry by entry, in that order."""
+        data = self.A.data
+        if len(constraint_rescaling):
+            data *= (1.0 / constraint_rescaling)[self.indices]
+        data *= (1.0 / variable_rescaling)[self.col_of_nz]
+
+
+def _view(matrix):
+    v = getattr(matrix, "_folp_view", None)
+    if v is None or v.A is not matrix:
+        v = _CscView(matrix)
+        matrix._folp_view = v
+    return v
+
+
 def _max_abs(matrix, dims):
     """vec(maximum(abs, matrix, dims=dims)) with Julia's dims (1: per column,
-    2: per row); structural zeros count as 0."""
-    a = abs(matrix)
-    if dims == 1:
-        return np.asarray(a.max(axis=0).todense()).reshape(-1) if a.nnz else np.zeros(matrix.shape[1])
-    return np.asarray(a.max(axis=1).todense()).reshape(-1) if a.nnz else np.zeros(matrix.shape[0])
+    2: per row); rows/columns without stored entries give 0."""
+    return _view(matrix).reduce(dims, np.abs(matrix.data), np.maximum)
 
 
 def _sum_f(matrix, dims, f):
     """vec(sum(f, matrix, dims=dims)) over stored entries (f(0) = 0 here)."""
-    m = matrix.copy()
-    m.data = f(m.data)
-    axis = 0 if dims == 1 else 1
-    return np.asarray(m.sum(axis=axis)).reshape(-1)
+    return _view(matrix).reduce(dims, f(matrix.data), np.add)
 
 
 def l2_norm(matrix, dimension):
     """preprocess.jl:99-113: scaled sum of squares to avoid overflow."""
+    v = _view(matrix)
     scale_factor = _max_abs(matrix, dimension)
     scale_factor[scale_factor == 0.0] = 1.0
-    if dimension == 1:
-        scaled = matrix @ sp.diags(1.0 / scale_factor)
-    else:
-        scaled = sp.diags(1.0 / scale_factor) @ matrix
-    return scale_factor * np.sqrt(_sum_f(sp.csc_matrix(scaled), dimension, np.square))
+    inv = 1.0 / scale_factor
+    scaled = matrix.data * (inv[v.col_of_nz] if dimension == 1 else inv[v.indices])
+    return scale_factor * np.sqrt(v.reduce(dimension, scaled * scaled, np.add))
 
 
 def scale_problem(problem, constraint_rescaling, variable_rescaling):
     """preprocess.jl:555-573 (in place)."""
     assert np.all(constraint_rescaling > 0) and np.all(variable_rescaling > 0)
     problem.objective_vector = problem.objective_vector / variable_rescaling
-    dinv = sp.diags(1.0 / variable_rescaling)
-    problem.objective_matrix = as_csc((dinv @ problem.objective_matrix) @ dinv)
+    if problem.objective_matrix.nnz:
+        dinv = sp.diags(1.0 / variable_rescaling)
+        problem.objective_matrix = as_csc((dinv @ problem.objective_matrix) @ dinv)
     problem.variable_upper_bound = problem.variable_upper_bound * variable_rescaling
     problem.variable_lower_bound = problem.variable_lower_bound * variable_rescaling
     problem.right_hand_side = problem.right_hand_side / constraint_rescaling
-    einv = sp.diags(1.0 / constraint_rescaling) if len(constraint_rescaling) else sp.csc_matrix((0, 0))
-    problem.constraint_matrix = as_csc((einv @ problem.constraint_matrix) @ dinv)
+    _view(problem.constraint_matrix).scale(constraint_rescaling, variable_rescaling)
 
 
 def unscale_problem(problem, constraint_rescaling, variable_rescaling):
@@ -140,8 +194,18 @@ def pock_chambolle_rescaling(problem, alpha):
     """preprocess.jl:508-539"""
     assert 0 <= alpha <= 2
     constraint_matrix = problem.constraint_matrix
-    variable_rescaling = np.sqrt(_sum_f(constraint_matrix, 1, lambda t: np.abs(t) ** (2 - alpha)))
-    constraint_rescaling = np.sqrt(_sum_f(constraint_matrix, 2, lambda t: np.abs(t) ** alpha))
+    m, n = constraint_matrix.shape
+    v = _view(constraint_matrix)
+    col_sum = _sum_f(constraint_matrix, 1, lambda t: np.abs(t) ** (2 - alpha))
+    row_sum = _sum_f(constraint_matrix, 2, lambda t: np.abs(t) ** alpha)
+    # Julia's mapreduce over a sparse matrix visits the structural zeros too,
+    # and 0.0^0 == 1.0: with exponent 0 every absent entry contributes 1.
+    if 2 - alpha == 0:
+        col_sum = col_sum + (m - v.col_counts)
+    if alpha == 0:
+        row_sum = row_sum + (n - np.bincount(v.indices, minlength=m))
+    variable_rescaling = np.sqrt(col_sum)
+    constraint_rescaling = np.sqrt(row_sum)
     variable_rescaling[variable_rescaling == 0.0] = 1.0
     constraint_rescaling[constraint_rescaling == 0.0] = 1.0
     scale_problem(problem, constraint_rescaling, variable_rescaling)
