@@ -64,9 +64,15 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # PDHG_FORCE_DIST=1: run the row-partitioned engine + RCCL even with one rank
+    # (how the N > 1 code path is exercised on a 1-GPU box).
+    force_dist = os.environ.get("PDHG_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     t0 = time.time()
     if args.workload == "pagerank":
@@ -85,7 +91,7 @@ def main():
     t_gen = time.time() - t0
 
     t0 = time.time()
-    if world > 1:
+    if dist is not None:
         from firstorderlp_jl_amd.distributed import make_row_partitioned_hip_engine
         eng = make_row_partitioned_hip_engine(problem, device_id=local_rank)
         local = eng.local
@@ -192,7 +198,7 @@ def main():
                                     "(BASELINE configs[4])") + ", adaptive step, zero start, "
                                    "no restarts/rescaling",
                        "m": m, "n": n, "nnz": nnz,
-                       "parallelism": "single GPU" if world == 1 else f"row-partition x{world} + RCCL all-reduce"},
+                       "parallelism": "single GPU" if dist is None else f"row-partition x{world} + RCCL all-reduce"},
             "trials_per_step": round(trials / args.steps, 4),
             "whole_iteration_GBps": round(b_iter * (trials / args.steps) / (ms_per_step * 1e-3) / 1e9, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
