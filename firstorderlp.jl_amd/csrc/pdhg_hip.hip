@@ -274,11 +274,43 @@ __device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, d
   if (head) acc[row] = s;
 }
 
-template <int MODE>
+// Variant for matrices with long same-row runs inside a tile (rows with hundreds
+// of entries): run lengths from two ballots, followers' products handed to the
+// run head through a 64-double LDS scratch per wave and added left to right
+// (same order as above; ~6x cheaper than lane shuffles for a 64-long run).
+__device__ __forceinline__ void tiled_chunk_scratch(double *acc, double *scratch, unsigned p, double v,
+                                                    double xv, int tile_shift, int lane) {
+  const bool valid = p != TW_PAD;
+  const unsigned row = valid ? (p >> tile_shift) : 0xFFFFFFFFu;
+  const double prod = v * xv;
+  const unsigned rowp = __shfl_up(row, 1, WAVE);
+  const bool head = valid && (lane == 0 || rowp != row);
+  const unsigned long long hmask = __ballot(head);
+  const unsigned long long vmask = __ballot(valid);
+  const unsigned long long above = (lane == WAVE - 1) ? 0ull : (hmask >> (lane + 1));
+  const int nvalid = __popcll(vmask);                                   // valid lanes are a prefix
+  const int len = above ? __ffsll((long long)above) : (nvalid - lane);  // run length (heads only)
+  if (__any(head && len > 1)) scratch[lane] = prod;
+  if (head) {
+    double s = acc[row] + prod;
+    int q = 1;
+    for (; q + 4 <= len; q += 4) {
+      const double t0 = scratch[lane + q], t1 = scratch[lane + q + 1];
+      const double t2 = scratch[lane + q + 2], t3 = scratch[lane + q + 3];
+      s = s + t0; s = s + t1; s = s + t2; s = s + t3;
+    }
+    for (; q < len; ++q) s = s + scratch[lane + q];
+    acc[row] = s;
+  }
+}
+
+template <int MODE, bool SCR>
 __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
-    const int2 *__restrict__ wave_rows, const int *__restrict__ tile_ptr, int nwaves,
-    int ntiles, int tile_shift, int TW_ROWS, const unsigned *__restrict__ pk,
-    const double *__restrict__ tv, const double *__restrict__ xin, EpiArgs e) {
+    const int2 *__restrict__ wave_rows, const int *__restrict__ step_ptr,
+    const int *__restrict__ wave_step_off, const int *__restrict__ step_tile,
+    const int *__restrict__ wg_step_off, int nwaves, int tile_shift, int TW_ROWS,
+    const unsigned *__restrict__ pk, const double *__restrict__ tv,
+    const double *__restrict__ xin, EpiArgs e) {
   constexpr int TW_THREADS = TW_WPB * WAVE;
   constexpr int U = TW_U;   // 64-entry chunks held in registers per (wave, tile)
   constexpr int D = 3;      // entry loads run D tiles ahead of the accumulate
@@ -287,6 +319,7 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   double(*red)[TW_WPB] = reinterpret_cast<double(*)[TW_WPB]>(tw_lds + TW_WPB * TW_ROWS);
   const int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x / WAVE;
+  double *scratch = tw_lds + TW_WPB * TW_ROWS + 3 * TW_WPB + wid * WAVE;   // SCR only: 64 doubles per wave
   const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * TW_WPB + wid);
   const bool live = w < nwaves;
   double acc3[3] = {0.0, 0.0, 0.0};
@@ -294,13 +327,19 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   int2 rr = make_int2(0, 0);
   if (live) rr = wave_rows[w];
   for (int r = lane; r < TW_ROWS; r += WAVE) acc[r] = 0.0;
-  const int *tp = tile_ptr + (size_t)(live ? w : 0) * (size_t)(ntiles + 1);
+  // This workgroup's step list: one step = one column tile, or a slice of a
+  // heavy tile (cells are cut on the host so that no wave has more than
+  // TW_U*64 entries in a step); tiles in which none of the 8 waves has an entry
+  // are skipped.  ntiles below is the number of STEPS of this workgroup.
+  const int ntiles = wg_step_off[blockIdx.x + 1] - wg_step_off[blockIdx.x];
+  const int *stile = step_tile + wg_step_off[blockIdx.x];
+  const int *tp = step_ptr + (live ? wave_step_off[w] : 0);
   const unsigned cmask = (1u << tile_shift) - 1u;
 
   unsigned p[R][U];
   double v[R][U];
   double xv[U];
-  int ks[R], ke[R];
+  int ks[R], ke[R], tl[R];
 
   auto load_set = [&](unsigned(&pp)[U], double(&vv)[U], int kbeg, int kend) {
 #pragma unroll
@@ -318,10 +357,12 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   for (int s = 0; s < D; ++s) {
     ks[s] = kprev;
     ke[s] = (live && s < ntiles) ? tp[s + 1] : kprev;
+    tl[s] = (s < ntiles) ? stile[s] : 0;
     kprev = ke[s];
     load_set(p[s], v[s], ks[s], ke[s]);
   }
   ks[D] = ke[D] = kprev;
+  tl[D] = 0;
 #pragma unroll
   for (int i = 0; i < U; ++i) { p[D][i] = TW_PAD; v[D][i] = 0.0; }
   int ke_ahead = (live && D < ntiles) ? tp[D + 1] : kprev;  // end of tile D
@@ -332,7 +373,7 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
       const int t = t0 + s;
       if (t < ntiles) {  // workgroup-uniform
         const int f = (s + D) % R;       // ring slot being refilled (held tile t-1)
-        const double *xt = xin + ((size_t)t << tile_shift);
+        const double *xt = xin + ((size_t)tl[s] << tile_shift);
         // 1. gathers for tile t (entries requested D steps ago).  Issued BEFORE
         //    the prefetch: a wave's loads return in order, so the L2-latency
         //    gathers must not queue behind HBM-latency streaming loads.
@@ -343,13 +384,15 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
         // 2. entry loads for tile t+D
         ks[f] = ke[(s + D - 1) % R];
         ke[f] = ke_ahead;
+        tl[f] = (t + D < ntiles) ? stile[t + D] : 0;
         load_set(p[f], v[f], ks[f], ke[f]);
         ke_ahead = (live && t + D + 1 < ntiles) ? tp[t + D + 2] : ke_ahead;  // end of tile t+D+1
         // 3. accumulate tile t
 #pragma unroll
         for (int i = 0; i < U; ++i) {
           if (ks[s] + i * WAVE < ke[s]) {  // wave-uniform
-            tiled_chunk(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
+            if (SCR) tiled_chunk_scratch(acc, scratch, p[s][i], v[s][i], xv[i], tile_shift, lane);
+            else tiled_chunk(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
           }
         }
         for (int kb = ks[s] + U * WAVE; kb < ke[s]; kb += WAVE) {  // cells beyond the register window
@@ -358,7 +401,8 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
           const unsigned pp = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
           const double vv = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
           const double xx = ok ? xt[pp & cmask] : 0.0;
-          tiled_chunk(acc, pp, vv, xx, tile_shift, lane);
+          if (SCR) tiled_chunk_scratch(acc, scratch, pp, vv, xx, tile_shift, lane);
+          else tiled_chunk(acc, pp, vv, xx, tile_shift, lane);
         }
         // 4. pacing barrier: keep the workgroup inside one column tile
         //    (without it the kernel is 1.7x slower: waves drift apart and the
@@ -852,7 +896,12 @@ struct CsrDev {
   bool tiled = false;
   int tile_shift = 0, nwaves = 0, ntiles = 0, tw_rows = 0;
   int2 *wave_rows = nullptr;
-  int *wave_ent = nullptr;   // [nwaves][ntiles+1] entry offsets per (wave, tile)
+  int *wave_ent = nullptr;        // per-wave entry offsets, one per step of its workgroup (+1)
+  int *wave_step_off = nullptr;   // [nwaves] start of a wave's offsets inside wave_ent
+  int *step_tile = nullptr;       // tile id of every step, workgroup after workgroup
+  int *wg_step_off = nullptr;     // [grid+1] start of a workgroup's steps inside step_tile
+  int64_t total_steps = 0;
+  bool tw_scratch = false;        // long same-row runs: use the LDS-scratch chunk variant
   unsigned *pk = nullptr;
   double *tv = nullptr;
   int slots() const { return grid + long_grid; }
@@ -879,8 +928,6 @@ int alloc_zero(double **dst, int64_t len) {
 // column tile (stable, so (row, col) order is kept inside a tile).
 int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::vector<int> &col,
                 const std::vector<double> &val, int tile_shift) {
-  const char *mode_env = getenv("PDHG_SPMV");
-  const bool forced = mode_env && !strcmp(mode_env, "tiled");
   // Geometry.  A CU holds 2 workgroups of 8 waves; the grid runs in rounds of
   // 256 CUs x 16 waves.  Rows per wave is chosen so that the rounds are full
   // (no tail round), within the LDS budget (160 KiB / 16 waves).
@@ -895,52 +942,93 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
   if (const char *ev = getenv("PDHG_TW_ROWS")) TW_ROWS = std::max(1, std::min(atoi(ev), max_rows));
   D.tw_rows = TW_ROWS;
   const int ntiles = std::max<int>(1, (int)((((int64_t)D.cols) + (1LL << tile_shift) - 1) >> tile_shift));
+  const unsigned cmask = (1u << tile_shift) - 1u;
+  const int WIN = TW_U * WAVE;  // entries a wave holds in registers per step
+  // pass 1: wave row blocks.  A wave owns <= TW_ROWS rows AND <= nnz_cap
+  // nonzeros: hub regions (PageRank's oldest nodes) would otherwise give one
+  // wave 100x the average work and the whole launch would wait for its workgroup.
+  const int64_t est_waves = std::max<int64_t>(1, ((int64_t)rows + TW_ROWS - 1) / TW_ROWS);
+  const int64_t nnz_cap = std::max<int64_t>(4096, 2 * (D.nnz / est_waves));   // 2x the average wave
   std::vector<int2> wave_rows;
-  std::vector<int> tile_ptr;
+  {
+    int r = 0;
+    while (r < rows) {
+      if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) { ++r; continue; }  // long row: separate path
+      const int r0 = r;
+      while (r < rows && (r - r0) < TW_ROWS && rowptr[r + 1] - rowptr[r] <= BLOCK_NNZ &&
+             (r == r0 || (int64_t)rowptr[r + 1] - rowptr[r0] <= nnz_cap)) ++r;
+      wave_rows.push_back(make_int2(r0, r));
+    }
+  }
+  const int nwaves = (int)wave_rows.size();
+  const int grid = (nwaves + TW_WPB - 1) / TW_WPB;
   std::vector<unsigned> pk;
   std::vector<double> tv;
   pk.reserve((size_t)D.nnz);
   tv.reserve((size_t)D.nnz);
-  std::vector<int> cnt((size_t)ntiles + 1);
-  const unsigned cmask = (1u << tile_shift) - 1u;
-  int64_t overflow = 0;   // entries beyond the per-(wave, tile) register window
-  int r = 0;
-  while (r < rows) {
-    if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) { ++r; continue; }  // long row: separate path
-    const int r0 = r;
-    while (r < rows && (r - r0) < TW_ROWS && rowptr[r + 1] - rowptr[r] <= BLOCK_NNZ) ++r;
-    const int k0 = rowptr[r0], k1 = rowptr[r];
-    std::fill(cnt.begin(), cnt.end(), 0);
-    for (int k = k0; k < k1; ++k) cnt[(col[k] >> tile_shift) + 1] += 1;
-    for (int t = 0; t < ntiles; ++t) cnt[t + 1] += cnt[t];
-    const size_t base = pk.size();
-    for (int t = 0; t <= ntiles; ++t) tile_ptr.push_back((int)(base + (size_t)cnt[t]));
-    for (int t = 0; t < ntiles; ++t) overflow += std::max(0, cnt[t + 1] - cnt[t] - TW_U * WAVE);
-    pk.resize(base + (size_t)(k1 - k0));
-    tv.resize(base + (size_t)(k1 - k0));
-    for (int rr = r0; rr < r; ++rr) {
-      const unsigned rl = (unsigned)(rr - r0) << tile_shift;
-      for (int k = rowptr[rr]; k < rowptr[rr + 1]; ++k) {
-        const int pos = cnt[col[k] >> tile_shift]++;
-        pk[base + pos] = rl | ((unsigned)col[k] & cmask);
-        tv[base + pos] = val[k];
+  std::vector<int> step_ptr, wave_step_off((size_t)std::max(nwaves, 1), 0), step_tile, wg_step_off(1, 0);
+  std::vector<std::vector<int>> cnt(TW_WPB, std::vector<int>((size_t)ntiles + 1));
+  std::vector<int> nsub((size_t)ntiles);
+  int max_run = 0;   // longest same-row run inside one tile
+  for (int g = 0; g < grid; ++g) {
+    const int w0 = g * TW_WPB, w1 = std::min(nwaves, w0 + TW_WPB);
+    // cell sizes of the workgroup's waves
+    std::fill(nsub.begin(), nsub.end(), 0);
+    for (int w = w0; w < w1; ++w) {
+      std::vector<int> &c = cnt[w - w0];
+      std::fill(c.begin(), c.end(), 0);
+      for (int k = rowptr[wave_rows[w].x]; k < rowptr[wave_rows[w].y]; ++k) c[(col[k] >> tile_shift) + 1] += 1;
+      for (int t = 0; t < ntiles; ++t) nsub[t] = std::max(nsub[t], (c[t + 1] + WIN - 1) / WIN);
+      for (int t = 0; t < ntiles; ++t) c[t + 1] += c[t];   // prefix: cell start offsets
+    }
+    // the workgroup's step list (heavy tiles repeated, empty tiles skipped)
+    for (int t = 0; t < ntiles; ++t)
+      for (int j = 0; j < nsub[t]; ++j) step_tile.push_back(t);
+    wg_step_off.push_back((int)step_tile.size());
+    // entries of each wave, tile-major (stable in (row, col)), and its step offsets
+    for (int w = w0; w < w1; ++w) {
+      std::vector<int> &c = cnt[w - w0];
+      const int r0 = wave_rows[w].x, r1 = wave_rows[w].y;
+      const size_t base = pk.size();
+      const int total = rowptr[r1] - rowptr[r0];
+      wave_step_off[w] = (int)step_ptr.size();
+      for (int t = 0; t < ntiles; ++t) {
+        const int cs = c[t], ce = c[t + 1], len = ce - cs;
+        const int per = nsub[t] ? (len + nsub[t] - 1) / nsub[t] : 0;
+        for (int j = 0; j < nsub[t]; ++j) step_ptr.push_back((int)base + std::min(ce, cs + j * per));
+      }
+      step_ptr.push_back((int)base + total);
+      pk.resize(base + (size_t)total);
+      tv.resize(base + (size_t)total);
+      std::vector<int> next(c.begin(), c.end() - 1);
+      for (int rr = r0; rr < r1; ++rr) {
+        const unsigned rl = (unsigned)(rr - r0) << tile_shift;
+        int run = 0, run_tile = -1;
+        for (int k = rowptr[rr]; k < rowptr[rr + 1]; ++k) {
+          const int tt = col[k] >> tile_shift;
+          run = (tt == run_tile) ? run + 1 : 1;
+          run_tile = tt;
+          if (run > max_run) max_run = run;
+          const int pos = next[tt]++;
+          pk[base + pos] = rl | ((unsigned)col[k] & cmask);
+          tv[base + pos] = val[k];
+        }
       }
     }
-    wave_rows.push_back(make_int2(r0, r));
   }
-  // Skewed matrices (hub columns concentrated in a few tiles, e.g. the
-  // PageRank LP) overflow the prefetch window and serialise on the pacing
-  // barrier; they also have natural cache locality, so the stream layout
-  // serves them better.  Keep the tiled layout only when overflow is rare.
-  if (!forced && overflow * 50 > (int64_t)pk.size()) return 0;
   D.tiled = true;
   D.tile_shift = tile_shift;
   D.ntiles = ntiles;
-  D.nwaves = (int)wave_rows.size();
-  D.grid = (D.nwaves + TW_WPB - 1) / TW_WPB;
+  D.nwaves = nwaves;
+  D.grid = grid;
+  D.total_steps = (int64_t)step_tile.size();
+  D.tw_scratch = max_run > 8;
   int rc;
   if ((rc = upload(&D.wave_rows, wave_rows))) return rc;
-  if ((rc = upload(&D.wave_ent, tile_ptr))) return rc;
+  if ((rc = upload(&D.wave_ent, step_ptr))) return rc;
+  if ((rc = upload(&D.wave_step_off, wave_step_off))) return rc;
+  if ((rc = upload(&D.step_tile, step_tile))) return rc;
+  if ((rc = upload(&D.wg_step_off, wg_step_off))) return rc;
   if ((rc = upload(&D.pk, pk))) return rc;
   if ((rc = upload(&D.tv, tv))) return rc;
   return 0;
@@ -1005,7 +1093,8 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
 
 void free_csr_dev(CsrDev &D) {
   void *ptrs[] = {D.rowptr, D.col, D.val, D.blks, D.long_row, D.long_chunk_ptr,
-                  D.chunk_row, D.chunk_off, D.chunk_partial, D.wave_rows, D.wave_ent, D.pk, D.tv};
+                  D.chunk_row, D.chunk_off, D.chunk_partial, D.wave_rows, D.wave_ent, D.pk, D.tv,
+                  D.wave_step_off, D.step_tile, D.wg_step_off};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   D = CsrDev();
 }
@@ -1089,16 +1178,27 @@ template <int MODE>
 int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
   if (D.tiled) {
     if (D.grid > 0) {
-      const size_t lds = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB);
-      static size_t attr_set[3] = {0, 0, 0};
-      if (attr_set[MODE] < lds) {
-        HIP_TRY(hipFuncSetAttribute((const void *)spmv_tiled_kernel<MODE>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[MODE] = lds;
+      const size_t lds = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_scratch ? TW_WPB * WAVE : 0));
+      static size_t attr_set[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+      if (D.tw_scratch) {
+        if (attr_set[MODE][1] < lds) {
+          HIP_TRY(hipFuncSetAttribute((const void *)spmv_tiled_kernel<MODE, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          attr_set[MODE][1] = lds;
+        }
+        hipLaunchKernelGGL((spmv_tiled_kernel<MODE, true>), dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
+                           D.wave_rows, D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves,
+                           D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
+      } else {
+        if (attr_set[MODE][0] < lds) {
+          HIP_TRY(hipFuncSetAttribute((const void *)spmv_tiled_kernel<MODE, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          attr_set[MODE][0] = lds;
+        }
+        hipLaunchKernelGGL((spmv_tiled_kernel<MODE, false>), dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
+                           D.wave_rows, D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves,
+                           D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
       }
-      hipLaunchKernelGGL(spmv_tiled_kernel<MODE>, dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
-                         D.wave_rows, D.wave_ent, D.nwaves, D.ntiles, D.tile_shift, D.tw_rows,
-                         D.pk, D.tv, xin, e);
     }
   } else if (D.grid > 0) {
     hipLaunchKernelGGL(spmv_stream_kernel<MODE>, dim3(D.grid), dim3(TPB), 0, h->stream,
