@@ -64,6 +64,14 @@ class TorchComm:
     def all_reduce_sum(self, tensor):
         self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def all_reduce_host(self, arr):
+        """Sum a float64 numpy vector over ranks (evaluation cadence only)."""
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
     def all_gather_host(self, arr, sizes):
         """Concatenate per-rank float64 numpy slices (evaluation cadence only)."""
         import torch
@@ -152,6 +160,15 @@ class RowPartitionedEngine:
     def set_current(self, x=None, y=None):
         self.local.set_current(x, None if y is None else y[self.lo:self.hi])
         self._refresh_dual_product()
+
+    # ---- standalone mat-vecs for the evaluation branch (host vectors) ----
+    def spmv(self, x):
+        """A*x: every rank multiplies its row block, slices are concatenated."""
+        return self.comm.all_gather_host(self.local.spmv(x), self.sizes)
+
+    def spmv_t(self, y):
+        """A'*y = sum_p A_p' y_p: local partial, then a sum over ranks."""
+        return self.comm.all_reduce_host(self.local.spmv_t(y[self.lo:self.hi]))
 
     def close(self):
         self.local.close()

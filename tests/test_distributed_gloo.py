@@ -113,3 +113,69 @@ def test_partition_rows_balances_nnz():
             tot += sh["constraint_matrix"].nnz
             assert sh["num_equalities"] == min(max(p.num_equalities - lo, 0), hi - lo)
         assert tot == p.constraint_matrix.nnz
+
+
+def _kat_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import folp_loader
+    folp_loader.load()
+    import torch.distributed as dist
+    from firstorderlp_jl_amd.distributed import (RowPartitionedEngine, TorchComm,
+                                                 partition_rows, shard_rows)
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import optimize
+    from firstorderlp_jl_amd.saddle_point import RestartScheme
+    from tests import kat_common
+    from tests.oracle_engine import OracleEngine
+    from tests import helpers as H
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def factory(problem):
+            ranges = partition_rows(problem.constraint_matrix, world)
+            lo, hi = ranges[rank]
+            return RowPartitionedEngine(OracleEngine(**shard_rows(problem, lo, hi)), TorchComm(), ranges)
+        params = kat_common.generate_primal_dual_hybrid_gradient_params(
+            iteration_limit=600, restart_scheme=RestartScheme.ADAPTIVE_NORMALIZED,
+            l_inf_ruiz_iterations=3, pock_chambolle_alpha=1.0)
+        out = optimize(params, H.example_lp(), factory)
+        q.put((rank, out.primal_solution, out.dual_solution, out.iteration_count,
+               out.termination_reason.name))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_full_optimize_row_partitioned_two_ranks():
+    """A whole reference-style solve (rescaling + adaptive restarts + termination
+    evaluation through the sharded A*x / A'*y) on 2 ranks: both ranks return the
+    reference KAT's optimum (test_primal_dual_hybrid_gradient.jl:130-147)."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_kat_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    # the same solve, unsharded, on the oracle engine
+    sys.path.insert(0, ROOT)
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import optimize
+    from firstorderlp_jl_amd.saddle_point import RestartScheme
+    from tests import kat_common
+    from tests.oracle_engine import OracleEngine
+    from tests import helpers as H
+    params = kat_common.generate_primal_dual_hybrid_gradient_params(
+        iteration_limit=600, restart_scheme=RestartScheme.ADAPTIVE_NORMALIZED,
+        l_inf_ruiz_iterations=3, pock_chambolle_alpha=1.0)
+    ref = optimize(params, H.example_lp(), OracleEngine.from_problem)
+    for (rank, x, y, iters, reason) in results:
+        np.testing.assert_allclose(x, [1.0, 0.0, 6.0, 2.0], atol=1e-5)   # the LP's optimum
+        np.testing.assert_allclose(y, [0.5, 4.0, 0.0], atol=1e-5)
+        np.testing.assert_allclose(x, ref.primal_solution, atol=1e-9)    # sharded == unsharded
+        np.testing.assert_allclose(y, ref.dual_solution, atol=1e-9)
+        assert iters == 600 and reason == "TERMINATION_REASON_ITERATION_LIMIT"
+    assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])
