@@ -137,7 +137,7 @@ def _kat_worker(rank, world, port, q):
             return RowPartitionedEngine(OracleEngine(**shard_rows(problem, lo, hi)), TorchComm(), ranges)
         params = kat_common.generate_primal_dual_hybrid_gradient_params(
             iteration_limit=600, restart_scheme=RestartScheme.ADAPTIVE_NORMALIZED,
-            l_inf_ruiz_iterations=3, pock_chambolle_alpha=1.0)
+            l_inf_ruiz_iterations=3)
         out = optimize(params, H.example_lp(), factory)
         q.put((rank, out.primal_solution, out.dual_solution, out.iteration_count,
                out.termination_reason.name))
@@ -170,12 +170,14 @@ def test_full_optimize_row_partitioned_two_ranks():
     from tests import helpers as H
     params = kat_common.generate_primal_dual_hybrid_gradient_params(
         iteration_limit=600, restart_scheme=RestartScheme.ADAPTIVE_NORMALIZED,
-        l_inf_ruiz_iterations=3, pock_chambolle_alpha=1.0)
+        l_inf_ruiz_iterations=3)
     ref = optimize(params, H.example_lp(), OracleEngine.from_problem)
     for (rank, x, y, iters, reason) in results:
-        np.testing.assert_allclose(x, [1.0, 0.0, 6.0, 2.0], atol=1e-3)   # the LP optimum
-        np.testing.assert_allclose(y, [0.5, 4.0, 0.0], atol=1e-3)
-        np.testing.assert_allclose(x, ref.primal_solution, atol=1e-9)    # sharded == unsharded
+        # restart decisions are discrete, so sharded and unsharded runs may take
+        # different (equally valid) paths; both must land on the LP's optimum
+        np.testing.assert_allclose(x, [1.0, 0.0, 6.0, 2.0], atol=1e-9)
+        np.testing.assert_allclose(y, [0.5, 4.0, 0.0], atol=1e-9)
+        np.testing.assert_allclose(x, ref.primal_solution, atol=1e-9)
         np.testing.assert_allclose(y, ref.dual_solution, atol=1e-9)
         assert iters == 600 and reason == "TERMINATION_REASON_ITERATION_LIMIT"
     assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])
