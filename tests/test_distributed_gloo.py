@@ -179,5 +179,7 @@ def test_full_optimize_row_partitioned_two_ranks():
         np.testing.assert_allclose(y, [0.5, 4.0, 0.0], atol=1e-9)
         np.testing.assert_allclose(x, ref.primal_solution, atol=1e-9)
         np.testing.assert_allclose(y, ref.dual_solution, atol=1e-9)
-        assert iters == 600 and reason == "TERMINATION_REASON_ITERATION_LIMIT"
+        # exact convergence makes movement == 0 -> NUMERICAL_ERROR exit (pdhg.jl:691-695)
+        assert iters <= 600 and reason in ("TERMINATION_REASON_ITERATION_LIMIT",
+                                           "TERMINATION_REASON_NUMERICAL_ERROR")
     assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])
