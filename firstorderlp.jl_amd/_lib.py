@@ -31,7 +31,7 @@ EXPORTS = [
     "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info",
     "pdhg_set_original_problem", "pdhg_eval_point", "pdhg_save_restart_point",
     "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound",
-    "pdhg_point_sumsq",
+    "pdhg_point_sumsq", "pdhg_rescale", "pdhg_get_problem_vectors", "pdhg_matrix_max_abs",
 ]
 
 K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_COUNT = range(6)
@@ -141,6 +141,12 @@ def lib():
     L.pdhg_point_sumsq.argtypes = [_vp, i32, _dp]
     L.pdhg_get_point.restype = i32
     L.pdhg_get_point.argtypes = [_vp, i32, _dp, _dp]
+    L.pdhg_rescale.restype = i32
+    L.pdhg_rescale.argtypes = [_vp, i32, i32, i32, d, _dp, _dp]
+    L.pdhg_get_problem_vectors.restype = i32
+    L.pdhg_get_problem_vectors.argtypes = [_vp, _dp, _dp, _dp, _dp]
+    L.pdhg_matrix_max_abs.restype = i32
+    L.pdhg_matrix_max_abs.argtypes = [_vp, _dp]
     L.pdhg_trust_region_bound.restype = i32
     L.pdhg_trust_region_bound.argtypes = [_vp, i32, d, d, d, i32, i32, _dp]
     _lib = L

@@ -870,6 +870,140 @@ __global__ __launch_bounds__(TPB) void tr_value_kernel(int n, int m, int ne, con
   block_reduce_store<2, 0>(a, partials, stride);
 }
 
+// ============================================================ rescaling on the device (N2)
+// rescale_problem (preprocess.jl:631-687) applied in place to every resident
+// layout.  One wave per CSR row (one-time work, simplicity over speed).
+enum { ROP_MAXABS = 0, ROP_SUMPOW = 1, ROP_SUMSQ_SCALED = 2 };
+
+// out[r] = max |a| ; sum |a|^p (+ structural zeros when p == 0: Julia's
+// mapreduce visits them and 0.0^0 == 1.0) ; sum (a * inv_scale[r])^2
+template <int OP>
+__global__ __launch_bounds__(TPB) void row_op_kernel(CsrView A, int cols, double pexp,
+                                                     const double *__restrict__ inv_scale,
+                                                     double *__restrict__ out) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int r = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+  if (r >= A.rows) return;
+  const int k0 = A.rowptr[r], k1 = A.rowptr[r + 1];
+  const double sc = (OP == ROP_SUMSQ_SCALED) ? inv_scale[r] : 1.0;
+  double acc = 0.0;
+  for (int k = k0 + lane; k < k1; k += WAVE) {
+    const double a = A.val[k];
+    if (OP == ROP_MAXABS) acc = fmax(acc, fabs(a));
+    else if (OP == ROP_SUMPOW) acc += pow(fabs(a), pexp);
+    else { const double t = a * sc; acc += t * t; }
+  }
+  acc = (OP == ROP_MAXABS) ? wave_max(acc) : wave_sum(acc);
+  if (lane == 0) {
+    if (OP == ROP_SUMPOW && pexp == 0.0) acc += (double)(cols - (k1 - k0));
+    out[r] = acc;
+  }
+}
+
+// val[k] = (val[k] * inv_a[ia]) * inv_b[ib] with ia/ib chosen so that the
+// multiplication order is always (a * (1/e_row_of_A)) * (1/d_col_of_A), as in
+// (Diagonal(1 ./ E) * A) * Diagonal(1 ./ D) (preprocess.jl:567-571).
+// transposed == false: CSR(A) (row -> E, col -> D); true: CSR(A') (row -> D, col -> E).
+__global__ __launch_bounds__(TPB) void scale_csr_kernel(int rows, const int *__restrict__ rowptr,
+                                                        const int *__restrict__ col, double *__restrict__ val,
+                                                        const double *__restrict__ inv_e,
+                                                        const double *__restrict__ inv_d, int transposed) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int r = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+  if (r >= rows) return;
+  const int k0 = rowptr[r], k1 = rowptr[r + 1];
+  for (int k = k0 + lane; k < k1; k += WAVE) {
+    const int c = col[k];
+    const double ie = transposed ? inv_e[c] : inv_e[r];
+    const double id = transposed ? inv_d[r] : inv_d[c];
+    val[k] = (val[k] * ie) * id;
+  }
+}
+
+// same for the tiled-sweep copy: one wave per wave-row-block, walking its steps
+__global__ __launch_bounds__(TPB) void scale_tiled_kernel(const int2 *__restrict__ wave_rows,
+                                                          const int *__restrict__ step_ptr,
+                                                          const int *__restrict__ wave_step_off,
+                                                          const int *__restrict__ step_tile,
+                                                          const int *__restrict__ wg_step_off, int nwaves,
+                                                          int tile_shift, const unsigned *__restrict__ pk,
+                                                          double *__restrict__ tv,
+                                                          const double *__restrict__ inv_e,
+                                                          const double *__restrict__ inv_d, int transposed) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int w = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+  if (w >= nwaves) return;
+  const int g = w / TW_WPB;
+  const int nst = wg_step_off[g + 1] - wg_step_off[g];
+  const int *stile = step_tile + wg_step_off[g];
+  const int *sp = step_ptr + wave_step_off[w];
+  const int r0 = wave_rows[w].x;
+  const unsigned cmask = (1u << tile_shift) - 1u;
+  for (int st = 0; st < nst; ++st) {
+    const int tile = stile[st];
+    for (int k = sp[st] + lane; k < sp[st + 1]; k += WAVE) {
+      const unsigned p = pk[k];
+      const int r = r0 + (int)(p >> tile_shift);
+      const int c = (int)(((unsigned)tile << tile_shift) | (p & cmask));
+      const double ie = transposed ? inv_e[c] : inv_e[r];
+      const double id = transposed ? inv_d[r] : inv_d[c];
+      tv[k] = (tv[k] * ie) * id;
+    }
+  }
+}
+
+// elementwise helpers on rescaling vectors
+//  mode 0: v = sqrt(v), zeros -> 1          (Ruiz / Pock-Chambolle factors)
+//  mode 1: v = sqrt(max(a, 0)) from a       (unused)  mode 2: inv = 1/v ; cum *= v
+__global__ __launch_bounds__(TPB) void resc_sqrt_kernel(int n, double *__restrict__ v) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+    double t = sqrt(v[i]);
+    if (t == 0.0) t = 1.0;
+    v[i] = t;
+  }
+}
+__global__ __launch_bounds__(TPB) void resc_l2norm_kernel(int n, const double *__restrict__ scale,
+                                                          double *__restrict__ sumsq_inout) {
+  // l2_norm (preprocess.jl:99-113): scale .* sqrt(sum (a/scale)^2)
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB)
+    sumsq_inout[i] = scale[i] * sqrt(sumsq_inout[i]);
+}
+__global__ __launch_bounds__(TPB) void resc_zero_to_one_inv_kernel(int n, double *__restrict__ v,
+                                                                   double *__restrict__ inv, int do_zero_to_one) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+    double t = v[i];
+    if (do_zero_to_one && t == 0.0) { t = 1.0; v[i] = t; }
+    inv[i] = 1.0 / t;
+  }
+}
+__global__ __launch_bounds__(TPB) void resc_apply_vectors_kernel(int n, int m, const double *__restrict__ dv,
+                                                                 const double *__restrict__ ev,
+                                                                 double *__restrict__ c, double *__restrict__ lb,
+                                                                 double *__restrict__ ub, double *__restrict__ b,
+                                                                 double *__restrict__ cum_d,
+                                                                 double *__restrict__ cum_e) {
+  // scale_problem (preprocess.jl:555-573): c ./= D ; ub .*= D ; lb .*= D ; b ./= E
+  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
+  for (int j = tid; j < n; j += st) {
+    const double d = dv[j];
+    c[j] = c[j] / d; ub[j] = ub[j] * d; lb[j] = lb[j] * d; cum_d[j] = cum_d[j] * d;
+  }
+  for (int i = tid; i < m; i += st) {
+    const double e = ev[i];
+    b[i] = b[i] / e; cum_e[i] = cum_e[i] * e;
+  }
+}
+__global__ __launch_bounds__(TPB) void fill_kernel(int n, double v, double *__restrict__ out) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) out[i] = v;
+}
+__global__ __launch_bounds__(TPB) void maxabs_kernel(int64_t n, const double *__restrict__ v,
+                                                     double *__restrict__ partials, int stride) {
+  RedAcc<0, 1> a;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+    a.m[0] = fmax(a.m[0], fabs(v[i]));
+  block_reduce_store<0, 1>(a, partials, stride);
+}
+
 // One-quantity variant writing to a device slot (row-partitioned form).
 __global__ __launch_bounds__(FINAL_TPB) void final_to_slot_kernel(const double *p, int cnt, double *slot) {
   __shared__ double red[3][FINAL_TPB / WAVE];
@@ -1938,6 +2072,114 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
   if ((rc = ev_finish(h, 2, 0, vv))) return rc;
   out[1] = vv[0]; out[2] = vv[1]; out[5] = tstar; out[6] = (double)passes;
   return 0;
+}
+
+// ---- rescaling on the device (N2) --------------------------------------------
+
+static int row_grid(int rows) { return std::max(1, (rows + (TPB / WAVE) - 1) / (TPB / WAVE)); }
+
+// one scale_problem step on every resident layout + the vectors
+static int apply_scaling(pdhg_handle *h, double *ev, double *dv, double *inv_e, double *inv_d,
+                         double *cum_e, double *cum_d) {
+  const int n = (int)h->n, m = (int)h->m;
+  hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, ev, inv_e, 0);
+  hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv, inv_d, 0);
+  CsrDev *L[2] = {&h->A, &h->At};
+  for (int t = 0; t < 2; ++t) {
+    CsrDev &D = *L[t];
+    if (D.nnz == 0) continue;
+    hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, D.rowptr,
+                       D.col, D.val, inv_e, inv_d, t);
+    if (D.tiled && D.nwaves > 0)
+      hipLaunchKernelGGL(scale_tiled_kernel, dim3(row_grid(D.nwaves)), dim3(TPB), 0, h->stream, D.wave_rows,
+                         D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves, D.tile_shift,
+                         D.pk, D.tv, inv_e, inv_d, t);
+  }
+  hipLaunchKernelGGL(resc_apply_vectors_kernel, dim3(h->ew_grid_nm), dim3(TPB), 0, h->stream, n, m, dv, ev,
+                     h->c, h->lb, h->ub, h->b, cum_d, cum_e);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int pdhg_rescale(pdhg_handle *h, int l_inf_ruiz_iterations, int l2_norm_rescaling,
+                 int use_pock_chambolle, double pock_chambolle_alpha,
+                 double *constraint_rescaling_out, double *variable_rescaling_out) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (h->has_q) return fail(-2, "device rescaling supports LPs only");
+  if (use_pock_chambolle && !(pock_chambolle_alpha >= 0.0 && pock_chambolle_alpha <= 2.0))
+    return fail(-1, "pock_chambolle_alpha must be in [0, 2]");
+  const int n = (int)h->n, m = (int)h->m;
+  double *ev = nullptr, *dv = nullptr, *inv_e = nullptr, *inv_d = nullptr, *cum_e = nullptr, *cum_d = nullptr;
+  double *tmp_e = nullptr, *tmp_d = nullptr;
+  auto cleanup = [&]() { for (double *p : {ev, dv, inv_e, inv_d, cum_e, cum_d, tmp_e, tmp_d}) if (p) (void)hipFree(p); };
+#define RS(expr) do { int _r = (expr); if (_r) { cleanup(); return _r; } } while (0)
+  RS(alloc_zero(&ev, m)); RS(alloc_zero(&dv, n)); RS(alloc_zero(&inv_e, m)); RS(alloc_zero(&inv_d, n));
+  RS(alloc_zero(&cum_e, m)); RS(alloc_zero(&cum_d, n)); RS(alloc_zero(&tmp_e, m)); RS(alloc_zero(&tmp_d, n));
+  hipLaunchKernelGGL(fill_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, 1.0, cum_e);
+  hipLaunchKernelGGL(fill_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, 1.0, cum_d);
+  const CsrView Av = h->A.view(), Atv = h->At.view();
+  // ruiz_rescaling, p = Inf (preprocess.jl:412-477): sqrt of the row / column max |a|, zeros -> 1
+  for (int it = 0; it < l_inf_ruiz_iterations; ++it) {
+    hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, Atv, m, 0.0, (const double *)nullptr, dv);
+    hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, Av, n, 0.0, (const double *)nullptr, ev);
+    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv);
+    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, ev);
+    RS(apply_scaling(h, ev, dv, inv_e, inv_d, cum_e, cum_d));
+  }
+  // l2_norm_rescaling (preprocess.jl:358-372): sqrt of the row / column L2 norms, zeros -> 1
+  if (l2_norm_rescaling) {
+    hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, Atv, m, 0.0, (const double *)nullptr, tmp_d);
+    hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, Av, n, 0.0, (const double *)nullptr, tmp_e);
+    hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, tmp_d, inv_d, 1);
+    hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, tmp_e, inv_e, 1);
+    hipLaunchKernelGGL(row_op_kernel<ROP_SUMSQ_SCALED>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, Atv, m, 0.0, inv_d, dv);
+    hipLaunchKernelGGL(row_op_kernel<ROP_SUMSQ_SCALED>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, Av, n, 0.0, inv_e, ev);
+    hipLaunchKernelGGL(resc_l2norm_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, tmp_d, dv);
+    hipLaunchKernelGGL(resc_l2norm_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, tmp_e, ev);
+    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv);   // norm 0 -> sqrt 0 -> 1
+    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, ev);
+    RS(apply_scaling(h, ev, dv, inv_e, inv_d, cum_e, cum_d));
+  }
+  // pock_chambolle_rescaling (preprocess.jl:508-539)
+  if (use_pock_chambolle) {
+    hipLaunchKernelGGL(row_op_kernel<ROP_SUMPOW>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, Atv, m, 2.0 - pock_chambolle_alpha, (const double *)nullptr, dv);
+    hipLaunchKernelGGL(row_op_kernel<ROP_SUMPOW>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, Av, n, pock_chambolle_alpha, (const double *)nullptr, ev);
+    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv);
+    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, ev);
+    RS(apply_scaling(h, ev, dv, inv_e, inv_d, cum_e, cum_d));
+  }
+  hipError_t e1 = hipGetLastError();
+  if (e1 != hipSuccess) { cleanup(); return fail((int)e1, hipGetErrorString(e1)); }
+  if (constraint_rescaling_out && m > 0)
+    (void)hipMemcpyAsync(constraint_rescaling_out, cum_e, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream);
+  if (variable_rescaling_out && n > 0)
+    (void)hipMemcpyAsync(variable_rescaling_out, cum_d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream);
+  hipError_t e2 = hipStreamSynchronize(h->stream);
+  cleanup();
+#undef RS
+  if (e2 != hipSuccess) return fail((int)e2, hipGetErrorString(e2));
+  return 0;
+}
+
+int pdhg_get_problem_vectors(pdhg_handle *h, double *c, double *b, double *lb, double *ub) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (c) HIP_TRY(hipMemcpyAsync(c, h->c, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  if (b) HIP_TRY(hipMemcpyAsync(b, h->b, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
+  if (lb) HIP_TRY(hipMemcpyAsync(lb, h->lb, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  if (ub) HIP_TRY(hipMemcpyAsync(ub, h->ub, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int pdhg_matrix_max_abs(pdhg_handle *h, double *out) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if ((rc = ev_alloc(h))) return rc;
+  hipLaunchKernelGGL(maxabs_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int64_t)h->At.nnz, h->At.val,
+                     h->ev_partials, h->ev_grid);
+  return ev_finish(h, 0, 1, out);
 }
 
 // ---- measurement ------------------------------------------------------------

@@ -156,6 +156,31 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_spmv_t(self._h, _pd(y), _pd(out)))
         return out
 
+    # ---- rescaling on the device (LP only) ------------------------------------------
+    supports_device_rescaling = True
+
+    def rescale(self, l_inf_ruiz_iterations, l2_norm_rescaling, pock_chambolle_alpha):
+        """rescale_problem (preprocess.jl:631-687) in place on the device;
+        returns (constraint_rescaling, variable_rescaling)."""
+        e, dvec = np.empty(self.m), np.empty(self.n)
+        use_pc = pock_chambolle_alpha is not None
+        _lib.check(self._L.pdhg_rescale(self._h, int(l_inf_ruiz_iterations),
+                                        int(bool(l2_norm_rescaling)), int(use_pc),
+                                        float(pock_chambolle_alpha) if use_pc else 0.0,
+                                        _pd(e), _pd(dvec)))
+        return e, dvec
+
+    def get_problem_vectors(self):
+        c, b = np.empty(self.n), np.empty(self.m)
+        lb, ub = np.empty(self.n), np.empty(self.n)
+        _lib.check(self._L.pdhg_get_problem_vectors(self._h, _pd(c), _pd(b), _pd(lb), _pd(ub)))
+        return c, b, lb, ub
+
+    def matrix_max_abs(self):
+        out = np.zeros(1)
+        _lib.check(self._L.pdhg_matrix_max_abs(self._h, _pd(out)))
+        return float(out[0])
+
     # ---- evaluation branch on the device (LP only) ---------------------------------
     supports_device_evaluation = True
 

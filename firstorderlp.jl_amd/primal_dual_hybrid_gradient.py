@@ -168,6 +168,7 @@ def take_step(step_params, solver_state, is_lp=True):
 # optimize(): the reference's outer loop (pdhg.jl:782-1049) on the host, with
 # every n-/m-length vector operation behind ``engine``.
 # ==============================================================================
+import os
 import time as _time
 
 from .evaluation import (POINT_AVERAGE, POINT_CURRENT, DeviceEvaluator,
@@ -290,17 +291,40 @@ def optimize(params, original_problem, engine_factory=None):
     Returns a ``SaddlePointOutput``."""
     validate(original_problem)
     qp_cache = cached_quadratic_program_info(original_problem)
-    scaled_problem = rescale_problem(params.l_inf_ruiz_iterations,
-                                     params.l2_norm_rescaling,
-                                     params.pock_chambolle_alpha,
-                                     params.verbosity, original_problem)
-    problem = scaled_problem.scaled_qp
-    primal_size = problem.num_variables
-    dual_size = problem.num_constraints
     if params.primal_importance <= 0 or not math.isfinite(params.primal_importance):
         raise ValueError("primal_importance must be positive and finite")
+    is_lp_original = is_linear_programming_problem(original_problem)
+    engine = None
+    if engine_factory is None and is_lp_original and os.environ.get("PDHG_HOST_RESCALE", "0") != "1":
+        # Product path for LPs: upload the ORIGINAL problem and rescale on the
+        # device (pdhg_rescale); only the n-/m-length vectors come back.
+        from .quadratic_programming import QuadraticProgrammingProblem, ScaledQpProblem
+        import scipy.sparse as _sp
+        engine = _default_engine_factory(original_problem)
+        constraint_rescaling, variable_rescaling = engine.rescale(
+            params.l_inf_ruiz_iterations, params.l2_norm_rescaling, params.pock_chambolle_alpha)
+        c_s, b_s, lb_s, ub_s = engine.get_problem_vectors()
+        m0, n0 = original_problem.constraint_matrix.shape
+        problem = QuadraticProgrammingProblem(
+            lb_s, ub_s, _sp.csc_matrix((n0, n0)), c_s, original_problem.objective_constant,
+            _sp.csc_matrix((m0, n0)),      # the scaled matrix lives on the device only
+            b_s, original_problem.num_equalities)
+        scaled_problem = ScaledQpProblem(original_problem, problem, constraint_rescaling,
+                                         variable_rescaling)
+        matrix_max_abs = engine.matrix_max_abs()
+    else:
+        scaled_problem = rescale_problem(params.l_inf_ruiz_iterations,
+                                         params.l2_norm_rescaling,
+                                         params.pock_chambolle_alpha,
+                                         params.verbosity, original_problem)
+        problem = scaled_problem.scaled_qp
+        data = problem.constraint_matrix.data
+        matrix_max_abs = float(np.max(np.abs(data))) if len(data) else 0.0   # norm(A, Inf) on a sparse matrix
+    primal_size = problem.num_variables
+    dual_size = problem.num_constraints
 
-    engine = (engine_factory or _default_engine_factory)(problem)
+    if engine is None:
+        engine = (engine_factory or _default_engine_factory)(problem)
     ops = EngineOps(engine, problem)
     original_ops = UnscaledEngineOps(engine, scaled_problem)
     is_lp = is_linear_programming_problem(problem)
@@ -308,9 +332,7 @@ def optimize(params, original_problem, engine_factory=None):
     policy = params.step_size_policy_params
 
     def inv_max_abs():
-        data = problem.constraint_matrix.data
-        mx = float(np.max(np.abs(data))) if len(data) else 0.0   # norm(A, Inf) on a sparse matrix
-        return math.inf if mx == 0.0 else 1.0 / mx
+        return math.inf if matrix_max_abs == 0.0 else 1.0 / matrix_max_abs
 
     if isinstance(policy, AdaptiveStepsizeParams):
         solver_state.cumulative_kkt_passes += 0.5

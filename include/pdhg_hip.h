@@ -195,6 +195,26 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
                             double dual_weight_norm, double radius, int range,
                             int approximate, double out[8]);
 
+/*
+ * ---- rescaling on the device ("next" row N2) --------------------------------
+ * rescale_problem (src/preprocess.jl:631-687) in place on a handle created from
+ * the ORIGINAL problem: l_inf_ruiz_iterations of ruiz_rescaling with p = Inf
+ * (:412-477), then l2_norm_rescaling (:358-372) if requested, then
+ * pock_chambolle_rescaling(alpha) (:508-539) if requested.  Every resident copy
+ * of the matrix is scaled entry by entry as (a * (1/e_i)) * (1/d_j), and c, b,
+ * lb, ub as scale_problem does (:555-573).  Outputs the cumulative
+ * constraint_rescaling[m] / variable_rescaling[n] (ScaledQpProblem,
+ * src/quadratic_programming.jl:293-298).  LP only.
+ */
+int pdhg_rescale(pdhg_handle *h, int l_inf_ruiz_iterations, int l2_norm_rescaling,
+                 int use_pock_chambolle, double pock_chambolle_alpha,
+                 double *constraint_rescaling_out, double *variable_rescaling_out);
+/* The handle's (possibly rescaled) objective_vector, right_hand_side and bounds. */
+int pdhg_get_problem_vectors(pdhg_handle *h, double *c, double *b, double *lb, double *ub);
+/* norm(constraint_matrix, Inf) = max |A_ij| of the resident matrix: the initial
+ * step size 1/norm(A, Inf) (src/primal_dual_hybrid_gradient.jl:823-826). */
+int pdhg_matrix_max_abs(pdhg_handle *h, double *out);
+
 /* ---- measurement ---------------------------------------------------------- */
 enum {
   PDHG_K_PRIMAL = 0,     /* x', xb elementwise                         */

@@ -1,0 +1,68 @@
+"""N2 on the device: pdhg_rescale against the host rescale_problem
+(firstorderlp.jl_amd/preprocess.py, itself pinned by the reference's
+test_qp_processing.jl KATs).  Ruiz (max-based) is bit-exact: same per-entry
+multiplication order; L2 / Pock-Chambolle factors come from sums whose order
+differs (wave tree vs sequential) -> 1e-13 relative."""
+import numpy as np
+import pytest
+
+from firstorderlp_jl_amd import HipPdhgEngine
+from firstorderlp_jl_amd.generators import pagerank_lp, random_lp
+from firstorderlp_jl_amd.preprocess import rescale_problem
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+MAKERS = {"random": lambda: random_lp(3000, 4000, 8, 3),
+          "skewed": lambda: H.skewed_lp(2500, 6000, 5),
+          "pagerank": lambda: pagerank_lp(20000, seed=2),
+          "example_lp": H.example_lp}
+
+
+@pytest.mark.parametrize("name", sorted(MAKERS))
+@pytest.mark.parametrize("ruiz,l2,alpha", [(10, False, None), (3, False, 1.0), (0, True, None),
+                                           (2, True, 0.0), (0, False, 2.0), (0, False, None)])
+def test_device_rescale_matches_host(gpu_required, name, ruiz, l2, alpha):
+    p = MAKERS[name]()
+    host = rescale_problem(ruiz, l2, alpha, 0, p)
+    eng = HipPdhgEngine.from_problem(p)
+    E, D = eng.rescale(ruiz, l2, alpha)
+    c, b, lb, ub = eng.get_problem_vectors()
+    exact = not l2 and alpha is None
+    def close(a, w):
+        if exact:
+            assert np.array_equal(a, w)
+        else:
+            np.testing.assert_allclose(a, w, rtol=1e-12, atol=0)
+    close(E, host.constraint_rescaling)
+    close(D, host.variable_rescaling)
+    s = host.scaled_qp
+    close(c, s.objective_vector); close(b, s.right_hand_side)
+    close(lb, s.variable_lower_bound); close(ub, s.variable_upper_bound)
+    mx = eng.matrix_max_abs()
+    want = float(np.abs(s.constraint_matrix.data).max())
+    assert mx == want if exact else abs(mx - want) <= 1e-12 * want
+    # the rescaled resident matrix itself, through both layouts
+    ref = HipPdhgEngine.from_problem(s)
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(eng.n), rng.standard_normal(eng.m)
+    for got, wantv in ((eng.spmv(x), ref.spmv(x)), (eng.spmv_t(y), ref.spmv_t(y))):
+        if exact:
+            assert np.array_equal(got, wantv)
+        else:
+            np.testing.assert_allclose(got, wantv, rtol=1e-11, atol=1e-11 * np.abs(wantv).max())
+
+
+def test_device_rescale_tiled_layout(gpu_required, monkeypatch):
+    monkeypatch.setenv("PDHG_SPMV", "tiled")
+    monkeypatch.setenv("PDHG_TILE_SHIFT", "9")
+    p = random_lp(5000, 7000, 9, 11)
+    host = rescale_problem(10, False, None, 0, p)
+    eng = HipPdhgEngine.from_problem(p)
+    assert eng.layout_info()["A_tiled_waves"] > 0
+    eng.rescale(10, False, None)
+    ref = HipPdhgEngine.from_problem(host.scaled_qp)
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(eng.n), rng.standard_normal(eng.m)
+    assert np.array_equal(eng.spmv(x), ref.spmv(x))
+    assert np.array_equal(eng.spmv_t(y), ref.spmv_t(y))
