@@ -129,6 +129,13 @@ class RowPartitionedEngine:
     def accept(self, avg_weight):
         self.local.accept(avg_weight)
 
+    def trial_primal(self, *a, **k):
+        raise NotImplementedError("the row-partitioned engine implements the adaptive and constant "
+                                  "step policies (pdhg_dist_trial_*); Malitsky-Pock needs the split "
+                                  "primal/dual trial, which is single-GPU only in this build")
+
+    trial_dual = add_current_primal_to_average = trial_primal
+
     def _refresh_dual_product(self):
         self.local.dist_dual_product_begin()
         self.comm.all_reduce_sum(self.local.exchange_tensor())

@@ -1,0 +1,69 @@
+"""Error behaviour of the C ABI: every entry point returns an int (0 ok, <0 bad
+argument / unsupported), no exception or crash crosses the boundary; the Python
+binding turns non-zero into PdhgHipError carrying pdhg_last_error()."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from firstorderlp_jl_amd import HipPdhgEngine, _lib, linear_programming_problem
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int64)
+
+
+def _raw_create(m, n, colptr, rowval, nzval, base, ne, c=None, b=None):
+    L = _lib.lib()
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+    rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nzval = np.ascontiguousarray(nzval, dtype=np.float64)
+    c = np.zeros(n) if c is None else c
+    b = np.zeros(m) if b is None else b
+    lb, ub = np.zeros(n), np.ones(n)
+    h = ctypes.c_void_p()
+    rc = L.pdhg_create(ctypes.byref(h), m, n, len(nzval), colptr.ctypes.data_as(_ip),
+                       rowval.ctypes.data_as(_ip), nzval.ctypes.data_as(_dp), base,
+                       c.ctypes.data_as(_dp), b.ctypes.data_as(_dp), lb.ctypes.data_as(_dp),
+                       ub.ctypes.data_as(_dp), ne, -1, None)
+    if rc == 0:
+        L.pdhg_destroy(h)
+    return rc, L.pdhg_last_error().decode()
+
+
+def test_create_rejects_bad_arguments(gpu_required):
+    ok = ([0, 1, 2], [0, 1], [1.0, 2.0])
+    assert _raw_create(2, 2, *ok, 0, 1)[0] == 0
+    assert _raw_create(2, 2, [1, 2, 3], [1, 2], [1.0, 2.0], 1, 1)[0] == 0     # Julia's 1-based arrays
+    rc, msg = _raw_create(2, 2, *ok, 2, 1)
+    assert rc < 0 and "index_base" in msg
+    rc, msg = _raw_create(2, 2, *ok, 0, 3)
+    assert rc < 0 and "num_equalities" in msg
+    rc, msg = _raw_create(2, 2, [0, 1, 2], [0, 5], [1.0, 2.0], 0, 1)
+    assert rc < 0 and "rowval" in msg
+    rc, msg = _raw_create(2, 2, [0, 2, 1], [0, 1], [1.0, 2.0], 0, 1)
+    assert rc < 0
+    rc, msg = _raw_create(2, 2, [1, 2, 3], [0, 1], [1.0, 2.0], 0, 1)
+    assert rc < 0 and "colptr" in msg
+
+
+def test_unsupported_and_misordered_calls(gpu_required):
+    eng = HipPdhgEngine.from_problem(H.example_lp())
+    with pytest.raises(_lib.PdhgHipError, match="average is empty"):
+        eng.restart_to_average()
+    with pytest.raises(_lib.PdhgHipError, match="pdhg_set_original_problem"):
+        eng.eval_point(_lib.POINT_CURRENT)
+    with pytest.raises(_lib.PdhgHipError, match="without begin"):
+        eng.dist_trial_end()
+    with pytest.raises(_lib.PdhgHipError, match="range"):
+        eng.trust_region_bound(_lib.POINT_CURRENT, 1.0, 1.0, 1.0, 7)
+    qp = HipPdhgEngine.from_problem(H.example_qp())
+    for call in (lambda: qp.dist_trial_begin(0.1, 1.0), lambda: qp.rescale(1, False, None),
+                 lambda: qp.trust_region_bound(_lib.POINT_CURRENT, 1.0, 1.0, 1.0, 0)):
+        with pytest.raises(_lib.PdhgHipError, match="LP"):
+            call()
+    # the engine is still usable after errors
+    raw = eng.trial_step(0.1, 1.0, 1.0)
+    assert np.all(np.isfinite(raw))
