@@ -26,6 +26,29 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def socket0_cores():
+    """One logical CPU per physical core of socket 0 (from /proc/cpuinfo)."""
+    seen, cpus = set(), []
+    cpu = phys = core = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh.read().split("\n") + [""]:
+                if line.startswith("processor"):
+                    cpu = int(line.split(":")[1])
+                elif line.startswith("physical id"):
+                    phys = int(line.split(":")[1])
+                elif line.startswith("core id"):
+                    core = int(line.split(":")[1])
+                elif not line.strip() and cpu is not None:
+                    if (phys or 0) == 0 and (phys, core) not in seen:
+                        seen.add((phys, core))
+                        cpus.append(cpu)
+                    cpu = phys = core = None
+    except OSError:
+        pass
+    return cpus or list(range(max(1, (os.cpu_count() or 2) // 2)))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +207,36 @@ def main():
                                   f"1 thread of {os.cpu_count()} host cores"}
         st.close()
 
+    # ---- second CPU comparator: the same step with OpenMP on ONE socket's cores
+    cpu_socket = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cores = socket0_cores()
+            os.environ["OMP_NUM_THREADS"] = str(len(cores))
+            os.environ["OMP_PROC_BIND"] = "true"
+            os.environ["GOMP_CPU_AFFINITY"] = " ".join(str(c) for c in cores)
+            from oracle.oracle import OmpCpuState
+            om = OmpCpuState(A.shape[0], A.shape[1], A.indptr, A.indices, A.data,
+                             problem.objective_vector, problem.right_hand_side,
+                             problem.variable_lower_bound, problem.variable_upper_bound,
+                             problem.num_equalities)
+            om.set_scalars(step0, pw0)
+            for _ in range(2):
+                om.take_step_adaptive(0.3, 0.6)
+            t0 = time.perf_counter()
+            its = 0
+            while its < 5 or (time.perf_counter() - t0 < 0.6 * args.cpu_baseline_seconds and its < 5000):
+                om.take_step_adaptive(0.3, 0.6)
+                its += 1
+            dt = time.perf_counter() - t0
+            cpu_socket = {"value": round(its / dt, 4), "unit": "iterations/s", "cores": om.threads(),
+                          "kind": "port-openmp",
+                          "sample": f"{its} adaptive take_step calls on the same LP, oracle/pdhg_cpu_omp.c, "
+                                    f"one thread per physical core of socket 0 ({len(cores)} cores)"}
+            om.close()
+        except Exception as exc:   # measurement extra: never fail the bench line for it
+            cpu_socket = {"error": repr(exc)}
+
     if rank == 0:
         m, n = A.shape
         b_pair = 24 * nnz + 16 * (m + n) + 4 * (m + n + 2)
@@ -201,12 +254,14 @@ def main():
                        "parallelism": "single GPU" if dist is None else f"row-partition x{world} + RCCL all-reduce"},
             "trials_per_step": round(trials / args.steps, 4),
             "whole_iteration_GBps": round(b_iter * (trials / args.steps) / (ms_per_step * 1e-3) / 1e9, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_socket": cpu_socket,
             "kernels": kernels,
             "setup_sec": {"generate": round(t_gen, 1), "create_upload": round(t_create, 1)},
         }
         if cpu_baseline:
             out["speedup_vs_cpu_port"] = round(value / cpu_baseline["value"], 1)
+        if cpu_socket and "value" in cpu_socket:
+            out["speedup_vs_cpu_socket"] = round(value / cpu_socket["value"], 1)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -243,3 +243,69 @@ class OracleState:
 
     def recompute_dual_product(self):
         self._L.oracle_recompute_dual_product(self._h)
+
+
+# ---- multi-threaded CPU comparator (pdhg_cpu_omp.c): measurement only -------------
+
+_OMP_PATH = os.path.join(_HERE, "libpdhg_cpu_omp.so")
+_omp = None
+
+
+def build_omp(force=False):
+    src = os.path.join(_HERE, "pdhg_cpu_omp.c")
+    if force or not os.path.exists(_OMP_PATH) or os.path.getmtime(_OMP_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpdhg_cpu_omp.so"], stdout=subprocess.DEVNULL)
+    return _OMP_PATH
+
+
+def omp_lib():
+    global _omp
+    if _omp is None:
+        build_omp()
+        _omp = ctypes.CDLL(_OMP_PATH)
+        _omp.omp_create.restype = ctypes.c_void_p
+        _omp.omp_get_step_size.restype = ctypes.c_double
+        _omp.omp_get_step_size.argtypes = [ctypes.c_void_p]
+        _omp.omp_get_total_iterations.restype = ctypes.c_int64
+        _omp.omp_get_total_iterations.argtypes = [ctypes.c_void_p]
+        _omp.omp_set_scalars.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
+        _omp.omp_take_step_adaptive.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
+        _omp.omp_destroy.argtypes = [ctypes.c_void_p]
+        _omp.omp_get_xy.argtypes = [ctypes.c_void_p, _c_double_p, _c_double_p]
+    return _omp
+
+
+class OmpCpuState:
+    """OpenMP adaptive-step PDHG on an LP (CSC 0-based arrays); bench comparator."""
+
+    def __init__(self, m, n, colptr, rowval, nzval, c, b, lb, ub, num_equalities):
+        L = omp_lib()
+        self.m, self.n = int(m), int(n)
+        colptr, rowval, nzval = _i(colptr), _i(rowval), _d(nzval)
+        c, b, lb, ub = _d(c), _d(b), _d(lb), _d(ub)
+        self._h = ctypes.c_void_p(L.omp_create(
+            ctypes.c_int64(m), ctypes.c_int64(n), _ip(colptr), _ip(rowval), _dp(nzval),
+            _dp(c), _dp(b), _dp(lb), _dp(ub), ctypes.c_int64(num_equalities)))
+        self._L = L
+
+    def threads(self):
+        return int(self._L.omp_threads())
+
+    def set_scalars(self, step_size, primal_weight):
+        self._L.omp_set_scalars(self._h, step_size, primal_weight)
+
+    def take_step_adaptive(self, reduction_exponent=0.3, growth_exponent=0.6):
+        return self._L.omp_take_step_adaptive(self._h, reduction_exponent, growth_exponent)
+
+    step_size = property(lambda s: s._L.omp_get_step_size(s._h))
+    total_number_iterations = property(lambda s: int(s._L.omp_get_total_iterations(s._h)))
+
+    def xy(self):
+        x, y = np.empty(self.n), np.empty(self.m)
+        self._L.omp_get_xy(self._h, _dp(x), _dp(y))
+        return x, y
+
+    def close(self):
+        if self._h:
+            self._L.omp_destroy(self._h)
+            self._h = None
