@@ -212,14 +212,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cores = socket0_cores()
-            os.environ["OMP_NUM_THREADS"] = str(len(cores))
-            os.environ["OMP_PROC_BIND"] = "true"
-            os.environ["GOMP_CPU_AFFINITY"] = " ".join(str(c) for c in cores)
             from oracle.oracle import OmpCpuState
             om = OmpCpuState(A.shape[0], A.shape[1], A.indptr, A.indices, A.data,
                              problem.objective_vector, problem.right_hand_side,
                              problem.variable_lower_bound, problem.variable_upper_bound,
-                             problem.num_equalities)
+                             problem.num_equalities, cpus=cores)
             om.set_scalars(step0, pw0)
             for _ in range(2):
                 om.take_step_adaptive(0.3, 0.6)

@@ -278,8 +278,11 @@ def omp_lib():
 class OmpCpuState:
     """OpenMP adaptive-step PDHG on an LP (CSC 0-based arrays); bench comparator."""
 
-    def __init__(self, m, n, colptr, rowval, nzval, c, b, lb, ub, num_equalities):
+    def __init__(self, m, n, colptr, rowval, nzval, c, b, lb, ub, num_equalities, cpus=None):
         L = omp_lib()
+        if cpus:
+            arr = (ctypes.c_int * len(cpus))(*cpus)
+            L.omp_configure(len(cpus), arr)
         self.m, self.n = int(m), int(n)
         colptr, rowval, nzval = _i(colptr), _i(rowval), _d(nzval)
         c, b, lb, ub = _d(c), _d(b), _d(lb), _d(ub)

@@ -11,8 +11,10 @@
  * CSR(A') (= the CSC arrays), vector updates and reductions parallel.  Same
  * per-element arithmetic (no FMA contraction); only reduction order differs.
  */
+#define _GNU_SOURCE
 #include <math.h>
 #include <omp.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -27,8 +29,45 @@ typedef struct {
   int64_t total_iterations;
 } omp_state;
 
-static double *zd(int64_t k) { return (double *)calloc((size_t)(k > 0 ? k : 1), sizeof(double)); }
-static double *cpd(const double *s, int64_t k) { double *p = zd(k); if (k > 0) memcpy(p, s, sizeof(double) * (size_t)k); return p; }
+/* Thread count and pinning are set explicitly (the process may already host an
+ * OpenMP runtime initialised by another library, so environment variables are
+ * too late): thread i is pinned to cpus[i]. */
+static int g_threads = 0;
+void omp_configure(int nthreads, const int *cpus) {
+  g_threads = nthreads > 0 ? nthreads : 1;
+  omp_set_dynamic(0);
+  omp_set_num_threads(g_threads);
+#pragma omp parallel num_threads(g_threads)
+  {
+    const int t = omp_get_thread_num();
+    if (cpus) {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      CPU_SET(cpus[t], &set);
+      sched_setaffinity(0, sizeof(set), &set);
+    }
+  }
+}
+
+/* first-touch by the (pinned) worker threads so pages land on their socket */
+static double *zd(int64_t k) {
+  double *p = (double *)malloc(sizeof(double) * (size_t)(k > 0 ? k : 1));
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < k; ++i) p[i] = 0.0;
+  return p;
+}
+static double *cpd(const double *s, int64_t k) {
+  double *p = (double *)malloc(sizeof(double) * (size_t)(k > 0 ? k : 1));
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < k; ++i) p[i] = s[i];
+  return p;
+}
+static int64_t *cpi(const int64_t *s, int64_t k) {
+  int64_t *p = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k > 0 ? k : 1));
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < k; ++i) p[i] = s[i];
+  return p;
+}
 
 omp_state *omp_create(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
                       const double *nzval, const double *c, const double *b, const double *lb,
@@ -36,11 +75,11 @@ omp_state *omp_create(int64_t m, int64_t n, const int64_t *colptr, const int64_t
   omp_state *s = (omp_state *)calloc(1, sizeof(omp_state));
   const int64_t nnz = colptr[n];
   s->m = m; s->n = n; s->ne = ne;
-  s->cp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1)); memcpy(s->cp, colptr, sizeof(int64_t) * (size_t)(n + 1));
-  s->ri = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz > 0 ? nnz : 1)); memcpy(s->ri, rowval, sizeof(int64_t) * (size_t)nnz);
+  s->cp = cpi(colptr, n + 1);
+  s->ri = cpi(rowval, nnz);
   s->vt = cpd(nzval, nnz);
   s->rp = (int64_t *)calloc((size_t)(m + 1), sizeof(int64_t));
-  s->ci = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz > 0 ? nnz : 1));
+  s->ci = cpi(rowval, nnz);   /* placeholder contents; first-touched in parallel, filled below */
   s->va = zd(nnz);
   for (int64_t k = 0; k < nnz; ++k) s->rp[rowval[k] + 1] += 1;
   for (int64_t i = 0; i < m; ++i) s->rp[i + 1] += s->rp[i];
@@ -66,7 +105,7 @@ void omp_destroy(omp_state *s) {
 void omp_set_scalars(omp_state *s, double step, double pw) { s->step_size = step; s->primal_weight = pw; }
 double omp_get_step_size(const omp_state *s) { return s->step_size; }
 int64_t omp_get_total_iterations(const omp_state *s) { return s->total_iterations; }
-int omp_threads(void) { return omp_get_max_threads(); }
+int omp_threads(void) { return g_threads > 0 ? g_threads : omp_get_max_threads(); }
 
 static inline double dmax(double a, double b) { return a > b ? a : b; }
 static inline double dmin(double a, double b) { return a < b ? a : b; }
