@@ -172,7 +172,9 @@ def main():
               key=lambda k: local.profile_read(k)[1])
     dk = kernels[local.kernel_name(dom)]
     traffic = None
-    try:   # PMC-derived bytes/launch, measured offline with rocprofv3 on this exact workload
+    try:   # PMC-derived bytes/launch, measured offline with rocprofv3 on this exact workload (1 GPU)
+        if dist is not None:
+            raise OSError("PMC traffic was collected for the single-GPU launch only")
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             traffic = json.load(fh).get(
                 f"{local.kernel_name(dom)}@m={A.shape[0]},n={A.shape[1]},nnz={nnz}")
