@@ -5,8 +5,8 @@ through the C ABI.
 
     python scripts/solve_qp.py --instance_path test.mps --output_dir out --method pdhg
 
-``--engine oracle`` runs the CPU restatement instead (plumbing check without a
-GPU, BASELINE configs[0]); it is a test aid and is labelled as such in the log.
+There is no CPU fallback: without a GPU the run fails loudly.  Tests exercise the
+same code path on CPU by passing ``engine_factory`` to ``main`` (tests/test_qp_io.py).
 """
 import argparse
 import gzip
@@ -66,8 +66,6 @@ def parse_command_line(argv=None):
     ap.add_argument("--malitsky_pock_downscaling_factor", type=float, default=0.7)
     ap.add_argument("--malitsky_pock_breaking_factor", type=float, default=0.99)
     ap.add_argument("--malitsky_pock_interpolation_coefficient", type=float, default=1.0)
-    ap.add_argument("--engine", choices=["hip", "oracle"], default="hip",
-                    help="hip (default, MI355X) or oracle (CPU restatement, test aid)")
     return ap.parse_args(argv)
 
 
@@ -138,7 +136,7 @@ def write_vector_to_file(filename, vector):
             fh.write(repr(float(x)) + "\n")
 
 
-def solve_instance_and_output(parameters, a, argv):
+def solve_instance_and_output(parameters, a, argv, engine_factory=None):
     """scripts/solve_qp.jl:65-162"""
     from firstorderlp_jl_amd import primal_dual_hybrid_gradient as pdhg
     from firstorderlp_jl_amd.preprocess import presolve, undo_presolve
@@ -154,13 +152,8 @@ def solve_instance_and_output(parameters, a, argv):
                              transform_bounds=a.transform_bounds_into_linear_constraints)
     if parameters.verbosity >= 1:
         print("Instance: ", instance_name)
-    factory = None
-    if a.engine == "oracle":
-        from tests.oracle_engine import OracleEngine
-        factory = OracleEngine.from_problem
-        print("NOTE: --engine oracle (CPU restatement, test aid) -- not the GPU product path")
     t0 = time.time()
-    output = pdhg.optimize(parameters, lp, factory)
+    output = pdhg.optimize(parameters, lp, engine_factory)
     running_time = time.time() - t0
     print(f"Elapsed time: {running_time} sec")
 
@@ -184,11 +177,13 @@ def solve_instance_and_output(parameters, a, argv):
     return output, primal, dual
 
 
-def main(argv=None):
+def main(argv=None, engine_factory=None):
+    """``engine_factory`` is a test hook (see primal_dual_hybrid_gradient.optimize);
+    the command line always uses the HIP engine."""
     argv = list(sys.argv[1:] if argv is None else argv)
     a = parse_command_line(argv)
     parameters = build_parameters(a)
-    return solve_instance_and_output(parameters, a, argv)
+    return solve_instance_and_output(parameters, a, argv, engine_factory)
 
 
 if __name__ == "__main__":

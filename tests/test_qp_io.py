@@ -106,10 +106,11 @@ def test_solve_qp_cli_trivial_lp_cpu_plumbing(tmp_path):
     """BASELINE configs[0]: test/trivial_lp_model.mps, --method pdhg, CPU path.
     Optimum: x = [0, 2], objective -2 (CI.yml:40-45 only requires exit 0)."""
     from scripts import solve_qp
+    from tests.oracle_engine import OracleEngine
     out = tmp_path / "out"
     argv = ["--instance_path", os.path.join(DATA, "trivial_lp_model.mps"), "--output_dir", str(out),
-            "--method", "pdhg", "--engine", "oracle", "--verbosity", "0"]
-    output, primal, dual = solve_qp.main(argv)
+            "--method", "pdhg", "--verbosity", "0"]
+    output, primal, dual = solve_qp.main(argv, engine_factory=OracleEngine.from_problem)
     assert output.termination_string == "OPTIMAL"
     np.testing.assert_allclose(primal, [0.0, 2.0], atol=1e-5)
     np.testing.assert_allclose(dual, [0.0], atol=1e-5)
