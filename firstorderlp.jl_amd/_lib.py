@@ -11,7 +11,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-LIB_PATH = os.path.join(CSRC, "libpdhg_hip.so")
+# PDHG_HIP_LIB: developer override used by tools/variants.sh to time -D variants
+LIB_PATH = os.environ.get("PDHG_HIP_LIB") or os.path.join(CSRC, "libpdhg_hip.so")
 SRC_PATH = os.path.join(CSRC, "pdhg_hip.hip")
 
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off",

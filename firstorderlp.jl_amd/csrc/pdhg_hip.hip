@@ -373,14 +373,22 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
       const int t = t0 + s;
       if (t < ntiles) {  // workgroup-uniform
         const int f = (s + D) % R;       // ring slot being refilled (held tile t-1)
+#ifdef TWD_ONE_TILE   // timing diagnostic, wrong results (tools/variants.sh): every gather hits tile 0
+        const double *xt = xin;
+#else
         const double *xt = xin + ((size_t)tl[s] << tile_shift);
+#endif
         // 1. gathers for tile t (entries requested D steps ago).  Issued BEFORE
         //    the prefetch: a wave's loads return in order, so the L2-latency
         //    gathers must not queue behind HBM-latency streaming loads.
         //    (Gathering one tile ahead was measured slower: it widens the L2
         //    working window of the sweep.)
 #pragma unroll
+#ifdef TWD_NO_GATHER  // timing diagnostic, wrong results: stream + accumulate only
+        for (int i = 0; i < U; ++i) xv[i] = 1.0 + (double)(size_t)xt * 0.0;
+#else
         for (int i = 0; i < U; ++i) xv[i] = (p[s][i] != TW_PAD) ? xt[p[s][i] & cmask] : 0.0;
+#endif
         // 2. entry loads for tile t+D
         ks[f] = ke[(s + D - 1) % R];
         ke[f] = ke_ahead;

@@ -1,0 +1,208 @@
+// Dev probe (not part of the product): the gather path of the tiled sweep in
+// isolation.  8-wave workgroups walk the column tiles in lock step (barrier per
+// tile); every wave loads E packed 16-bit column offsets per tile and gathers
+// x[tile_base + off].  No values, no accumulators: what does the gather
+// instruction form (64-bit vaddr / SGPR base + 32-bit offset / buffer load) and
+// the pacing cost?   usage: sweep_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <random>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+constexpr int WPB = 8, WAVE = 64;
+
+template <int FORM, int E, bool BAR, bool VALS>
+__global__ __launch_bounds__(WPB * WAVE) void sweep(const unsigned *__restrict__ pk, const double *__restrict__ tv,
+                                                    const double *__restrict__ x, double *__restrict__ out,
+                                                    int ntiles, int shift) {
+  extern __shared__ double lds[];
+  constexpr int C = E / WAVE;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const size_t w = (size_t)blockIdx.x * WPB + wid;
+  const unsigned *my = pk + w * (size_t)ntiles * E;
+  const double *myv = tv + w * (size_t)ntiles * E;
+  const unsigned cmask = (1u << shift) - 1u;
+  double s = 0.0;
+  unsigned p[2][C];
+  double vv[2][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { p[0][c] = __builtin_nontemporal_load(my + c * WAVE + lane); if (VALS) vv[0][c] = __builtin_nontemporal_load(myv + c * WAVE + lane); }
+  for (int t0 = 0; t0 < ntiles; t0 += 2) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int t = t0 + b;
+      if (t < ntiles) {
+        const double *xt = x + ((size_t)t << shift);
+        double g[C];
+        if (FORM == 0) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) g[c] = xt[p[b][c] & cmask];
+        } else if (FORM == 1) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const unsigned off = (p[b][c] & cmask) * 8u;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(g[c]) : "v"(off), "s"(xt) : "memory");
+          }
+        } else {
+          __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)xt, 0, (int)(8u << shift), 0x00020000);
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            auto q = __builtin_amdgcn_raw_buffer_load_b64(r, (int)((p[b][c] & cmask) * 8u), 0, 0);
+            g[c] = __builtin_bit_cast(double, q);
+          }
+        }
+        if (t + 1 < ntiles) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            p[b ^ 1][c] = __builtin_nontemporal_load(my + (size_t)(t + 1) * E + c * WAVE + lane);
+            if (VALS) vv[b ^ 1][c] = __builtin_nontemporal_load(myv + (size_t)(t + 1) * E + c * WAVE + lane);
+          }
+        }
+        if (FORM == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < C; ++c) s += VALS ? g[c] * vv[b][c] : g[c];
+        if (BAR) __syncthreads();
+      }
+    }
+  }
+  out[(size_t)blockIdx.x * WPB * WAVE + threadIdx.x] = s + lds[0] * 0.0;
+}
+
+template <typename F>
+float time_it(F f, int reps = 5) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f(); CK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < reps; ++r) {
+    CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+  }
+  return best;
+}
+
+
+// Loader-wave variant: a 9th wave streams every (workgroup, step) block of
+// packed offsets + values into an LDS ring by LDS-DMA (global_load_lds, nt); the
+// 8 consumers read their entries from LDS, so their vector-memory queue holds
+// gathers only.  Layout: block (wg, t) = 8 waves x E entries, contiguous.
+template <int E, int S, int XPF>
+__global__ __launch_bounds__((WPB + 1) * WAVE) void sweep_ring(const unsigned *__restrict__ pk, const double *__restrict__ tv,
+                                                               const double *__restrict__ x, double *__restrict__ out,
+                                                               int ntiles, int shift) {
+  extern __shared__ double lds[];
+  constexpr int BLK = WPB * E;                 // entries per (wg, step)
+  constexpr int NP = BLK * 4 / 1024;           // DMA instructions for the packed part
+  constexpr int NV = BLK * 8 / 1024;
+  double *ring_v = lds;                                            // [S][BLK] doubles
+  unsigned *ring_p = reinterpret_cast<unsigned *>(lds + S * BLK);  // [S][BLK] u32
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const unsigned *gp = pk + (size_t)blockIdx.x * ntiles * BLK;
+  const double *gv = tv + (size_t)blockIdx.x * ntiles * BLK;
+  if (wid == WPB) {
+    auto issue = [&](int j) {
+      const int jj = min(j, ntiles - 1);
+      const int slot = j % S;
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        __builtin_amdgcn_global_load_lds(gp + (size_t)jj * BLK + i * 256 + lane * 4,
+                                         (__attribute__((address_space(3))) void *)(ring_p + slot * BLK + i * 256), 16, 0, 2);
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        __builtin_amdgcn_global_load_lds(gv + (size_t)jj * BLK + i * 128 + lane * 2,
+                                         (__attribute__((address_space(3))) void *)(ring_v + slot * BLK + i * 128), 16, 0, 2);
+    };
+    int sink = 0;   // destination of the never-waited touches: must stay allocated while they are in flight
+    for (int j = 0; j < S - 1; ++j) issue(j);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (NP + NV)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < ntiles; ++t) {
+      issue(t + S - 1);
+      if (XPF > 0 && t + XPF < ntiles) {   // touch a 1/64 slice of a later x tile (64 co-resident WGs per XCD)
+        const char *xl = reinterpret_cast<const char *>(x + ((size_t)(t + XPF) << shift)) + (size_t)(((blockIdx.x >> 3) & 63) * 64 + lane) * 128;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(xl) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (NP + NV) + 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (NP + NV)) : "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
+    if (sink == 0x7fffffff) out[0] = 0.0;
+    return;
+  }
+  constexpr int C = E / WAVE;
+  const unsigned cmask = (1u << shift) - 1u;
+  double s = 0.0;
+  __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < ntiles; ++t) {
+    const int slot = t % S;
+    const double *xt = x + ((size_t)t << shift);
+    unsigned p[C]; double vv[C], g[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] = ring_p[slot * BLK + wid * E + c * WAVE + lane]; vv[c] = ring_v[slot * BLK + wid * E + c * WAVE + lane]; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) g[c] = xt[p[c] & cmask];
+#pragma unroll
+    for (int c = 0; c < C; ++c) s += g[c] * vv[c];
+    __syncthreads();
+  }
+  out[(size_t)blockIdx.x * WPB * WAVE + threadIdx.x] = s;
+}
+
+template <int E, int S, int XPF>
+void run_ring(const char *name, const unsigned *pk, const double *tv, const double *x, double *out, int nwaves, int ntiles, int shift, size_t lds) {
+  CK(hipFuncSetAttribute((const void *)sweep_ring<E, S, XPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  float ms = time_it([&] { hipLaunchKernelGGL((sweep_ring<E, S, XPF>), dim3(nwaves / WPB), dim3((WPB + 1) * WAVE), lds, 0, pk, tv, x, out, ntiles, shift); });
+  double cnt = (double)nwaves * ntiles * E;
+  printf("%-34s E=%3d lds=%3zuK: %.3f ms  %.1f G gathers/s\n", name, E, lds >> 10, ms, cnt / ms / 1e6);
+}
+
+template <int FORM, int E, bool BAR, bool VALS>
+void run(const char *name, const unsigned *pk, const double *tv, const double *x, double *out, int nwaves, int ntiles, int shift, size_t lds) {
+  CK(hipFuncSetAttribute((const void *)sweep<FORM, E, BAR, VALS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  float ms = time_it([&] { hipLaunchKernelGGL((sweep<FORM, E, BAR, VALS>), dim3(nwaves / WPB), dim3(WPB * WAVE), lds, 0, pk, tv, x, out, ntiles, shift); });
+  double cnt = (double)nwaves * ntiles * E;
+  printf("%-34s E=%3d lds=%3zuK: %.3f ms  %.1f G gathers/s\n", name, E, lds >> 10, ms, cnt / ms / 1e6);
+}
+
+int main() {
+  setvbuf(stdout, NULL, _IONBF, 0);
+  const int shift = 16, ntiles = 153, nwaves = 8192;
+  const size_t N = (size_t)ntiles << shift;
+  const size_t maxE = 128;
+  const size_t cnt = (size_t)nwaves * ntiles * maxE;
+  std::vector<unsigned> h(cnt);
+  std::mt19937 rng(1);
+  for (size_t i = 0; i < cnt; ++i) h[i] = ((rng() & 0x3FFu) << 16) | (rng() & 0xFFFFu);
+  unsigned *pk; CK(hipMalloc(&pk, cnt * 4)); CK(hipMemcpy(pk, h.data(), cnt * 4, hipMemcpyHostToDevice));
+  double *tv; CK(hipMalloc(&tv, cnt * 8)); CK(hipMemset(tv, 0, cnt * 8));
+  double *x; CK(hipMalloc(&x, N * 8)); CK(hipMemset(x, 0, N * 8));
+  double *out; CK(hipMalloc(&out, (size_t)nwaves * WAVE * 8));
+  const size_t L2WG = 78 << 10, L4WG = 38 << 10;
+  run<0, 64, true, false>("vaddr64 barrier", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<1, 64, true, false>("saddr+voff32 barrier", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<2, 64, true, false>("buffer_load barrier", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<0, 128, true, false>("vaddr64 barrier", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<1, 128, true, false>("saddr+voff32 barrier", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<2, 128, true, false>("buffer_load barrier", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<0, 128, false, false>("vaddr64 NO barrier", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<2, 128, false, false>("buffer_load NO barrier", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<0, 128, true, false>("vaddr64 barrier 4WG/CU", pk, tv, x, out, nwaves, ntiles, shift, L4WG);
+  run<2, 128, true, false>("buffer_load barrier 4WG/CU", pk, tv, x, out, nwaves, ntiles, shift, L4WG);
+  run<0, 128, true, true>("vaddr64 barrier +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<2, 128, true, true>("buffer_load barrier +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<2, 64, true, true>("buffer_load barrier +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run<2, 128, true, true>("buffer_load barrier +vals 4WG/CU", pk, tv, x, out, nwaves, ntiles, shift, L4WG);
+  run_ring<64, 4, 0>("ring S=4 +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_ring<64, 3, 0>("ring S=3 +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_ring<64, 6, 0>("ring S=6 +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_ring<128, 4, 0>("ring S=4 +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_ring<64, 4, 2>("ring S=4 +vals xprefetch+2", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_ring<64, 4, 4>("ring S=4 +vals xprefetch+4", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_ring<128, 4, 2>("ring S=4 +vals xprefetch+2", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  return 0;
+}
