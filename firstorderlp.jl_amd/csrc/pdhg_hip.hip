@@ -1808,6 +1808,20 @@ int pdhg_dist_trial_begin(pdhg_handle *h, double step_size, double primal_weight
   return 0;
 }
 
+int pdhg_dist_trial_dual_begin(pdhg_handle *h, double step_size, double primal_weight, double theta) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (h->has_q) return fail(-2, "row-partitioned form supports LPs only");
+  hipLaunchKernelGGL(xbar_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->x, h->x_next, theta, h->xbar);
+  HIP_TRY(hipGetLastError());
+  if ((rc = launch_dual(h, primal_weight * step_size))) return rc;
+  if ((rc = launch_aty_plain(h, h->y_next, h->aty_next))) return rc;
+  hipLaunchKernelGGL(final_to_slot_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->pA, h->A.slots(), h->aty_next + h->n);
+  HIP_TRY(hipGetLastError());
+  h->dist_pending = true;
+  return 0;
+}
+
 void *pdhg_dist_exchange_ptr(pdhg_handle *h) { return h ? (void *)h->aty_next : nullptr; }
 
 int pdhg_dist_trial_end(pdhg_handle *h, double out[5]) {

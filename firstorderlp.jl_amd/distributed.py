@@ -129,12 +129,18 @@ class RowPartitionedEngine:
     def accept(self, avg_weight):
         self.local.accept(avg_weight)
 
-    def trial_primal(self, *a, **k):
-        raise NotImplementedError("the row-partitioned engine implements the adaptive and constant "
-                                  "step policies (pdhg_dist_trial_*); Malitsky-Pock needs the split "
-                                  "primal/dual trial, which is single-GPU only in this build")
+    # Malitsky-Pock (pdhg.jl:555-647): the primal half is rank-local, every
+    # linesearch iteration costs one all-reduce like an adaptive trial.
+    def trial_primal(self, step_size, primal_weight):
+        self.local.trial_primal(step_size, primal_weight)
 
-    trial_dual = add_current_primal_to_average = trial_primal
+    def trial_dual(self, step_size, primal_weight, theta):
+        self.local.dist_trial_dual_begin(step_size, primal_weight, theta)
+        self.comm.all_reduce_sum(self.local.exchange_tensor())
+        return self.local.dist_trial_end()
+
+    def add_current_primal_to_average(self, weight):
+        self.local.add_current_primal_to_average(weight)
 
     def _refresh_dual_product(self):
         self.local.dist_dual_product_begin()

@@ -224,6 +224,10 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_dist_trial_begin(self._h, step_size,
                                                  primal_weight, theta))
 
+    def dist_trial_dual_begin(self, step_size, primal_weight, theta):
+        _lib.check(self._L.pdhg_dist_trial_dual_begin(self._h, step_size,
+                                                      primal_weight, theta))
+
     def dist_trial_end(self):
         out = np.empty(5)
         _lib.check(self._L.pdhg_dist_trial_end(self._h, _pd(out)))

@@ -136,6 +136,15 @@ int pdhg_spmv_t(pdhg_handle *h, const double *y, double *out);
 int pdhg_dist_trial_begin(pdhg_handle *h, double step_size,
                           double primal_weight, double theta);
 int pdhg_dist_trial_end(pdhg_handle *h, double out[5]);
+/*
+ * Malitsky-Pock linesearch in the row-partitioned form (pdhg.jl:555-647):
+ * pdhg_trial_primal is rank-local (x, A'y and c are replicated), then per
+ * linesearch iteration dual_begin forms xb = x' + theta (x' - x), y'_p and the
+ * local partial A_p' y'_p exactly like pdhg_dist_trial_begin; the caller
+ * all-reduces the exchange buffer and calls pdhg_dist_trial_end.
+ */
+int pdhg_dist_trial_dual_begin(pdhg_handle *h, double step_size,
+                               double primal_weight, double theta);
 /* Device pointer to the current exchange buffer (n+1 doubles). */
 void *pdhg_dist_exchange_ptr(pdhg_handle *h);
 /* Same split for A'y recompute after set_current/restart: partial then finish. */

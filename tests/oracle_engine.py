@@ -106,6 +106,12 @@ class OracleEngine:
         self._exchange[self.n] = raw[2]       # local sum dy_p^2
         self._dist_pending = (xn, yn)
 
+    def dist_trial_dual_begin(self, step_size, primal_weight, theta):
+        raw, xn, yn, an = self.st.trial_dual(step_size, primal_weight, theta)
+        self._exchange[:self.n] = an
+        self._exchange[self.n] = raw[2]
+        self._dist_pending = (xn, yn)
+
     def exchange_tensor(self):
         import torch
         return torch.from_numpy(self._exchange)

@@ -183,3 +183,80 @@ def test_full_optimize_row_partitioned_two_ranks():
         assert iters <= 600 and reason in ("TERMINATION_REASON_ITERATION_LIMIT",
                                            "TERMINATION_REASON_NUMERICAL_ERROR")
     assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])
+
+
+# ---- Malitsky-Pock linesearch in the row-partitioned form ---------------------
+
+MP_STEPS = 30
+
+
+def _mp_params():
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import MalitskyPockStepsizeParameters
+    return MalitskyPockStepsizeParameters(downscaling_factor=0.7, breaking_factor=0.99,
+                                          interpolation_coefficient=1.0)
+
+
+def _mp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import folp_loader
+    folp_loader.load()
+    import torch.distributed as dist
+    from firstorderlp_jl_amd.distributed import (RowPartitionedEngine, TorchComm,
+                                                 partition_rows, shard_rows)
+    from firstorderlp_jl_amd.generators import random_lp
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import PdhgSolverState, take_step
+    from tests.oracle_engine import OracleEngine
+    from tests import helpers as H
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = random_lp(500, 400, 5, seed=11)
+        ranges = partition_rows(p.constraint_matrix, world)
+        lo, hi = ranges[rank]
+        eng = RowPartitionedEngine(OracleEngine(**shard_rows(p, lo, hi)), TorchComm(), ranges)
+        step, pw = H.initial_step_and_weight(p)
+        state = PdhgSolverState(eng, step_size=step, primal_weight=pw, ratio_step_sizes=1.0)
+        for _ in range(MP_STEPS):
+            take_step(_mp_params(), state)
+        x, y = eng.get_current()
+        xa, ya = eng.get_average()
+        q.put((rank, x, y, xa, ya, state.step_size, state.ratio_step_sizes,
+               state.total_number_iterations, eng.average_info()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_malitsky_pock_row_partitioned_matches_unsharded_oracle():
+    sys.path.insert(0, ROOT)
+    from firstorderlp_jl_amd.generators import random_lp
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import PdhgSolverState, take_step
+    from tests.oracle_engine import OracleEngine
+    from tests import helpers as H
+    world = 2
+    port = 27500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mp_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    p = random_lp(500, 400, 5, seed=11)
+    ref = OracleEngine.from_problem(p)
+    step, pw = H.initial_step_and_weight(p)
+    state = PdhgSolverState(ref, step_size=step, primal_weight=pw, ratio_step_sizes=1.0)
+    for _ in range(MP_STEPS):
+        take_step(_mp_params(), state)
+    x, y = ref.get_current()
+    xa, ya = ref.get_average()
+    for (rank, rx, ry, rxa, rya, rstep, rratio, rtot, rinfo) in results:
+        assert rtot == state.total_number_iterations     # same linesearch trip counts
+        assert abs(rstep - state.step_size) <= 1e-12 * state.step_size
+        assert abs(rratio - state.ratio_step_sizes) <= 1e-12
+        assert rinfo[0] == ref.average_info()[0]
+        for got, want in ((rx, x), (ry, y), (rxa, xa), (rya, ya)):
+            np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-11)

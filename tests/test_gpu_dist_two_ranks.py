@@ -15,7 +15,13 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-M, N, NNZ_PER_ROW, SEED, STEPS = 30000, 24000, 8, 21, 60
+M, N, NNZ_PER_ROW, SEED, STEPS, MP_STEPS = 30000, 24000, 8, 21, 60, 25
+
+
+def MP_PARAMS():
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import MalitskyPockStepsizeParameters
+    return MalitskyPockStepsizeParameters(downscaling_factor=0.7, breaking_factor=0.99,
+                                          interpolation_coefficient=1.0)
 
 
 def _worker(rank, world, port, q):
@@ -46,7 +52,13 @@ def _worker(rank, world, port, q):
         eng.restart_to_average()
         aty = eng.get_dual_product()
         ax = eng.spmv(x)
-        q.put((rank, x, y, xa, ya, aty, ax, decisions, state.step_size))
+        # Malitsky-Pock linesearch (split primal / dual trial) from the restarted point
+        mstate = PdhgSolverState(eng, step_size=state.step_size, primal_weight=pw, ratio_step_sizes=1.0)
+        for _ in range(MP_STEPS):
+            take_step(MP_PARAMS(), mstate)
+        xm, ym = eng.get_current()
+        q.put((rank, x, y, xa, ya, aty, ax, decisions, state.step_size,
+               xm, ym, mstate.total_number_iterations, mstate.step_size))
     finally:
         dist.destroy_process_group()
 
@@ -81,6 +93,11 @@ def test_two_hip_shards_on_one_gpu_match_single_engine(gpu_required):
         decisions.append(ss.total_number_iterations - before)
     xs, ys = seng.get_current()
     xas, yas = seng.get_average()
+    seng.restart_to_average()
+    ms = PdhgSolverState(seng, step_size=ss.step_size, primal_weight=pw, ratio_step_sizes=1.0)
+    for _ in range(MP_STEPS):
+        take_step(MP_PARAMS(), ms)
+    xms, yms = seng.get_current()
 
     r0, r1 = results
     # every rank holds the same replicated vectors, bit for bit
@@ -98,3 +115,9 @@ def test_two_hip_shards_on_one_gpu_match_single_engine(gpu_required):
     A = p.constraint_matrix
     np.testing.assert_allclose(r0[5], A.T @ r0[4], rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(r0[6], A @ r0[1], rtol=1e-11, atol=1e-11)
+    # Malitsky-Pock: same linesearch trip counts, same iterates
+    assert np.array_equal(r0[9], r1[9]) and np.array_equal(r0[10], r1[10])
+    assert r0[11] == r1[11] == ms.total_number_iterations
+    assert abs(r0[12] - ms.step_size) <= 1e-9 * ms.step_size
+    np.testing.assert_allclose(r0[9], xms, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(r0[10], yms, rtol=1e-9, atol=1e-9)
