@@ -180,9 +180,17 @@ def main():
                 f"{local.kernel_name(dom)}@m={A.shape[0]},n={A.shape[1]},nnz={nnz}")
     except OSError:
         pass
+    try:     # the box's own streaming ceiling next to the spec figure
+        triad = round(local.measure_triad(1 << 26, 5), 1)
+    except Exception:   # measurement extra
+        triad = None
     roofline = {"bound": "hbm", "kernel": local.kernel_name(dom),
                 "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(dk["achieved_GBps"] / HBM_PEAK_GBS, 4),
+                "peak_measured_triad": triad,
+                "frac_of_triad": round(dk["achieved_GBps"] / triad, 4) if triad else None,
+                "note": "a random 8-byte gather per nonzero bounds this kernel (L2 request path), not HBM "
+                        "streaming: DESIGN.md section 4, profiles/r01_sweep_probe.txt",
                 "traffic": traffic, "avg_launch_ms": dk["avg_ms"],
                 "algorithmic_bytes_per_launch": dk["algorithmic_bytes"]}
 

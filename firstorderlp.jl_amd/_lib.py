@@ -29,7 +29,7 @@ EXPORTS = [
     "pdhg_spmv_t", "pdhg_dist_trial_begin", "pdhg_dist_trial_end", "pdhg_dist_trial_dual_begin",
     "pdhg_dist_exchange_ptr", "pdhg_dist_dual_product_begin",
     "pdhg_dist_dual_product_end", "pdhg_profile_enable", "pdhg_profile_read",
-    "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info",
+    "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info", "pdhg_measure_triad",
     "pdhg_set_original_problem", "pdhg_eval_point", "pdhg_save_restart_point",
     "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound",
     "pdhg_point_sumsq", "pdhg_rescale", "pdhg_get_problem_vectors", "pdhg_matrix_max_abs",
@@ -112,6 +112,8 @@ def lib():
     L.pdhg_spmv_t.argtypes = [_vp, _dp, _dp]
     L.pdhg_dist_trial_begin.restype = i32
     L.pdhg_dist_trial_begin.argtypes = [_vp, d, d, d]
+    L.pdhg_measure_triad.restype = i32
+    L.pdhg_measure_triad.argtypes = [_vp, i64, i32, _dp]
     L.pdhg_dist_trial_dual_begin.restype = i32
     L.pdhg_dist_trial_dual_begin.argtypes = [_vp, d, d, d]
     L.pdhg_dist_trial_end.restype = i32

@@ -1515,7 +1515,7 @@ int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
 extern "C" {
 
 const char *pdhg_last_error(void) { return g_last_error.c_str(); }
-int pdhg_abi_version(void) { return 2; }
+int pdhg_abi_version(void) { return 3; }
 
 const char *pdhg_kernel_name(int kernel_id) {
   switch (kernel_id) {
@@ -2231,6 +2231,52 @@ int64_t pdhg_kernel_algorithmic_bytes(pdhg_handle *h, int kernel_id) {
     case PDHG_K_ACCEPT: return 8 * 3 * (n + m);
     default: return -1;
   }
+}
+
+namespace {
+__global__ __launch_bounds__(TPB) void triad_kernel(int64_t len2, const double2 *__restrict__ b,
+                                                    const double2 *__restrict__ c, double s,
+                                                    double2 *__restrict__ a) {
+  const int64_t stride = (int64_t)gridDim.x * TPB;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < len2; i += stride) {
+    const double2 bv = b[i], cv = c[i];
+    a[i] = make_double2(bv.x + s * cv.x, bv.y + s * cv.y);
+  }
+}
+}  // namespace
+
+int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (len <= 0 || (len & 1) || reps <= 0 || !gbps) return fail(-1, "bad triad arguments (len must be even)");
+  double *buf = nullptr;
+  HIP_TRY(hipMalloc((void **)&buf, sizeof(double) * 3 * (size_t)len));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float best = 1e30f;
+  hipError_t err = hipMemsetAsync(buf, 0, sizeof(double) * 3 * (size_t)len, h->stream);
+  if (err == hipSuccess) err = hipEventCreate(&e0);
+  if (err == hipSuccess) err = hipEventCreate(&e1);
+  const int64_t len2 = len / 2;
+  const int grids[3] = {256 * 8, 256 * 16, 256 * 64};   // grid-stride; keep the best shape
+  for (int g = 0; g < 3 && err == hipSuccess; ++g) {
+    for (int r = 0; r <= reps && err == hipSuccess; ++r) {   // pass 0 warms up
+      (void)hipEventRecord(e0, h->stream);
+      hipLaunchKernelGGL(triad_kernel, dim3(grids[g]), dim3(TPB), 0, h->stream, len2,
+                         reinterpret_cast<const double2 *>(buf + len), reinterpret_cast<const double2 *>(buf + 2 * len),
+                         0.5, reinterpret_cast<double2 *>(buf));
+      (void)hipEventRecord(e1, h->stream);
+      err = hipEventSynchronize(e1);
+      float ms = 0.f;
+      if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+      if (r > 0 && ms < best) best = ms;
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(buf);
+  HIP_TRY(err);
+  *gbps = 24.0 * (double)(2 * len2) / ((double)best * 1e-3) / 1e9;
+  return 0;
 }
 
 int pdhg_layout_info(pdhg_handle *h, int64_t info[12]) {

@@ -219,6 +219,12 @@ class HipPdhgEngine:
             int(bool(approximate)), _pd(out)))
         return out
 
+    def measure_triad(self, length=1 << 26, reps=5):
+        """GB/s of a = b + s*c over ``length`` doubles on this device (measurement only)."""
+        out = ctypes.c_double()
+        _lib.check(self._L.pdhg_measure_triad(self._h, int(length), int(reps), ctypes.byref(out)))
+        return out.value
+
     # ---- row-partitioned form --------------------------------------------------
     def dist_trial_begin(self, step_size, primal_weight, theta=1.0):
         _lib.check(self._L.pdhg_dist_trial_begin(self._h, step_size,

@@ -246,6 +246,10 @@ const char *pdhg_kernel_name(int kernel_id);
  * chunks, max row nnz}, [4..7] same for CSR(A'), [8],[9] tiled-sweep waves of
  * A / A' (0 = stream layout), [10],[11] their log2(tile columns). */
 int pdhg_layout_info(pdhg_handle *h, int64_t info[12]);
+/* Measurement only: best-of-`reps` rate of a[i] = b[i] + s*c[i] over `len`
+ * doubles on this handle's device and stream (24*len bytes per pass), in GB/s --
+ * the box's own streaming ceiling to put beside the 8 TB/s spec figure. */
+int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps);
 
 #ifdef __cplusplus
 }
