@@ -1459,6 +1459,18 @@ int choose_tile_shift(int64_t cols, int64_t nnz, int64_t rows) {
   const char *mode = getenv("PDHG_SPMV");
   const char *ts = getenv("PDHG_TILE_SHIFT");
   int shift = ts ? atoi(ts) : 16;   // 64K columns = 512 KiB of the gathered vector (best of 14..19 on MI355X)
+  if (!ts && rows > 0) {
+    // Few rows (a row shard of a multi-GPU run): a wave then owns few rows and a
+    // 64K-column tile gives it well under one 64-entry chunk per step.  128K-column
+    // tiles double the chunk fill (config S, 1/8 row shard: 0.200 -> 0.137 ms;
+    // 1/4 shard 0.242 -> 0.222 ms; full matrix and the transposes stay at 64K).
+    const int64_t slots = 256LL * 2 * TW_WPB;
+    const int64_t rounds = std::max<int64_t>(1, (rows + slots * TW_MAX_ROWS - 1) / (slots * TW_MAX_ROWS));
+    const int64_t rpw = std::max<int64_t>(64, (rows + slots * rounds - 1) / (slots * rounds));
+    const int64_t ntiles16 = std::max<int64_t>(1, (cols + 65535) >> 16);
+    const double per_step = (double)nnz / (double)rows * (double)rpw / (double)ntiles16;
+    if (per_step < 48.0 && ntiles16 >= 4) shift = 17;
+  }
   if (shift < 6) shift = 6;
   if (shift > 22) shift = 22;                            // leave >= 10 bits for row_local
   if (((cols + (1LL << shift) - 1) >> shift) > 65536) return 0;  // tile table would be huge

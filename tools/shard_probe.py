@@ -13,7 +13,7 @@ from firstorderlp_jl_amd import _lib
 
 p = random_lp(10_000_000, 10_000_000, 10, 12345)
 step0 = 1.0 / float(np.abs(p.constraint_matrix.data).max())
-for P in (1, 2, 4, 8):
+for P in [int(v) for v in os.environ.get("SHARD_P", "1,2,4,8").split(",")]:
     lo, hi = partition_rows(p.constraint_matrix, P)[0]
     t0 = time.time()
     eng = pkg.HipPdhgEngine(**shard_rows(p, lo, hi))
