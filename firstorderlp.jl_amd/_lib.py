@@ -42,10 +42,10 @@ POINT_CURRENT, POINT_AVERAGE, POINT_RESTART = range(3)
 def build(force=False, verbose=False):
     """Cross-compile the HIP library for gfx950 with hipcc (no GPU needed)."""
     hipcc = os.environ.get("HIPCC", "hipcc")
+    sources = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))] + \
+              [os.path.join(INCLUDE, "pdhg_hip.h")]
     if not force and os.path.exists(LIB_PATH) and \
-            os.path.getmtime(LIB_PATH) >= max(
-                os.path.getmtime(SRC_PATH),
-                os.path.getmtime(os.path.join(INCLUDE, "pdhg_hip.h"))):
+            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(f) for f in sources):
         return LIB_PATH
     cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", LIB_PATH, SRC_PATH]
     if verbose:

@@ -1,0 +1,236 @@
+// eval_kernels.hpp -- part of the single translation unit pdhg_hip.hip (included there, in order).
+// Evaluation branch on the device (N1): fused residual/objective reductions, distances, trust-region probes.
+#pragma once
+
+namespace {
+
+// ============================================================ evaluation branch (N1)
+// Evaluation-cadence kernels (every termination_evaluation_frequency
+// iterations): plain SpMVs into temporaries followed by elementwise kernels
+// with multi-quantity sum/max reductions.  Simplicity over fusion here: the
+// extra vector passes are noise at this cadence.
+constexpr int EV_MAXQ = 20;
+
+template <int NS, int NM>
+struct RedAcc {
+  double s[NS > 0 ? NS : 1];
+  double m[NM > 0 ? NM : 1];
+  __device__ RedAcc() {
+    for (int i = 0; i < (NS > 0 ? NS : 1); ++i) s[i] = 0.0;
+    for (int i = 0; i < (NM > 0 ? NM : 1); ++i) m[i] = 0.0;
+  }
+};
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, WAVE));
+  return v;
+}
+
+// partials[q*stride + blockIdx.x]: q < NS sums, then NM maxes (all maxes are of non-negative values)
+template <int NS, int NM>
+__device__ __forceinline__ void block_reduce_store(const RedAcc<NS, NM> &a, double *partials, int stride) {
+  __shared__ double red[NS + NM][TPB / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) { const double w = wave_sum(a.s[q]); if (lane == 0) red[q][wid] = w; }
+#pragma unroll
+  for (int q = 0; q < NM; ++q) { const double w = wave_max(a.m[q]); if (lane == 0) red[NS + q][wid] = w; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { double t = 0.0; for (int w = 0; w < TPB / WAVE; ++w) t += red[q][w]; partials[q * stride + blockIdx.x] = t; }
+#pragma unroll
+    for (int q = 0; q < NM; ++q) { double t = 0.0; for (int w = 0; w < TPB / WAVE; ++w) t = fmax(t, red[NS + q][w]); partials[(NS + q) * stride + blockIdx.x] = t; }
+  }
+}
+
+__global__ __launch_bounds__(FINAL_TPB) void multi_final_kernel(const double *__restrict__ partials, int stride,
+                                                                int count, int ns, int nm, double *__restrict__ out) {
+  __shared__ double red[3][FINAL_TPB / WAVE];
+  for (int q = 0; q < ns + nm; ++q) {
+    const double *p = partials + (size_t)q * stride;
+    const bool is_max = q >= ns;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < count; i += FINAL_TPB) v = is_max ? fmax(v, p[i]) : v + p[i];
+    v = is_max ? wave_max(v) : wave_sum(v);
+    if ((threadIdx.x & (WAVE - 1)) == 0) red[0][threadIdx.x / WAVE] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < FINAL_TPB / WAVE; ++w) t = is_max ? fmax(t, red[0][w]) : t + red[0][w];
+      out[q] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// Row side of compute_convergence_information / compute_infeasibility_information
+// (iteration_stats_utils.jl:30-63, 157-197, 228-349) on the UNSCALED point:
+//   activities A_o x_o = E .* (A_s x_s),  y_o = y_s ./ E.
+// sums: 0 sum viol^2, 1 sum y_o^2, 2 b_o.y_o, 3 sum max(-y_o,0)^2 (ineq rows)
+// maxs: 0 max|viol|, 1 max|viol_homogeneous|, 2 max|y_o|, 3 max max(-y_o,0)
+__global__ __launch_bounds__(TPB) void eval_rows_kernel(int m, int ne, const double *__restrict__ ax_s,
+                                                        const double *__restrict__ py, const double *__restrict__ E,
+                                                        const double *__restrict__ b_o, double *__restrict__ partials,
+                                                        int stride) {
+  RedAcc<4, 4> a;
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < m; i += gridDim.x * TPB) {
+    const double e = E[i];
+    const double act = e * ax_s[i];
+    const double r = b_o[i] - act;
+    const double rh = 0.0 - act;
+    const bool eq = i < ne;
+    const double viol = eq ? r : fmax(r, 0.0);
+    const double violh = eq ? rh : fmax(rh, 0.0);
+    const double yo = py[i] / e;
+    const double dres = eq ? 0.0 : fmax(-yo, 0.0);
+    a.s[0] += viol * viol; a.s[1] += yo * yo; a.s[2] += b_o[i] * yo; a.s[3] += dres * dres;
+    a.m[0] = fmax(a.m[0], fabs(viol)); a.m[1] = fmax(a.m[1], fabs(violh));
+    a.m[2] = fmax(a.m[2], fabs(yo)); a.m[3] = fmax(a.m[3], dres);
+  }
+  block_reduce_store<4, 4>(a, partials, stride);
+}
+
+// Column side (LP): g = c_o - D .* (A_s' y_s), reduced costs, bound violations,
+// and the homogeneous (c = 0) dual statistics for the infeasibility certificate.
+// sums: 0 sum resid^2, 1 sum bound*rc, 2 sum x_o^2, 3 c_o.x_o, 4 sum bound-viol^2, 5 sum bound*rc_h
+// maxs: 0 max|resid|, 1 max|x_o|, 2 max bound viol, 3 max|resid_h|, 4 max|rc_h|, 5 max ray bound viol
+__global__ __launch_bounds__(TPB) void eval_cols_kernel(int n, const double *__restrict__ aty_s,
+                                                        const double *__restrict__ px, const double *__restrict__ D,
+                                                        const double *__restrict__ c_o, const double *__restrict__ lb_o,
+                                                        const double *__restrict__ ub_o, double *__restrict__ partials,
+                                                        int stride) {
+  RedAcc<6, 6> a;
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) {
+    const double d = D[j];
+    const double aty = d * aty_s[j];
+    const double xo = px[j] / d;
+    const double lb = lb_o[j], ub = ub_o[j];
+    const bool lbf = isfinite(lb), ubf = isfinite(ub);
+    // compute_reduced_costs_from_primal_gradient        iteration_stats_utils.jl:128-148
+    const double g = c_o[j] - aty;
+    const double rc = ((g > 0.0) ? lbf : ubf) ? g : 0.0;
+    const double resid = g - rc;
+    const double contrib = (rc == 0.0) ? 0.0 : ((rc > 0.0 ? lb : ub) * rc);
+    const double gh = 0.0 - aty;
+    const double rch = ((gh > 0.0) ? lbf : ubf) ? gh : 0.0;
+    const double residh = gh - rch;
+    const double contribh = (rch == 0.0) ? 0.0 : ((rch > 0.0 ? lb : ub) * rch);
+    const double lv = fmax(lb - xo, 0.0), uv = fmax(xo - ub, 0.0);
+    const double rayv = fmax(lbf ? fmax(-xo, 0.0) : 0.0, ubf ? fmax(xo, 0.0) : 0.0);
+    a.s[0] += resid * resid; a.s[1] += contrib; a.s[2] += xo * xo; a.s[3] += c_o[j] * xo;
+    a.s[4] += lv * lv + uv * uv; a.s[5] += contribh;
+    a.m[0] = fmax(a.m[0], fabs(resid)); a.m[1] = fmax(a.m[1], fabs(xo)); a.m[2] = fmax(a.m[2], fmax(lv, uv));
+    a.m[3] = fmax(a.m[3], fabs(residh)); a.m[4] = fmax(a.m[4], fabs(rch)); a.m[5] = fmax(a.m[5], rayv);
+  }
+  block_reduce_store<6, 6>(a, partials, stride);
+}
+
+// sum (a-b)^2 over two vector pairs: distances to the last restart point
+// (saddle_point.jl:445-477, 911-920; weights are uniform per block in PDHG).
+__global__ __launch_bounds__(TPB) void dist2_kernel(int n, int m, const double *__restrict__ xa,
+                                                    const double *__restrict__ xb, const double *__restrict__ ya,
+                                                    const double *__restrict__ yb, double *__restrict__ partials,
+                                                    int stride) {
+  RedAcc<2, 0> a;
+  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
+  for (int j = tid; j < n; j += st) { const double d = xb ? xa[j] - xb[j] : xa[j]; a.s[0] += d * d; }
+  for (int i = tid; i < m; i += st) { const double d = yb ? ya[i] - yb[i] : ya[i]; a.s[1] += d * d; }
+  block_reduce_store<2, 0>(a, partials, stride);
+}
+
+// bound_optimal_objective (trust_region_utils.jl:271-360) set-up on the SCALED
+// problem at point z = (x, y): gradient g = [c - A'y ; -(b - A x)], direction
+// d = -g/w (0 if the bound blocks it), breakpoint thr (trust_region_utils.jl:86-110).
+// range: 0 both blocks (EUCLIDEAN_NORM), 1 primal only, 2 dual only (MAX_NORM halves).
+// sums: 0 c.x, 1 x.(A'y), 2 y.b, 3 sum_{thr=inf} w d^2, 4 sum g^2 (in range),
+//       5 sum w d^2 (in range), 6 sum g.d primal, 7 sum g.d dual, 8 sum x^2, 9 sum y^2
+// maxs: 0 max finite thr (in range)
+__global__ __launch_bounds__(TPB) void tr_setup_kernel(int n, int m, int ne, const double *__restrict__ px,
+                                                       const double *__restrict__ py, const double *__restrict__ aty_s,
+                                                       const double *__restrict__ ax_s, const double *__restrict__ c_s,
+                                                       const double *__restrict__ b_s, const double *__restrict__ lb_s,
+                                                       const double *__restrict__ ub_s, double wp, double wd, int range,
+                                                       double *__restrict__ gvec, double *__restrict__ dir,
+                                                       double *__restrict__ thr, double *__restrict__ partials,
+                                                       int stride) {
+  RedAcc<10, 1> a;
+  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
+  for (int k = tid; k < n + m; k += st) {
+    const bool primal = k < n;
+    const int i = primal ? k : k - n;
+    double z, g, lo, hi, w;
+    if (primal) {
+      z = px[i]; g = c_s[i] - aty_s[i]; lo = lb_s[i]; hi = ub_s[i]; w = wp;
+      a.s[0] += c_s[i] * z; a.s[1] += z * aty_s[i]; a.s[8] += z * z;
+    } else {
+      z = py[i]; g = -(b_s[i] - ax_s[i]); lo = (i < ne) ? -INFINITY : 0.0; hi = INFINITY; w = wd;
+      a.s[2] += z * b_s[i]; a.s[9] += z * z;
+    }
+    const bool in_range = (range == 0) || (range == 1 && primal) || (range == 2 && !primal);
+    double d = 0.0, t = 0.0;
+    if (in_range && !((z >= hi && g <= 0.0) || (z <= lo && g >= 0.0))) {
+      d = -g / w;
+      if (d > 0.0) t = (hi - z) / d;
+      else if (d < 0.0) t = (lo - z) / d;
+      else t = 0.0;
+    }
+    gvec[k] = g; dir[k] = d; thr[k] = t;
+    if (in_range) {
+      a.s[4] += g * g;
+      a.s[5] += w * d * d;
+      if (primal) a.s[6] += g * d; else a.s[7] += g * d;
+      if (isinf(t)) a.s[3] += w * d * d; else a.m[0] = fmax(a.m[0], t);
+    }
+  }
+  block_reduce_store<10, 1>(a, partials, stride);
+}
+
+// radius^2 as a function of the step t at K probe values:
+//   low_k = sum_{thr <= t_k} w d^2 thr^2 ,  high_k = sum_{thr > t_k} w d^2
+constexpr int TR_K = 7;
+struct TrProbes { double t[TR_K]; };
+__global__ __launch_bounds__(TPB) void tr_probe_kernel(int n, int total, const double *__restrict__ dir,
+                                                       const double *__restrict__ thr, double wp, double wd,
+                                                       TrProbes pr, double *__restrict__ partials, int stride) {
+  RedAcc<2 * TR_K, 0> a;
+  for (int k = blockIdx.x * TPB + threadIdx.x; k < total; k += gridDim.x * TPB) {
+    const double d = dir[k];
+    if (d == 0.0) continue;
+    const double w = (k < n) ? wp : wd;
+    const double t = thr[k];
+    const double wd2 = w * d * d;
+    const double lowc = wd2 * t * t;   // inf for thr = inf: never selected below
+#pragma unroll
+    for (int q = 0; q < TR_K; ++q) {
+      if (t <= pr.t[q]) a.s[2 * q] += lowc; else a.s[2 * q + 1] += wd2;
+    }
+  }
+  block_reduce_store<2 * TR_K, 0>(a, partials, stride);
+}
+
+// value parts sum g_i (clamp(z_i + t d_i) - z_i), primal block and dual block
+__global__ __launch_bounds__(TPB) void tr_value_kernel(int n, int m, int ne, const double *__restrict__ px,
+                                                       const double *__restrict__ py, const double *__restrict__ lb_s,
+                                                       const double *__restrict__ ub_s, const double *__restrict__ gvec,
+                                                       const double *__restrict__ dir, double t,
+                                                       double *__restrict__ partials, int stride) {
+  RedAcc<2, 0> a;
+  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
+  for (int k = tid; k < n + m; k += st) {
+    const bool primal = k < n;
+    const int i = primal ? k : k - n;
+    const double d = dir[k];
+    if (d == 0.0) continue;
+    const double z = primal ? px[i] : py[i];
+    const double lo = primal ? lb_s[i] : ((i < ne) ? -INFINITY : 0.0);
+    const double hi = primal ? ub_s[i] : INFINITY;
+    const double cand = fmin(fmax(z + t * d, lo), hi);   // clamp.(center + t*direction, lb, ub)
+    const double v = gvec[k] * (cand - z);
+    if (primal) a.s[0] += v; else a.s[1] += v;
+  }
+  block_reduce_store<2, 0>(a, partials, stride);
+}
+
+}  // namespace

@@ -1,0 +1,237 @@
+// layout.hpp -- part of the single translation unit pdhg_hip.hip (included there, in order).
+// Host side of the device layouts: CsrDev, uploads, the stream/tiled builders.
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------- host side
+
+struct CsrDev {
+  int rows = 0, cols = 0;
+  int64_t nnz = 0;
+  int *rowptr = nullptr, *col = nullptr;
+  double *val = nullptr;
+  int2 *blks = nullptr;
+  int nblk = 0, per_xcd = 0, grid = 0;
+  int nlong = 0, nchunks = 0, long_grid = 0;
+  int *long_row = nullptr, *long_chunk_ptr = nullptr, *chunk_row = nullptr, *chunk_off = nullptr;
+  double *chunk_partial = nullptr;
+  int64_t max_row_nnz = 0;
+  // tiled-sweep layout (optional)
+  bool tiled = false;
+  int tile_shift = 0, nwaves = 0, ntiles = 0, tw_rows = 0;
+  int2 *wave_rows = nullptr;
+  int *wave_ent = nullptr;        // per-wave entry offsets, one per step of its workgroup (+1)
+  int *wave_step_off = nullptr;   // [nwaves] start of a wave's offsets inside wave_ent
+  int *step_tile = nullptr;       // tile id of every step, workgroup after workgroup
+  int *wg_step_off = nullptr;     // [grid+1] start of a workgroup's steps inside step_tile
+  int64_t total_steps = 0;
+  bool tw_scratch = false;        // long same-row runs: use the LDS-scratch chunk variant
+  unsigned *pk = nullptr;
+  double *tv = nullptr;
+  int slots() const { return grid + long_grid; }
+  CsrView view() const { return CsrView{rows, rowptr, col, val}; }
+};
+
+template <typename T>
+int upload(T **dst, const std::vector<T> &src) {
+  const size_t bytes = sizeof(T) * std::max<size_t>(src.size(), 1);
+  HIP_TRY(hipMalloc((void **)dst, bytes));
+  if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int alloc_zero(double **dst, int64_t len) {
+  const size_t bytes = sizeof(double) * (size_t)std::max<int64_t>(len, 1);
+  HIP_TRY(hipMalloc((void **)dst, bytes));
+  HIP_TRY(hipMemset(*dst, 0, bytes));
+  return 0;
+}
+
+// Host-side construction of the tiled-sweep layout: wave row blocks (runs of
+// <= TW_ROWS consecutive non-long rows) and their entries counting-sorted by
+// column tile (stable, so (row, col) order is kept inside a tile).
+int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::vector<int> &col,
+                const std::vector<double> &val, int tile_shift) {
+  // Geometry.  A CU holds 2 workgroups of 8 waves; the grid runs in rounds of
+  // 256 CUs x 16 waves.  Rows per wave is chosen so that the rounds are full
+  // (no tail round), within the LDS budget (160 KiB / 16 waves).
+  const int64_t slots = 256LL * 2 * TW_WPB;               // resident waves per round
+  const int max_rows = std::min<int>(TW_MAX_ROWS, 1 << (32 - tile_shift));
+  int TW_ROWS;
+  {
+    int64_t rounds = std::max<int64_t>(1, ((int64_t)rows + slots * max_rows - 1) / (slots * max_rows));
+    int64_t rpw = ((int64_t)rows + slots * rounds - 1) / (slots * rounds);
+    TW_ROWS = (int)std::max<int64_t>(64, std::min<int64_t>(max_rows, rpw));
+  }
+  if (const char *ev = getenv("PDHG_TW_ROWS")) TW_ROWS = std::max(1, std::min(atoi(ev), max_rows));
+  D.tw_rows = TW_ROWS;
+  const int ntiles = std::max<int>(1, (int)((((int64_t)D.cols) + (1LL << tile_shift) - 1) >> tile_shift));
+  const unsigned cmask = (1u << tile_shift) - 1u;
+  const int WIN = TW_U * WAVE;  // entries a wave holds in registers per step
+  // pass 1: wave row blocks.  A wave owns <= TW_ROWS rows AND <= nnz_cap
+  // nonzeros: hub regions (PageRank's oldest nodes) would otherwise give one
+  // wave 100x the average work and the whole launch would wait for its workgroup.
+  const int64_t est_waves = std::max<int64_t>(1, ((int64_t)rows + TW_ROWS - 1) / TW_ROWS);
+  const int64_t nnz_cap = std::max<int64_t>(4096, 2 * (D.nnz / est_waves));   // 2x the average wave
+  std::vector<int2> wave_rows;
+  {
+    int r = 0;
+    while (r < rows) {
+      if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) { ++r; continue; }  // long row: separate path
+      const int r0 = r;
+      while (r < rows && (r - r0) < TW_ROWS && rowptr[r + 1] - rowptr[r] <= BLOCK_NNZ &&
+             (r == r0 || (int64_t)rowptr[r + 1] - rowptr[r0] <= nnz_cap)) ++r;
+      wave_rows.push_back(make_int2(r0, r));
+    }
+  }
+  const int nwaves = (int)wave_rows.size();
+  const int grid = (nwaves + TW_WPB - 1) / TW_WPB;
+  std::vector<unsigned> pk;
+  std::vector<double> tv;
+  pk.reserve((size_t)D.nnz);
+  tv.reserve((size_t)D.nnz);
+  std::vector<int> step_ptr, wave_step_off((size_t)std::max(nwaves, 1), 0), step_tile, wg_step_off(1, 0);
+  std::vector<std::vector<int>> cnt(TW_WPB, std::vector<int>((size_t)ntiles + 1));
+  std::vector<int> nsub((size_t)ntiles);
+  int max_run = 0;   // longest same-row run inside one tile
+  for (int g = 0; g < grid; ++g) {
+    const int w0 = g * TW_WPB, w1 = std::min(nwaves, w0 + TW_WPB);
+    // cell sizes of the workgroup's waves
+    std::fill(nsub.begin(), nsub.end(), 0);
+    for (int w = w0; w < w1; ++w) {
+      std::vector<int> &c = cnt[w - w0];
+      std::fill(c.begin(), c.end(), 0);
+      for (int k = rowptr[wave_rows[w].x]; k < rowptr[wave_rows[w].y]; ++k) c[(col[k] >> tile_shift) + 1] += 1;
+      for (int t = 0; t < ntiles; ++t) nsub[t] = std::max(nsub[t], (c[t + 1] + WIN - 1) / WIN);
+      for (int t = 0; t < ntiles; ++t) c[t + 1] += c[t];   // prefix: cell start offsets
+    }
+    // the workgroup's step list (heavy tiles repeated, empty tiles skipped)
+    for (int t = 0; t < ntiles; ++t)
+      for (int j = 0; j < nsub[t]; ++j) step_tile.push_back(t);
+    wg_step_off.push_back((int)step_tile.size());
+    // entries of each wave, tile-major (stable in (row, col)), and its step offsets
+    for (int w = w0; w < w1; ++w) {
+      std::vector<int> &c = cnt[w - w0];
+      const int r0 = wave_rows[w].x, r1 = wave_rows[w].y;
+      const size_t base = pk.size();
+      const int total = rowptr[r1] - rowptr[r0];
+      wave_step_off[w] = (int)step_ptr.size();
+      for (int t = 0; t < ntiles; ++t) {
+        const int cs = c[t], ce = c[t + 1], len = ce - cs;
+        const int per = nsub[t] ? (len + nsub[t] - 1) / nsub[t] : 0;
+        for (int j = 0; j < nsub[t]; ++j) step_ptr.push_back((int)base + std::min(ce, cs + j * per));
+      }
+      step_ptr.push_back((int)base + total);
+      pk.resize(base + (size_t)total);
+      tv.resize(base + (size_t)total);
+      std::vector<int> next(c.begin(), c.end() - 1);
+      for (int rr = r0; rr < r1; ++rr) {
+        const unsigned rl = (unsigned)(rr - r0) << tile_shift;
+        int run = 0, run_tile = -1;
+        for (int k = rowptr[rr]; k < rowptr[rr + 1]; ++k) {
+          const int tt = col[k] >> tile_shift;
+          run = (tt == run_tile) ? run + 1 : 1;
+          run_tile = tt;
+          if (run > max_run) max_run = run;
+          const int pos = next[tt]++;
+          pk[base + pos] = rl | ((unsigned)col[k] & cmask);
+          tv[base + pos] = val[k];
+        }
+      }
+    }
+  }
+  // Rows with long same-row runs inside a tile (hub rows of the PageRank LP,
+  // dense-ish blocks) are summed by one lane, sequentially, to keep the
+  // ascending-column order; the stream layout does that from LDS with 8 reads
+  // in flight and wins on such matrices (PageRank-1M: 0.106 ms vs 0.18 ms), and
+  // hubs give it natural cache locality anyway.  PDHG_SPMV=tiled overrides.
+  {
+    const char *mode_env = getenv("PDHG_SPMV");
+    const bool forced = mode_env && !strcmp(mode_env, "tiled");
+    if (!forced && max_run > 32) return 0;
+  }
+  D.tiled = true;
+  D.tile_shift = tile_shift;
+  D.ntiles = ntiles;
+  D.nwaves = nwaves;
+  D.grid = grid;
+  D.total_steps = (int64_t)step_tile.size();
+  D.tw_scratch = max_run > 8;
+  int rc;
+  if ((rc = upload(&D.wave_rows, wave_rows))) return rc;
+  if ((rc = upload(&D.wave_ent, step_ptr))) return rc;
+  if ((rc = upload(&D.wave_step_off, wave_step_off))) return rc;
+  if ((rc = upload(&D.step_tile, step_tile))) return rc;
+  if ((rc = upload(&D.wg_step_off, wg_step_off))) return rc;
+  if ((rc = upload(&D.pk, pk))) return rc;
+  if ((rc = upload(&D.tv, tv))) return rc;
+  return 0;
+}
+
+int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
+                  const std::vector<int> &col, const std::vector<double> &val,
+                  bool remap, int tile_shift = 0) {
+  D.rows = rows;
+  D.cols = cols;
+  D.nnz = rowptr[rows];
+  std::vector<int2> blks;
+  std::vector<int> long_row, long_chunk_ptr(1, 0), chunk_row, chunk_off;
+  int r = 0;
+  while (r < rows) {
+    int len = rowptr[r + 1] - rowptr[r];
+    D.max_row_nnz = std::max<int64_t>(D.max_row_nnz, len);
+    if (len > BLOCK_NNZ) {
+      const int l = (int)long_row.size();
+      long_row.push_back(r);
+      for (int off = 0; off < len; off += LONG_CHUNK) {
+        chunk_row.push_back(r);
+        chunk_off.push_back(off);
+      }
+      long_chunk_ptr.push_back((int)chunk_row.size());
+      (void)l;
+      ++r;
+      continue;
+    }
+    const int r0 = r;
+    int nn = 0;
+    while (r < rows && (r - r0) < MAX_ROWS_PER_BLOCK) {
+      len = rowptr[r + 1] - rowptr[r];
+      if (len > BLOCK_NNZ - nn) break;
+      D.max_row_nnz = std::max<int64_t>(D.max_row_nnz, len);
+      nn += len;
+      ++r;
+    }
+    blks.push_back(make_int2(r0, r));
+  }
+  D.nblk = (int)blks.size();
+  D.per_xcd = (D.nblk + NUM_XCD - 1) / NUM_XCD;
+  D.grid = remap ? D.per_xcd * NUM_XCD : D.nblk;
+  D.nlong = (int)long_row.size();
+  D.nchunks = (int)chunk_row.size();
+  D.long_grid = (D.nlong + TPB - 1) / TPB;
+  int rc;
+  if ((rc = upload(&D.rowptr, rowptr))) return rc;
+  if ((rc = upload(&D.col, col))) return rc;
+  if ((rc = upload(&D.val, val))) return rc;
+  if ((rc = upload(&D.blks, blks))) return rc;
+  if ((rc = upload(&D.long_row, long_row))) return rc;
+  if ((rc = upload(&D.long_chunk_ptr, long_chunk_ptr))) return rc;
+  if ((rc = upload(&D.chunk_row, chunk_row))) return rc;
+  if ((rc = upload(&D.chunk_off, chunk_off))) return rc;
+  if ((rc = alloc_zero(&D.chunk_partial, D.nchunks))) return rc;
+  if (tile_shift > 0) {
+    if ((rc = build_tiled(D, rows, rowptr, col, val, tile_shift))) return rc;
+  }
+  return 0;
+}
+
+void free_csr_dev(CsrDev &D) {
+  void *ptrs[] = {D.rowptr, D.col, D.val, D.blks, D.long_row, D.long_chunk_ptr,
+                  D.chunk_row, D.chunk_off, D.chunk_partial, D.wave_rows, D.wave_ent, D.pk, D.tv,
+                  D.wave_step_off, D.step_tile, D.wg_step_off};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  D = CsrDev();
+}
+
+}  // namespace

@@ -28,1230 +28,15 @@
 
 #include "pdhg_hip.h"
 
-namespace {
-
-constexpr int TPB = 256;             // 4 waves of 64
-constexpr int WAVE = 64;
-constexpr int BLOCK_NNZ = 2048;      // products staged in LDS per workgroup (16 KiB)
-constexpr int UNROLL = BLOCK_NNZ / TPB;
-constexpr int MAX_ROWS_PER_BLOCK = 4 * TPB;
-constexpr int LONG_CHUNK = 8192;     // nnz per workgroup for rows longer than BLOCK_NNZ
-constexpr int NUM_XCD = 8;
-constexpr int EW_MAX_BLOCKS = 256 * 8;  // elementwise kernels: grid-stride above this
-constexpr int FINAL_TPB = 1024;
-// tiled-sweep layout (SpMV v2)
-constexpr int TW_WPB = 8;              // waves per workgroup (512 threads), 2 workgroups per CU
-constexpr int TW_MAX_ROWS = 1272;      // rows owned by one wave: 2 x 8 x 1272 x 8 B fits the 160 KiB LDS
-constexpr unsigned TW_PAD = 0xFFFFFFFFu;
-constexpr int TW_U = 3;               // 64-entry chunks prefetched per wave per tile
-
-thread_local std::string g_last_error;
-
-int fail(int code, const std::string &msg) {
-  g_last_error = msg;
-  return code;
-}
-
-#define HIP_TRY(expr)                                                        \
-  do {                                                                       \
-    hipError_t _e = (expr);                                                  \
-    if (_e != hipSuccess) {                                                  \
-      g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);      \
-      return (int)_e > 0 ? (int)_e : 999;                                    \
-    }                                                                        \
-  } while (0)
-
-// ---------------------------------------------------------------- device utils
-
-// Julia's max/min on Float64 for non-NaN inputs, including signed zeros
-// (saddle_point.jl:88-91, :115 use min(ub, max(lb, v)) and max(y, 0.0)).
-__device__ __forceinline__ double jl_max(double a, double b) {
-  return (a > b) ? a : ((b > a) ? b : (signbit(a) ? b : a));
-}
-__device__ __forceinline__ double jl_min(double a, double b) {
-  return (a < b) ? a : ((b < a) ? b : (signbit(a) ? a : b));
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-  return v;
-}
-
-// Deterministic block reduction of up to 3 per-thread accumulators; thread 0
-// of the block returns the totals in acc[].  `red` is LDS [3][TPB/WAVE].
-template <int NQ, int THREADS>
-__device__ __forceinline__ void block_sum(double (&acc)[3],
-                                          double (*red)[THREADS / WAVE]) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wid = threadIdx.x / WAVE;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const double w = wave_sum(acc[q]);
-    if (lane == 0) red[q][wid] = w;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      double s = 0.0;
-#pragma unroll
-      for (int w = 0; w < THREADS / WAVE; ++w) s += red[q][w];
-      acc[q] = s;
-    }
-  }
-}
-
-// ---------------------------------------------------------------- CSR views
-
-struct CsrView {
-  int rows;
-  const int *rowptr;   // [rows+1]
-  const int *col;      // [nnz]
-  const double *val;   // [nnz]
-};
-
-enum { MODE_PLAIN = 0, MODE_DUAL = 1, MODE_ATY = 2 };
-
-// Everything a row epilogue may touch.  Passed by value to the kernels.
-struct EpiArgs {
-  // MODE_PLAIN
-  double *out;
-  // MODE_DUAL: y' = proj(y + sigma*(b - A xbar)); partial sum dy^2
-  const double *y;
-  const double *b;
-  double *y_next;
-  double sigma;
-  int num_eq;
-  // MODE_ATY: A'y' written; partial dx.(A'y'-A'y), dx^2, (A'y'-A'y)^2
-  const double *x;
-  const double *x_next;
-  const double *aty;
-  double *aty_next;
-  // block partials: partials[q*stride + slot]
-  double *partials;
-  int stride;
-};
-
-template <int MODE>
-__device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
-                                             double (&acc)[3]) {
-  if (MODE == MODE_PLAIN) {
-    e.out[r] = s;
-  } else if (MODE == MODE_DUAL) {
-    // compute_dual_gradient: b .- A*x              saddle_point.jl:1102-1107
-    const double yo = e.y[r];
-    const double dg = e.b[r] - s;
-    // next_dual = y .+ (pw*step) .* dual_gradient   pdhg.jl:489-490
-    const double t = e.sigma * dg;
-    double yn = yo + t;
-    // project_dual!: only inequality rows           saddle_point.jl:110-117
-    if (r >= e.num_eq) yn = jl_max(yn, 0.0);
-    e.y_next[r] = yn;
-    const double dy = yn - yo;                       // pdhg.jl:535
-    acc[0] += dy * dy;
-  } else {
-    // next_dual_product = A' * next_dual            pdhg.jl:492
-    e.aty_next[r] = s;
-    const double dx = e.x_next[r] - e.x[r];          // pdhg.jl:534
-    const double dd = s - e.aty[r];                  // pdhg.jl:543
-    acc[0] += dx * dd;
-    acc[1] += dx * dx;
-    acc[2] += dd * dd;
-  }
-}
-
-template <int MODE>
-struct ModeNQ { static constexpr int value = (MODE == MODE_PLAIN) ? 0 : (MODE == MODE_DUAL ? 1 : 3); };
-
-// CSR "stream" kernel: a workgroup owns a run of consecutive rows holding at
-// most BLOCK_NNZ nonzeros.  Phase 1 streams val/col with fully coalesced
-// loads (UNROLL independent load chains per lane for memory-level
-// parallelism), gathers x and parks the products in LDS.  Phase 2: one lane
-// per row adds that row's products in ascending column order -- the same
-// order as Julia's SparseMatrixCSC A*x / A'*y loops, so short rows are
-// bit-identical to the sequential CPU result -- and applies the fused
-// epilogue.  Block->XCD: hardware places block b on XCD b%8; with `remap`
-// each XCD walks a contiguous eighth of the row blocks so its private 4 MiB
-// L2 sees a contiguous slice of the gathered vector for banded/local
-// matrices.
-template <int MODE>
-__global__ __launch_bounds__(TPB) void spmv_stream_kernel(
-    CsrView A, const double *__restrict__ xin, const int2 *__restrict__ blks,
-    int nblk, int per_xcd, int remap, EpiArgs e) {
-  __shared__ double prod[BLOCK_NNZ];
-  __shared__ double red[3][TPB / WAVE];
-  const int b = blockIdx.x;
-  const int blk = remap ? ((b & (NUM_XCD - 1)) * per_xcd + (b >> 3)) : b;
-  double acc[3] = {0.0, 0.0, 0.0};
-  const bool active = remap ? ((b >> 3) < per_xcd && blk < nblk) : (blk < nblk);
-  if (active) {
-    const int2 rr = blks[blk];
-    const int r0 = rr.x, r1 = rr.y;
-    const int k0 = A.rowptr[r0];
-    const int k1 = A.rowptr[r1];
-    const int tid = threadIdx.x;
-    int cidx[UNROLL];
-    double v[UNROLL];
-    double xv[UNROLL];
-#pragma unroll
-    for (int i = 0; i < UNROLL; ++i) {
-      const int k = k0 + tid + i * TPB;
-      const bool ok = k < k1;
-      cidx[i] = ok ? __builtin_nontemporal_load(A.col + k) : 0;
-      v[i] = ok ? __builtin_nontemporal_load(A.val + k) : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < UNROLL; ++i) {
-      const int k = k0 + tid + i * TPB;
-      xv[i] = (k < k1) ? xin[cidx[i]] : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < UNROLL; ++i) {
-      const int k = tid + i * TPB;
-      if (k0 + k < k1) prod[k] = v[i] * xv[i];
-    }
-    __syncthreads();
-    for (int r = r0 + tid; r < r1; r += TPB) {
-      const int ks = A.rowptr[r] - k0;
-      const int ke = A.rowptr[r + 1] - k0;
-      double s = 0.0;
-      int k = ks;
-      // 8 LDS reads in flight, adds still strictly left to right (bit-exact
-      // order); a row of ~2K products is otherwise one LDS latency per add.
-      for (; k + 8 <= ke; k += 8) {
-        const double t0 = prod[k], t1 = prod[k + 1], t2 = prod[k + 2], t3 = prod[k + 3];
-        const double t4 = prod[k + 4], t5 = prod[k + 5], t6 = prod[k + 6], t7 = prod[k + 7];
-        s = s + t0; s = s + t1; s = s + t2; s = s + t3;
-        s = s + t4; s = s + t5; s = s + t6; s = s + t7;
-      }
-      for (; k < ke; ++k) s = s + prod[k];
-      row_epilogue<MODE>(e, r, s, acc);
-    }
-  }
-  constexpr int NQ = ModeNQ<MODE>::value;
-  if (NQ > 0) {
-    block_sum<NQ, TPB>(acc, red);
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) e.partials[q * e.stride + b] = acc[q];
-    }
-  }
-}
-
-// CSR "tiled sweep" kernel (SpMV v2) for matrices whose gathered vector is far
-// larger than the 4 MiB per-XCD L2.  Measured on MI355X (tools/gather_probe):
-// a uniformly random 8-byte gather tops out at ~56 G/s over an 80 MB vector but
-// reaches ~190-245 G/s when the window fits L2.
-// Layout: every wave owns up to TW_ROWS consecutive rows and streams ITS
-// nonzeros, pre-sorted on the host by (column tile, row, column) and packed
-// tile-locally as {row_local << tile_shift | col_local} + value, with one
-// offset per (wave, tile).  A workgroup is 8 such waves; all of them process
-// tile t, then meet at a barrier -- the barrier is pacing, not correctness: it
-// keeps the 16 waves of a CU (and, statistically, the CUs of an XCD) inside
-// the same ~1 MiB slice of the gathered vector, which therefore stays in L2.
-// The next tile's entries are prefetched into registers before the barrier.
-// Accumulators live in the wave's private LDS slice; one wave's DS operations
-// execute in order, each row receives its products in ascending column order
-// (tile-major order preserves it) => bit-identical to the sequential CPU
-// loops.  Entries of one row inside a tile are adjacent; the run head adds
-// them left to right via lane shuffles.
-__device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, double xv,
-                                            int tile_shift, int lane) {
-  const bool valid = p != TW_PAD;
-  const unsigned row = valid ? (p >> tile_shift) : 0xFFFFFFFFu;
-  const double prod = v * xv;
-  const unsigned rowp = __shfl_up(row, 1, WAVE);
-  const bool head = valid && (lane == 0 || rowp != row);
-  double s = head ? acc[row] : 0.0;
-  for (int j = 0; j < WAVE; ++j) {
-    const double pj = __shfl_down(prod, j, WAVE);
-    const unsigned rj = __shfl_down(row, j, WAVE);
-    const bool take = head && (lane + j < WAVE) && (rj == row);
-    if (!__any(take)) break;
-    if (take) s = s + pj;
-  }
-  if (head) acc[row] = s;
-}
-
-// Variant for matrices with long same-row runs inside a tile (rows with hundreds
-// of entries): run lengths from two ballots, followers' products handed to the
-// run head through a 64-double LDS scratch per wave and added left to right
-// (same order as above; ~6x cheaper than lane shuffles for a 64-long run).
-__device__ __forceinline__ void tiled_chunk_scratch(double *acc, double *scratch, unsigned p, double v,
-                                                    double xv, int tile_shift, int lane) {
-  const bool valid = p != TW_PAD;
-  const unsigned row = valid ? (p >> tile_shift) : 0xFFFFFFFFu;
-  const double prod = v * xv;
-  const unsigned rowp = __shfl_up(row, 1, WAVE);
-  const bool head = valid && (lane == 0 || rowp != row);
-  const unsigned long long hmask = __ballot(head);
-  const unsigned long long vmask = __ballot(valid);
-  const unsigned long long above = (lane == WAVE - 1) ? 0ull : (hmask >> (lane + 1));
-  const int nvalid = __popcll(vmask);                                   // valid lanes are a prefix
-  const int len = above ? __ffsll((long long)above) : (nvalid - lane);  // run length (heads only)
-  if (__any(head && len > 1)) scratch[lane] = prod;
-  if (head) {
-    double s = acc[row] + prod;
-    int q = 1;
-    for (; q + 4 <= len; q += 4) {
-      const double t0 = scratch[lane + q], t1 = scratch[lane + q + 1];
-      const double t2 = scratch[lane + q + 2], t3 = scratch[lane + q + 3];
-      s = s + t0; s = s + t1; s = s + t2; s = s + t3;
-    }
-    for (; q < len; ++q) s = s + scratch[lane + q];
-    acc[row] = s;
-  }
-}
-
-template <int MODE, bool SCR>
-__global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
-    const int2 *__restrict__ wave_rows, const int *__restrict__ step_ptr,
-    const int *__restrict__ wave_step_off, const int *__restrict__ step_tile,
-    const int *__restrict__ wg_step_off, int nwaves, int tile_shift, int TW_ROWS,
-    const unsigned *__restrict__ pk, const double *__restrict__ tv,
-    const double *__restrict__ xin, EpiArgs e) {
-  constexpr int TW_THREADS = TW_WPB * WAVE;
-  constexpr int U = TW_U;   // 64-entry chunks held in registers per (wave, tile)
-  constexpr int D = 3;      // entry loads run D tiles ahead of the accumulate
-  constexpr int R = D + 1;  // register ring (statically indexed: the tile loop is unrolled R times)
-  extern __shared__ double tw_lds[];  // [TW_WPB][TW_ROWS] accumulators, then red[3][TW_WPB]
-  double(*red)[TW_WPB] = reinterpret_cast<double(*)[TW_WPB]>(tw_lds + TW_WPB * TW_ROWS);
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wid = threadIdx.x / WAVE;
-  double *scratch = tw_lds + TW_WPB * TW_ROWS + 3 * TW_WPB + wid * WAVE;   // SCR only: 64 doubles per wave
-  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * TW_WPB + wid);
-  const bool live = w < nwaves;
-  double acc3[3] = {0.0, 0.0, 0.0};
-  double *acc = tw_lds + wid * TW_ROWS;
-  int2 rr = make_int2(0, 0);
-  if (live) rr = wave_rows[w];
-  for (int r = lane; r < TW_ROWS; r += WAVE) acc[r] = 0.0;
-  // This workgroup's step list: one step = one column tile, or a slice of a
-  // heavy tile (cells are cut on the host so that no wave has more than
-  // TW_U*64 entries in a step); tiles in which none of the 8 waves has an entry
-  // are skipped.  ntiles below is the number of STEPS of this workgroup.
-  const int ntiles = wg_step_off[blockIdx.x + 1] - wg_step_off[blockIdx.x];
-  const int *stile = step_tile + wg_step_off[blockIdx.x];
-  const int *tp = step_ptr + (live ? wave_step_off[w] : 0);
-  const unsigned cmask = (1u << tile_shift) - 1u;
-
-  unsigned p[R][U];
-  double v[R][U];
-  double xv[U];
-  int ks[R], ke[R], tl[R];
-
-  auto load_set = [&](unsigned(&pp)[U], double(&vv)[U], int kbeg, int kend) {
-#pragma unroll
-    for (int i = 0; i < U; ++i) {
-      const int k = kbeg + i * WAVE + lane;
-      const bool ok = k < kend;
-      pp[i] = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
-      vv[i] = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
-    }
-  };
-
-  // prologue: entries of tiles 0..D-1
-  int kprev = live ? tp[0] : 0;
-#pragma unroll
-  for (int s = 0; s < D; ++s) {
-    ks[s] = kprev;
-    ke[s] = (live && s < ntiles) ? tp[s + 1] : kprev;
-    tl[s] = (s < ntiles) ? stile[s] : 0;
-    kprev = ke[s];
-    load_set(p[s], v[s], ks[s], ke[s]);
-  }
-  ks[D] = ke[D] = kprev;
-  tl[D] = 0;
-#pragma unroll
-  for (int i = 0; i < U; ++i) { p[D][i] = TW_PAD; v[D][i] = 0.0; }
-  int ke_ahead = (live && D < ntiles) ? tp[D + 1] : kprev;  // end of tile D
-
-  for (int t0 = 0; t0 < ntiles; t0 += R) {
-#pragma unroll
-    for (int s = 0; s < R; ++s) {
-      const int t = t0 + s;
-      if (t < ntiles) {  // workgroup-uniform
-        const int f = (s + D) % R;       // ring slot being refilled (held tile t-1)
-#ifdef TWD_ONE_TILE   // timing diagnostic, wrong results (tools/variants.sh): every gather hits tile 0
-        const double *xt = xin;
-#else
-        const double *xt = xin + ((size_t)tl[s] << tile_shift);
-#endif
-        // 1. gathers for tile t (entries requested D steps ago).  Issued BEFORE
-        //    the prefetch: a wave's loads return in order, so the L2-latency
-        //    gathers must not queue behind HBM-latency streaming loads.
-        //    (Gathering one tile ahead was measured slower: it widens the L2
-        //    working window of the sweep.)
-#pragma unroll
-#ifdef TWD_NO_GATHER  // timing diagnostic, wrong results: stream + accumulate only
-        for (int i = 0; i < U; ++i) xv[i] = 1.0 + (double)(size_t)xt * 0.0;
-#else
-        for (int i = 0; i < U; ++i) xv[i] = (p[s][i] != TW_PAD) ? xt[p[s][i] & cmask] : 0.0;
-#endif
-        // 2. entry loads for tile t+D
-        ks[f] = ke[(s + D - 1) % R];
-        ke[f] = ke_ahead;
-        tl[f] = (t + D < ntiles) ? stile[t + D] : 0;
-        load_set(p[f], v[f], ks[f], ke[f]);
-        ke_ahead = (live && t + D + 1 < ntiles) ? tp[t + D + 2] : ke_ahead;  // end of tile t+D+1
-        // 3. accumulate tile t
-#pragma unroll
-        for (int i = 0; i < U; ++i) {
-          if (ks[s] + i * WAVE < ke[s]) {  // wave-uniform
-            if (SCR) tiled_chunk_scratch(acc, scratch, p[s][i], v[s][i], xv[i], tile_shift, lane);
-            else tiled_chunk(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
-          }
-        }
-        for (int kb = ks[s] + U * WAVE; kb < ke[s]; kb += WAVE) {  // cells beyond the register window
-          const int k = kb + lane;
-          const bool ok = k < ke[s];
-          const unsigned pp = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
-          const double vv = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
-          const double xx = ok ? xt[pp & cmask] : 0.0;
-          if (SCR) tiled_chunk_scratch(acc, scratch, pp, vv, xx, tile_shift, lane);
-          else tiled_chunk(acc, pp, vv, xx, tile_shift, lane);
-        }
-        // 4. pacing barrier: keep the workgroup inside one column tile
-        //    (without it the kernel is 1.7x slower: waves drift apart and the
-        //    gathers stop hitting L2)
-        __syncthreads();
-      }
-    }
-  }
-  const int nrows = rr.y - rr.x;
-  for (int r = lane; r < nrows; r += WAVE) row_epilogue<MODE>(e, rr.x + r, acc[r], acc3);
-  constexpr int NQ = ModeNQ<MODE>::value;
-  if (NQ > 0) {
-    block_sum<NQ, TW_THREADS>(acc3, red);
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) e.partials[q * e.stride + blockIdx.x] = acc3[q];
-    }
-  }
-}
-
-// Rows longer than BLOCK_NNZ: split into LONG_CHUNK pieces, one workgroup
-// each (tree sum inside the chunk), partial per chunk.
-__global__ __launch_bounds__(TPB) void spmv_long_partial_kernel(
-    CsrView A, const double *__restrict__ xin, const int *__restrict__ chunk_row,
-    const int *__restrict__ chunk_off, double *__restrict__ chunk_partial) {
-  __shared__ double red[3][TPB / WAVE];
-  const int c = blockIdx.x;
-  const int r = chunk_row[c];
-  const int kbeg = A.rowptr[r] + chunk_off[c];
-  const int kend = min(kbeg + LONG_CHUNK, A.rowptr[r + 1]);
-  double acc[3] = {0.0, 0.0, 0.0};
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int k = kbeg + threadIdx.x;
-  for (; k + 3 * TPB < kend; k += 4 * TPB) {
-    const int c0 = __builtin_nontemporal_load(A.col + k);
-    const int c1 = __builtin_nontemporal_load(A.col + k + TPB);
-    const int c2 = __builtin_nontemporal_load(A.col + k + 2 * TPB);
-    const int c3 = __builtin_nontemporal_load(A.col + k + 3 * TPB);
-    const double v0 = __builtin_nontemporal_load(A.val + k);
-    const double v1 = __builtin_nontemporal_load(A.val + k + TPB);
-    const double v2 = __builtin_nontemporal_load(A.val + k + 2 * TPB);
-    const double v3 = __builtin_nontemporal_load(A.val + k + 3 * TPB);
-    s0 += v0 * xin[c0];
-    s1 += v1 * xin[c1];
-    s2 += v2 * xin[c2];
-    s3 += v3 * xin[c3];
-  }
-  for (; k < kend; k += TPB) s0 += A.val[k] * xin[A.col[k]];
-  acc[0] = (s0 + s1) + (s2 + s3);
-  block_sum<1, TPB>(acc, red);
-  if (threadIdx.x == 0) chunk_partial[c] = acc[0];
-}
-
-// One lane per long row: add the chunk partials in order, run the epilogue.
-template <int MODE>
-__global__ __launch_bounds__(TPB) void spmv_long_final_kernel(
-    const int *__restrict__ long_row, const int *__restrict__ long_chunk_ptr,
-    int nlong, const double *__restrict__ chunk_partial, EpiArgs e,
-    int slot_base) {
-  __shared__ double red[3][TPB / WAVE];
-  double acc[3] = {0.0, 0.0, 0.0};
-  const int l = blockIdx.x * TPB + threadIdx.x;
-  if (l < nlong) {
-    double s = 0.0;
-    for (int c = long_chunk_ptr[l]; c < long_chunk_ptr[l + 1]; ++c)
-      s = s + chunk_partial[c];
-    row_epilogue<MODE>(e, long_row[l], s, acc);
-  }
-  constexpr int NQ = ModeNQ<MODE>::value;
-  if (NQ > 0) {
-    block_sum<NQ, TPB>(acc, red);
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        e.partials[q * e.stride + slot_base + blockIdx.x] = acc[q];
-    }
-  }
-}
-
-// ---------------------------------------------------------------- elementwise
-
-// K1+K2: x' = proj(x - tau*(Qx + c - A'y)), xbar = x' + theta*(x' - x).
-//   compute_primal_gradient_from_dual_product  saddle_point.jl:1093-1100
-//   next_primal = x .- (step/pw) .* g          pdhg.jl:466-467
-//   projection!                                saddle_point.jl:87-92
-//   xbar                                       pdhg.jl:486-487
-template <bool HAS_Q, bool WRITE_XBAR>
-__device__ __forceinline__ void primal_one(double x, double c, double aty,
-                                           double qx, double lb, double ub,
-                                           double tau, double theta, double &xn,
-                                           double &xb) {
-  const double q = HAS_Q ? qx : 0.0;
-  const double t0 = q + c;
-  const double g = t0 - aty;
-  const double t1 = tau * g;
-  double v = x - t1;
-  v = jl_min(ub, jl_max(lb, v));
-  xn = v;
-  if (WRITE_XBAR) {
-    const double d = v - x;
-    const double t2 = theta * d;
-    xb = v + t2;
-  }
-}
-
-template <bool HAS_Q, bool WRITE_XBAR>
-__global__ __launch_bounds__(TPB) void primal_kernel(
-    int n, const double *__restrict__ x, const double *__restrict__ c,
-    const double *__restrict__ aty, const double *__restrict__ qx,
-    const double *__restrict__ lb, const double *__restrict__ ub, double tau,
-    double theta, double *__restrict__ x_next, double *__restrict__ xbar) {
-  const int npair = n >> 1;
-  const int stride = gridDim.x * TPB;
-  for (int p = blockIdx.x * TPB + threadIdx.x; p < npair; p += stride) {
-    const double2 xv = reinterpret_cast<const double2 *>(x)[p];
-    const double2 cv = reinterpret_cast<const double2 *>(c)[p];
-    const double2 av = reinterpret_cast<const double2 *>(aty)[p];
-    const double2 lv = reinterpret_cast<const double2 *>(lb)[p];
-    const double2 uv = reinterpret_cast<const double2 *>(ub)[p];
-    double2 qv = {0.0, 0.0};
-    if (HAS_Q) qv = reinterpret_cast<const double2 *>(qx)[p];
-    double2 xn, xb;
-    primal_one<HAS_Q, WRITE_XBAR>(xv.x, cv.x, av.x, qv.x, lv.x, uv.x, tau, theta, xn.x, xb.x);
-    primal_one<HAS_Q, WRITE_XBAR>(xv.y, cv.y, av.y, qv.y, lv.y, uv.y, tau, theta, xn.y, xb.y);
-    reinterpret_cast<double2 *>(x_next)[p] = xn;
-    if (WRITE_XBAR) reinterpret_cast<double2 *>(xbar)[p] = xb;
-  }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const int j = n - 1;
-    double xn, xb;
-    primal_one<HAS_Q, WRITE_XBAR>(x[j], c[j], aty[j], HAS_Q ? qx[j] : 0.0, lb[j], ub[j], tau, theta, xn, xb);
-    x_next[j] = xn;
-    if (WRITE_XBAR) xbar[j] = xb;
-  }
-}
-
-// xbar = x' + theta*(x' - x) on its own (Malitsky-Pock retries, pdhg.jl:590-601)
-__global__ __launch_bounds__(TPB) void xbar_kernel(int n, const double *__restrict__ x,
-                                                   const double *__restrict__ x_next,
-                                                   double theta, double *__restrict__ xbar) {
-  const int stride = gridDim.x * TPB;
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) {
-    const double v = x_next[j];
-    const double d = v - x[j];
-    const double t = theta * d;
-    xbar[j] = v + t;
-  }
-}
-
-// dx = x' - x  (for the QP interaction term 0.5*dx'Q dx, pdhg.jl:536-541)
-__global__ __launch_bounds__(TPB) void diff_kernel(int n, const double *__restrict__ a,
-                                                   const double *__restrict__ b,
-                                                   double *__restrict__ out) {
-  const int stride = gridDim.x * TPB;
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) out[j] = a[j] - b[j];
-}
-
-// Reductions over the replicated n-vectors (row-partitioned form, after the
-// all-reduce delivered A'y'):  dx.(A'y'-A'y), dx^2, (A'y'-A'y)^2.
-__global__ __launch_bounds__(TPB) void interaction_kernel(
-    int n, const double *__restrict__ x, const double *__restrict__ x_next,
-    const double *__restrict__ aty, const double *__restrict__ aty_next,
-    double *__restrict__ partials, int pstride) {
-  __shared__ double red[3][TPB / WAVE];
-  double acc[3] = {0.0, 0.0, 0.0};
-  const int stride = gridDim.x * TPB;
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) {
-    const double dx = x_next[j] - x[j];
-    const double dd = aty_next[j] - aty[j];
-    acc[0] += dx * dd;
-    acc[1] += dx * dx;
-    acc[2] += dd * dd;
-  }
-  block_sum<3, TPB>(acc, red);
-  if (threadIdx.x == 0) {
-    partials[0 * pstride + blockIdx.x] = acc[0];
-    partials[1 * pstride + blockIdx.x] = acc[1];
-    partials[2 * pstride + blockIdx.x] = acc[2];
-  }
-}
-
-// dot(a, b) partials (QP term)
-__global__ __launch_bounds__(TPB) void dot_kernel(int n, const double *__restrict__ a,
-                                                  const double *__restrict__ b,
-                                                  double *__restrict__ partials) {
-  __shared__ double red[3][TPB / WAVE];
-  double acc[3] = {0.0, 0.0, 0.0};
-  const int stride = gridDim.x * TPB;
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) acc[0] += a[j] * b[j];
-  block_sum<1, TPB>(acc, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
-}
-
-// K7: sum_x += w*x', sum_y += w*y'      saddle_point.jl:258-259, 271
-__global__ __launch_bounds__(TPB) void accept_kernel(int n, int m, double w,
-                                                     const double *__restrict__ xs,
-                                                     double *__restrict__ sum_x,
-                                                     const double *__restrict__ ys,
-                                                     double *__restrict__ sum_y) {
-  const int stride = gridDim.x * TPB;
-  const int tid = blockIdx.x * TPB + threadIdx.x;
-  for (int j = tid; j < n; j += stride) {
-    const double t = xs[j] * w;
-    sum_x[j] = sum_x[j] + t;
-  }
-  for (int i = tid; i < m; i += stride) {
-    const double t = ys[i] * w;
-    sum_y[i] = sum_y[i] + t;
-  }
-}
-
-// compute_average: sum / weight (a division, saddle_point.jl:296-301)
-__global__ __launch_bounds__(TPB) void div_kernel(int n, const double *__restrict__ s,
-                                                  double w, double *__restrict__ out) {
-  const int stride = gridDim.x * TPB;
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) out[j] = s[j] / w;
-}
-
-// Second-stage, fixed-order sum of the block partials.  One workgroup.
-// spec[q] = {ptr, count}; out[q] = sum(ptr[0..count)).  count==0 -> 0.
-struct FinalSpec {
-  const double *ptr[5];
-  int count[5];
-  double *out;     // 5 doubles (host-mapped or device)
-};
-__global__ __launch_bounds__(FINAL_TPB) void final_reduce_kernel(FinalSpec sp) {
-  __shared__ double red[3][FINAL_TPB / WAVE];
-  for (int q = 0; q < 5; ++q) {
-    double acc[3] = {0.0, 0.0, 0.0};
-    const double *p = sp.ptr[q];
-    const int cnt = sp.count[q];
-    for (int i = threadIdx.x; i < cnt; i += FINAL_TPB) acc[0] += p[i];
-    block_sum<1, FINAL_TPB>(acc, red);
-    if (threadIdx.x == 0) sp.out[q] = acc[0];
-    __syncthreads();
-  }
-}
-
-// ============================================================ evaluation branch (N1)
-// Evaluation-cadence kernels (every termination_evaluation_frequency
-// iterations): plain SpMVs into temporaries followed by elementwise kernels
-// with multi-quantity sum/max reductions.  Simplicity over fusion here: the
-// extra vector passes are noise at this cadence.
-constexpr int EV_MAXQ = 20;
-
-template <int NS, int NM>
-struct RedAcc {
-  double s[NS > 0 ? NS : 1];
-  double m[NM > 0 ? NM : 1];
-  __device__ RedAcc() {
-    for (int i = 0; i < (NS > 0 ? NS : 1); ++i) s[i] = 0.0;
-    for (int i = 0; i < (NM > 0 ? NM : 1); ++i) m[i] = 0.0;
-  }
-};
-
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = WAVE / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, WAVE));
-  return v;
-}
-
-// partials[q*stride + blockIdx.x]: q < NS sums, then NM maxes (all maxes are of non-negative values)
-template <int NS, int NM>
-__device__ __forceinline__ void block_reduce_store(const RedAcc<NS, NM> &a, double *partials, int stride) {
-  __shared__ double red[NS + NM][TPB / WAVE];
-  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
-#pragma unroll
-  for (int q = 0; q < NS; ++q) { const double w = wave_sum(a.s[q]); if (lane == 0) red[q][wid] = w; }
-#pragma unroll
-  for (int q = 0; q < NM; ++q) { const double w = wave_max(a.m[q]); if (lane == 0) red[NS + q][wid] = w; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int q = 0; q < NS; ++q) { double t = 0.0; for (int w = 0; w < TPB / WAVE; ++w) t += red[q][w]; partials[q * stride + blockIdx.x] = t; }
-#pragma unroll
-    for (int q = 0; q < NM; ++q) { double t = 0.0; for (int w = 0; w < TPB / WAVE; ++w) t = fmax(t, red[NS + q][w]); partials[(NS + q) * stride + blockIdx.x] = t; }
-  }
-}
-
-__global__ __launch_bounds__(FINAL_TPB) void multi_final_kernel(const double *__restrict__ partials, int stride,
-                                                                int count, int ns, int nm, double *__restrict__ out) {
-  __shared__ double red[3][FINAL_TPB / WAVE];
-  for (int q = 0; q < ns + nm; ++q) {
-    const double *p = partials + (size_t)q * stride;
-    const bool is_max = q >= ns;
-    double v = 0.0;
-    for (int i = threadIdx.x; i < count; i += FINAL_TPB) v = is_max ? fmax(v, p[i]) : v + p[i];
-    v = is_max ? wave_max(v) : wave_sum(v);
-    if ((threadIdx.x & (WAVE - 1)) == 0) red[0][threadIdx.x / WAVE] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double t = 0.0;
-      for (int w = 0; w < FINAL_TPB / WAVE; ++w) t = is_max ? fmax(t, red[0][w]) : t + red[0][w];
-      out[q] = t;
-    }
-    __syncthreads();
-  }
-}
-
-// Row side of compute_convergence_information / compute_infeasibility_information
-// (iteration_stats_utils.jl:30-63, 157-197, 228-349) on the UNSCALED point:
-//   activities A_o x_o = E .* (A_s x_s),  y_o = y_s ./ E.
-// sums: 0 sum viol^2, 1 sum y_o^2, 2 b_o.y_o, 3 sum max(-y_o,0)^2 (ineq rows)
-// maxs: 0 max|viol|, 1 max|viol_homogeneous|, 2 max|y_o|, 3 max max(-y_o,0)
-__global__ __launch_bounds__(TPB) void eval_rows_kernel(int m, int ne, const double *__restrict__ ax_s,
-                                                        const double *__restrict__ py, const double *__restrict__ E,
-                                                        const double *__restrict__ b_o, double *__restrict__ partials,
-                                                        int stride) {
-  RedAcc<4, 4> a;
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < m; i += gridDim.x * TPB) {
-    const double e = E[i];
-    const double act = e * ax_s[i];
-    const double r = b_o[i] - act;
-    const double rh = 0.0 - act;
-    const bool eq = i < ne;
-    const double viol = eq ? r : fmax(r, 0.0);
-    const double violh = eq ? rh : fmax(rh, 0.0);
-    const double yo = py[i] / e;
-    const double dres = eq ? 0.0 : fmax(-yo, 0.0);
-    a.s[0] += viol * viol; a.s[1] += yo * yo; a.s[2] += b_o[i] * yo; a.s[3] += dres * dres;
-    a.m[0] = fmax(a.m[0], fabs(viol)); a.m[1] = fmax(a.m[1], fabs(violh));
-    a.m[2] = fmax(a.m[2], fabs(yo)); a.m[3] = fmax(a.m[3], dres);
-  }
-  block_reduce_store<4, 4>(a, partials, stride);
-}
-
-// Column side (LP): g = c_o - D .* (A_s' y_s), reduced costs, bound violations,
-// and the homogeneous (c = 0) dual statistics for the infeasibility certificate.
-// sums: 0 sum resid^2, 1 sum bound*rc, 2 sum x_o^2, 3 c_o.x_o, 4 sum bound-viol^2, 5 sum bound*rc_h
-// maxs: 0 max|resid|, 1 max|x_o|, 2 max bound viol, 3 max|resid_h|, 4 max|rc_h|, 5 max ray bound viol
-__global__ __launch_bounds__(TPB) void eval_cols_kernel(int n, const double *__restrict__ aty_s,
-                                                        const double *__restrict__ px, const double *__restrict__ D,
-                                                        const double *__restrict__ c_o, const double *__restrict__ lb_o,
-                                                        const double *__restrict__ ub_o, double *__restrict__ partials,
-                                                        int stride) {
-  RedAcc<6, 6> a;
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) {
-    const double d = D[j];
-    const double aty = d * aty_s[j];
-    const double xo = px[j] / d;
-    const double lb = lb_o[j], ub = ub_o[j];
-    const bool lbf = isfinite(lb), ubf = isfinite(ub);
-    // compute_reduced_costs_from_primal_gradient        iteration_stats_utils.jl:128-148
-    const double g = c_o[j] - aty;
-    const double rc = ((g > 0.0) ? lbf : ubf) ? g : 0.0;
-    const double resid = g - rc;
-    const double contrib = (rc == 0.0) ? 0.0 : ((rc > 0.0 ? lb : ub) * rc);
-    const double gh = 0.0 - aty;
-    const double rch = ((gh > 0.0) ? lbf : ubf) ? gh : 0.0;
-    const double residh = gh - rch;
-    const double contribh = (rch == 0.0) ? 0.0 : ((rch > 0.0 ? lb : ub) * rch);
-    const double lv = fmax(lb - xo, 0.0), uv = fmax(xo - ub, 0.0);
-    const double rayv = fmax(lbf ? fmax(-xo, 0.0) : 0.0, ubf ? fmax(xo, 0.0) : 0.0);
-    a.s[0] += resid * resid; a.s[1] += contrib; a.s[2] += xo * xo; a.s[3] += c_o[j] * xo;
-    a.s[4] += lv * lv + uv * uv; a.s[5] += contribh;
-    a.m[0] = fmax(a.m[0], fabs(resid)); a.m[1] = fmax(a.m[1], fabs(xo)); a.m[2] = fmax(a.m[2], fmax(lv, uv));
-    a.m[3] = fmax(a.m[3], fabs(residh)); a.m[4] = fmax(a.m[4], fabs(rch)); a.m[5] = fmax(a.m[5], rayv);
-  }
-  block_reduce_store<6, 6>(a, partials, stride);
-}
-
-// sum (a-b)^2 over two vector pairs: distances to the last restart point
-// (saddle_point.jl:445-477, 911-920; weights are uniform per block in PDHG).
-__global__ __launch_bounds__(TPB) void dist2_kernel(int n, int m, const double *__restrict__ xa,
-                                                    const double *__restrict__ xb, const double *__restrict__ ya,
-                                                    const double *__restrict__ yb, double *__restrict__ partials,
-                                                    int stride) {
-  RedAcc<2, 0> a;
-  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
-  for (int j = tid; j < n; j += st) { const double d = xb ? xa[j] - xb[j] : xa[j]; a.s[0] += d * d; }
-  for (int i = tid; i < m; i += st) { const double d = yb ? ya[i] - yb[i] : ya[i]; a.s[1] += d * d; }
-  block_reduce_store<2, 0>(a, partials, stride);
-}
-
-// bound_optimal_objective (trust_region_utils.jl:271-360) set-up on the SCALED
-// problem at point z = (x, y): gradient g = [c - A'y ; -(b - A x)], direction
-// d = -g/w (0 if the bound blocks it), breakpoint thr (trust_region_utils.jl:86-110).
-// range: 0 both blocks (EUCLIDEAN_NORM), 1 primal only, 2 dual only (MAX_NORM halves).
-// sums: 0 c.x, 1 x.(A'y), 2 y.b, 3 sum_{thr=inf} w d^2, 4 sum g^2 (in range),
-//       5 sum w d^2 (in range), 6 sum g.d primal, 7 sum g.d dual, 8 sum x^2, 9 sum y^2
-// maxs: 0 max finite thr (in range)
-__global__ __launch_bounds__(TPB) void tr_setup_kernel(int n, int m, int ne, const double *__restrict__ px,
-                                                       const double *__restrict__ py, const double *__restrict__ aty_s,
-                                                       const double *__restrict__ ax_s, const double *__restrict__ c_s,
-                                                       const double *__restrict__ b_s, const double *__restrict__ lb_s,
-                                                       const double *__restrict__ ub_s, double wp, double wd, int range,
-                                                       double *__restrict__ gvec, double *__restrict__ dir,
-                                                       double *__restrict__ thr, double *__restrict__ partials,
-                                                       int stride) {
-  RedAcc<10, 1> a;
-  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
-  for (int k = tid; k < n + m; k += st) {
-    const bool primal = k < n;
-    const int i = primal ? k : k - n;
-    double z, g, lo, hi, w;
-    if (primal) {
-      z = px[i]; g = c_s[i] - aty_s[i]; lo = lb_s[i]; hi = ub_s[i]; w = wp;
-      a.s[0] += c_s[i] * z; a.s[1] += z * aty_s[i]; a.s[8] += z * z;
-    } else {
-      z = py[i]; g = -(b_s[i] - ax_s[i]); lo = (i < ne) ? -INFINITY : 0.0; hi = INFINITY; w = wd;
-      a.s[2] += z * b_s[i]; a.s[9] += z * z;
-    }
-    const bool in_range = (range == 0) || (range == 1 && primal) || (range == 2 && !primal);
-    double d = 0.0, t = 0.0;
-    if (in_range && !((z >= hi && g <= 0.0) || (z <= lo && g >= 0.0))) {
-      d = -g / w;
-      if (d > 0.0) t = (hi - z) / d;
-      else if (d < 0.0) t = (lo - z) / d;
-      else t = 0.0;
-    }
-    gvec[k] = g; dir[k] = d; thr[k] = t;
-    if (in_range) {
-      a.s[4] += g * g;
-      a.s[5] += w * d * d;
-      if (primal) a.s[6] += g * d; else a.s[7] += g * d;
-      if (isinf(t)) a.s[3] += w * d * d; else a.m[0] = fmax(a.m[0], t);
-    }
-  }
-  block_reduce_store<10, 1>(a, partials, stride);
-}
-
-// radius^2 as a function of the step t at K probe values:
-//   low_k = sum_{thr <= t_k} w d^2 thr^2 ,  high_k = sum_{thr > t_k} w d^2
-constexpr int TR_K = 7;
-struct TrProbes { double t[TR_K]; };
-__global__ __launch_bounds__(TPB) void tr_probe_kernel(int n, int total, const double *__restrict__ dir,
-                                                       const double *__restrict__ thr, double wp, double wd,
-                                                       TrProbes pr, double *__restrict__ partials, int stride) {
-  RedAcc<2 * TR_K, 0> a;
-  for (int k = blockIdx.x * TPB + threadIdx.x; k < total; k += gridDim.x * TPB) {
-    const double d = dir[k];
-    if (d == 0.0) continue;
-    const double w = (k < n) ? wp : wd;
-    const double t = thr[k];
-    const double wd2 = w * d * d;
-    const double lowc = wd2 * t * t;   // inf for thr = inf: never selected below
-#pragma unroll
-    for (int q = 0; q < TR_K; ++q) {
-      if (t <= pr.t[q]) a.s[2 * q] += lowc; else a.s[2 * q + 1] += wd2;
-    }
-  }
-  block_reduce_store<2 * TR_K, 0>(a, partials, stride);
-}
-
-// value parts sum g_i (clamp(z_i + t d_i) - z_i), primal block and dual block
-__global__ __launch_bounds__(TPB) void tr_value_kernel(int n, int m, int ne, const double *__restrict__ px,
-                                                       const double *__restrict__ py, const double *__restrict__ lb_s,
-                                                       const double *__restrict__ ub_s, const double *__restrict__ gvec,
-                                                       const double *__restrict__ dir, double t,
-                                                       double *__restrict__ partials, int stride) {
-  RedAcc<2, 0> a;
-  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
-  for (int k = tid; k < n + m; k += st) {
-    const bool primal = k < n;
-    const int i = primal ? k : k - n;
-    const double d = dir[k];
-    if (d == 0.0) continue;
-    const double z = primal ? px[i] : py[i];
-    const double lo = primal ? lb_s[i] : ((i < ne) ? -INFINITY : 0.0);
-    const double hi = primal ? ub_s[i] : INFINITY;
-    const double cand = fmin(fmax(z + t * d, lo), hi);   // clamp.(center + t*direction, lb, ub)
-    const double v = gvec[k] * (cand - z);
-    if (primal) a.s[0] += v; else a.s[1] += v;
-  }
-  block_reduce_store<2, 0>(a, partials, stride);
-}
-
-// ============================================================ rescaling on the device (N2)
-// rescale_problem (preprocess.jl:631-687) applied in place to every resident
-// layout.  One wave per CSR row (one-time work, simplicity over speed).
-enum { ROP_MAXABS = 0, ROP_SUMPOW = 1, ROP_SUMSQ_SCALED = 2 };
-
-// out[r] = max |a| ; sum |a|^p (+ structural zeros when p == 0: Julia's
-// mapreduce visits them and 0.0^0 == 1.0) ; sum (a * inv_scale[r])^2
-template <int OP>
-__global__ __launch_bounds__(TPB) void row_op_kernel(CsrView A, int cols, double pexp,
-                                                     const double *__restrict__ inv_scale,
-                                                     double *__restrict__ out) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int r = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
-  if (r >= A.rows) return;
-  const int k0 = A.rowptr[r], k1 = A.rowptr[r + 1];
-  const double sc = (OP == ROP_SUMSQ_SCALED) ? inv_scale[r] : 1.0;
-  double acc = 0.0;
-  for (int k = k0 + lane; k < k1; k += WAVE) {
-    const double a = A.val[k];
-    if (OP == ROP_MAXABS) acc = fmax(acc, fabs(a));
-    else if (OP == ROP_SUMPOW) acc += pow(fabs(a), pexp);
-    else { const double t = a * sc; acc += t * t; }
-  }
-  acc = (OP == ROP_MAXABS) ? wave_max(acc) : wave_sum(acc);
-  if (lane == 0) {
-    if (OP == ROP_SUMPOW && pexp == 0.0) acc += (double)(cols - (k1 - k0));
-    out[r] = acc;
-  }
-}
-
-// val[k] = (val[k] * inv_a[ia]) * inv_b[ib] with ia/ib chosen so that the
-// multiplication order is always (a * (1/e_row_of_A)) * (1/d_col_of_A), as in
-// (Diagonal(1 ./ E) * A) * Diagonal(1 ./ D) (preprocess.jl:567-571).
-// transposed == false: CSR(A) (row -> E, col -> D); true: CSR(A') (row -> D, col -> E).
-__global__ __launch_bounds__(TPB) void scale_csr_kernel(int rows, const int *__restrict__ rowptr,
-                                                        const int *__restrict__ col, double *__restrict__ val,
-                                                        const double *__restrict__ inv_e,
-                                                        const double *__restrict__ inv_d, int transposed) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int r = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
-  if (r >= rows) return;
-  const int k0 = rowptr[r], k1 = rowptr[r + 1];
-  for (int k = k0 + lane; k < k1; k += WAVE) {
-    const int c = col[k];
-    const double ie = transposed ? inv_e[c] : inv_e[r];
-    const double id = transposed ? inv_d[r] : inv_d[c];
-    val[k] = (val[k] * ie) * id;
-  }
-}
-
-// same for the tiled-sweep copy: one wave per wave-row-block, walking its steps
-__global__ __launch_bounds__(TPB) void scale_tiled_kernel(const int2 *__restrict__ wave_rows,
-                                                          const int *__restrict__ step_ptr,
-                                                          const int *__restrict__ wave_step_off,
-                                                          const int *__restrict__ step_tile,
-                                                          const int *__restrict__ wg_step_off, int nwaves,
-                                                          int tile_shift, const unsigned *__restrict__ pk,
-                                                          double *__restrict__ tv,
-                                                          const double *__restrict__ inv_e,
-                                                          const double *__restrict__ inv_d, int transposed) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int w = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
-  if (w >= nwaves) return;
-  const int g = w / TW_WPB;
-  const int nst = wg_step_off[g + 1] - wg_step_off[g];
-  const int *stile = step_tile + wg_step_off[g];
-  const int *sp = step_ptr + wave_step_off[w];
-  const int r0 = wave_rows[w].x;
-  const unsigned cmask = (1u << tile_shift) - 1u;
-  for (int st = 0; st < nst; ++st) {
-    const int tile = stile[st];
-    for (int k = sp[st] + lane; k < sp[st + 1]; k += WAVE) {
-      const unsigned p = pk[k];
-      const int r = r0 + (int)(p >> tile_shift);
-      const int c = (int)(((unsigned)tile << tile_shift) | (p & cmask));
-      const double ie = transposed ? inv_e[c] : inv_e[r];
-      const double id = transposed ? inv_d[r] : inv_d[c];
-      tv[k] = (tv[k] * ie) * id;
-    }
-  }
-}
-
-// elementwise helpers on rescaling vectors
-//  mode 0: v = sqrt(v), zeros -> 1          (Ruiz / Pock-Chambolle factors)
-//  mode 1: v = sqrt(max(a, 0)) from a       (unused)  mode 2: inv = 1/v ; cum *= v
-__global__ __launch_bounds__(TPB) void resc_sqrt_kernel(int n, double *__restrict__ v) {
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-    double t = sqrt(v[i]);
-    if (t == 0.0) t = 1.0;
-    v[i] = t;
-  }
-}
-__global__ __launch_bounds__(TPB) void resc_l2norm_kernel(int n, const double *__restrict__ scale,
-                                                          double *__restrict__ sumsq_inout) {
-  // l2_norm (preprocess.jl:99-113): scale .* sqrt(sum (a/scale)^2)
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB)
-    sumsq_inout[i] = scale[i] * sqrt(sumsq_inout[i]);
-}
-__global__ __launch_bounds__(TPB) void resc_zero_to_one_inv_kernel(int n, double *__restrict__ v,
-                                                                   double *__restrict__ inv, int do_zero_to_one) {
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
-    double t = v[i];
-    if (do_zero_to_one && t == 0.0) { t = 1.0; v[i] = t; }
-    inv[i] = 1.0 / t;
-  }
-}
-__global__ __launch_bounds__(TPB) void resc_apply_vectors_kernel(int n, int m, const double *__restrict__ dv,
-                                                                 const double *__restrict__ ev,
-                                                                 double *__restrict__ c, double *__restrict__ lb,
-                                                                 double *__restrict__ ub, double *__restrict__ b,
-                                                                 double *__restrict__ cum_d,
-                                                                 double *__restrict__ cum_e) {
-  // scale_problem (preprocess.jl:555-573): c ./= D ; ub .*= D ; lb .*= D ; b ./= E
-  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
-  for (int j = tid; j < n; j += st) {
-    const double d = dv[j];
-    c[j] = c[j] / d; ub[j] = ub[j] * d; lb[j] = lb[j] * d; cum_d[j] = cum_d[j] * d;
-  }
-  for (int i = tid; i < m; i += st) {
-    const double e = ev[i];
-    b[i] = b[i] / e; cum_e[i] = cum_e[i] * e;
-  }
-}
-__global__ __launch_bounds__(TPB) void fill_kernel(int n, double v, double *__restrict__ out) {
-  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) out[i] = v;
-}
-__global__ __launch_bounds__(TPB) void maxabs_kernel(int64_t n, const double *__restrict__ v,
-                                                     double *__restrict__ partials, int stride) {
-  RedAcc<0, 1> a;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
-    a.m[0] = fmax(a.m[0], fabs(v[i]));
-  block_reduce_store<0, 1>(a, partials, stride);
-}
-
-// One-quantity variant writing to a device slot (row-partitioned form).
-__global__ __launch_bounds__(FINAL_TPB) void final_to_slot_kernel(const double *p, int cnt, double *slot) {
-  __shared__ double red[3][FINAL_TPB / WAVE];
-  double acc[3] = {0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < cnt; i += FINAL_TPB) acc[0] += p[i];
-  block_sum<1, FINAL_TPB>(acc, red);
-  if (threadIdx.x == 0) *slot = acc[0];
-}
-
-// ---------------------------------------------------------------- host side
-
-struct CsrDev {
-  int rows = 0, cols = 0;
-  int64_t nnz = 0;
-  int *rowptr = nullptr, *col = nullptr;
-  double *val = nullptr;
-  int2 *blks = nullptr;
-  int nblk = 0, per_xcd = 0, grid = 0;
-  int nlong = 0, nchunks = 0, long_grid = 0;
-  int *long_row = nullptr, *long_chunk_ptr = nullptr, *chunk_row = nullptr, *chunk_off = nullptr;
-  double *chunk_partial = nullptr;
-  int64_t max_row_nnz = 0;
-  // tiled-sweep layout (optional)
-  bool tiled = false;
-  int tile_shift = 0, nwaves = 0, ntiles = 0, tw_rows = 0;
-  int2 *wave_rows = nullptr;
-  int *wave_ent = nullptr;        // per-wave entry offsets, one per step of its workgroup (+1)
-  int *wave_step_off = nullptr;   // [nwaves] start of a wave's offsets inside wave_ent
-  int *step_tile = nullptr;       // tile id of every step, workgroup after workgroup
-  int *wg_step_off = nullptr;     // [grid+1] start of a workgroup's steps inside step_tile
-  int64_t total_steps = 0;
-  bool tw_scratch = false;        // long same-row runs: use the LDS-scratch chunk variant
-  unsigned *pk = nullptr;
-  double *tv = nullptr;
-  int slots() const { return grid + long_grid; }
-  CsrView view() const { return CsrView{rows, rowptr, col, val}; }
-};
-
-template <typename T>
-int upload(T **dst, const std::vector<T> &src) {
-  const size_t bytes = sizeof(T) * std::max<size_t>(src.size(), 1);
-  HIP_TRY(hipMalloc((void **)dst, bytes));
-  if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
-  return 0;
-}
-
-int alloc_zero(double **dst, int64_t len) {
-  const size_t bytes = sizeof(double) * (size_t)std::max<int64_t>(len, 1);
-  HIP_TRY(hipMalloc((void **)dst, bytes));
-  HIP_TRY(hipMemset(*dst, 0, bytes));
-  return 0;
-}
-
-// Host-side construction of the tiled-sweep layout: wave row blocks (runs of
-// <= TW_ROWS consecutive non-long rows) and their entries counting-sorted by
-// column tile (stable, so (row, col) order is kept inside a tile).
-int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::vector<int> &col,
-                const std::vector<double> &val, int tile_shift) {
-  // Geometry.  A CU holds 2 workgroups of 8 waves; the grid runs in rounds of
-  // 256 CUs x 16 waves.  Rows per wave is chosen so that the rounds are full
-  // (no tail round), within the LDS budget (160 KiB / 16 waves).
-  const int64_t slots = 256LL * 2 * TW_WPB;               // resident waves per round
-  const int max_rows = std::min<int>(TW_MAX_ROWS, 1 << (32 - tile_shift));
-  int TW_ROWS;
-  {
-    int64_t rounds = std::max<int64_t>(1, ((int64_t)rows + slots * max_rows - 1) / (slots * max_rows));
-    int64_t rpw = ((int64_t)rows + slots * rounds - 1) / (slots * rounds);
-    TW_ROWS = (int)std::max<int64_t>(64, std::min<int64_t>(max_rows, rpw));
-  }
-  if (const char *ev = getenv("PDHG_TW_ROWS")) TW_ROWS = std::max(1, std::min(atoi(ev), max_rows));
-  D.tw_rows = TW_ROWS;
-  const int ntiles = std::max<int>(1, (int)((((int64_t)D.cols) + (1LL << tile_shift) - 1) >> tile_shift));
-  const unsigned cmask = (1u << tile_shift) - 1u;
-  const int WIN = TW_U * WAVE;  // entries a wave holds in registers per step
-  // pass 1: wave row blocks.  A wave owns <= TW_ROWS rows AND <= nnz_cap
-  // nonzeros: hub regions (PageRank's oldest nodes) would otherwise give one
-  // wave 100x the average work and the whole launch would wait for its workgroup.
-  const int64_t est_waves = std::max<int64_t>(1, ((int64_t)rows + TW_ROWS - 1) / TW_ROWS);
-  const int64_t nnz_cap = std::max<int64_t>(4096, 2 * (D.nnz / est_waves));   // 2x the average wave
-  std::vector<int2> wave_rows;
-  {
-    int r = 0;
-    while (r < rows) {
-      if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) { ++r; continue; }  // long row: separate path
-      const int r0 = r;
-      while (r < rows && (r - r0) < TW_ROWS && rowptr[r + 1] - rowptr[r] <= BLOCK_NNZ &&
-             (r == r0 || (int64_t)rowptr[r + 1] - rowptr[r0] <= nnz_cap)) ++r;
-      wave_rows.push_back(make_int2(r0, r));
-    }
-  }
-  const int nwaves = (int)wave_rows.size();
-  const int grid = (nwaves + TW_WPB - 1) / TW_WPB;
-  std::vector<unsigned> pk;
-  std::vector<double> tv;
-  pk.reserve((size_t)D.nnz);
-  tv.reserve((size_t)D.nnz);
-  std::vector<int> step_ptr, wave_step_off((size_t)std::max(nwaves, 1), 0), step_tile, wg_step_off(1, 0);
-  std::vector<std::vector<int>> cnt(TW_WPB, std::vector<int>((size_t)ntiles + 1));
-  std::vector<int> nsub((size_t)ntiles);
-  int max_run = 0;   // longest same-row run inside one tile
-  for (int g = 0; g < grid; ++g) {
-    const int w0 = g * TW_WPB, w1 = std::min(nwaves, w0 + TW_WPB);
-    // cell sizes of the workgroup's waves
-    std::fill(nsub.begin(), nsub.end(), 0);
-    for (int w = w0; w < w1; ++w) {
-      std::vector<int> &c = cnt[w - w0];
-      std::fill(c.begin(), c.end(), 0);
-      for (int k = rowptr[wave_rows[w].x]; k < rowptr[wave_rows[w].y]; ++k) c[(col[k] >> tile_shift) + 1] += 1;
-      for (int t = 0; t < ntiles; ++t) nsub[t] = std::max(nsub[t], (c[t + 1] + WIN - 1) / WIN);
-      for (int t = 0; t < ntiles; ++t) c[t + 1] += c[t];   // prefix: cell start offsets
-    }
-    // the workgroup's step list (heavy tiles repeated, empty tiles skipped)
-    for (int t = 0; t < ntiles; ++t)
-      for (int j = 0; j < nsub[t]; ++j) step_tile.push_back(t);
-    wg_step_off.push_back((int)step_tile.size());
-    // entries of each wave, tile-major (stable in (row, col)), and its step offsets
-    for (int w = w0; w < w1; ++w) {
-      std::vector<int> &c = cnt[w - w0];
-      const int r0 = wave_rows[w].x, r1 = wave_rows[w].y;
-      const size_t base = pk.size();
-      const int total = rowptr[r1] - rowptr[r0];
-      wave_step_off[w] = (int)step_ptr.size();
-      for (int t = 0; t < ntiles; ++t) {
-        const int cs = c[t], ce = c[t + 1], len = ce - cs;
-        const int per = nsub[t] ? (len + nsub[t] - 1) / nsub[t] : 0;
-        for (int j = 0; j < nsub[t]; ++j) step_ptr.push_back((int)base + std::min(ce, cs + j * per));
-      }
-      step_ptr.push_back((int)base + total);
-      pk.resize(base + (size_t)total);
-      tv.resize(base + (size_t)total);
-      std::vector<int> next(c.begin(), c.end() - 1);
-      for (int rr = r0; rr < r1; ++rr) {
-        const unsigned rl = (unsigned)(rr - r0) << tile_shift;
-        int run = 0, run_tile = -1;
-        for (int k = rowptr[rr]; k < rowptr[rr + 1]; ++k) {
-          const int tt = col[k] >> tile_shift;
-          run = (tt == run_tile) ? run + 1 : 1;
-          run_tile = tt;
-          if (run > max_run) max_run = run;
-          const int pos = next[tt]++;
-          pk[base + pos] = rl | ((unsigned)col[k] & cmask);
-          tv[base + pos] = val[k];
-        }
-      }
-    }
-  }
-  // Rows with long same-row runs inside a tile (hub rows of the PageRank LP,
-  // dense-ish blocks) are summed by one lane, sequentially, to keep the
-  // ascending-column order; the stream layout does that from LDS with 8 reads
-  // in flight and wins on such matrices (PageRank-1M: 0.106 ms vs 0.18 ms), and
-  // hubs give it natural cache locality anyway.  PDHG_SPMV=tiled overrides.
-  {
-    const char *mode_env = getenv("PDHG_SPMV");
-    const bool forced = mode_env && !strcmp(mode_env, "tiled");
-    if (!forced && max_run > 32) return 0;
-  }
-  D.tiled = true;
-  D.tile_shift = tile_shift;
-  D.ntiles = ntiles;
-  D.nwaves = nwaves;
-  D.grid = grid;
-  D.total_steps = (int64_t)step_tile.size();
-  D.tw_scratch = max_run > 8;
-  int rc;
-  if ((rc = upload(&D.wave_rows, wave_rows))) return rc;
-  if ((rc = upload(&D.wave_ent, step_ptr))) return rc;
-  if ((rc = upload(&D.wave_step_off, wave_step_off))) return rc;
-  if ((rc = upload(&D.step_tile, step_tile))) return rc;
-  if ((rc = upload(&D.wg_step_off, wg_step_off))) return rc;
-  if ((rc = upload(&D.pk, pk))) return rc;
-  if ((rc = upload(&D.tv, tv))) return rc;
-  return 0;
-}
-
-int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
-                  const std::vector<int> &col, const std::vector<double> &val,
-                  bool remap, int tile_shift = 0) {
-  D.rows = rows;
-  D.cols = cols;
-  D.nnz = rowptr[rows];
-  std::vector<int2> blks;
-  std::vector<int> long_row, long_chunk_ptr(1, 0), chunk_row, chunk_off;
-  int r = 0;
-  while (r < rows) {
-    int len = rowptr[r + 1] - rowptr[r];
-    D.max_row_nnz = std::max<int64_t>(D.max_row_nnz, len);
-    if (len > BLOCK_NNZ) {
-      const int l = (int)long_row.size();
-      long_row.push_back(r);
-      for (int off = 0; off < len; off += LONG_CHUNK) {
-        chunk_row.push_back(r);
-        chunk_off.push_back(off);
-      }
-      long_chunk_ptr.push_back((int)chunk_row.size());
-      (void)l;
-      ++r;
-      continue;
-    }
-    const int r0 = r;
-    int nn = 0;
-    while (r < rows && (r - r0) < MAX_ROWS_PER_BLOCK) {
-      len = rowptr[r + 1] - rowptr[r];
-      if (len > BLOCK_NNZ - nn) break;
-      D.max_row_nnz = std::max<int64_t>(D.max_row_nnz, len);
-      nn += len;
-      ++r;
-    }
-    blks.push_back(make_int2(r0, r));
-  }
-  D.nblk = (int)blks.size();
-  D.per_xcd = (D.nblk + NUM_XCD - 1) / NUM_XCD;
-  D.grid = remap ? D.per_xcd * NUM_XCD : D.nblk;
-  D.nlong = (int)long_row.size();
-  D.nchunks = (int)chunk_row.size();
-  D.long_grid = (D.nlong + TPB - 1) / TPB;
-  int rc;
-  if ((rc = upload(&D.rowptr, rowptr))) return rc;
-  if ((rc = upload(&D.col, col))) return rc;
-  if ((rc = upload(&D.val, val))) return rc;
-  if ((rc = upload(&D.blks, blks))) return rc;
-  if ((rc = upload(&D.long_row, long_row))) return rc;
-  if ((rc = upload(&D.long_chunk_ptr, long_chunk_ptr))) return rc;
-  if ((rc = upload(&D.chunk_row, chunk_row))) return rc;
-  if ((rc = upload(&D.chunk_off, chunk_off))) return rc;
-  if ((rc = alloc_zero(&D.chunk_partial, D.nchunks))) return rc;
-  if (tile_shift > 0) {
-    if ((rc = build_tiled(D, rows, rowptr, col, val, tile_shift))) return rc;
-  }
-  return 0;
-}
-
-void free_csr_dev(CsrDev &D) {
-  void *ptrs[] = {D.rowptr, D.col, D.val, D.blks, D.long_row, D.long_chunk_ptr,
-                  D.chunk_row, D.chunk_off, D.chunk_partial, D.wave_rows, D.wave_ent, D.pk, D.tv,
-                  D.wave_step_off, D.step_tile, D.wg_step_off};
-  for (void *p : ptrs) if (p) (void)hipFree(p);
-  D = CsrDev();
-}
-
-}  // namespace
+// The kernels and layout builders live in the headers below; they form ONE
+// translation unit with this file (the tiled kernel is sensitive to code
+// placement, and one TU keeps every launch a direct call).
+#include "common.hpp"
+#include "spmv_kernels.hpp"
+#include "vector_kernels.hpp"
+#include "eval_kernels.hpp"
+#include "rescale_kernels.hpp"
+#include "layout.hpp"
 
 struct pdhg_handle {
   int device = 0;

@@ -1,0 +1,395 @@
+// spmv_kernels.hpp -- part of the single translation unit pdhg_hip.hip (included there, in order).
+// The two SpMV layouts (CSR-adaptive "stream", L2-tiled "sweep"), the long-row path and their fused epilogues.
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------- CSR views
+
+struct CsrView {
+  int rows;
+  const int *rowptr;   // [rows+1]
+  const int *col;      // [nnz]
+  const double *val;   // [nnz]
+};
+
+enum { MODE_PLAIN = 0, MODE_DUAL = 1, MODE_ATY = 2 };
+
+// Everything a row epilogue may touch.  Passed by value to the kernels.
+struct EpiArgs {
+  // MODE_PLAIN
+  double *out;
+  // MODE_DUAL: y' = proj(y + sigma*(b - A xbar)); partial sum dy^2
+  const double *y;
+  const double *b;
+  double *y_next;
+  double sigma;
+  int num_eq;
+  // MODE_ATY: A'y' written; partial dx.(A'y'-A'y), dx^2, (A'y'-A'y)^2
+  const double *x;
+  const double *x_next;
+  const double *aty;
+  double *aty_next;
+  // block partials: partials[q*stride + slot]
+  double *partials;
+  int stride;
+};
+
+template <int MODE>
+__device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
+                                             double (&acc)[3]) {
+  if (MODE == MODE_PLAIN) {
+    e.out[r] = s;
+  } else if (MODE == MODE_DUAL) {
+    // compute_dual_gradient: b .- A*x              saddle_point.jl:1102-1107
+    const double yo = e.y[r];
+    const double dg = e.b[r] - s;
+    // next_dual = y .+ (pw*step) .* dual_gradient   pdhg.jl:489-490
+    const double t = e.sigma * dg;
+    double yn = yo + t;
+    // project_dual!: only inequality rows           saddle_point.jl:110-117
+    if (r >= e.num_eq) yn = jl_max(yn, 0.0);
+    e.y_next[r] = yn;
+    const double dy = yn - yo;                       // pdhg.jl:535
+    acc[0] += dy * dy;
+  } else {
+    // next_dual_product = A' * next_dual            pdhg.jl:492
+    e.aty_next[r] = s;
+    const double dx = e.x_next[r] - e.x[r];          // pdhg.jl:534
+    const double dd = s - e.aty[r];                  // pdhg.jl:543
+    acc[0] += dx * dd;
+    acc[1] += dx * dx;
+    acc[2] += dd * dd;
+  }
+}
+
+template <int MODE>
+struct ModeNQ { static constexpr int value = (MODE == MODE_PLAIN) ? 0 : (MODE == MODE_DUAL ? 1 : 3); };
+
+// CSR "stream" kernel: a workgroup owns a run of consecutive rows holding at
+// most BLOCK_NNZ nonzeros.  Phase 1 streams val/col with fully coalesced
+// loads (UNROLL independent load chains per lane for memory-level
+// parallelism), gathers x and parks the products in LDS.  Phase 2: one lane
+// per row adds that row's products in ascending column order -- the same
+// order as Julia's SparseMatrixCSC A*x / A'*y loops, so short rows are
+// bit-identical to the sequential CPU result -- and applies the fused
+// epilogue.  Block->XCD: hardware places block b on XCD b%8; with `remap`
+// each XCD walks a contiguous eighth of the row blocks so its private 4 MiB
+// L2 sees a contiguous slice of the gathered vector for banded/local
+// matrices.
+template <int MODE>
+__global__ __launch_bounds__(TPB) void spmv_stream_kernel(
+    CsrView A, const double *__restrict__ xin, const int2 *__restrict__ blks,
+    int nblk, int per_xcd, int remap, EpiArgs e) {
+  __shared__ double prod[BLOCK_NNZ];
+  __shared__ double red[3][TPB / WAVE];
+  const int b = blockIdx.x;
+  const int blk = remap ? ((b & (NUM_XCD - 1)) * per_xcd + (b >> 3)) : b;
+  double acc[3] = {0.0, 0.0, 0.0};
+  const bool active = remap ? ((b >> 3) < per_xcd && blk < nblk) : (blk < nblk);
+  if (active) {
+    const int2 rr = blks[blk];
+    const int r0 = rr.x, r1 = rr.y;
+    const int k0 = A.rowptr[r0];
+    const int k1 = A.rowptr[r1];
+    const int tid = threadIdx.x;
+    int cidx[UNROLL];
+    double v[UNROLL];
+    double xv[UNROLL];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+      const int k = k0 + tid + i * TPB;
+      const bool ok = k < k1;
+      cidx[i] = ok ? __builtin_nontemporal_load(A.col + k) : 0;
+      v[i] = ok ? __builtin_nontemporal_load(A.val + k) : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+      const int k = k0 + tid + i * TPB;
+      xv[i] = (k < k1) ? xin[cidx[i]] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+      const int k = tid + i * TPB;
+      if (k0 + k < k1) prod[k] = v[i] * xv[i];
+    }
+    __syncthreads();
+    for (int r = r0 + tid; r < r1; r += TPB) {
+      const int ks = A.rowptr[r] - k0;
+      const int ke = A.rowptr[r + 1] - k0;
+      double s = 0.0;
+      int k = ks;
+      // 8 LDS reads in flight, adds still strictly left to right (bit-exact
+      // order); a row of ~2K products is otherwise one LDS latency per add.
+      for (; k + 8 <= ke; k += 8) {
+        const double t0 = prod[k], t1 = prod[k + 1], t2 = prod[k + 2], t3 = prod[k + 3];
+        const double t4 = prod[k + 4], t5 = prod[k + 5], t6 = prod[k + 6], t7 = prod[k + 7];
+        s = s + t0; s = s + t1; s = s + t2; s = s + t3;
+        s = s + t4; s = s + t5; s = s + t6; s = s + t7;
+      }
+      for (; k < ke; ++k) s = s + prod[k];
+      row_epilogue<MODE>(e, r, s, acc);
+    }
+  }
+  constexpr int NQ = ModeNQ<MODE>::value;
+  if (NQ > 0) {
+    block_sum<NQ, TPB>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) e.partials[q * e.stride + b] = acc[q];
+    }
+  }
+}
+
+// CSR "tiled sweep" kernel (SpMV v2) for matrices whose gathered vector is far
+// larger than the 4 MiB per-XCD L2.  Measured on MI355X (tools/gather_probe):
+// a uniformly random 8-byte gather tops out at ~56 G/s over an 80 MB vector but
+// reaches ~190-245 G/s when the window fits L2.
+// Layout: every wave owns up to TW_ROWS consecutive rows and streams ITS
+// nonzeros, pre-sorted on the host by (column tile, row, column) and packed
+// tile-locally as {row_local << tile_shift | col_local} + value, with one
+// offset per (wave, tile).  A workgroup is 8 such waves; all of them process
+// tile t, then meet at a barrier -- the barrier is pacing, not correctness: it
+// keeps the 16 waves of a CU (and, statistically, the CUs of an XCD) inside
+// the same ~1 MiB slice of the gathered vector, which therefore stays in L2.
+// The next tile's entries are prefetched into registers before the barrier.
+// Accumulators live in the wave's private LDS slice; one wave's DS operations
+// execute in order, each row receives its products in ascending column order
+// (tile-major order preserves it) => bit-identical to the sequential CPU
+// loops.  Entries of one row inside a tile are adjacent; the run head adds
+// them left to right via lane shuffles.
+__device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, double xv,
+                                            int tile_shift, int lane) {
+  const bool valid = p != TW_PAD;
+  const unsigned row = valid ? (p >> tile_shift) : 0xFFFFFFFFu;
+  const double prod = v * xv;
+  const unsigned rowp = __shfl_up(row, 1, WAVE);
+  const bool head = valid && (lane == 0 || rowp != row);
+  double s = head ? acc[row] : 0.0;
+  for (int j = 0; j < WAVE; ++j) {
+    const double pj = __shfl_down(prod, j, WAVE);
+    const unsigned rj = __shfl_down(row, j, WAVE);
+    const bool take = head && (lane + j < WAVE) && (rj == row);
+    if (!__any(take)) break;
+    if (take) s = s + pj;
+  }
+  if (head) acc[row] = s;
+}
+
+// Variant for matrices with long same-row runs inside a tile (rows with hundreds
+// of entries): run lengths from two ballots, followers' products handed to the
+// run head through a 64-double LDS scratch per wave and added left to right
+// (same order as above; ~6x cheaper than lane shuffles for a 64-long run).
+__device__ __forceinline__ void tiled_chunk_scratch(double *acc, double *scratch, unsigned p, double v,
+                                                    double xv, int tile_shift, int lane) {
+  const bool valid = p != TW_PAD;
+  const unsigned row = valid ? (p >> tile_shift) : 0xFFFFFFFFu;
+  const double prod = v * xv;
+  const unsigned rowp = __shfl_up(row, 1, WAVE);
+  const bool head = valid && (lane == 0 || rowp != row);
+  const unsigned long long hmask = __ballot(head);
+  const unsigned long long vmask = __ballot(valid);
+  const unsigned long long above = (lane == WAVE - 1) ? 0ull : (hmask >> (lane + 1));
+  const int nvalid = __popcll(vmask);                                   // valid lanes are a prefix
+  const int len = above ? __ffsll((long long)above) : (nvalid - lane);  // run length (heads only)
+  if (__any(head && len > 1)) scratch[lane] = prod;
+  if (head) {
+    double s = acc[row] + prod;
+    int q = 1;
+    for (; q + 4 <= len; q += 4) {
+      const double t0 = scratch[lane + q], t1 = scratch[lane + q + 1];
+      const double t2 = scratch[lane + q + 2], t3 = scratch[lane + q + 3];
+      s = s + t0; s = s + t1; s = s + t2; s = s + t3;
+    }
+    for (; q < len; ++q) s = s + scratch[lane + q];
+    acc[row] = s;
+  }
+}
+
+template <int MODE, bool SCR>
+__global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
+    const int2 *__restrict__ wave_rows, const int *__restrict__ step_ptr,
+    const int *__restrict__ wave_step_off, const int *__restrict__ step_tile,
+    const int *__restrict__ wg_step_off, int nwaves, int tile_shift, int TW_ROWS,
+    const unsigned *__restrict__ pk, const double *__restrict__ tv,
+    const double *__restrict__ xin, EpiArgs e) {
+  constexpr int TW_THREADS = TW_WPB * WAVE;
+  constexpr int U = TW_U;   // 64-entry chunks held in registers per (wave, tile)
+  constexpr int D = 3;      // entry loads run D tiles ahead of the accumulate
+  constexpr int R = D + 1;  // register ring (statically indexed: the tile loop is unrolled R times)
+  extern __shared__ double tw_lds[];  // [TW_WPB][TW_ROWS] accumulators, then red[3][TW_WPB]
+  double(*red)[TW_WPB] = reinterpret_cast<double(*)[TW_WPB]>(tw_lds + TW_WPB * TW_ROWS);
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x / WAVE;
+  double *scratch = tw_lds + TW_WPB * TW_ROWS + 3 * TW_WPB + wid * WAVE;   // SCR only: 64 doubles per wave
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * TW_WPB + wid);
+  const bool live = w < nwaves;
+  double acc3[3] = {0.0, 0.0, 0.0};
+  double *acc = tw_lds + wid * TW_ROWS;
+  int2 rr = make_int2(0, 0);
+  if (live) rr = wave_rows[w];
+  for (int r = lane; r < TW_ROWS; r += WAVE) acc[r] = 0.0;
+  // This workgroup's step list: one step = one column tile, or a slice of a
+  // heavy tile (cells are cut on the host so that no wave has more than
+  // TW_U*64 entries in a step); tiles in which none of the 8 waves has an entry
+  // are skipped.  ntiles below is the number of STEPS of this workgroup.
+  const int ntiles = wg_step_off[blockIdx.x + 1] - wg_step_off[blockIdx.x];
+  const int *stile = step_tile + wg_step_off[blockIdx.x];
+  const int *tp = step_ptr + (live ? wave_step_off[w] : 0);
+  const unsigned cmask = (1u << tile_shift) - 1u;
+
+  unsigned p[R][U];
+  double v[R][U];
+  double xv[U];
+  int ks[R], ke[R], tl[R];
+
+  auto load_set = [&](unsigned(&pp)[U], double(&vv)[U], int kbeg, int kend) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int k = kbeg + i * WAVE + lane;
+      const bool ok = k < kend;
+      pp[i] = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
+      vv[i] = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
+    }
+  };
+
+  // prologue: entries of tiles 0..D-1
+  int kprev = live ? tp[0] : 0;
+#pragma unroll
+  for (int s = 0; s < D; ++s) {
+    ks[s] = kprev;
+    ke[s] = (live && s < ntiles) ? tp[s + 1] : kprev;
+    tl[s] = (s < ntiles) ? stile[s] : 0;
+    kprev = ke[s];
+    load_set(p[s], v[s], ks[s], ke[s]);
+  }
+  ks[D] = ke[D] = kprev;
+  tl[D] = 0;
+#pragma unroll
+  for (int i = 0; i < U; ++i) { p[D][i] = TW_PAD; v[D][i] = 0.0; }
+  int ke_ahead = (live && D < ntiles) ? tp[D + 1] : kprev;  // end of tile D
+
+  for (int t0 = 0; t0 < ntiles; t0 += R) {
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+      const int t = t0 + s;
+      if (t < ntiles) {  // workgroup-uniform
+        const int f = (s + D) % R;       // ring slot being refilled (held tile t-1)
+#ifdef TWD_ONE_TILE   // timing diagnostic, wrong results (tools/variants.sh): every gather hits tile 0
+        const double *xt = xin;
+#else
+        const double *xt = xin + ((size_t)tl[s] << tile_shift);
+#endif
+        // 1. gathers for tile t (entries requested D steps ago).  Issued BEFORE
+        //    the prefetch: a wave's loads return in order, so the L2-latency
+        //    gathers must not queue behind HBM-latency streaming loads.
+        //    (Gathering one tile ahead was measured slower: it widens the L2
+        //    working window of the sweep.)
+#pragma unroll
+#ifdef TWD_NO_GATHER  // timing diagnostic, wrong results: stream + accumulate only
+        for (int i = 0; i < U; ++i) xv[i] = 1.0 + (double)(size_t)xt * 0.0;
+#else
+        for (int i = 0; i < U; ++i) xv[i] = (p[s][i] != TW_PAD) ? xt[p[s][i] & cmask] : 0.0;
+#endif
+        // 2. entry loads for tile t+D
+        ks[f] = ke[(s + D - 1) % R];
+        ke[f] = ke_ahead;
+        tl[f] = (t + D < ntiles) ? stile[t + D] : 0;
+        load_set(p[f], v[f], ks[f], ke[f]);
+        ke_ahead = (live && t + D + 1 < ntiles) ? tp[t + D + 2] : ke_ahead;  // end of tile t+D+1
+        // 3. accumulate tile t
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+          if (ks[s] + i * WAVE < ke[s]) {  // wave-uniform
+            if (SCR) tiled_chunk_scratch(acc, scratch, p[s][i], v[s][i], xv[i], tile_shift, lane);
+            else tiled_chunk(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
+          }
+        }
+        for (int kb = ks[s] + U * WAVE; kb < ke[s]; kb += WAVE) {  // cells beyond the register window
+          const int k = kb + lane;
+          const bool ok = k < ke[s];
+          const unsigned pp = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
+          const double vv = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
+          const double xx = ok ? xt[pp & cmask] : 0.0;
+          if (SCR) tiled_chunk_scratch(acc, scratch, pp, vv, xx, tile_shift, lane);
+          else tiled_chunk(acc, pp, vv, xx, tile_shift, lane);
+        }
+        // 4. pacing barrier: keep the workgroup inside one column tile
+        //    (without it the kernel is 1.7x slower: waves drift apart and the
+        //    gathers stop hitting L2)
+        __syncthreads();
+      }
+    }
+  }
+  const int nrows = rr.y - rr.x;
+  for (int r = lane; r < nrows; r += WAVE) row_epilogue<MODE>(e, rr.x + r, acc[r], acc3);
+  constexpr int NQ = ModeNQ<MODE>::value;
+  if (NQ > 0) {
+    block_sum<NQ, TW_THREADS>(acc3, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) e.partials[q * e.stride + blockIdx.x] = acc3[q];
+    }
+  }
+}
+
+// Rows longer than BLOCK_NNZ: split into LONG_CHUNK pieces, one workgroup
+// each (tree sum inside the chunk), partial per chunk.
+__global__ __launch_bounds__(TPB) void spmv_long_partial_kernel(
+    CsrView A, const double *__restrict__ xin, const int *__restrict__ chunk_row,
+    const int *__restrict__ chunk_off, double *__restrict__ chunk_partial) {
+  __shared__ double red[3][TPB / WAVE];
+  const int c = blockIdx.x;
+  const int r = chunk_row[c];
+  const int kbeg = A.rowptr[r] + chunk_off[c];
+  const int kend = min(kbeg + LONG_CHUNK, A.rowptr[r + 1]);
+  double acc[3] = {0.0, 0.0, 0.0};
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = kbeg + threadIdx.x;
+  for (; k + 3 * TPB < kend; k += 4 * TPB) {
+    const int c0 = __builtin_nontemporal_load(A.col + k);
+    const int c1 = __builtin_nontemporal_load(A.col + k + TPB);
+    const int c2 = __builtin_nontemporal_load(A.col + k + 2 * TPB);
+    const int c3 = __builtin_nontemporal_load(A.col + k + 3 * TPB);
+    const double v0 = __builtin_nontemporal_load(A.val + k);
+    const double v1 = __builtin_nontemporal_load(A.val + k + TPB);
+    const double v2 = __builtin_nontemporal_load(A.val + k + 2 * TPB);
+    const double v3 = __builtin_nontemporal_load(A.val + k + 3 * TPB);
+    s0 += v0 * xin[c0];
+    s1 += v1 * xin[c1];
+    s2 += v2 * xin[c2];
+    s3 += v3 * xin[c3];
+  }
+  for (; k < kend; k += TPB) s0 += A.val[k] * xin[A.col[k]];
+  acc[0] = (s0 + s1) + (s2 + s3);
+  block_sum<1, TPB>(acc, red);
+  if (threadIdx.x == 0) chunk_partial[c] = acc[0];
+}
+
+// One lane per long row: add the chunk partials in order, run the epilogue.
+template <int MODE>
+__global__ __launch_bounds__(TPB) void spmv_long_final_kernel(
+    const int *__restrict__ long_row, const int *__restrict__ long_chunk_ptr,
+    int nlong, const double *__restrict__ chunk_partial, EpiArgs e,
+    int slot_base) {
+  __shared__ double red[3][TPB / WAVE];
+  double acc[3] = {0.0, 0.0, 0.0};
+  const int l = blockIdx.x * TPB + threadIdx.x;
+  if (l < nlong) {
+    double s = 0.0;
+    for (int c = long_chunk_ptr[l]; c < long_chunk_ptr[l + 1]; ++c)
+      s = s + chunk_partial[c];
+    row_epilogue<MODE>(e, long_row[l], s, acc);
+  }
+  constexpr int NQ = ModeNQ<MODE>::value;
+  if (NQ > 0) {
+    block_sum<NQ, TPB>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        e.partials[q * e.stride + slot_base + blockIdx.x] = acc[q];
+    }
+  }
+}
+
+}  // namespace

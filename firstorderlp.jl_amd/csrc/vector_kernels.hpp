@@ -1,0 +1,166 @@
+// vector_kernels.hpp -- part of the single translation unit pdhg_hip.hip (included there, in order).
+// Elementwise PDHG kernels (primal step, xbar, interaction, accept/average) and the final reductions.
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------- elementwise
+
+// K1+K2: x' = proj(x - tau*(Qx + c - A'y)), xbar = x' + theta*(x' - x).
+//   compute_primal_gradient_from_dual_product  saddle_point.jl:1093-1100
+//   next_primal = x .- (step/pw) .* g          pdhg.jl:466-467
+//   projection!                                saddle_point.jl:87-92
+//   xbar                                       pdhg.jl:486-487
+template <bool HAS_Q, bool WRITE_XBAR>
+__device__ __forceinline__ void primal_one(double x, double c, double aty,
+                                           double qx, double lb, double ub,
+                                           double tau, double theta, double &xn,
+                                           double &xb) {
+  const double q = HAS_Q ? qx : 0.0;
+  const double t0 = q + c;
+  const double g = t0 - aty;
+  const double t1 = tau * g;
+  double v = x - t1;
+  v = jl_min(ub, jl_max(lb, v));
+  xn = v;
+  if (WRITE_XBAR) {
+    const double d = v - x;
+    const double t2 = theta * d;
+    xb = v + t2;
+  }
+}
+
+template <bool HAS_Q, bool WRITE_XBAR>
+__global__ __launch_bounds__(TPB) void primal_kernel(
+    int n, const double *__restrict__ x, const double *__restrict__ c,
+    const double *__restrict__ aty, const double *__restrict__ qx,
+    const double *__restrict__ lb, const double *__restrict__ ub, double tau,
+    double theta, double *__restrict__ x_next, double *__restrict__ xbar) {
+  const int npair = n >> 1;
+  const int stride = gridDim.x * TPB;
+  for (int p = blockIdx.x * TPB + threadIdx.x; p < npair; p += stride) {
+    const double2 xv = reinterpret_cast<const double2 *>(x)[p];
+    const double2 cv = reinterpret_cast<const double2 *>(c)[p];
+    const double2 av = reinterpret_cast<const double2 *>(aty)[p];
+    const double2 lv = reinterpret_cast<const double2 *>(lb)[p];
+    const double2 uv = reinterpret_cast<const double2 *>(ub)[p];
+    double2 qv = {0.0, 0.0};
+    if (HAS_Q) qv = reinterpret_cast<const double2 *>(qx)[p];
+    double2 xn, xb;
+    primal_one<HAS_Q, WRITE_XBAR>(xv.x, cv.x, av.x, qv.x, lv.x, uv.x, tau, theta, xn.x, xb.x);
+    primal_one<HAS_Q, WRITE_XBAR>(xv.y, cv.y, av.y, qv.y, lv.y, uv.y, tau, theta, xn.y, xb.y);
+    reinterpret_cast<double2 *>(x_next)[p] = xn;
+    if (WRITE_XBAR) reinterpret_cast<double2 *>(xbar)[p] = xb;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int j = n - 1;
+    double xn, xb;
+    primal_one<HAS_Q, WRITE_XBAR>(x[j], c[j], aty[j], HAS_Q ? qx[j] : 0.0, lb[j], ub[j], tau, theta, xn, xb);
+    x_next[j] = xn;
+    if (WRITE_XBAR) xbar[j] = xb;
+  }
+}
+
+// xbar = x' + theta*(x' - x) on its own (Malitsky-Pock retries, pdhg.jl:590-601)
+__global__ __launch_bounds__(TPB) void xbar_kernel(int n, const double *__restrict__ x,
+                                                   const double *__restrict__ x_next,
+                                                   double theta, double *__restrict__ xbar) {
+  const int stride = gridDim.x * TPB;
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) {
+    const double v = x_next[j];
+    const double d = v - x[j];
+    const double t = theta * d;
+    xbar[j] = v + t;
+  }
+}
+
+// dx = x' - x  (for the QP interaction term 0.5*dx'Q dx, pdhg.jl:536-541)
+__global__ __launch_bounds__(TPB) void diff_kernel(int n, const double *__restrict__ a,
+                                                   const double *__restrict__ b,
+                                                   double *__restrict__ out) {
+  const int stride = gridDim.x * TPB;
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) out[j] = a[j] - b[j];
+}
+
+// Reductions over the replicated n-vectors (row-partitioned form, after the
+// all-reduce delivered A'y'):  dx.(A'y'-A'y), dx^2, (A'y'-A'y)^2.
+__global__ __launch_bounds__(TPB) void interaction_kernel(
+    int n, const double *__restrict__ x, const double *__restrict__ x_next,
+    const double *__restrict__ aty, const double *__restrict__ aty_next,
+    double *__restrict__ partials, int pstride) {
+  __shared__ double red[3][TPB / WAVE];
+  double acc[3] = {0.0, 0.0, 0.0};
+  const int stride = gridDim.x * TPB;
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) {
+    const double dx = x_next[j] - x[j];
+    const double dd = aty_next[j] - aty[j];
+    acc[0] += dx * dd;
+    acc[1] += dx * dx;
+    acc[2] += dd * dd;
+  }
+  block_sum<3, TPB>(acc, red);
+  if (threadIdx.x == 0) {
+    partials[0 * pstride + blockIdx.x] = acc[0];
+    partials[1 * pstride + blockIdx.x] = acc[1];
+    partials[2 * pstride + blockIdx.x] = acc[2];
+  }
+}
+
+// dot(a, b) partials (QP term)
+__global__ __launch_bounds__(TPB) void dot_kernel(int n, const double *__restrict__ a,
+                                                  const double *__restrict__ b,
+                                                  double *__restrict__ partials) {
+  __shared__ double red[3][TPB / WAVE];
+  double acc[3] = {0.0, 0.0, 0.0};
+  const int stride = gridDim.x * TPB;
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) acc[0] += a[j] * b[j];
+  block_sum<1, TPB>(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+// K7: sum_x += w*x', sum_y += w*y'      saddle_point.jl:258-259, 271
+__global__ __launch_bounds__(TPB) void accept_kernel(int n, int m, double w,
+                                                     const double *__restrict__ xs,
+                                                     double *__restrict__ sum_x,
+                                                     const double *__restrict__ ys,
+                                                     double *__restrict__ sum_y) {
+  const int stride = gridDim.x * TPB;
+  const int tid = blockIdx.x * TPB + threadIdx.x;
+  for (int j = tid; j < n; j += stride) {
+    const double t = xs[j] * w;
+    sum_x[j] = sum_x[j] + t;
+  }
+  for (int i = tid; i < m; i += stride) {
+    const double t = ys[i] * w;
+    sum_y[i] = sum_y[i] + t;
+  }
+}
+
+// compute_average: sum / weight (a division, saddle_point.jl:296-301)
+__global__ __launch_bounds__(TPB) void div_kernel(int n, const double *__restrict__ s,
+                                                  double w, double *__restrict__ out) {
+  const int stride = gridDim.x * TPB;
+  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) out[j] = s[j] / w;
+}
+
+// Second-stage, fixed-order sum of the block partials.  One workgroup.
+// spec[q] = {ptr, count}; out[q] = sum(ptr[0..count)).  count==0 -> 0.
+struct FinalSpec {
+  const double *ptr[5];
+  int count[5];
+  double *out;     // 5 doubles (host-mapped or device)
+};
+__global__ __launch_bounds__(FINAL_TPB) void final_reduce_kernel(FinalSpec sp) {
+  __shared__ double red[3][FINAL_TPB / WAVE];
+  for (int q = 0; q < 5; ++q) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    const double *p = sp.ptr[q];
+    const int cnt = sp.count[q];
+    for (int i = threadIdx.x; i < cnt; i += FINAL_TPB) acc[0] += p[i];
+    block_sum<1, FINAL_TPB>(acc, red);
+    if (threadIdx.x == 0) sp.out[q] = acc[0];
+    __syncthreads();
+  }
+}
+
+}  // namespace
