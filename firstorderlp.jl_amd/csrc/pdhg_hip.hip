@@ -74,6 +74,12 @@ struct pdhg_handle {
   double *x_r = nullptr, *y_r = nullptr;          // last restart point
   double *px_avg = nullptr, *py_avg = nullptr;    // materialised average
   double *ev_ax = nullptr, *ev_aty = nullptr;     // A*x (m), A'*y (n) at the evaluated point
+  // The evaluation branch asks for the same products several times per check
+  // (eval_point, then one or more trust-region bounds at the same point): keep
+  // A*x and A'*y of the CURRENT and the AVERAGE point until the state changes.
+  double *ev_cax[2] = {nullptr, nullptr}, *ev_caty[2] = {nullptr, nullptr};
+  uint64_t state_version = 1;                      // bumped by everything that moves x, y, the sums or A
+  uint64_t ev_cversion[2] = {0, 0}, avg_version = 0;
   double *tr_g = nullptr, *tr_dir = nullptr, *tr_thr = nullptr;  // n+m each
   double *ev_partials = nullptr, *ev_out = nullptr, *ev_host = nullptr;
   int ev_grid = 1;
@@ -396,6 +402,7 @@ int pdhg_set_objective_matrix(pdhg_handle *h, int64_t q_nnz, const int64_t *q_co
                               const int64_t *q_rowval, const double *q_nzval, int index_base) {
   int rc = check_handle(h);
   if (rc) return rc;
+  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
   if (h->has_q) { free_csr_dev(h->Q); free_csr_dev(h->Qt); h->has_q = false; }
   bool all_zero = true;
   for (int64_t k = 0; k < q_nnz; ++k) if (q_nzval[k] != 0.0) all_zero = false;
@@ -421,7 +428,8 @@ void pdhg_destroy(pdhg_handle *h) {
                     h->aty, h->aty_next, h->sum_x, h->sum_y, h->qx, h->tmp_n, h->tmp_n2,
                     h->tmp_m, h->pA, h->pAt, h->pQ, h->d_out, h->E, h->Dv, h->c_o, h->b_o, h->lb_o,
                     h->ub_o, h->x_r, h->y_r, h->px_avg, h->py_avg, h->ev_ax, h->ev_aty, h->tr_g,
-                    h->tr_dir, h->tr_thr, h->ev_partials, h->ev_out};
+                    h->tr_dir, h->tr_thr, h->ev_partials, h->ev_out, h->ev_cax[0], h->ev_cax[1],
+                    h->ev_caty[0], h->ev_caty[1]};
   for (double *p : bufs) if (p) (void)hipFree(p);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->ev_host) (void)hipHostFree(h->ev_host);
@@ -466,6 +474,7 @@ int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, doub
 int pdhg_accept(pdhg_handle *h, double avg_weight) {
   int rc = check_handle(h);
   if (rc) return rc;
+  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
   {
     ProfScope ps(h, PDHG_K_ACCEPT);
     hipLaunchKernelGGL(accept_kernel, dim3(h->ew_grid_nm), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m,
@@ -483,6 +492,7 @@ int pdhg_accept(pdhg_handle *h, double avg_weight) {
 int pdhg_add_current_primal_to_average(pdhg_handle *h, double weight) {
   int rc = check_handle(h);
   if (rc) return rc;
+  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
   hipLaunchKernelGGL(accept_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, 0, weight,
                      h->x, h->sum_x, h->y, h->sum_y);
   HIP_TRY(hipGetLastError());
@@ -516,6 +526,7 @@ int pdhg_get_average(pdhg_handle *h, double *x_avg, double *y_avg) {
 int pdhg_reset_average(pdhg_handle *h) {
   int rc = check_handle(h);
   if (rc) return rc;
+  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
   HIP_TRY(hipMemsetAsync(h->sum_x, 0, sizeof(double) * (size_t)std::max<int64_t>(h->n, 1), h->stream));
   HIP_TRY(hipMemsetAsync(h->sum_y, 0, sizeof(double) * (size_t)std::max<int64_t>(h->m, 1), h->stream));
   h->sum_x_count = h->sum_y_count = 0;
@@ -526,6 +537,7 @@ int pdhg_reset_average(pdhg_handle *h) {
 int pdhg_restart_to_average(pdhg_handle *h) {
   int rc = check_handle(h);
   if (rc) return rc;
+  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
   if (h->sum_x_count == 0 || h->sum_y_count == 0) return fail(-1, "average is empty");
   hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->sum_x, h->sum_x_weights, h->x);
   hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, (int)h->m, h->sum_y, h->sum_y_weights, h->y);
@@ -556,6 +568,7 @@ int pdhg_get_trial(pdhg_handle *h, double *x_next, double *y_next, double *aty_n
 int pdhg_set_current(pdhg_handle *h, const double *x, const double *y) {
   int rc = check_handle(h);
   if (rc) return rc;
+  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
   if (x) HIP_TRY(hipMemcpyAsync(h->x, x, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
   if (y) HIP_TRY(hipMemcpyAsync(h->y, y, sizeof(double) * (size_t)h->m, hipMemcpyHostToDevice, h->stream));
   rc = launch_aty_plain(h, h->y, h->aty);
@@ -644,6 +657,7 @@ int pdhg_dist_dual_product_begin(pdhg_handle *h) {
 int pdhg_dist_dual_product_end(pdhg_handle *h) {
   int rc = check_handle(h);
   if (rc) return rc;
+  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
   std::swap(h->aty, h->aty_next);
   return 0;
 }
@@ -659,6 +673,10 @@ static int ev_alloc(pdhg_handle *h) {
   HIP_TRY(hipHostMalloc((void **)&h->ev_host, EV_MAXQ * sizeof(double), hipHostMallocDefault));
   if ((rc = alloc_zero(&h->ev_ax, h->m))) return rc;
   if ((rc = alloc_zero(&h->ev_aty, h->n))) return rc;
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = alloc_zero(&h->ev_cax[k], h->m))) return rc;
+    if ((rc = alloc_zero(&h->ev_caty[k], h->n))) return rc;
+  }
   if ((rc = alloc_zero(&h->px_avg, h->n))) return rc;
   if ((rc = alloc_zero(&h->py_avg, h->m))) return rc;
   if ((rc = alloc_zero(&h->x_r, h->n))) return rc;   // zeros == the initial restart point (pdhg.jl:869)
@@ -683,13 +701,37 @@ static int select_point(pdhg_handle *h, int point, const double **px, const doub
   if (point == PDHG_POINT_RESTART) { *px = h->x_r; *py = h->y_r; return 0; }
   if (point == PDHG_POINT_AVERAGE) {
     if (h->sum_x_count == 0 || h->sum_y_count == 0) return fail(-1, "average is empty");
-    hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->sum_x, h->sum_x_weights, h->px_avg);
-    hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, (int)h->m, h->sum_y, h->sum_y_weights, h->py_avg);
-    HIP_TRY(hipGetLastError());
+    if (h->avg_version != h->state_version) {
+      hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->sum_x, h->sum_x_weights, h->px_avg);
+      hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, (int)h->m, h->sum_y, h->sum_y_weights, h->py_avg);
+      HIP_TRY(hipGetLastError());
+      h->avg_version = h->state_version;
+    }
     *px = h->px_avg; *py = h->py_avg;
     return 0;
   }
   return fail(-1, "unknown point selector");
+}
+
+// A*x and A'*y at a point selected by select_point (cached for CURRENT / AVERAGE).
+static int point_products(pdhg_handle *h, int point, const double *px, const double *py,
+                          const double **ax, const double **aty) {
+  int rc;
+  double *dax = h->ev_ax, *daty = h->ev_aty;
+  const bool cached = point == PDHG_POINT_CURRENT || point == PDHG_POINT_AVERAGE;
+  if (cached) {
+    const int k = point == PDHG_POINT_CURRENT ? 0 : 1;
+    dax = h->ev_cax[k]; daty = h->ev_caty[k];
+    if (h->ev_cversion[k] == h->state_version) { *ax = dax; *aty = daty; return 0; }
+    h->ev_cversion[k] = h->state_version;
+  }
+  EpiArgs e{};
+  e.out = dax;
+  if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, px, e))) return rc;
+  e.out = daty;
+  if ((rc = launch_spmv<MODE_PLAIN>(h, h->At, py, e))) return rc;
+  *ax = dax; *aty = daty;
+  return 0;
 }
 
 int pdhg_set_original_problem(pdhg_handle *h, const double *constraint_rescaling,
@@ -721,15 +763,12 @@ int pdhg_eval_point(pdhg_handle *h, int point, double out[20]) {
   if (!h->has_original) return fail(-1, "pdhg_set_original_problem has not been called");
   const double *px, *py;
   if ((rc = select_point(h, point, &px, &py))) return rc;
-  EpiArgs e{};
-  e.out = h->ev_ax;
-  if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, px, e))) return rc;
-  e.out = h->ev_aty;
-  if ((rc = launch_spmv<MODE_PLAIN>(h, h->At, py, e))) return rc;
+  const double *ax, *aty;
+  if ((rc = point_products(h, point, px, py, &ax, &aty))) return rc;
   hipLaunchKernelGGL(eval_rows_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->m, (int)h->num_eq,
-                     h->ev_ax, py, h->E, h->b_o, h->ev_partials, h->ev_grid);
+                     ax, py, h->E, h->b_o, h->ev_partials, h->ev_grid);
   if ((rc = ev_finish(h, 4, 4, out))) return rc;
-  hipLaunchKernelGGL(eval_cols_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, h->ev_aty, px,
+  hipLaunchKernelGGL(eval_cols_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, aty, px,
                      h->Dv, h->c_o, h->lb_o, h->ub_o, h->ev_partials, h->ev_grid);
   return ev_finish(h, 6, 6, out + 8);
 }
@@ -792,13 +831,10 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
     if ((rc = alloc_zero(&h->tr_thr, total))) return rc;
   }
   const double wp = primal_weight_norm, wd = dual_weight_norm;
-  EpiArgs e{};
-  e.out = h->ev_ax;
-  if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, px, e))) return rc;
-  e.out = h->ev_aty;
-  if ((rc = launch_spmv<MODE_PLAIN>(h, h->At, py, e))) return rc;
+  const double *ax, *aty;
+  if ((rc = point_products(h, point, px, py, &ax, &aty))) return rc;
   hipLaunchKernelGGL(tr_setup_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m,
-                     (int)h->num_eq, px, py, h->ev_aty, h->ev_ax, h->c, h->b, h->lb, h->ub, wp, wd, range,
+                     (int)h->num_eq, px, py, aty, ax, h->c, h->b, h->lb, h->ub, wp, wd, range,
                      h->tr_g, h->tr_dir, h->tr_thr, h->ev_partials, h->ev_grid);
   double r[EV_MAXQ];
   if ((rc = ev_finish(h, 10, 1, r))) return rc;
@@ -925,6 +961,7 @@ int pdhg_rescale(pdhg_handle *h, int l_inf_ruiz_iterations, int l2_norm_rescalin
                  double *constraint_rescaling_out, double *variable_rescaling_out) {
   int rc = check_handle(h);
   if (rc) return rc;
+  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
   if (h->has_q) return fail(-2, "device rescaling supports LPs only");
   if (use_pock_chambolle && !(pock_chambolle_alpha >= 0.0 && pock_chambolle_alpha <= 2.0))
     return fail(-1, "pock_chambolle_alpha must be in [0, 2]");

@@ -107,3 +107,50 @@ def test_device_restart_bookkeeping(gpu_required):
     x, y = eng.get_current()
     assert abs(dx2 - float((x - xa) @ (x - xa))) <= 1e-12 * dx2
     assert abs(dy2 - float((y - ya) @ (y - ya))) <= 1e-12 * dy2
+
+
+def test_cached_point_products_match_recomputation(gpu_required):
+    """pdhg_eval_point / pdhg_trust_region_bound keep A*x and A'*y of the CURRENT
+    and AVERAGE points until the state changes.  Engine `a` uses the cache the
+    way optimize() does; engine `b` is forced to recompute before every call (a
+    value-preserving set_current bumps the state version).  Every output must be
+    bit-identical, across accepts, an average reset and a restart."""
+    p = random_lp(20000, 16000, 8, 17)
+    sp_ = rescale_problem(3, False, 1.0, 0, p)
+    engines = []
+    for _ in range(2):
+        eng = HipPdhgEngine.from_problem(sp_.scaled_qp)
+        DeviceEvaluator(eng, sp_, cached_quadratic_program_info(p))   # uploads the original problem
+        step, pw = H.initial_step_and_weight(sp_.scaled_qp)
+        engines.append((eng, PdhgSolverState(eng, step_size=step, primal_weight=pw)))
+    (a, sa), (b, sb) = engines
+
+    def probe(eng, invalidate):
+        out = []
+        for point in (POINT_AVERAGE, POINT_CURRENT, POINT_AVERAGE):
+            for call in (lambda: eng.eval_point(point),
+                         lambda: eng.trust_region_bound(point, 1.3, 0.7, 0.5, 0),   # both blocks
+                         lambda: eng.trust_region_bound(point, 1.3, 0.7, 2.0, 1),   # primal half (MAX_NORM)
+                         lambda: eng.trust_region_bound(point, 1.3, 0.7, 2.0, 2),   # dual half
+                         lambda: np.array(eng.distance_to_restart(point))):
+                if invalidate:
+                    eng.set_current(None, None)
+                out.append(call())
+        return out
+
+    def both_equal():
+        for u, v in zip(probe(a, False), probe(b, True)):
+            assert np.array_equal(u, v, equal_nan=True)
+
+    for phase in range(4):
+        for _ in range(7):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), sa)
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), sb)
+        both_equal()
+        both_equal()          # a second round right away: everything served from the cache on `a`
+        if phase == 1:
+            a.save_restart_point(); b.save_restart_point()
+            a.reset_average(); b.reset_average()
+        if phase == 2:
+            a.restart_to_average(); b.restart_to_average()
+            a.reset_average(); b.reset_average()
