@@ -718,7 +718,8 @@ static int point_products(pdhg_handle *h, int point, const double *px, const dou
                           const double **ax, const double **aty) {
   int rc;
   double *dax = h->ev_ax, *daty = h->ev_aty;
-  const bool cached = point == PDHG_POINT_CURRENT || point == PDHG_POINT_AVERAGE;
+  static const bool cache_off = getenv("PDHG_NO_EVAL_CACHE") != nullptr;   // debugging aid
+  const bool cached = !cache_off && (point == PDHG_POINT_CURRENT || point == PDHG_POINT_AVERAGE);
   if (cached) {
     const int k = point == PDHG_POINT_CURRENT ? 0 : 1;
     dax = h->ev_cax[k]; daty = h->ev_caty[k];
