@@ -92,6 +92,48 @@ def test_iterates_match_cpu_at_1e10_given_same_decisions(gpu_required, name, m, 
     assert np.abs(ya - yo).max() / max(1.0, np.abs(yo).max()) <= 1e-10
 
 
+@pytest.mark.timeout(600)
+def test_forced_decisions_long_horizon_on_the_tiled_layout(gpu_required):
+    """The same comparison at a size where BOTH mat-vecs use the L2-tiled sweep
+    (600k x 600k, 4.8M nonzeros; gathered vectors of 4.8 MB > one XCD's L2): 150
+    accepted adaptive steps driven by the oracle's scalars.  With identical step
+    sizes every kernel on the path is bit-exact, so the iterates and the average
+    must be bitwise equal, not merely within 1e-10."""
+    from firstorderlp_jl_amd.generators import random_lp
+    p = random_lp(600_000, 600_000, 8, seed=77)
+    eng = HipPdhgEngine.from_problem(p)
+    info = eng.layout_info()
+    assert info["A_tiled_waves"] > 0 and info["At_tiled_waves"] > 0
+    st = H.oracle_from_problem(p)
+    step, pw = H.initial_step_and_weight(p)
+    total, accepted, entry_step = 0, 0, step
+    while accepted < 150:
+        total += 1
+        x_old, y_old, aty_old = st.x, st.y, st.aty
+        raw_o, xn, yn, an = st.trial_step(step, pw, 1.0)
+        raw_g = eng.trial_step(step, pw, 1.0)
+        dx, dy, dd = xn - x_old, yn - y_old, an - aty_old
+        bounds = [np.abs(dx * dd).sum(), (dx * dx).sum(), (dy * dy).sum(), (dd * dd).sum()]
+        for q in range(4):
+            assert abs(raw_g[q] - raw_o[q]) <= 1e-13 * bounds[q] + 1e-300, (total, q)
+        accept, new_step, movement = _adaptive_decisions(raw_o, step, pw, total)
+        assert movement > 0.0
+        if accept:
+            st.step_size = entry_step
+            st.accept(xn, yn, an)
+            eng.accept(entry_step)
+            accepted += 1
+            entry_step = new_step
+            if accepted in (1, 10, 100, 150):
+                x, y = eng.get_current()
+                assert np.array_equal(x, st.x) and np.array_equal(y, st.y), accepted
+        step = new_step
+    assert total > accepted          # the run contains rejected trials too
+    xa, ya = eng.get_average()
+    xo, yo = st.compute_average()
+    assert np.array_equal(xa, xo) and np.array_equal(ya, yo)
+
+
 @pytest.mark.parametrize("name,m,n,nnz,ne", [("afiro_like", 27, 32, 83, 8), ("adlittle_like", 56, 97, 383, 15)])
 def test_free_running_trajectories(gpu_required, name, m, n, nnz, ne):
     """Each side using its OWN scalars: 1e-10 on the first 10 accepted steps with
