@@ -169,6 +169,66 @@ void run(const char *name, const unsigned *pk, const double *tv, const double *x
   printf("%-34s E=%3d lds=%3zuK: %.3f ms  %.1f G gathers/s\n", name, E, lds >> 10, ms, cnt / ms / 1e6);
 }
 
+
+// Stream-load cache policy experiment: packed offsets and values through raw
+// buffer loads with cache-policy bits AUX (gfx940+: bit0 sc0, bit1 nt, bit4 sc1);
+// gathers are plain global loads.  Does any policy reduce the interference of
+// the entry stream with the L2-resident gathers?
+template <int E, int AUX>
+__global__ __launch_bounds__(WPB * WAVE) void sweep_aux(const unsigned *__restrict__ pk, const double *__restrict__ tv,
+                                                        const double *__restrict__ x, double *__restrict__ out,
+                                                        int ntiles, int shift, unsigned pk_bytes, unsigned tv_bytes) {
+  extern __shared__ double lds[];
+  constexpr int C = E / WAVE;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const unsigned w = blockIdx.x * WPB + wid;
+  __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void *)pk, 0, (int)pk_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)tv, 0, (int)tv_bytes, 0x00020000);
+  const unsigned base = w * (unsigned)ntiles * E;
+  const unsigned cmask = (1u << shift) - 1u;
+  double s = 0.0;
+  unsigned p[2][C];
+  double vv[2][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    p[0][c] = __builtin_amdgcn_raw_buffer_load_b32(rp, (int)((base + c * WAVE + lane) * 4u), 0, AUX);
+    vv[0][c] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rv, (int)((base + c * WAVE + lane) * 8u), 0, AUX));
+  }
+  for (int t0 = 0; t0 < ntiles; t0 += 2) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int t = t0 + b;
+      if (t < ntiles) {
+        const double *xt = x + ((size_t)t << shift);
+        double g[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c] = xt[p[b][c] & cmask];
+        if (t + 1 < ntiles) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const unsigned k = base + (unsigned)(t + 1) * E + c * WAVE + lane;
+            p[b ^ 1][c] = __builtin_amdgcn_raw_buffer_load_b32(rp, (int)(k * 4u), 0, AUX);
+            vv[b ^ 1][c] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rv, (int)(k * 8u), 0, AUX));
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) s += g[c] * vv[b][c];
+        __syncthreads();
+      }
+    }
+  }
+  out[(size_t)blockIdx.x * WPB * WAVE + threadIdx.x] = s + lds[0] * 0.0;
+}
+
+template <int E, int AUX>
+void run_aux(const unsigned *pk, const double *tv, const double *x, double *out, int nwaves, int ntiles, int shift, size_t lds) {
+  CK(hipFuncSetAttribute((const void *)sweep_aux<E, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const unsigned pkb = (unsigned)((size_t)nwaves * ntiles * E * 4), tvb = (unsigned)((size_t)nwaves * ntiles * E * 8);
+  float ms = time_it([&] { hipLaunchKernelGGL((sweep_aux<E, AUX>), dim3(nwaves / WPB), dim3(WPB * WAVE), lds, 0, pk, tv, x, out, ntiles, shift, pkb, tvb); });
+  double cnt = (double)nwaves * ntiles * E;
+  printf("stream loads aux=%2d (sc0=%d nt=%d sc1=%d) +vals   E=%3d: %.3f ms  %.1f G gathers/s\n", AUX, AUX & 1, (AUX >> 1) & 1, (AUX >> 4) & 1, E, ms, cnt / ms / 1e6);
+}
+
 int main() {
   setvbuf(stdout, NULL, _IONBF, 0);
   const int shift = 16, ntiles = 153, nwaves = 8192;
@@ -197,6 +257,18 @@ int main() {
   run<2, 128, true, true>("buffer_load barrier +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run<2, 64, true, true>("buffer_load barrier +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run<2, 128, true, true>("buffer_load barrier +vals 4WG/CU", pk, tv, x, out, nwaves, ntiles, shift, L4WG);
+  run_aux<64, 0>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<64, 2>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<64, 1>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<64, 3>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<64, 16>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<64, 17>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<64, 18>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<64, 19>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<128, 0>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<128, 2>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<128, 18>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_aux<128, 19>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run_ring<64, 4, 0>("ring S=4 +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run_ring<64, 3, 0>("ring S=3 +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run_ring<64, 6, 0>("ring S=6 +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
