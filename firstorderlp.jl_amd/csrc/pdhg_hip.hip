@@ -608,8 +608,7 @@ int pdhg_spmv_t(pdhg_handle *h, const double *y, double *out) {
 int pdhg_dist_trial_begin(pdhg_handle *h, double step_size, double primal_weight, double theta) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (h->has_q) return fail(-2, "row-partitioned form supports LPs only");
-  if ((rc = launch_primal(h, step_size / primal_weight, theta, true))) return rc;
+  if ((rc = launch_primal(h, step_size / primal_weight, theta, true))) return rc;   // Q (if any) is replicated
   if ((rc = launch_dual(h, primal_weight * step_size))) return rc;
   if ((rc = launch_aty_plain(h, h->y_next, h->aty_next))) return rc;
   hipLaunchKernelGGL(final_to_slot_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->pA, h->A.slots(), h->aty_next + h->n);
@@ -621,7 +620,6 @@ int pdhg_dist_trial_begin(pdhg_handle *h, double step_size, double primal_weight
 int pdhg_dist_trial_dual_begin(pdhg_handle *h, double step_size, double primal_weight, double theta) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (h->has_q) return fail(-2, "row-partitioned form supports LPs only");
   hipLaunchKernelGGL(xbar_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->x, h->x_next, theta, h->xbar);
   HIP_TRY(hipGetLastError());
   if ((rc = launch_dual(h, primal_weight * step_size))) return rc;
@@ -642,7 +640,9 @@ int pdhg_dist_trial_end(pdhg_handle *h, double out[5]) {
   hipLaunchKernelGGL(interaction_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->x, h->x_next,
                      h->aty, h->aty_next, h->pAt, h->pAt_stride);
   HIP_TRY(hipGetLastError());
-  return finish_scalars(h, h->pAt, h->ew_grid_n, h->pAt_stride, h->aty_next + h->n, 1, 0, out);
+  int qcount = 0;
+  if ((rc = launch_q_interaction(h, &qcount))) return rc;   // 0.5 dx'Q dx on the replicated vectors (QP)
+  return finish_scalars(h, h->pAt, h->ew_grid_n, h->pAt_stride, h->aty_next + h->n, 1, qcount, out);
 }
 
 // A'y recompute in two halves: local partial into the exchange buffer

@@ -40,7 +40,9 @@ def partition_rows(constraint_matrix, world_size):
 def shard_rows(problem, lo, hi):
     """The arguments of a local engine for rows [lo, hi) of ``problem``."""
     A = problem.constraint_matrix.tocsr()[lo:hi, :]
+    Q = getattr(problem, "objective_matrix", None)
     return dict(
+        objective_matrix=Q if (Q is not None and Q.nnz > 0) else None,   # replicated on every rank
         constraint_matrix=as_csc(A),
         objective_vector=problem.objective_vector,
         right_hand_side=problem.right_hand_side[lo:hi],

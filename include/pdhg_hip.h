@@ -131,6 +131,8 @@ int pdhg_spmv_t(pdhg_handle *h, const double *y, double *out);
  *   (caller all-reduces(sum) the n+1 doubles at pdhg_dist_exchange_ptr over
  *    RCCL, e.g. torch.distributed.all_reduce on the same stream)
  *   end   : reductions on the replicated n-vectors; out[] as pdhg_trial_step.
+ * QPs: the objective matrix is replicated on every rank (pdhg_set_objective_matrix
+ * on each handle); Q x and 0.5 dx'Q dx are computed on the replicated vectors.
  * No reference counterpart (the reference is single-process).
  */
 int pdhg_dist_trial_begin(pdhg_handle *h, double step_size,

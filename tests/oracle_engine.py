@@ -16,9 +16,11 @@ class OracleEngine:
         A = constraint_matrix
         self.m, self.n = A.shape
         self._A = A
+        self._Q = None
         q = (None, None, None)
         if objective_matrix is not None and objective_matrix.nnz > 0:
             Q = objective_matrix
+            self._Q = Q
             q = (Q.indptr, Q.indices, Q.data)
         self.st = orc.OracleState(self.m, self.n, A.indptr, A.indices, A.data,
                                   objective_vector, right_hand_side,
@@ -121,8 +123,9 @@ class OracleEngine:
         an = self._exchange[:self.n].copy()
         dx = xn - self.st.x
         dd = an - self.st.aty
+        qterm = 0.5 * float(dx @ (self._Q @ dx)) if self._Q is not None else 0.0
         raw = np.array([float(dx @ dd), float(dx @ dx), float(self._exchange[self.n]),
-                        float(dd @ dd), 0.0])
+                        float(dd @ dd), qterm])
         self._trial = (xn, yn, an)
         return raw
 

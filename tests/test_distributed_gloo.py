@@ -260,3 +260,76 @@ def test_malitsky_pock_row_partitioned_matches_unsharded_oracle():
         assert rinfo[0] == ref.average_info()[0]
         for got, want in ((rx, x), (ry, y), (rxa, xa), (rya, ya)):
             np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-11)
+
+
+# ---- QP (objective matrix replicated on every rank) in the row-partitioned form ----
+
+def _qp_problem():
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd.generators import random_lp
+    p = random_lp(300, 200, 5, seed=23)
+    rng = np.random.default_rng(4)
+    B = sp.random(200, 200, density=0.02, random_state=5, format="csc")
+    p.objective_matrix = sp.csc_matrix(B.T @ B + sp.diags(rng.uniform(0.0, 1.0, 200)))
+    return p
+
+
+def _qp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import folp_loader
+    folp_loader.load()
+    import torch.distributed as dist
+    from firstorderlp_jl_amd.distributed import (RowPartitionedEngine, TorchComm,
+                                                 partition_rows, shard_rows)
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
+        AdaptiveStepsizeParams, PdhgSolverState, take_step)
+    from tests.oracle_engine import OracleEngine
+    from tests import helpers as H
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = _qp_problem()
+        ranges = partition_rows(p.constraint_matrix, world)
+        lo, hi = ranges[rank]
+        eng = RowPartitionedEngine(OracleEngine(**shard_rows(p, lo, hi)), TorchComm(), ranges)
+        step, pw = H.initial_step_and_weight(p)
+        state = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+        for _ in range(40):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), state)
+        x, y = eng.get_current()
+        q.put((rank, x, y, state.step_size, state.total_number_iterations))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_qp_row_partitioned_matches_unsharded_oracle():
+    sys.path.insert(0, ROOT)
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
+        AdaptiveStepsizeParams, PdhgSolverState, take_step)
+    from tests.oracle_engine import OracleEngine
+    from tests import helpers as H
+    world = 2
+    port = 25500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_qp_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    p = _qp_problem()
+    ref = OracleEngine.from_problem(p)
+    step, pw = H.initial_step_and_weight(p)
+    state = PdhgSolverState(ref, step_size=step, primal_weight=pw)
+    for _ in range(40):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), state)
+    x, y = ref.get_current()
+    for (rank, rx, ry, rstep, rtot) in results:
+        assert rtot == state.total_number_iterations
+        assert abs(rstep - state.step_size) <= 1e-12 * state.step_size
+        np.testing.assert_allclose(rx, x, rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(ry, y, rtol=1e-11, atol=1e-11)

@@ -60,7 +60,7 @@ def test_unsupported_and_misordered_calls(gpu_required):
     with pytest.raises(_lib.PdhgHipError, match="range"):
         eng.trust_region_bound(_lib.POINT_CURRENT, 1.0, 1.0, 1.0, 7)
     qp = HipPdhgEngine.from_problem(H.example_qp())
-    for call in (lambda: qp.dist_trial_begin(0.1, 1.0), lambda: qp.rescale(1, False, None),
+    for call in (lambda: qp.rescale(1, False, None),
                  lambda: qp.trust_region_bound(_lib.POINT_CURRENT, 1.0, 1.0, 1.0, 0)):
         with pytest.raises(_lib.PdhgHipError, match="LP"):
             call()

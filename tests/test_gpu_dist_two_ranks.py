@@ -121,3 +121,71 @@ def test_two_hip_shards_on_one_gpu_match_single_engine(gpu_required):
     assert abs(r0[12] - ms.step_size) <= 1e-9 * ms.step_size
     np.testing.assert_allclose(r0[9], xms, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(r0[10], yms, rtol=1e-9, atol=1e-9)
+
+
+# ---- QP: the objective matrix is replicated, 0.5 dx'Q dx joins the step scalars ----
+
+def _qp_problem():
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd.generators import random_lp
+    p = random_lp(6000, 5000, 6, seed=31)
+    B = sp.random(5000, 5000, density=0.001, random_state=6, format="csc")
+    p.objective_matrix = sp.csc_matrix(B.T @ B + sp.diags(np.random.default_rng(8).uniform(0.0, 1.0, 5000)))
+    return p
+
+
+def _qp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import folp_loader
+    folp_loader.load()
+    import torch.distributed as dist
+    from firstorderlp_jl_amd.distributed import make_row_partitioned_hip_engine
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
+        AdaptiveStepsizeParams, PdhgSolverState, take_step)
+    from tests import helpers as H
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = _qp_problem()
+        eng = make_row_partitioned_hip_engine(p, device_id=0)
+        step, pw = H.initial_step_and_weight(p)
+        state = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+        for _ in range(40):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), state)
+        x, y = eng.get_current()
+        q.put((rank, x, y, state.step_size, state.total_number_iterations))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_hip_shards_qp_match_single_engine(gpu_required):
+    from firstorderlp_jl_amd import HipPdhgEngine
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
+        AdaptiveStepsizeParams, PdhgSolverState, take_step)
+    from tests import helpers as H
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_qp_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = sorted((q.get(timeout=500) for _ in range(world)), key=lambda r: r[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    p = _qp_problem()
+    seng = HipPdhgEngine.from_problem(p)
+    step, pw = H.initial_step_and_weight(p)
+    ss = PdhgSolverState(seng, step_size=step, primal_weight=pw)
+    for _ in range(40):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), ss)
+    xs, ys = seng.get_current()
+    r0, r1 = results
+    assert np.array_equal(r0[1], r1[1]) and np.array_equal(r0[2], r1[2])
+    assert r0[4] == r1[4] == ss.total_number_iterations
+    assert abs(r0[3] - ss.step_size) <= 1e-9 * ss.step_size
+    np.testing.assert_allclose(r0[1], xs, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(r0[2], ys, rtol=1e-9, atol=1e-9)
