@@ -26,7 +26,8 @@ EXPORTS = [
     "pdhg_add_current_primal_to_average", "pdhg_get_average_info",
     "pdhg_get_average", "pdhg_reset_average", "pdhg_restart_to_average",
     "pdhg_get_current", "pdhg_set_current", "pdhg_get_trial", "pdhg_spmv",
-    "pdhg_spmv_t", "pdhg_dist_trial_begin", "pdhg_dist_trial_end", "pdhg_dist_trial_dual_begin",
+    "pdhg_spmv_t", "pdhg_dist_trial_begin", "pdhg_dist_trial_end", "pdhg_dist_trial_dual_begin", "pdhg_dist_parts",
+    "pdhg_dist_trial_begin_part", "pdhg_dist_trial_dual_begin_part",
     "pdhg_dist_exchange_ptr", "pdhg_dist_dual_product_begin",
     "pdhg_dist_dual_product_end", "pdhg_profile_enable", "pdhg_profile_read",
     "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info", "pdhg_measure_triad",
@@ -112,6 +113,12 @@ def lib():
     L.pdhg_spmv_t.argtypes = [_vp, _dp, _dp]
     L.pdhg_dist_trial_begin.restype = i32
     L.pdhg_dist_trial_begin.argtypes = [_vp, d, d, d]
+    L.pdhg_dist_parts.restype = i32
+    L.pdhg_dist_parts.argtypes = [_vp, i32, _ip]
+    L.pdhg_dist_trial_begin_part.restype = i32
+    L.pdhg_dist_trial_begin_part.argtypes = [_vp, d, d, d, i32, i32]
+    L.pdhg_dist_trial_dual_begin_part.restype = i32
+    L.pdhg_dist_trial_dual_begin_part.argtypes = [_vp, d, d, d, i32, i32]
     L.pdhg_measure_triad.restype = i32
     L.pdhg_measure_triad.argtypes = [_vp, i64, i32, _dp]
     L.pdhg_dist_trial_dual_begin.restype = i32

@@ -29,6 +29,7 @@ struct CsrDev {
   bool tw_scratch = false;        // long same-row runs: use the LDS-scratch chunk variant
   unsigned *pk = nullptr;
   double *tv = nullptr;
+  std::vector<int> wg_first_row;  // host copy: first row of every tiled workgroup (+ rows), for partial launches
   int slots() const { return grid + long_grid; }
   CsrView view() const { return CsrView{rows, rowptr, col, val}; }
 };
@@ -151,6 +152,9 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
     const bool forced = mode_env && !strcmp(mode_env, "tiled");
     if (!forced && max_run > 32) return 0;
   }
+  D.wg_first_row.resize((size_t)grid + 1);
+  for (int g = 0; g < grid; ++g) D.wg_first_row[g] = wave_rows[(size_t)g * TW_WPB].x;
+  D.wg_first_row[grid] = rows;
   D.tiled = true;
   D.tile_shift = tile_shift;
   D.ntiles = ntiles;

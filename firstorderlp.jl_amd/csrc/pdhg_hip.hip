@@ -90,6 +90,7 @@ struct pdhg_handle {
   int64_t prof_count[PDHG_K_COUNT] = {0};
   double prof_ms[PDHG_K_COUNT] = {0};
   bool dist_pending = false;
+  std::vector<int> dist_part_wg;   // workgroup boundaries of the parts handed out by pdhg_dist_parts
 };
 
 namespace {
@@ -152,6 +153,42 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
                        D.view(), xin, D.chunk_row, D.chunk_off, D.chunk_partial);
     hipLaunchKernelGGL(spmv_long_final_kernel<MODE>, dim3(D.long_grid), dim3(TPB), 0, h->stream,
                        D.long_row, D.long_chunk_ptr, D.nlong, D.chunk_partial, e, D.grid);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// MODE_PLAIN product restricted to the tiled workgroups [g0, g1) (their rows are a
+// contiguous range of the output); `with_long` also runs the long-row path.
+// The kernel is the one launch_spmv uses: the per-wave / per-workgroup tables
+// are simply passed from offset g0 (row numbers and entry offsets are absolute).
+int launch_spmv_plain_part(pdhg_handle *h, const CsrDev &D, const double *xin, double *out,
+                           int g0, int g1, bool with_long) {
+  if (!D.tiled) return fail(-1, "partial launch needs the tiled layout");
+  EpiArgs e{};
+  e.out = out;
+  if (with_long && D.nlong > 0) {
+    hipLaunchKernelGGL(spmv_long_partial_kernel, dim3(D.nchunks), dim3(TPB), 0, h->stream,
+                       D.view(), xin, D.chunk_row, D.chunk_off, D.chunk_partial);
+    hipLaunchKernelGGL(spmv_long_final_kernel<MODE_PLAIN>, dim3(D.long_grid), dim3(TPB), 0, h->stream,
+                       D.long_row, D.long_chunk_ptr, D.nlong, D.chunk_partial, e, D.grid);
+  }
+  if (g1 > g0) {
+    const size_t lds = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_scratch ? TW_WPB * WAVE : 0));
+    const int w0 = g0 * TW_WPB;
+    if (D.tw_scratch) {
+      HIP_TRY(hipFuncSetAttribute((const void *)spmv_tiled_kernel<MODE_PLAIN, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, true>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
+                         D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
+                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
+    } else {
+      HIP_TRY(hipFuncSetAttribute((const void *)spmv_tiled_kernel<MODE_PLAIN, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, false>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
+                         D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
+                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
+    }
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -628,6 +665,72 @@ int pdhg_dist_trial_dual_begin(pdhg_handle *h, double step_size, double primal_w
   HIP_TRY(hipGetLastError());
   h->dist_pending = true;
   return 0;
+}
+
+// ---- the same trial in parts, so that the caller can all-reduce finished column
+// ranges of the exchange buffer while later ones are still being computed --------
+
+int pdhg_dist_parts(pdhg_handle *h, int max_parts, int64_t *bounds) {
+  int rc = check_handle(h);
+  if (rc) return rc < 0 ? rc : -rc;
+  if (max_parts < 1 || !bounds) return fail(-1, "max_parts < 1 or bounds == NULL");
+  const CsrDev &D = h->At;
+  // A part is a whole number of residency rounds (256 CUs x 2 workgroups): a
+  // smaller launch would leave CUs idle and cost more than the overlap buys.
+  const char *rw = getenv("PDHG_DIST_ROUND_WGS");   // tests use a finer granule on small problems
+  const int round_wgs = rw ? std::max(1, atoi(rw)) : 256 * 2;
+  const int rounds = D.tiled ? D.grid / round_wgs : 0;
+  const int parts = std::max(1, std::min(max_parts, rounds));
+  h->dist_part_wg.assign((size_t)parts + 1, 0);
+  for (int k = 0; k <= parts; ++k) {
+    const int g = (k == parts) ? D.grid : round_wgs * (int)(((int64_t)rounds * k) / parts);
+    h->dist_part_wg[k] = D.tiled ? g : 0;
+    bounds[k] = (k == 0) ? 0 : (k == parts ? h->n : (int64_t)D.wg_first_row[g]);
+  }
+  h->dist_part_wg[parts] = D.tiled ? D.grid : 0;
+  return parts;
+}
+
+static int dist_part_common(pdhg_handle *h, int part, int nparts) {
+  if (nparts != (int)h->dist_part_wg.size() - 1) return fail(-1, "nparts does not match pdhg_dist_parts");
+  if (part < 0 || part >= nparts) return fail(-1, "part out of range");
+  int rc;
+  if (nparts == 1) {
+    if ((rc = launch_aty_plain(h, h->y_next, h->aty_next))) return rc;
+  } else {
+    ProfScope ps(h, PDHG_K_SPMV_ATY);
+    if ((rc = launch_spmv_plain_part(h, h->At, h->y_next, h->aty_next, h->dist_part_wg[part],
+                                     h->dist_part_wg[part + 1], part == 0))) return rc;
+  }
+  if (part == nparts - 1) {
+    hipLaunchKernelGGL(final_to_slot_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->pA, h->A.slots(), h->aty_next + h->n);
+    HIP_TRY(hipGetLastError());
+    h->dist_pending = true;
+  }
+  return 0;
+}
+
+int pdhg_dist_trial_begin_part(pdhg_handle *h, double step_size, double primal_weight, double theta,
+                               int part, int nparts) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (part == 0) {
+    if ((rc = launch_primal(h, step_size / primal_weight, theta, true))) return rc;
+    if ((rc = launch_dual(h, primal_weight * step_size))) return rc;
+  }
+  return dist_part_common(h, part, nparts);
+}
+
+int pdhg_dist_trial_dual_begin_part(pdhg_handle *h, double step_size, double primal_weight, double theta,
+                                    int part, int nparts) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (part == 0) {
+    hipLaunchKernelGGL(xbar_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->x, h->x_next, theta, h->xbar);
+    HIP_TRY(hipGetLastError());
+    if ((rc = launch_dual(h, primal_weight * step_size))) return rc;
+  }
+  return dist_part_common(h, part, nparts);
 }
 
 void *pdhg_dist_exchange_ptr(pdhg_handle *h) { return h ? (void *)h->aty_next : nullptr; }

@@ -15,6 +15,8 @@ Every rank ends with bitwise-identical A'y' (the all-reduce delivers one
 result to all ranks) and therefore takes identical accept/reject decisions.
 The reference has no counterpart (single process, single thread).
 """
+import os
+
 import numpy as np
 
 from .quadratic_programming import as_csc
@@ -65,6 +67,14 @@ class TorchComm:
 
     def all_reduce_sum(self, tensor):
         self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def all_reduce_sum_async(self, tensor):
+        """Start the all-reduce and return its work handle: with RCCL the collective
+        is ordered after what the current stream has queued so far and runs on the
+        communicator's stream, so kernels launched next overlap it; ``wait()`` orders
+        the current stream after it."""
+        return self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group,
+                                    async_op=True)
 
     def all_reduce_host(self, arr):
         """Sum a float64 numpy vector over ranks (evaluation cadence only)."""
@@ -121,11 +131,38 @@ class RowPartitionedEngine:
         self.n = local.n
         self.m = self.row_ranges[-1][1]
         assert local.m == self.hi - self.lo
+        self._bounds = None
 
     # ---- hot path ----
+    def _parts(self):
+        """Column ranges of the exchange buffer (pdhg_dist_parts), asked once."""
+        if self._bounds is None:
+            want = int(os.environ.get("PDHG_DIST_PARTS", "4"))
+            useful = self.comm.world_size > 1 or "PDHG_DIST_PARTS" in os.environ   # nothing to overlap alone
+            self._bounds = self.local.dist_parts(want) if (want > 1 and useful) else [0, self.n]
+        return self._bounds
+
+    def _exchange_in_parts(self, begin_part, step_size, primal_weight, theta):
+        """Part k's columns are all-reduced while part k+1 is still being computed
+        (A_p'y'_p is produced range by range); one collective per part, the last
+        one also carries slot [n]."""
+        bounds = self._parts()
+        nparts = len(bounds) - 1
+        works = []
+        for k in range(nparts):
+            begin_part(step_size, primal_weight, theta, k, nparts)
+            t = self.local.exchange_tensor()
+            hi = bounds[k + 1] + (1 if k == nparts - 1 else 0)
+            works.append(self.comm.all_reduce_sum_async(t[bounds[k]:hi]))
+        for w in works:
+            w.wait()
+
     def trial_step(self, step_size, primal_weight, theta=1.0):
-        self.local.dist_trial_begin(step_size, primal_weight, theta)
-        self.comm.all_reduce_sum(self.local.exchange_tensor())
+        if len(self._parts()) > 2:
+            self._exchange_in_parts(self.local.dist_trial_begin_part, step_size, primal_weight, theta)
+        else:
+            self.local.dist_trial_begin(step_size, primal_weight, theta)
+            self.comm.all_reduce_sum(self.local.exchange_tensor())
         return self.local.dist_trial_end()
 
     def accept(self, avg_weight):
@@ -137,8 +174,11 @@ class RowPartitionedEngine:
         self.local.trial_primal(step_size, primal_weight)
 
     def trial_dual(self, step_size, primal_weight, theta):
-        self.local.dist_trial_dual_begin(step_size, primal_weight, theta)
-        self.comm.all_reduce_sum(self.local.exchange_tensor())
+        if len(self._parts()) > 2:
+            self._exchange_in_parts(self.local.dist_trial_dual_begin_part, step_size, primal_weight, theta)
+        else:
+            self.local.dist_trial_dual_begin(step_size, primal_weight, theta)
+            self.comm.all_reduce_sum(self.local.exchange_tensor())
         return self.local.dist_trial_end()
 
     def add_current_primal_to_average(self, weight):

@@ -234,6 +234,22 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_dist_trial_dual_begin(self._h, step_size,
                                                       primal_weight, theta))
 
+    def dist_parts(self, max_parts):
+        """Column ranges in which the partial A_p'y'_p can be produced and exchanged."""
+        bounds = np.zeros(int(max_parts) + 1, dtype=np.int64)
+        parts = self._L.pdhg_dist_parts(self._h, int(max_parts), _pi(bounds))
+        if parts < 1:
+            _lib.check(parts if parts else -1)
+        return [int(b) for b in bounds[:parts + 1]]
+
+    def dist_trial_begin_part(self, step_size, primal_weight, theta, part, nparts):
+        _lib.check(self._L.pdhg_dist_trial_begin_part(self._h, step_size, primal_weight,
+                                                      theta, int(part), int(nparts)))
+
+    def dist_trial_dual_begin_part(self, step_size, primal_weight, theta, part, nparts):
+        _lib.check(self._L.pdhg_dist_trial_dual_begin_part(self._h, step_size, primal_weight,
+                                                           theta, int(part), int(nparts)))
+
     def dist_trial_end(self):
         out = np.empty(5)
         _lib.check(self._L.pdhg_dist_trial_end(self._h, _pd(out)))

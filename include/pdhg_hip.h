@@ -147,6 +147,23 @@ int pdhg_dist_trial_end(pdhg_handle *h, double out[5]);
  */
 int pdhg_dist_trial_dual_begin(pdhg_handle *h, double step_size,
                                double primal_weight, double theta);
+/*
+ * The same two calls in PARTS, to overlap the exchange with the product that
+ * feeds it.  pdhg_dist_parts cuts the n columns of A_p' y'_p into at most
+ * max_parts contiguous ranges aligned to the tiled layout's workgroups and
+ * returns how many (1 when the layout cannot be cut); bounds[0..parts] are the
+ * range limits (bounds[0] = 0, bounds[parts] = n).  Part 0 also runs x', xb and
+ * y'_p; after part k returns (launches are asynchronous), columns
+ * [bounds[k], bounds[k+1]) of the exchange buffer are final on the stream -- the
+ * last part also fills slot [n] -- and the caller may start all-reducing that
+ * range while the next part computes.  pdhg_dist_trial_end follows the last
+ * all-reduce as before.
+ */
+int pdhg_dist_parts(pdhg_handle *h, int max_parts, int64_t *bounds);
+int pdhg_dist_trial_begin_part(pdhg_handle *h, double step_size, double primal_weight,
+                               double theta, int part, int nparts);
+int pdhg_dist_trial_dual_begin_part(pdhg_handle *h, double step_size, double primal_weight,
+                                    double theta, int part, int nparts);
 /* Device pointer to the current exchange buffer (n+1 doubles). */
 void *pdhg_dist_exchange_ptr(pdhg_handle *h);
 /* Same split for A'y recompute after set_current/restart: partial then finish. */

@@ -108,6 +108,20 @@ class OracleEngine:
         self._exchange[self.n] = raw[2]       # local sum dy_p^2
         self._dist_pending = (xn, yn)
 
+    # part-wise variants: the oracle produces everything in part 0 (the point of the
+    # parts is overlap on the GPU); the host logic still exchanges range by range.
+    def dist_parts(self, max_parts):
+        k = max(1, min(int(max_parts), self.n))
+        return [int(round(self.n * i / k)) for i in range(k + 1)]
+
+    def dist_trial_begin_part(self, step_size, primal_weight, theta, part, nparts):
+        if part == 0:
+            self.dist_trial_begin(step_size, primal_weight, theta)
+
+    def dist_trial_dual_begin_part(self, step_size, primal_weight, theta, part, nparts):
+        if part == 0:
+            self.dist_trial_dual_begin(step_size, primal_weight, theta)
+
     def dist_trial_dual_begin(self, step_size, primal_weight, theta):
         raw, xn, yn, an = self.st.trial_dual(step_size, primal_weight, theta)
         self._exchange[:self.n] = an

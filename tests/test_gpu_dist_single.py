@@ -10,7 +10,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_row_partitioned_engine_world1_matches_single_engine(gpu_required):
+@pytest.mark.parametrize("parts", ["1", "4"])
+def test_row_partitioned_engine_world1_matches_single_engine(gpu_required, parts, monkeypatch):
+    # parts=4: the exchange is issued range by range with async RCCL all-reduces
+    # (pdhg_dist_trial_begin_part), overlapping the partial products of A_p'y'_p
+    monkeypatch.setenv("PDHG_DIST_PARTS", parts)
+    monkeypatch.setenv("PDHG_DIST_ROUND_WGS", "64")   # parts are whole residency rounds (512 WGs) by default
     import torch
     import torch.distributed as dist
     from firstorderlp_jl_amd import HipPdhgEngine
@@ -20,16 +25,18 @@ def test_row_partitioned_engine_world1_matches_single_engine(gpu_required):
         AdaptiveStepsizeParams, PdhgSolverState, take_step)
     from tests import helpers as H
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29700 + 2 * (os.getpid() % 200) + (parts == "4"))
     created = False
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1,
                                 device_id=torch.device("cuda", 0))
         created = True
     try:
-        p = random_lp(20000, 15000, 8, seed=9)
+        p = random_lp(700000, 600000, 6, seed=9) if parts == "4" else random_lp(20000, 15000, 8, seed=9)
         deng = make_row_partitioned_hip_engine(p, device_id=0)
+        if parts == "4":   # large enough for the tiled layout, which is what can be cut into parts
+            assert len(deng._parts()) == 5
         seng = HipPdhgEngine.from_problem(p)
         step, pw = H.initial_step_and_weight(p)
         ds = PdhgSolverState(deng, step_size=step, primal_weight=pw)

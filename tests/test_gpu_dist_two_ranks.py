@@ -15,7 +15,8 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-M, N, NNZ_PER_ROW, SEED, STEPS, MP_STEPS = 30000, 24000, 8, 21, 60, 25
+# large enough that each rank's A_p' (600k x 600k) uses the tiled layout, so the exchange runs in 4 parts
+M, N, NNZ_PER_ROW, SEED, STEPS, MP_STEPS = 1_200_000, 600_000, 5, 21, 60, 25
 
 
 def MP_PARAMS():
@@ -36,10 +37,12 @@ def _worker(rank, world, port, q):
     from tests import helpers as H
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["PDHG_DIST_ROUND_WGS"] = "64"     # default granule is a residency round of 512 workgroups
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = random_lp(M, N, NNZ_PER_ROW, seed=SEED)
         eng = make_row_partitioned_hip_engine(p, device_id=0)
+        assert len(eng._parts()) == 5, eng._parts()      # 4 column ranges, exchanged while the next is computed
         step, pw = H.initial_step_and_weight(p)
         state = PdhgSolverState(eng, step_size=step, primal_weight=pw)
         decisions = []
