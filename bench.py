@@ -68,6 +68,12 @@ def parse():
 
 def main():
     args = parse()
+    # Native libraries print to stdout too (RCCL's version banner on communicator
+    # creation, for one).  The contract is ONE JSON line on rank 0's stdout: send
+    # file descriptor 1 to stderr until that line is written.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import folp_loader
@@ -276,7 +282,10 @@ def main():
             out["speedup_vs_cpu_port"] = round(value / cpu_baseline["value"], 1)
         if cpu_socket and "value" in cpu_socket:
             out["speedup_vs_cpu_socket"] = round(value / cpu_socket["value"], 1)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
 
