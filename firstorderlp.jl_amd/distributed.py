@@ -76,6 +76,14 @@ class TorchComm:
         return self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group,
                                     async_op=True)
 
+    def all_reduce_min_host(self, arr):
+        """Element-wise minimum of a small int64 numpy vector over ranks (set-up only)."""
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return t.cpu().numpy()
+
     def all_reduce_host(self, arr):
         """Sum a float64 numpy vector over ranks (evaluation cadence only)."""
         import torch
@@ -135,11 +143,24 @@ class RowPartitionedEngine:
 
     # ---- hot path ----
     def _parts(self):
-        """Column ranges of the exchange buffer (pdhg_dist_parts), asked once."""
+        """Column ranges of the exchange buffer, agreed by all ranks once.  Every
+        rank cuts its own A_p' by ITS workgroups (pdhg_dist_parts), so the local
+        limits differ from rank to rank; a range may be exchanged once every rank
+        has finished it, hence the element-wise minimum of the limits -- and no
+        cutting at all unless every rank can cut into the same number of parts."""
         if self._bounds is None:
             want = int(os.environ.get("PDHG_DIST_PARTS", "4"))
             useful = self.comm.world_size > 1 or "PDHG_DIST_PARTS" in os.environ   # nothing to overlap alone
-            self._bounds = self.local.dist_parts(want) if (want > 1 and useful) else [0, self.n]
+            local = list(self.local.dist_parts(want)) if (want > 1 and useful) else [0, self.n]
+            k = len(local) - 1
+            kmin, neg_kmax = self.comm.all_reduce_min_host(np.array([k, -k]))
+            if kmin != -neg_kmax or kmin < 2:
+                if k > 1:
+                    self.local.dist_parts(1)         # the library launches what it handed out last
+                self._bounds = [0, self.n]
+            else:
+                agreed = self.comm.all_reduce_min_host(np.array(local))
+                self._bounds = [0] + [int(b) for b in agreed[1:-1]] + [self.n]
         return self._bounds
 
     def _exchange_in_parts(self, begin_part, step_size, primal_weight, theta):
