@@ -94,22 +94,28 @@ __global__ __launch_bounds__(TPB) void eval_rows_kernel(int m, int ne, const dou
 
 // Column side (LP): g = c_o - D .* (A_s' y_s), reduced costs, bound violations,
 // and the homogeneous (c = 0) dual statistics for the infeasibility certificate.
-// sums: 0 sum resid^2, 1 sum bound*rc, 2 sum x_o^2, 3 c_o.x_o, 4 sum bound-viol^2, 5 sum bound*rc_h
-// maxs: 0 max|resid|, 1 max|x_o|, 2 max bound viol, 3 max|resid_h|, 4 max|rc_h|, 5 max ray bound viol
+// sums: 0 sum resid^2, 1 sum bound*rc, 2 sum x_o^2, 3 c_o.x_o, 4 sum bound-viol^2, 5 sum bound*rc_h,
+//       6 x_o.(Q_o x_o)
+// maxs: 0 max|resid|, 1 max|x_o|, 2 max bound viol, 3 max|resid_h|, 4 max|rc_h|, 5 max ray bound viol,
+//       6 max|Q_o x_o|
+// qx_s = Q_s x_s on the scaled point (NULL for an LP); Q_o x_o = D .* (Q_s x_s) because Q_s = D^-1 Q_o D^-1.
 __global__ __launch_bounds__(TPB) void eval_cols_kernel(int n, const double *__restrict__ aty_s,
+                                                        const double *__restrict__ qx_s,
                                                         const double *__restrict__ px, const double *__restrict__ D,
                                                         const double *__restrict__ c_o, const double *__restrict__ lb_o,
                                                         const double *__restrict__ ub_o, double *__restrict__ partials,
                                                         int stride) {
-  RedAcc<6, 6> a;
+  RedAcc<7, 7> a;
   for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += gridDim.x * TPB) {
     const double d = D[j];
     const double aty = d * aty_s[j];
     const double xo = px[j] / d;
+    const double qxo = qx_s ? d * qx_s[j] : 0.0;
     const double lb = lb_o[j], ub = ub_o[j];
     const bool lbf = isfinite(lb), ubf = isfinite(ub);
     // compute_reduced_costs_from_primal_gradient        iteration_stats_utils.jl:128-148
-    const double g = c_o[j] - aty;
+    // primal gradient Q x + c - A'y                        saddle_point.jl:1093-1100
+    const double g = qx_s ? (qxo + c_o[j]) - aty : c_o[j] - aty;
     const double rc = ((g > 0.0) ? lbf : ubf) ? g : 0.0;
     const double resid = g - rc;
     const double contrib = (rc == 0.0) ? 0.0 : ((rc > 0.0 ? lb : ub) * rc);
@@ -120,11 +126,12 @@ __global__ __launch_bounds__(TPB) void eval_cols_kernel(int n, const double *__r
     const double lv = fmax(lb - xo, 0.0), uv = fmax(xo - ub, 0.0);
     const double rayv = fmax(lbf ? fmax(-xo, 0.0) : 0.0, ubf ? fmax(xo, 0.0) : 0.0);
     a.s[0] += resid * resid; a.s[1] += contrib; a.s[2] += xo * xo; a.s[3] += c_o[j] * xo;
-    a.s[4] += lv * lv + uv * uv; a.s[5] += contribh;
+    a.s[4] += lv * lv + uv * uv; a.s[5] += contribh; a.s[6] += xo * qxo;
+    a.m[6] = fmax(a.m[6], fabs(qxo));
     a.m[0] = fmax(a.m[0], fabs(resid)); a.m[1] = fmax(a.m[1], fabs(xo)); a.m[2] = fmax(a.m[2], fmax(lv, uv));
     a.m[3] = fmax(a.m[3], fabs(residh)); a.m[4] = fmax(a.m[4], fabs(rch)); a.m[5] = fmax(a.m[5], rayv);
   }
-  block_reduce_store<6, 6>(a, partials, stride);
+  block_reduce_store<7, 7>(a, partials, stride);
 }
 
 // sum (a-b)^2 over two vector pairs: distances to the last restart point
@@ -145,24 +152,28 @@ __global__ __launch_bounds__(TPB) void dist2_kernel(int n, int m, const double *
 // d = -g/w (0 if the bound blocks it), breakpoint thr (trust_region_utils.jl:86-110).
 // range: 0 both blocks (EUCLIDEAN_NORM), 1 primal only, 2 dual only (MAX_NORM halves).
 // sums: 0 c.x, 1 x.(A'y), 2 y.b, 3 sum_{thr=inf} w d^2, 4 sum g^2 (in range),
-//       5 sum w d^2 (in range), 6 sum g.d primal, 7 sum g.d dual, 8 sum x^2, 9 sum y^2
+//       5 sum w d^2 (in range), 6 sum g.d primal, 7 sum g.d dual, 8 sum x^2, 9 sum y^2, 10 x.(Q x)
 // maxs: 0 max finite thr (in range)
+// qx_s = Q x at the point (NULL for an LP): the primal gradient is Q x + c - A'y.
 __global__ __launch_bounds__(TPB) void tr_setup_kernel(int n, int m, int ne, const double *__restrict__ px,
                                                        const double *__restrict__ py, const double *__restrict__ aty_s,
+                                                       const double *__restrict__ qx_s,
                                                        const double *__restrict__ ax_s, const double *__restrict__ c_s,
                                                        const double *__restrict__ b_s, const double *__restrict__ lb_s,
                                                        const double *__restrict__ ub_s, double wp, double wd, int range,
                                                        double *__restrict__ gvec, double *__restrict__ dir,
                                                        double *__restrict__ thr, double *__restrict__ partials,
                                                        int stride) {
-  RedAcc<10, 1> a;
+  RedAcc<11, 1> a;
   const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
   for (int k = tid; k < n + m; k += st) {
     const bool primal = k < n;
     const int i = primal ? k : k - n;
     double z, g, lo, hi, w;
     if (primal) {
-      z = px[i]; g = c_s[i] - aty_s[i]; lo = lb_s[i]; hi = ub_s[i]; w = wp;
+      z = px[i]; lo = lb_s[i]; hi = ub_s[i]; w = wp;
+      if (qx_s) { g = (qx_s[i] + c_s[i]) - aty_s[i]; a.s[10] += z * qx_s[i]; }
+      else g = c_s[i] - aty_s[i];
       a.s[0] += c_s[i] * z; a.s[1] += z * aty_s[i]; a.s[8] += z * z;
     } else {
       z = py[i]; g = -(b_s[i] - ax_s[i]); lo = (i < ne) ? -INFINITY : 0.0; hi = INFINITY; w = wd;
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(TPB) void tr_setup_kernel(int n, int m, int ne, con
       if (isinf(t)) a.s[3] += w * d * d; else a.m[0] = fmax(a.m[0], t);
     }
   }
-  block_reduce_store<10, 1>(a, partials, stride);
+  block_reduce_store<11, 1>(a, partials, stride);
 }
 
 // radius^2 as a function of the step t at K probe values:

@@ -78,6 +78,7 @@ struct pdhg_handle {
   // (eval_point, then one or more trust-region bounds at the same point): keep
   // A*x and A'*y of the CURRENT and the AVERAGE point until the state changes.
   double *ev_cax[2] = {nullptr, nullptr}, *ev_caty[2] = {nullptr, nullptr};
+  double *ev_cqx[2] = {nullptr, nullptr}, *ev_qx = nullptr;   // Q*x at those points (QP only)
   uint64_t state_version = 1;                      // bumped by everything that moves x, y, the sums or A
   uint64_t ev_cversion[2] = {0, 0}, avg_version = 0;
   double *tr_g = nullptr, *tr_dir = nullptr, *tr_thr = nullptr;  // n+m each
@@ -466,7 +467,7 @@ void pdhg_destroy(pdhg_handle *h) {
                     h->tmp_m, h->pA, h->pAt, h->pQ, h->d_out, h->E, h->Dv, h->c_o, h->b_o, h->lb_o,
                     h->ub_o, h->x_r, h->y_r, h->px_avg, h->py_avg, h->ev_ax, h->ev_aty, h->tr_g,
                     h->tr_dir, h->tr_thr, h->ev_partials, h->ev_out, h->ev_cax[0], h->ev_cax[1],
-                    h->ev_caty[0], h->ev_caty[1]};
+                    h->ev_caty[0], h->ev_caty[1], h->ev_cqx[0], h->ev_cqx[1], h->ev_qx};
   for (double *p : bufs) if (p) (void)hipFree(p);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->ev_host) (void)hipHostFree(h->ev_host);
@@ -816,25 +817,38 @@ static int select_point(pdhg_handle *h, int point, const double **px, const doub
   return fail(-1, "unknown point selector");
 }
 
-// A*x and A'*y at a point selected by select_point (cached for CURRENT / AVERAGE).
+// A*x, A'*y and (QP) Q*x at a point selected by select_point (cached for CURRENT / AVERAGE).
 static int point_products(pdhg_handle *h, int point, const double *px, const double *py,
-                          const double **ax, const double **aty) {
+                          const double **ax, const double **aty, const double **qx) {
   int rc;
   double *dax = h->ev_ax, *daty = h->ev_aty;
+  double **dqx = &h->ev_qx;
   static const bool cache_off = getenv("PDHG_NO_EVAL_CACHE") != nullptr;   // debugging aid
   const bool cached = !cache_off && (point == PDHG_POINT_CURRENT || point == PDHG_POINT_AVERAGE);
+  bool fresh = true;
   if (cached) {
     const int k = point == PDHG_POINT_CURRENT ? 0 : 1;
-    dax = h->ev_cax[k]; daty = h->ev_caty[k];
-    if (h->ev_cversion[k] == h->state_version) { *ax = dax; *aty = daty; return 0; }
+    dax = h->ev_cax[k]; daty = h->ev_caty[k]; dqx = &h->ev_cqx[k];
+    fresh = h->ev_cversion[k] != h->state_version;
     h->ev_cversion[k] = h->state_version;
   }
-  EpiArgs e{};
-  e.out = dax;
-  if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, px, e))) return rc;
-  e.out = daty;
-  if ((rc = launch_spmv<MODE_PLAIN>(h, h->At, py, e))) return rc;
+  if (h->has_q && !*dqx) {
+    if ((rc = alloc_zero(dqx, h->n))) return rc;
+    fresh = true;
+  }
+  if (fresh) {
+    EpiArgs e{};
+    e.out = dax;
+    if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, px, e))) return rc;
+    e.out = daty;
+    if ((rc = launch_spmv<MODE_PLAIN>(h, h->At, py, e))) return rc;
+    if (h->has_q) {
+      e.out = *dqx;
+      if ((rc = launch_spmv<MODE_PLAIN>(h, h->Q, px, e))) return rc;
+    }
+  }
   *ax = dax; *aty = daty;
+  *qx = h->has_q ? *dqx : nullptr;
   return 0;
 }
 
@@ -843,7 +857,6 @@ int pdhg_set_original_problem(pdhg_handle *h, const double *constraint_rescaling
                               const double *lb_o, const double *ub_o) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (h->has_q) return fail(-2, "device evaluation supports LPs only");
   if (!constraint_rescaling || !variable_rescaling || !c_o || !lb_o || !ub_o || (h->m > 0 && !b_o))
     return fail(-1, "null input array");
   auto up = [&](double **dst, const double *src, int64_t len) -> int {
@@ -861,20 +874,24 @@ int pdhg_set_original_problem(pdhg_handle *h, const double *constraint_rescaling
   return ev_alloc(h);
 }
 
-int pdhg_eval_point(pdhg_handle *h, int point, double out[20]) {
+int pdhg_eval_point(pdhg_handle *h, int point, double out[24]) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!h->has_original) return fail(-1, "pdhg_set_original_problem has not been called");
   const double *px, *py;
   if ((rc = select_point(h, point, &px, &py))) return rc;
-  const double *ax, *aty;
-  if ((rc = point_products(h, point, px, py, &ax, &aty))) return rc;
+  const double *ax, *aty, *qx;
+  if ((rc = point_products(h, point, px, py, &ax, &aty, &qx))) return rc;
   hipLaunchKernelGGL(eval_rows_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->m, (int)h->num_eq,
                      ax, py, h->E, h->b_o, h->ev_partials, h->ev_grid);
   if ((rc = ev_finish(h, 4, 4, out))) return rc;
-  hipLaunchKernelGGL(eval_cols_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, aty, px,
+  hipLaunchKernelGGL(eval_cols_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, aty, qx, px,
                      h->Dv, h->c_o, h->lb_o, h->ub_o, h->ev_partials, h->ev_grid);
-  return ev_finish(h, 6, 6, out + 8);
+  double r[14];
+  if ((rc = ev_finish(h, 7, 7, r))) return rc;
+  for (int q = 0; q < 6; ++q) { out[8 + q] = r[q]; out[14 + q] = r[7 + q]; }
+  out[20] = r[6]; out[21] = r[13]; out[22] = out[23] = 0.0;
+  return 0;
 }
 
 int pdhg_save_restart_point(pdhg_handle *h) {
@@ -924,7 +941,6 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
                             double radius, int range, int approximate, double out[8]) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (h->has_q) return fail(-2, "device trust region supports LPs only");
   if (range < 0 || range > 2) return fail(-1, "range must be 0, 1 or 2");
   const double *px, *py;
   if ((rc = select_point(h, point, &px, &py))) return rc;
@@ -935,19 +951,19 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
     if ((rc = alloc_zero(&h->tr_thr, total))) return rc;
   }
   const double wp = primal_weight_norm, wd = dual_weight_norm;
-  const double *ax, *aty;
-  if ((rc = point_products(h, point, px, py, &ax, &aty))) return rc;
+  const double *ax, *aty, *qx;
+  if ((rc = point_products(h, point, px, py, &ax, &aty, &qx))) return rc;
   hipLaunchKernelGGL(tr_setup_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m,
-                     (int)h->num_eq, px, py, aty, ax, h->c, h->b, h->lb, h->ub, wp, wd, range,
+                     (int)h->num_eq, px, py, aty, qx, ax, h->c, h->b, h->lb, h->ub, wp, wd, range,
                      h->tr_g, h->tr_dir, h->tr_thr, h->ev_partials, h->ev_grid);
   double r[EV_MAXQ];
-  if ((rc = ev_finish(h, 10, 1, r))) return rc;
+  if ((rc = ev_finish(h, 11, 1, r))) return rc;
   // compute_lagrangian_value (saddle_point.jl:1109-1120) without objective_constant
-  out[0] = r[0] - r[1] + r[2];
+  out[0] = 0.5 * r[10] + r[0] - r[1] + r[2];
   out[1] = out[2] = 0.0;
   out[3] = r[8]; out[4] = r[9];
   out[5] = 0.0; out[6] = 0.0; out[7] = 0.0;
-  const double hinf = r[3], g2 = r[4], wd2_all = r[5], tmax = r[10];
+  const double hinf = r[3], g2 = r[4], wd2_all = r[5], tmax = r[11];
   const double r2 = radius * radius;
   if (approximate) {
     // approximately_solve_bound_constrained_trust_region (trust_region_utils.jl:194-224)

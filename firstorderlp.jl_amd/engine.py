@@ -189,7 +189,7 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_set_original_problem(self._h, *[_pd(a) for a in arrs]))
 
     def eval_point(self, point):
-        out = np.empty(20)
+        out = np.empty(24)
         _lib.check(self._L.pdhg_eval_point(self._h, point, _pd(out)))
         return out
 

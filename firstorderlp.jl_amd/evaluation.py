@@ -107,12 +107,14 @@ class DeviceEvaluator:
         from the device's raw sums/maxes (include/pdhg_hip.h, pdhg_eval_point)."""
         r = self.engine.eval_point(point)
         (S0, S1, S2, S3, M0, M1, M2, M3,
-         T0, T1, T2, T3, T4, T5, N0, N1, N2, N3, N4, N5) = [float(v) for v in r]
+         T0, T1, T2, T3, T4, T5, N0, N1, N2, N3, N4, N5) = [float(v) for v in r[:20]]
+        xqx, max_qx = float(r[20]), float(r[21])        # x'Qx and |Qx|_inf (0 for an LP)
         qp = self.qp_cache
         eps_ratio = _div(termination_criteria.eps_optimal_absolute,
                          termination_criteria.eps_optimal_relative)
         ci = ConvergenceInformation()
-        ci.primal_objective = self.objective_constant_original + T3
+        # primal_obj: c'x + 0.5 x'Qx + constant                    iteration_stats_utils.jl:66-75
+        ci.primal_objective = self.objective_constant_original + T3 + 0.5 * xqx
         ci.l_inf_primal_residual = max(M0, N2)
         ci.l2_primal_residual = math.sqrt(S0 + T4)
         ci.relative_l_inf_primal_residual = _div(ci.l_inf_primal_residual,
@@ -121,7 +123,8 @@ class DeviceEvaluator:
                                               eps_ratio + qp.l2_norm_primal_right_hand_side)
         ci.l_inf_primal_variable = N1
         ci.l2_primal_variable = math.sqrt(T2)
-        ci.dual_objective = S2 + self.objective_constant_original + T1
+        # base dual objective b'y + constant - 0.5 x'Qx, plus bound*rc   iteration_stats_utils.jl:180-196
+        ci.dual_objective = (S2 + self.objective_constant_original - 0.5 * xqx) + T1
         ci.l_inf_dual_residual = max(M3, N0)
         ci.l2_dual_residual = math.sqrt(S3 + T0)
         ci.relative_l_inf_dual_residual = _div(ci.l_inf_dual_residual,
@@ -140,7 +143,7 @@ class DeviceEvaluator:
         s = N1 if N1 != 0.0 else 1.0                    # primal ray scaled to unit inf-norm
         ii.max_primal_ray_infeasibility = max(M1, N5) / s
         ii.primal_ray_linear_objective = T3 / s
-        ii.primal_ray_quadratic_norm = 0.0              # LP
+        ii.primal_ray_quadratic_norm = max_qx / s       # |Q ray|_inf     iteration_stats_utils.jl:316-317
         scaling_factor = max(M2, N4)
         if scaling_factor != 0.0:
             ii.max_dual_ray_infeasibility = max(M3, N3) / scaling_factor

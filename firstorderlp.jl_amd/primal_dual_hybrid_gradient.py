@@ -364,7 +364,7 @@ def optimize(params, original_problem, engine_factory=None):
     start_time = _time.time()
     time_spent_doing_basic_algorithm = 0.0
 
-    if is_lp and getattr(engine, "supports_device_evaluation", False):
+    if getattr(engine, "supports_device_evaluation", False):
         ev = DeviceEvaluator(engine, scaled_problem, qp_cache)
     else:
         ev = HostEvaluator(engine, scaled_problem, qp_cache, ops, original_ops)

@@ -195,9 +195,10 @@ int pdhg_set_original_problem(pdhg_handle *h, const double *constraint_rescaling
  *        out[12] sum bound-violation^2   out[13] sum bound*rc (c=0)
  *        out[14] max|g-rc|   out[15] max|x_o|   out[16] max bound violation
  *        out[17] max|g-rc| (c=0)  out[18] max|rc| (c=0)  out[19] max ray bound violation
- * with g = c_o - A_o'y_o and rc the reduced costs (iteration_stats_utils.jl:128-148).
+ *        out[20] x_o.(Q_o x_o)   out[21] max|Q_o x_o|   (both 0 for an LP; out[22..23] reserved)
+ * with g = Q_o x_o + c_o - A_o'y_o and rc the reduced costs (iteration_stats_utils.jl:128-148).
  */
-int pdhg_eval_point(pdhg_handle *h, int point, double out[20]);
+int pdhg_eval_point(pdhg_handle *h, int point, double out[24]);
 
 /* last_restart_info.{primal,dual}_solution .= current (saddle_point.jl:921-922). */
 int pdhg_save_restart_point(pdhg_handle *h);

@@ -44,11 +44,20 @@ def _close(a, b, rel=1e-9, scale=1.0):
         assert abs(a - b) <= rel * max(abs(a), abs(b), scale), (a, b)
 
 
+def _random_qp():
+    import scipy.sparse as sp
+    p = random_lp(2500, 3000, 7, 19)
+    B = sp.random(3000, 3000, density=0.002, random_state=2, format="csc")
+    p.objective_matrix = sp.csc_matrix(B.T @ B + sp.diags(np.random.default_rng(3).uniform(0.0, 2.0, 3000)))
+    return p
+
+
 @pytest.mark.parametrize("maker", [lambda: random_lp(3000, 4000, 8, 3),
+                                   _random_qp,
                                    lambda: H.skewed_lp(2500, 6000, 5),
                                    lambda: pagerank_lp(20000, seed=2),
                                    lambda: H.example_lp()],
-                         ids=["random", "skewed_freevars", "pagerank", "example_lp"])
+                         ids=["random", "random_qp", "skewed_freevars", "pagerank", "example_lp"])
 def test_device_evaluation_matches_host(gpu_required, maker):
     eng, ev_h, ev_d, st = _setup(maker())
     tc = construct_termination_criteria()
