@@ -356,7 +356,7 @@ int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
 extern "C" {
 
 const char *pdhg_last_error(void) { return g_last_error.c_str(); }
-int pdhg_abi_version(void) { return 3; }
+int pdhg_abi_version(void) { return 4; }
 
 const char *pdhg_kernel_name(int kernel_id) {
   switch (kernel_id) {
