@@ -1070,6 +1070,14 @@ static int apply_scaling(pdhg_handle *h, double *ev, double *dv, double *inv_e, 
                          D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves, D.tile_shift,
                          D.pk, D.tv, inv_e, inv_d, t);
   }
+  if (h->has_q) {
+    // objective_matrix = (D^-1 Q) D^-1 (preprocess.jl:562-564); Qt holds Q' entry by entry, so the
+    // "transposed" order reproduces the same two roundings on it
+    hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Q.rows)), dim3(TPB), 0, h->stream, h->Q.rows, h->Q.rowptr,
+                       h->Q.col, h->Q.val, inv_d, inv_d, 0);
+    hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Qt.rows)), dim3(TPB), 0, h->stream, h->Qt.rows, h->Qt.rowptr,
+                       h->Qt.col, h->Qt.val, inv_d, inv_d, 1);
+  }
   hipLaunchKernelGGL(resc_apply_vectors_kernel, dim3(h->ew_grid_nm), dim3(TPB), 0, h->stream, n, m, dv, ev,
                      h->c, h->lb, h->ub, h->b, cum_d, cum_e);
   HIP_TRY(hipGetLastError());
@@ -1082,7 +1090,6 @@ int pdhg_rescale(pdhg_handle *h, int l_inf_ruiz_iterations, int l2_norm_rescalin
   int rc = check_handle(h);
   if (rc) return rc;
   h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
-  if (h->has_q) return fail(-2, "device rescaling supports LPs only");
   if (use_pock_chambolle && !(pock_chambolle_alpha >= 0.0 && pock_chambolle_alpha <= 2.0))
     return fail(-1, "pock_chambolle_alpha must be in [0, 2]");
   const int n = (int)h->n, m = (int)h->m;
@@ -1099,6 +1106,10 @@ int pdhg_rescale(pdhg_handle *h, int l_inf_ruiz_iterations, int l2_norm_rescalin
   for (int it = 0; it < l_inf_ruiz_iterations; ++it) {
     hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, Atv, m, 0.0, (const double *)nullptr, dv);
     hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, Av, n, 0.0, (const double *)nullptr, ev);
+    if (h->has_q) {   // QP: column max over the constraint AND the objective matrix (preprocess.jl:425-433)
+      hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->Qt.view(), n, 0.0, (const double *)nullptr, tmp_d);
+      hipLaunchKernelGGL(resc_max_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv, tmp_d);
+    }
     hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv);
     hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, ev);
     RS(apply_scaling(h, ev, dv, inv_e, inv_d, cum_e, cum_d));

@@ -127,6 +127,11 @@ __global__ __launch_bounds__(TPB) void resc_apply_vectors_kernel(int n, int m, c
     b[i] = b[i] / e; cum_e[i] = cum_e[i] * e;
   }
 }
+// a = max(a, b): column max over [A; Q] for the QP Ruiz step (preprocess.jl:425-433)
+__global__ __launch_bounds__(TPB) void resc_max_kernel(int n, double *__restrict__ a, const double *__restrict__ b) {
+  for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) a[i] = fmax(a[i], b[i]);
+}
+
 __global__ __launch_bounds__(TPB) void fill_kernel(int n, double v, double *__restrict__ out) {
   for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) out[i] = v;
 }

@@ -156,7 +156,7 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_spmv_t(self._h, _pd(y), _pd(out)))
         return out
 
-    # ---- rescaling on the device (LP only) ------------------------------------------
+    # ---- rescaling on the device --------------------------------------------------
     supports_device_rescaling = True
 
     def rescale(self, l_inf_ruiz_iterations, l2_norm_rescaling, pock_chambolle_alpha):
@@ -181,7 +181,7 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_matrix_max_abs(self._h, _pd(out)))
         return float(out[0])
 
-    # ---- evaluation branch on the device (LP only) ---------------------------------
+    # ---- evaluation branch on the device -------------------------------------------
     supports_device_evaluation = True
 
     def set_original_problem(self, constraint_rescaling, variable_rescaling, c_o, b_o, lb_o, ub_o):

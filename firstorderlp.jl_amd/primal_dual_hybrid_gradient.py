@@ -295,9 +295,10 @@ def optimize(params, original_problem, engine_factory=None):
         raise ValueError("primal_importance must be positive and finite")
     is_lp_original = is_linear_programming_problem(original_problem)
     engine = None
-    if engine_factory is None and is_lp_original and os.environ.get("PDHG_HOST_RESCALE", "0") != "1":
-        # Product path for LPs: upload the ORIGINAL problem and rescale on the
-        # device (pdhg_rescale); only the n-/m-length vectors come back.
+    if engine_factory is None and os.environ.get("PDHG_HOST_RESCALE", "0") != "1":
+        # Product path: upload the ORIGINAL problem and rescale on the device
+        # (pdhg_rescale); only the n-/m-length vectors come back.  The scaled
+        # constraint (and objective) matrix lives on the device only.
         from .quadratic_programming import QuadraticProgrammingProblem, ScaledQpProblem
         import scipy.sparse as _sp
         engine = _default_engine_factory(original_problem)
@@ -327,7 +328,7 @@ def optimize(params, original_problem, engine_factory=None):
         engine = (engine_factory or _default_engine_factory)(problem)
     ops = EngineOps(engine, problem)
     original_ops = UnscaledEngineOps(engine, scaled_problem)
-    is_lp = is_linear_programming_problem(problem)
+    is_lp = is_lp_original       # (the host copy of a device-rescaled problem carries no matrices)
     solver_state = PdhgSolverState(engine)   # zeros(...) state, pdhg.jl:805-819
     policy = params.step_size_policy_params
 

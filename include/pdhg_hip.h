@@ -174,7 +174,8 @@ int pdhg_dist_dual_product_end(pdhg_handle *h);
  * ---- evaluation branch on the device ("next" row N1) -----------------------
  * Everything optimize()'s evaluation/restart branch (pdhg.jl:892-1023) needs,
  * reduced to scalars on the device so that only scalars cross the boundary.
- * LP only (a QP keeps the host-side evaluation).
+ * LPs and QPs (for a QP the objective matrix set by pdhg_set_objective_matrix
+ * contributes Q x to the gradient and 0.5 x'Qx to the objectives).
  */
 enum { PDHG_POINT_CURRENT = 0, PDHG_POINT_AVERAGE = 1, PDHG_POINT_RESTART = 2 };
 
@@ -233,7 +234,9 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
  * of the matrix is scaled entry by entry as (a * (1/e_i)) * (1/d_j), and c, b,
  * lb, ub as scale_problem does (:555-573).  Outputs the cumulative
  * constraint_rescaling[m] / variable_rescaling[n] (ScaledQpProblem,
- * src/quadratic_programming.jl:293-298).  LP only.
+ * src/quadratic_programming.jl:293-298).  With an objective matrix the Ruiz
+ * column factors take the max over the columns of [A; Q] (:425-433) and both
+ * resident copies of Q become (D^-1 Q) D^-1 (:562-564).
  */
 int pdhg_rescale(pdhg_handle *h, int l_inf_ruiz_iterations, int l2_norm_rescaling,
                  int use_pock_chambolle, double pock_chambolle_alpha,

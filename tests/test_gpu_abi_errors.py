@@ -59,9 +59,8 @@ def test_unsupported_and_misordered_calls(gpu_required):
         eng.dist_trial_end()
     with pytest.raises(_lib.PdhgHipError, match="range"):
         eng.trust_region_bound(_lib.POINT_CURRENT, 1.0, 1.0, 1.0, 7)
-    qp = HipPdhgEngine.from_problem(H.example_qp())
-    with pytest.raises(_lib.PdhgHipError, match="LP"):      # device rescaling is the one LP-only entry point
-        qp.rescale(1, False, None)
+    with pytest.raises(_lib.PdhgHipError, match="alpha"):
+        eng.rescale(0, False, 2.5)
     # the engine is still usable after errors
     raw = eng.trial_step(0.1, 1.0, 1.0)
     assert np.all(np.isfinite(raw))

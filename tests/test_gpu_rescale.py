@@ -66,3 +66,41 @@ def test_device_rescale_tiled_layout(gpu_required, monkeypatch):
     x, y = rng.standard_normal(eng.n), rng.standard_normal(eng.m)
     assert np.array_equal(eng.spmv(x), ref.spmv(x))
     assert np.array_equal(eng.spmv_t(y), ref.spmv_t(y))
+
+
+@pytest.mark.parametrize("ruiz,l2,alpha", [(10, False, None), (4, False, 1.0), (0, True, None)])
+def test_device_rescale_qp(gpu_required, ruiz, l2, alpha):
+    """QP: the Ruiz column factors take the max over [A; Q] columns and the
+    objective matrix is scaled to (D^-1 Q) D^-1 on the device (preprocess.jl:425-433,
+    562-564).  Checked through the scaling vectors and through a trial step, whose
+    primal update multiplies by the resident Q."""
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd.generators import random_lp
+    p = random_lp(1500, 1200, 6, seed=13)
+    B = sp.random(1200, 1200, density=0.004, random_state=9, format="csc")
+    p.objective_matrix = sp.csc_matrix(5.0 * (B.T @ B) + sp.diags(np.random.default_rng(1).uniform(0.0, 3.0, 1200)))
+    host = rescale_problem(ruiz, l2, alpha, 0, p)
+    eng = HipPdhgEngine.from_problem(p)
+    E, D = eng.rescale(ruiz, l2, alpha)
+    exact = not l2 and alpha is None
+    def close(a, w):
+        if exact:
+            assert np.array_equal(a, w)
+        else:
+            np.testing.assert_allclose(a, w, rtol=1e-12, atol=0)
+    close(E, host.constraint_rescaling)
+    close(D, host.variable_rescaling)
+    ref = HipPdhgEngine.from_problem(host.scaled_qp)
+    rng = np.random.default_rng(2)
+    x0, y0 = np.abs(rng.standard_normal(eng.n)), rng.standard_normal(eng.m)
+    for e in (eng, ref):
+        e.set_current(x0, y0)
+    ra, rb = eng.trial_step(0.05, 1.3), ref.trial_step(0.05, 1.3)
+    ta, tb = eng.get_trial(), ref.get_trial()
+    if exact:
+        assert np.array_equal(ra, rb)
+        assert all(np.array_equal(u, v) for u, v in zip(ta, tb))
+    else:
+        np.testing.assert_allclose(ra, rb, rtol=1e-9)
+        for u, v in zip(ta, tb):
+            np.testing.assert_allclose(u, v, rtol=1e-10, atol=1e-12)
