@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -387,10 +388,17 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   if (dev >= ndev) return fail(-1, "device_id out of range");
   HIP_TRY(hipSetDevice(dev));
 
+  const bool verbose = getenv("PDHG_VERBOSE") != nullptr;   // phase timings of the set-up on stderr
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
+  const auto t_start = now();
   std::vector<int> t_rowptr, t_col, rowptr, col;
   std::vector<double> t_val, val;
   int rc = csc_to_both(m, n, nnz, colptr, rowval, nzval, index_base, t_rowptr, t_col, t_val, rowptr, col, val);
   if (rc) return rc;
+  const auto t_conv = now();
 
   pdhg_handle *h = new pdhg_handle();
   h->device = dev;
@@ -405,7 +413,12 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   }
 #define CK(expr) do { int _rc = (expr); if (_rc) { pdhg_destroy(h); return _rc; } } while (0)
   CK(build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, choose_tile_shift(n, nnz, m)));
+  const auto t_a = now();
   CK(build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, choose_tile_shift(m, nnz, n)));
+  const auto t_at = now();
+  if (verbose)
+    fprintf(stderr, "pdhg_create: CSC -> CSR(A), CSR(A') %.2fs; layouts + upload A %.2fs, A' %.2fs\n",
+            secs(t_start, t_conv), secs(t_conv, t_a), secs(t_a, t_at));
   auto up = [&](double **dst, const double *src, int64_t len) -> int {
     int r2 = alloc_zero(dst, len);
     if (r2) return r2;
