@@ -120,27 +120,32 @@ struct ProfScope {
   }
 };
 
+// The opt-in for > 64 KiB of dynamic LDS is per device and per kernel instance,
+// and must only ever grow: another handle on the same device may need more than
+// this one (hipFuncSetAttribute sets the limit, it does not raise it).
+int ensure_lds_limit(pdhg_handle *h, int mode, bool scratch, size_t lds, const void *func) {
+  static size_t limit[64][3][2] = {};
+  size_t &cur = limit[h->device & 63][mode][scratch ? 1 : 0];
+  if (cur < lds) {
+    HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    cur = lds;
+  }
+  return 0;
+}
+
 template <int MODE>
 int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
   if (D.tiled) {
     if (D.grid > 0) {
       const size_t lds = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_scratch ? TW_WPB * WAVE : 0));
-      static size_t attr_set[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+      int rc;
       if (D.tw_scratch) {
-        if (attr_set[MODE][1] < lds) {
-          HIP_TRY(hipFuncSetAttribute((const void *)spmv_tiled_kernel<MODE, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          attr_set[MODE][1] = lds;
-        }
+        if ((rc = ensure_lds_limit(h, MODE, true, lds, (const void *)spmv_tiled_kernel<MODE, true>))) return rc;
         hipLaunchKernelGGL((spmv_tiled_kernel<MODE, true>), dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
                            D.wave_rows, D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves,
                            D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
       } else {
-        if (attr_set[MODE][0] < lds) {
-          HIP_TRY(hipFuncSetAttribute((const void *)spmv_tiled_kernel<MODE, false>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          attr_set[MODE][0] = lds;
-        }
+        if ((rc = ensure_lds_limit(h, MODE, false, lds, (const void *)spmv_tiled_kernel<MODE, false>))) return rc;
         hipLaunchKernelGGL((spmv_tiled_kernel<MODE, false>), dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
                            D.wave_rows, D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves,
                            D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
@@ -179,14 +184,14 @@ int launch_spmv_plain_part(pdhg_handle *h, const CsrDev &D, const double *xin, d
     const size_t lds = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_scratch ? TW_WPB * WAVE : 0));
     const int w0 = g0 * TW_WPB;
     if (D.tw_scratch) {
-      HIP_TRY(hipFuncSetAttribute((const void *)spmv_tiled_kernel<MODE_PLAIN, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int rc = ensure_lds_limit(h, MODE_PLAIN, true, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, true>);
+      if (rc) return rc;
       hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, true>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
                          D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
                          D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
     } else {
-      HIP_TRY(hipFuncSetAttribute((const void *)spmv_tiled_kernel<MODE_PLAIN, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int rc = ensure_lds_limit(h, MODE_PLAIN, false, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, false>);
+      if (rc) return rc;
       hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, false>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
                          D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
                          D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
