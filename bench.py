@@ -91,6 +91,13 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # Dev aid for 1-GPU boxes: PDHG_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # uses gloo on the device exchange tensor (RCCL refuses two ranks per device),
+    # so the world_size > 1 code of this script can be exercised; timings of such
+    # a run mean nothing.
+    share_gpu = os.environ.get("PDHG_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     # PDHG_FORCE_DIST=1: run the row-partitioned engine + RCCL even with one rank
@@ -100,8 +107,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     t0 = time.time()
     if args.workload == "pagerank":
