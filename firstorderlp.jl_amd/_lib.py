@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("PDHG_HIP_LIB") or os.path.join(CSRC, "libpdhg_hip.so"
 SRC_PATH = os.path.join(CSRC, "pdhg_hip.hip")
 
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off",
-               "-std=c++17", "-shared", "-fPIC"]
+               "-std=c++17", "-shared", "-fPIC", "-pthread"]
 
 # every symbol include/pdhg_hip.h declares
 EXPORTS = [

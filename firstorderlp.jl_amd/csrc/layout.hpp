@@ -49,6 +49,23 @@ int alloc_zero(double **dst, int64_t len) {
   return 0;
 }
 
+// Run f(begin, end) over [0, n) cut into contiguous ranges, one host thread per
+// range (PDHG_HOST_THREADS, default min(16, hardware threads)); fewer threads when
+// a range would hold less than `grain` items, inline when one is enough.
+template <typename F>
+void parallel_ranges(int n, int grain, F f) {
+  int threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char *ev = getenv("PDHG_HOST_THREADS")) threads = std::max(1, atoi(ev));
+  threads = std::min(threads, std::max(1, n / std::max(1, grain)));
+  if (threads <= 1) { f(0, n); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) {
+    const int b = (int)((int64_t)n * t / threads), e = (int)((int64_t)n * (t + 1) / threads);
+    pool.emplace_back([=, &f] { f(b, e); });
+  }
+  for (std::thread &th : pool) th.join();
+}
+
 // Host-side construction of the tiled-sweep layout: wave row blocks (runs of
 // <= TW_ROWS consecutive non-long rows) and their entries counting-sorted by
 // column tile (stable, so (row, col) order is kept inside a tile).
@@ -88,17 +105,14 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
   }
   const int nwaves = (int)wave_rows.size();
   const int grid = (nwaves + TW_WPB - 1) / TW_WPB;
-  std::vector<unsigned> pk;
-  std::vector<double> tv;
-  pk.reserve((size_t)D.nnz);
-  tv.reserve((size_t)D.nnz);
-  std::vector<int> step_ptr, wave_step_off((size_t)std::max(nwaves, 1), 0), step_tile, wg_step_off(1, 0);
-  std::vector<std::vector<int>> cnt(TW_WPB, std::vector<int>((size_t)ntiles + 1));
-  std::vector<int> nsub((size_t)ntiles);
-  int max_run = 0;   // longest same-row run inside one tile
-  for (int g = 0; g < grid; ++g) {
+  // The per-workgroup work below (count the cells, cut heavy ones into steps,
+  // scatter the entries tile-major) is independent from workgroup to workgroup
+  // once the output offsets are known, so it runs on host threads in two passes
+  // (A: sizes, serial prefix sums, B: fill).  The result does not depend on the
+  // number of threads.
+  std::vector<int> wg_nsteps((size_t)std::max(grid, 1), 0);
+  auto count_cells = [&](int g, std::vector<std::vector<int>> &cnt, std::vector<int> &nsub) {
     const int w0 = g * TW_WPB, w1 = std::min(nwaves, w0 + TW_WPB);
-    // cell sizes of the workgroup's waves
     std::fill(nsub.begin(), nsub.end(), 0);
     for (int w = w0; w < w1; ++w) {
       std::vector<int> &c = cnt[w - w0];
@@ -107,41 +121,77 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
       for (int t = 0; t < ntiles; ++t) nsub[t] = std::max(nsub[t], (c[t + 1] + WIN - 1) / WIN);
       for (int t = 0; t < ntiles; ++t) c[t + 1] += c[t];   // prefix: cell start offsets
     }
-    // the workgroup's step list (heavy tiles repeated, empty tiles skipped)
-    for (int t = 0; t < ntiles; ++t)
-      for (int j = 0; j < nsub[t]; ++j) step_tile.push_back(t);
-    wg_step_off.push_back((int)step_tile.size());
-    // entries of each wave, tile-major (stable in (row, col)), and its step offsets
-    for (int w = w0; w < w1; ++w) {
-      std::vector<int> &c = cnt[w - w0];
-      const int r0 = wave_rows[w].x, r1 = wave_rows[w].y;
-      const size_t base = pk.size();
-      const int total = rowptr[r1] - rowptr[r0];
-      wave_step_off[w] = (int)step_ptr.size();
-      for (int t = 0; t < ntiles; ++t) {
-        const int cs = c[t], ce = c[t + 1], len = ce - cs;
-        const int per = nsub[t] ? (len + nsub[t] - 1) / nsub[t] : 0;
-        for (int j = 0; j < nsub[t]; ++j) step_ptr.push_back((int)base + std::min(ce, cs + j * per));
-      }
-      step_ptr.push_back((int)base + total);
-      pk.resize(base + (size_t)total);
-      tv.resize(base + (size_t)total);
-      std::vector<int> next(c.begin(), c.end() - 1);
-      for (int rr = r0; rr < r1; ++rr) {
-        const unsigned rl = (unsigned)(rr - r0) << tile_shift;
-        int run = 0, run_tile = -1;
-        for (int k = rowptr[rr]; k < rowptr[rr + 1]; ++k) {
-          const int tt = col[k] >> tile_shift;
-          run = (tt == run_tile) ? run + 1 : 1;
-          run_tile = tt;
-          if (run > max_run) max_run = run;
-          const int pos = next[tt]++;
-          pk[base + pos] = rl | ((unsigned)col[k] & cmask);
-          tv[base + pos] = val[k];
-        }
-      }
+  };
+  // pass A: steps per workgroup (heavy tiles repeated, empty tiles skipped)
+  parallel_ranges(grid, 8, [&](int g_begin, int g_end) {
+    std::vector<std::vector<int>> cnt(TW_WPB, std::vector<int>((size_t)ntiles + 1));
+    std::vector<int> nsub((size_t)ntiles);
+    for (int g = g_begin; g < g_end; ++g) {
+      count_cells(g, cnt, nsub);
+      int steps = 0;
+      for (int t = 0; t < ntiles; ++t) steps += nsub[t];
+      wg_nsteps[g] = steps;
+    }
+  });
+  std::vector<int> wave_step_off((size_t)std::max(nwaves, 1), 0), wg_step_off((size_t)grid + 1, 0);
+  std::vector<int64_t> wave_base((size_t)nwaves + 1, 0);
+  int64_t step_ptr_len = 0;
+  for (int g = 0; g < grid; ++g) {
+    wg_step_off[g + 1] = wg_step_off[g] + wg_nsteps[g];
+    for (int w = g * TW_WPB; w < std::min(nwaves, (g + 1) * TW_WPB); ++w) {
+      wave_step_off[w] = (int)step_ptr_len;
+      step_ptr_len += wg_nsteps[g] + 1;
+      wave_base[w + 1] = wave_base[w] + (rowptr[wave_rows[w].y] - rowptr[wave_rows[w].x]);
     }
   }
+  if (step_ptr_len >= INT32_MAX) return fail(-2, "tiled layout: step table too large for 32-bit offsets");
+  std::vector<unsigned> pk((size_t)wave_base[nwaves]);
+  std::vector<double> tv((size_t)wave_base[nwaves]);
+  std::vector<int> step_ptr((size_t)step_ptr_len), step_tile((size_t)wg_step_off[grid]);
+  std::vector<int> max_run_of((size_t)std::max(grid, 1), 0);   // longest same-row run inside one tile, per workgroup
+  // pass B: step lists, per-wave step offsets and the entries, tile-major (stable in (row, col))
+  parallel_ranges(grid, 8, [&](int g_begin, int g_end) {
+    std::vector<std::vector<int>> cnt(TW_WPB, std::vector<int>((size_t)ntiles + 1));
+    std::vector<int> nsub((size_t)ntiles), next((size_t)ntiles);
+    for (int g = g_begin; g < g_end; ++g) {
+      const int w0 = g * TW_WPB, w1 = std::min(nwaves, w0 + TW_WPB);
+      count_cells(g, cnt, nsub);
+      int *st = step_tile.data() + wg_step_off[g];
+      for (int t = 0; t < ntiles; ++t)
+        for (int j = 0; j < nsub[t]; ++j) *st++ = t;
+      int max_run = 0;
+      for (int w = w0; w < w1; ++w) {
+        std::vector<int> &c = cnt[w - w0];
+        const int r0 = wave_rows[w].x, r1 = wave_rows[w].y;
+        const int64_t base = wave_base[w];
+        const int total = rowptr[r1] - rowptr[r0];
+        int *sp = step_ptr.data() + wave_step_off[w];
+        for (int t = 0; t < ntiles; ++t) {
+          const int cs = c[t], ce = c[t + 1], len = ce - cs;
+          const int per = nsub[t] ? (len + nsub[t] - 1) / nsub[t] : 0;
+          for (int j = 0; j < nsub[t]; ++j) *sp++ = (int)base + std::min(ce, cs + j * per);
+        }
+        *sp++ = (int)base + total;
+        std::copy(c.begin(), c.end() - 1, next.begin());
+        for (int rr = r0; rr < r1; ++rr) {
+          const unsigned rl = (unsigned)(rr - r0) << tile_shift;
+          int run = 0, run_tile = -1;
+          for (int k = rowptr[rr]; k < rowptr[rr + 1]; ++k) {
+            const int tt = col[k] >> tile_shift;
+            run = (tt == run_tile) ? run + 1 : 1;
+            run_tile = tt;
+            if (run > max_run) max_run = run;
+            const int pos = next[tt]++;
+            pk[(size_t)base + pos] = rl | ((unsigned)col[k] & cmask);
+            tv[(size_t)base + pos] = val[k];
+          }
+        }
+      }
+      max_run_of[g] = max_run;
+    }
+  });
+  int max_run = 0;
+  for (int g = 0; g < grid; ++g) max_run = std::max(max_run, max_run_of[g]);
   // Rows with long same-row runs inside a tile (hub rows of the PageRank LP,
   // dense-ish blocks) are summed by one lane, sequentially, to keep the
   // ascending-column order; the stream layout does that from LDS with 8 reads

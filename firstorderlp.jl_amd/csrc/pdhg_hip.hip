@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -25,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pdhg_hip.h"
@@ -333,25 +335,49 @@ int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
     t_rowptr[j] = (int)v;
   }
   t_col.resize(nnz);
-  t_val.assign(nzval, nzval + nnz);
+  t_val.resize(nnz);
+  // CSR(A') is the CSC input itself (32-bit, 0-based); copied on host threads.
+  std::atomic<int> bad{0};
+  if (nnz > 0) parallel_ranges((int)std::min<int64_t>(nnz, 1 << 20), 1 << 15, [&](int cb, int ce) {
+    const int64_t chunks = std::min<int64_t>(nnz, 1 << 20);
+    const int64_t kb = nnz * cb / chunks, ke = nnz * ce / chunks;
+    for (int64_t k = kb; k < ke; ++k) {
+      const int64_t r = rowval[k] - base;
+      if (r < 0 || r >= rows) { bad.store(1); return; }
+      t_col[k] = (int)r;
+      t_val[k] = nzval[k];
+    }
+  });
+  if (bad.load()) return fail(-1, "rowval out of range");
+  // CSR(A): a counting sort by row.  Every thread owns a contiguous range of ROWS
+  // and walks all columns in ascending order, counting and then placing only the
+  // entries of its rows -- so each row receives its entries in ascending column
+  // order (what the sequential loop produces) and the writes of a thread stay
+  // inside its own slice of col/val.
   rowptr.assign(rows + 1, 0);
-  for (int64_t k = 0; k < nnz; ++k) {
-    const int64_t r = rowval[k] - base;
-    if (r < 0 || r >= rows) return fail(-1, "rowval out of range");
-    t_col[k] = (int)r;
-    rowptr[r + 1] += 1;
-  }
+  const int row_grain = nnz >= (1 << 22) ? 1 : INT32_MAX;   // below ~4M nonzeros one thread is faster
+  parallel_ranges((int)rows, row_grain, [&](int rb, int re) {
+    for (int64_t k = 0; k < nnz; ++k) {
+      const int r = t_col[k];
+      if (r >= rb && r < re) rowptr[r + 1] += 1;
+    }
+  });
   for (int64_t i = 0; i < rows; ++i) rowptr[i + 1] += rowptr[i];
   col.resize(nnz);
   val.resize(nnz);
   std::vector<int> next(rowptr.begin(), rowptr.end() - 1);
-  for (int64_t j = 0; j < cols; ++j) {
-    for (int k = t_rowptr[j]; k < t_rowptr[j + 1]; ++k) {
-      const int p = next[t_col[k]]++;
-      col[p] = (int)j;
-      val[p] = t_val[k];
+  parallel_ranges((int)rows, row_grain, [&](int rb, int re) {
+    for (int64_t j = 0; j < cols; ++j) {
+      for (int k = t_rowptr[j]; k < t_rowptr[j + 1]; ++k) {
+        const int r = t_col[k];
+        if (r >= rb && r < re) {
+          const int p = next[r]++;
+          col[p] = (int)j;
+          val[p] = t_val[k];
+        }
+      }
     }
-  }
+  });
   return 0;
 }
 

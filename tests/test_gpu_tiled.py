@@ -97,3 +97,29 @@ def test_tiled_trajectory_matches_stream_and_oracle(gpu_required, tiled_env, mon
     np.testing.assert_allclose(x1, st.x, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(y1, st.y, rtol=1e-9, atol=1e-9)
     assert s1.total_number_iterations == st.total_number_iterations
+
+
+def test_layout_construction_is_independent_of_host_threads(gpu_required, monkeypatch):
+    """pdhg_create builds CSR(A) and both tiled layouts on host threads
+    (PDHG_HOST_THREADS); 1 thread and 13 threads must give the same device
+    layout: identical statistics and bitwise identical products (and both equal
+    to the oracle's sequential loops)."""
+    from firstorderlp_jl_amd.generators import random_lp
+    from oracle import oracle as orc
+    p = random_lp(700_000, 650_000, 7, seed=101)          # 4.9M nonzeros: above the threading threshold
+    A = p.constraint_matrix
+    rng = np.random.default_rng(5)
+    x, y = rng.standard_normal(A.shape[1]), rng.standard_normal(A.shape[0])
+    outs = []
+    for threads in ("1", "13"):
+        monkeypatch.setenv("PDHG_HOST_THREADS", threads)
+        eng = HipPdhgEngine.from_problem(p)
+        info = eng.layout_info()
+        assert info["A_tiled_waves"] > 0 and info["At_tiled_waves"] > 0
+        outs.append((info, eng.spmv(x), eng.spmv_t(y)))
+        eng.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    m, n = A.shape
+    assert np.array_equal(outs[0][1], orc.spmv(m, n, A.indptr, A.indices, A.data, x))
+    assert np.array_equal(outs[0][2], orc.spmv_t(m, n, A.indptr, A.indices, A.data, y))

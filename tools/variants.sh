@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p firstorderlp.jl_amd/csrc/variants
 while [ $# -ge 2 ]; do
-  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -shared -fPIC $2 -I include \
+  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -shared -fPIC -pthread $2 -I include \
     -o firstorderlp.jl_amd/csrc/variants/libpdhg_$1.so firstorderlp.jl_amd/csrc/pdhg_hip.hip &
   shift 2
 done
