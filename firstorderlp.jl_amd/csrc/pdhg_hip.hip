@@ -12,7 +12,7 @@
 //   interaction etc. primal_dual_hybrid_gradient.jl:527-549
 //   accept/average   primal_dual_hybrid_gradient.jl:500-519, saddle_point.jl:252-301
 //
-// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -shared -fPIC
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -shared -fPIC -pthread
 // (-ffp-contract=off: elementwise updates must round like Julia's unfused
 //  broadcasts; the product a*x and the sum are separate roundings).
 #include <hip/hip_runtime.h>
