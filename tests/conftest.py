@@ -17,6 +17,17 @@ def pytest_configure(config):
         "markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build what the tests load if it is missing or stale (the same steps as
+    __graft_entry__.build(); hipcc cross-compiles without a GPU, both are no-ops
+    when up to date)."""
+    from firstorderlp_jl_amd import _lib
+    from oracle import oracle
+    _lib.build()
+    oracle.build()
+    oracle.build_omp()
+
+
 def has_gpu():
     try:
         import torch
