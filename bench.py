@@ -82,6 +82,8 @@ def main():
     from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
         AdaptiveStepsizeParams, PdhgSolverState, take_step)
     from firstorderlp_jl_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        _lib.build()       # fresh clone on a 1-GPU box; normally the in-tree library is already there
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
