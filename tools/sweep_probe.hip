@@ -229,6 +229,23 @@ void run_aux(const unsigned *pk, const double *tv, const double *x, double *out,
   printf("stream loads aux=%2d (sc0=%d nt=%d sc1=%d) +vals   E=%3d: %.3f ms  %.1f G gathers/s\n", AUX, AUX & 1, (AUX >> 1) & 1, (AUX >> 4) & 1, E, ms, cnt / ms / 1e6);
 }
 
+// Ceiling: every workgroup gathers from ONE window that is resident in every
+// XCD's L2 (512 KB; far larger than the 32 KB L1), no barriers, no tiles, full
+// occupancy -- the chip's rate for L2-hit 8-byte gathers with a 4-byte index
+// stream and nothing else going on.
+template <int U>
+__global__ __launch_bounds__(256) void l2_gather_peak(const unsigned *__restrict__ pk, const double *__restrict__ x,
+                                                      double *__restrict__ out, size_t count, unsigned mask) {
+  size_t base = (size_t)blockIdx.x * 256 * U + threadIdx.x;
+  unsigned c[U];
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < U; ++i) { size_t k = base + (size_t)i * 256; c[i] = k < count ? __builtin_nontemporal_load(pk + k) : 0u; }
+#pragma unroll
+  for (int i = 0; i < U; ++i) s += x[c[i] & mask];
+  out[((size_t)blockIdx.x * 256 + threadIdx.x) & 0x7FFFF] = s;
+}
+
 int main() {
   setvbuf(stdout, NULL, _IONBF, 0);
   const int shift = 16, ntiles = 153, nwaves = 8192;
@@ -257,6 +274,12 @@ int main() {
   run<2, 128, true, true>("buffer_load barrier +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run<2, 64, true, true>("buffer_load barrier +vals", pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run<2, 128, true, true>("buffer_load barrier +vals 4WG/CU", pk, tv, x, out, nwaves, ntiles, shift, L4WG);
+  for (unsigned bits : {12u, 14u, 16u, 18u}) {
+    const size_t count = (size_t)nwaves * ntiles * 128;
+    const size_t blocks = (count + 256 * 8 - 1) / (256 * 8);
+    float ms = time_it([&] { hipLaunchKernelGGL(l2_gather_peak<8>, dim3((unsigned)blocks), dim3(256), 0, 0, pk, x, out, count, (1u << bits) - 1u); });
+    printf("pure gather peak, one %4u KB window shared by all workgroups: %.3f ms  %.1f G gathers/s\n", (8u << bits) >> 10, ms, count / ms / 1e6);
+  }
   run_aux<64, 0>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run_aux<64, 2>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run_aux<64, 1>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
