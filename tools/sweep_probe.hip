@@ -170,6 +170,75 @@ void run(const char *name, const unsigned *pk, const double *tv, const double *x
 }
 
 
+// Pacing with SLACK instead of a full barrier: every wave publishes the number of
+// tiles it has finished in LDS and, before starting tile t, only waits until all
+// waves of the workgroup have finished tile t - 1 - SLACK.  SLACK = 0 behaves like
+// the barrier; SLACK = 1 lets a wave run one tile ahead of the slowest one.
+template <int E, int SLACK>
+__global__ __launch_bounds__(WPB * WAVE) void sweep_slack(const unsigned *__restrict__ pk, const double *__restrict__ tv,
+                                                          const double *__restrict__ x, double *__restrict__ out,
+                                                          int ntiles, int shift) {
+  extern __shared__ double lds[];
+  volatile int *prog = reinterpret_cast<volatile int *>(lds);   // [WPB]
+  constexpr int C = E / WAVE;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x < WPB) prog[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t w = (size_t)blockIdx.x * WPB + wid;
+  const unsigned *my = pk + w * (size_t)ntiles * E;
+  const double *myv = tv + w * (size_t)ntiles * E;
+  const unsigned cmask = (1u << shift) - 1u;
+  double s = 0.0;
+  unsigned p[2][C];
+  double vv[2][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { p[0][c] = __builtin_nontemporal_load(my + c * WAVE + lane); vv[0][c] = __builtin_nontemporal_load(myv + c * WAVE + lane); }
+  for (int t0 = 0; t0 < ntiles; t0 += 2) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int t = t0 + b;
+      if (t < ntiles) {
+        // wait until every wave has finished tile t - 1 - SLACK
+        const int need = t - SLACK;
+        if (need > 0) {
+          for (;;) {
+            const int mine = (lane < WPB) ? prog[lane] : 0x7fffffff;
+            int mn = mine;
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) mn = min(mn, __shfl_down(mn, off, WAVE));
+            mn = __builtin_amdgcn_readfirstlane(mn);
+            if (mn >= need) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        const double *xt = x + ((size_t)t << shift);
+        double g[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c] = xt[p[b][c] & cmask];
+        if (t + 1 < ntiles) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            p[b ^ 1][c] = __builtin_nontemporal_load(my + (size_t)(t + 1) * E + c * WAVE + lane);
+            vv[b ^ 1][c] = __builtin_nontemporal_load(myv + (size_t)(t + 1) * E + c * WAVE + lane);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) s += g[c] * vv[b][c];
+        if (lane == 0) prog[wid] = t + 1;
+      }
+    }
+  }
+  out[(size_t)blockIdx.x * WPB * WAVE + threadIdx.x] = s;
+}
+
+template <int E, int SLACK>
+void run_slack(const unsigned *pk, const double *tv, const double *x, double *out, int nwaves, int ntiles, int shift, size_t lds) {
+  CK(hipFuncSetAttribute((const void *)sweep_slack<E, SLACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  float ms = time_it([&] { hipLaunchKernelGGL((sweep_slack<E, SLACK>), dim3(nwaves / WPB), dim3(WPB * WAVE), lds, 0, pk, tv, x, out, ntiles, shift); });
+  double cnt = (double)nwaves * ntiles * E;
+  printf("LDS-progress pacing, slack %d tile(s) +vals   E=%3d: %.3f ms  %.1f G gathers/s\n", SLACK, E, ms, cnt / ms / 1e6);
+}
+
 // Stream-load cache policy experiment: packed offsets and values through raw
 // buffer loads with cache-policy bits AUX (gfx940+: bit0 sc0, bit1 nt, bit4 sc1);
 // gathers are plain global loads.  Does any policy reduce the interference of
@@ -288,6 +357,13 @@ int main() {
     printf("pure gather peak, one %4u KB window shared by all workgroups: %.3f ms  %.1f G gathers/s | with the 8-byte value stream %.3f ms  %.1f G/s\n",
            (8u << bits) >> 10, ms, count / ms / 1e6, mv, count / mv / 1e6);
   }
+  run_slack<64, 0>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_slack<64, 1>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_slack<64, 2>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_slack<64, 4>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_slack<128, 0>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_slack<128, 1>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
+  run_slack<128, 2>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run_aux<64, 0>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run_aux<64, 2>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run_aux<64, 1>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
