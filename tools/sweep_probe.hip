@@ -239,6 +239,83 @@ void run_slack(const unsigned *pk, const double *tv, const double *x, double *ou
   printf("LDS-progress pacing, slack %d tile(s) +vals   E=%3d: %.3f ms  %.1f G gathers/s\n", SLACK, E, ms, cnt / ms / 1e6);
 }
 
+// XCD-wide pacing: a persistent grid of 512 workgroups (2 per CU, all resident),
+// workgroup b on XCD b % 8; after every tile one thread bumps its XCD's counter
+// and the workgroup waits (bounded spin) until all 64 workgroups of the XCD have
+// finished that tile.  EVERY is how many tiles pass between two XCD syncs.
+template <int E, int EVERY>
+__global__ __launch_bounds__(WPB * WAVE) void sweep_xcd(const unsigned *__restrict__ pk, const double *__restrict__ tv,
+                                                        const double *__restrict__ x, double *__restrict__ out,
+                                                        int ntiles, int shift, unsigned *__restrict__ counters,
+                                                        unsigned epoch_base, int wgs_per_xcd) {
+  extern __shared__ double lds[];
+  constexpr int C = E / WAVE;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const size_t w = (size_t)blockIdx.x * WPB + wid;
+  const unsigned *my = pk + w * (size_t)ntiles * E;
+  const double *myv = tv + w * (size_t)ntiles * E;
+  const unsigned cmask = (1u << shift) - 1u;
+  unsigned *ctr = counters + (blockIdx.x & 7) * 32;   // one 128-byte line per XCD
+  double s = 0.0;
+  unsigned p[2][C];
+  double vv[2][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { p[0][c] = __builtin_nontemporal_load(my + c * WAVE + lane); vv[0][c] = __builtin_nontemporal_load(myv + c * WAVE + lane); }
+  int syncs = 0;
+  for (int t0 = 0; t0 < ntiles; t0 += 2) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int t = t0 + b;
+      if (t < ntiles) {
+        const double *xt = x + ((size_t)t << shift);
+        double g[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c] = xt[p[b][c] & cmask];
+        if (t + 1 < ntiles) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            p[b ^ 1][c] = __builtin_nontemporal_load(my + (size_t)(t + 1) * E + c * WAVE + lane);
+            vv[b ^ 1][c] = __builtin_nontemporal_load(myv + (size_t)(t + 1) * E + c * WAVE + lane);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) s += g[c] * vv[b][c];
+        __syncthreads();
+        if ((t + 1) % EVERY == 0) {
+          ++syncs;
+          if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = epoch_base + (unsigned)syncs * (unsigned)wgs_per_xcd;
+            for (int spin = 0; spin < 200000; ++spin) {   // bounded: never hang the GPU
+              if ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) break;
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+  out[(size_t)blockIdx.x * WPB * WAVE + threadIdx.x] = s + lds[0] * 0.0;
+}
+
+template <int E, int EVERY>
+void run_xcd(const unsigned *pk, const double *tv, const double *x, double *out, int ntiles, int shift, size_t lds) {
+  const int grid = 512, nwaves = grid * WPB;
+  unsigned *ctr; CK(hipMalloc(&ctr, 8 * 128)); CK(hipMemset(ctr, 0, 8 * 128));
+  CK(hipFuncSetAttribute((const void *)sweep_xcd<E, EVERY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  unsigned launches = 0;
+  const unsigned per_launch = (unsigned)(ntiles / EVERY) * 64u;
+  float ms = time_it([&] {
+    hipLaunchKernelGGL((sweep_xcd<E, EVERY>), dim3(grid), dim3(WPB * WAVE), lds, 0, pk, tv, x, out, ntiles, shift, ctr,
+                       launches * per_launch, 64);
+    ++launches;
+  });
+  double cnt = (double)nwaves * ntiles * E;
+  printf("XCD-wide pacing every %2d tile(s), 512 persistent workgroups +vals   E=%3d: %.3f ms  %.1f G gathers/s\n", EVERY, E, ms, cnt / ms / 1e6);
+  CK(hipFree(ctr));
+}
+
 // Stream-load cache policy experiment: packed offsets and values through raw
 // buffer loads with cache-policy bits AUX (gfx940+: bit0 sc0, bit1 nt, bit4 sc1);
 // gathers are plain global loads.  Does any policy reduce the interference of
@@ -357,6 +434,14 @@ int main() {
     printf("pure gather peak, one %4u KB window shared by all workgroups: %.3f ms  %.1f G gathers/s | with the 8-byte value stream %.3f ms  %.1f G/s\n",
            (8u << bits) >> 10, ms, count / ms / 1e6, mv, count / mv / 1e6);
   }
+  run<0, 64, true, true>("vaddr64 barrier +vals, 512 WGs only", pk, tv, x, out, 4096, ntiles, shift, L2WG);
+  run<0, 128, true, true>("vaddr64 barrier +vals, 512 WGs only", pk, tv, x, out, 4096, ntiles, shift, L2WG);
+  run_xcd<64, 1>(pk, tv, x, out, ntiles, shift, L2WG);
+  run_xcd<64, 2>(pk, tv, x, out, ntiles, shift, L2WG);
+  run_xcd<64, 4>(pk, tv, x, out, ntiles, shift, L2WG);
+  run_xcd<128, 1>(pk, tv, x, out, ntiles, shift, L2WG);
+  run_xcd<128, 2>(pk, tv, x, out, ntiles, shift, L2WG);
+  run_xcd<128, 4>(pk, tv, x, out, ntiles, shift, L2WG);
   run_slack<64, 0>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run_slack<64, 1>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
   run_slack<64, 2>(pk, tv, x, out, nwaves, ntiles, shift, L2WG);
