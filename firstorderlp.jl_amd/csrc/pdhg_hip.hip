@@ -324,8 +324,8 @@ int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
                 std::vector<int> &t_rowptr, std::vector<int> &t_col, std::vector<double> &t_val,
                 std::vector<int> &rowptr, std::vector<int> &col, std::vector<double> &val) {
   if (rows < 0 || cols < 0 || nnz < 0) return fail(-1, "negative dimension");
-  if (rows >= INT32_MAX || cols >= INT32_MAX || nnz >= INT32_MAX)
-    return fail(-2, "dimensions/nnz >= 2^31 need the 64-bit index path (not built)");
+  if (rows >= INT32_MAX || cols >= INT32_MAX || nnz >= INT32_MAX || rows + cols >= INT32_MAX)
+    return fail(-2, "m, n, m + n or nnz >= 2^31 need the 64-bit index path (not built)");
   if (colptr[0] != base) return fail(-1, "colptr[0] != index_base");
   if (colptr[cols] - base != nnz) return fail(-1, "colptr[n] - base != nnz");
   t_rowptr.resize(cols + 1);

@@ -288,7 +288,18 @@ def optimize(params, original_problem, engine_factory=None):
 
     ``engine_factory(scaled_qp) -> engine`` builds the device state; the
     default is the HIP engine on the current GPU and there is no CPU fallback.
-    Returns a ``SaddlePointOutput``."""
+    Returns a ``SaddlePointOutput``.  The engine (device memory) is released on
+    every exit path, exceptions included."""
+    created = []
+    try:
+        return _optimize(params, original_problem, engine_factory, created)
+    finally:
+        for eng in created:
+            if hasattr(eng, "close"):
+                eng.close()
+
+
+def _optimize(params, original_problem, engine_factory, created):
     validate(original_problem)
     qp_cache = cached_quadratic_program_info(original_problem)
     if params.primal_importance <= 0 or not math.isfinite(params.primal_importance):
@@ -302,6 +313,7 @@ def optimize(params, original_problem, engine_factory=None):
         from .quadratic_programming import QuadraticProgrammingProblem, ScaledQpProblem
         import scipy.sparse as _sp
         engine = _default_engine_factory(original_problem)
+        created.append(engine)
         constraint_rescaling, variable_rescaling = engine.rescale(
             params.l_inf_ruiz_iterations, params.l2_norm_rescaling, params.pock_chambolle_alpha)
         c_s, b_s, lb_s, ub_s = engine.get_problem_vectors()
@@ -326,6 +338,7 @@ def optimize(params, original_problem, engine_factory=None):
 
     if engine is None:
         engine = (engine_factory or _default_engine_factory)(problem)
+        created.append(engine)
     ops = EngineOps(engine, problem)
     original_ops = UnscaledEngineOps(engine, scaled_problem)
     is_lp = is_lp_original       # (the host copy of a device-rescaled problem carries no matrices)
@@ -425,8 +438,6 @@ def optimize(params, original_problem, engine_factory=None):
                 out = unscaled_saddle_point_output(
                     scaled_problem, avg_primal_solution, avg_dual_solution,
                     termination_reason, iteration - 1, iteration_stats)
-                if hasattr(engine, "close"):
-                    engine.close()
                 return out
 
             current_iteration_stats.restart_used = run_restart_scheme(

@@ -101,9 +101,8 @@ def read_mps(stream, fixed_format=False):
     rhs, ranges = {}, {}
     c0 = 0.0
     lvar, uvar = [], []
-    q_rows, q_cols, q_vals = [], [], []
+    q_rows, q_cols, q_vals, q_full = [], [], [], []   # q_full[k]: triple k came from QMATRIX (both triangles given)
     section = None
-    qmatrix_full = False
     for raw in stream:
         if isinstance(raw, bytes):
             raw = raw.decode("utf-8", "replace")
@@ -117,7 +116,6 @@ def read_mps(stream, fixed_format=False):
                 break
             if section == "OBJSENSE" and len(tok) > 1 and tok[1].upper().startswith("MAX"):
                 raise ValueError("OBJSENSE MAX is not supported (the reference asserts objsense == :notset)")
-            qmatrix_full = section == "QMATRIX"
             continue
         f = _fixed_fields(line) if fixed_format else line.split()
         if section == "OBJSENSE":
@@ -195,6 +193,7 @@ def read_mps(stream, fixed_format=False):
         elif section in ("QUADOBJ", "QMATRIX"):
             i, j, v = col_index[f[0]], col_index[f[1]], float(f[2])
             q_rows.append(i); q_cols.append(j); q_vals.append(v)
+            q_full.append(section == "QMATRIX")
         elif section in ("NAME", None):
             continue
         else:
@@ -229,9 +228,9 @@ def read_mps(stream, fixed_format=False):
         c[j] = v
     # quadratic_programming_io.jl:166-178: QUADOBJ holds one triangle; mirror it
     qr, qc, qv = [], [], []
-    for i, j, v in zip(q_rows, q_cols, q_vals):
+    for i, j, v, full in zip(q_rows, q_cols, q_vals, q_full):
         qr.append(i); qc.append(j); qv.append(v)
-        if i != j and not qmatrix_full:
+        if i != j and not full:
             qr.append(j); qc.append(i); qv.append(v)
     Q = sp.csc_matrix((qv, (qr, qc)), shape=(nvar, nvar), dtype=np.float64)
     return TwoSidedQpProblem(np.array(lvar, dtype=np.float64), np.array(uvar, dtype=np.float64),

@@ -102,6 +102,36 @@ ENDATA
     assert np.array_equal(q.constraint_matrix.toarray(), [[1, -1, 0], [2, 0, 1], [0, 1, 0]])
 
 
+def test_qmatrix_before_another_section_is_not_mirrored():
+    """QMATRIX lists both triangles; a section following it (BOUNDS here) must
+    not turn its entries into QUADOBJ-style triangles that get mirrored again."""
+    import io
+    from firstorderlp_jl_amd.quadratic_programming_io import read_mps
+    text = """NAME q
+ROWS
+ N obj
+ G c1
+COLUMNS
+ x obj 1 c1 1
+ y obj 1 c1 1
+RHS
+ rhs c1 1
+QMATRIX
+ x x 2
+ x y 0.5
+ y x 0.5
+ y y 3
+BOUNDS
+ UP bnd x 4
+ENDATA
+"""
+    q = read_mps(io.StringIO(text))
+    assert np.array_equal(q.objective_matrix.toarray(), [[2.0, 0.5], [0.5, 3.0]])
+    assert q.variable_upper_bound[0] == 4.0
+    q2 = read_mps(io.StringIO(text.replace("QMATRIX", "QUADOBJ").replace(" y x 0.5\n", "")))
+    assert np.array_equal(q2.objective_matrix.toarray(), [[2.0, 0.5], [0.5, 3.0]])
+
+
 def test_solve_qp_cli_trivial_lp_cpu_plumbing(tmp_path):
     """BASELINE configs[0]: test/trivial_lp_model.mps, --method pdhg, CPU path.
     Optimum: x = [0, 2], objective -2 (CI.yml:40-45 only requires exit 0)."""
