@@ -17,6 +17,9 @@ SRC_PATH = os.path.join(CSRC, "pdhg_hip.hip")
 
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off",
                "-std=c++17", "-shared", "-fPIC", "-pthread"]
+# RCCL: the library owns the multi-GPU exchange (csrc/dist.hpp)
+ROCM_LIB = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+LINK_FLAGS = ["-L" + ROCM_LIB, "-lrccl", "-Wl,-rpath," + ROCM_LIB]
 
 # every symbol include/pdhg_hip.h declares
 EXPORTS = [
@@ -26,17 +29,18 @@ EXPORTS = [
     "pdhg_add_current_primal_to_average", "pdhg_get_average_info",
     "pdhg_get_average", "pdhg_reset_average", "pdhg_restart_to_average",
     "pdhg_get_current", "pdhg_set_current", "pdhg_get_trial", "pdhg_spmv",
-    "pdhg_spmv_t", "pdhg_dist_trial_begin", "pdhg_dist_trial_end", "pdhg_dist_trial_dual_begin", "pdhg_dist_parts",
-    "pdhg_dist_trial_begin_part", "pdhg_dist_trial_dual_begin_part",
-    "pdhg_dist_exchange_ptr", "pdhg_dist_dual_product_begin",
-    "pdhg_dist_dual_product_end", "pdhg_profile_enable", "pdhg_profile_read",
+    "pdhg_spmv_t", "pdhg_dist_get_unique_id", "pdhg_create_dist", "pdhg_create_multi",
+    "pdhg_dist_info", "pdhg_profile_enable", "pdhg_profile_read",
     "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info", "pdhg_measure_triad",
     "pdhg_set_original_problem", "pdhg_eval_point", "pdhg_save_restart_point",
     "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound",
     "pdhg_point_sumsq", "pdhg_rescale", "pdhg_get_problem_vectors", "pdhg_matrix_max_abs",
 ]
 
-K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_COUNT = range(6)
+ABI_VERSION = 5
+UNIQUE_ID_BYTES = 128
+(K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_ALLGATHER, K_REDUCE_SCATTER,
+ K_INTERACTION, K_COUNT) = range(9)
 POINT_CURRENT, POINT_AVERAGE, POINT_RESTART = range(3)
 
 
@@ -48,11 +52,15 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and \
             os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(f) for f in sources):
         return LIB_PATH
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", LIB_PATH, SRC_PATH]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-o", LIB_PATH, SRC_PATH] + LINK_FLAGS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB_PATH
+
+
+class PdhgHipError(RuntimeError):
+    pass
 
 
 _lib = None
@@ -73,6 +81,16 @@ def lib():
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     L = ctypes.CDLL(LIB_PATH)
     d, i64, i32 = ctypes.c_double, ctypes.c_int64, ctypes.c_int
+    # a stale library (older ABI: different out[] lengths, missing entry points)
+    # must fail here, not as a buffer overrun deep inside a solve
+    missing = [name for name in EXPORTS if not hasattr(L, name)]
+    L.pdhg_abi_version.restype = i32
+    L.pdhg_abi_version.argtypes = []
+    version = L.pdhg_abi_version() if not missing or "pdhg_abi_version" not in missing else None
+    if missing or version != ABI_VERSION:
+        raise PdhgHipError(
+            f"{LIB_PATH} is stale: abi {version} (need {ABI_VERSION}), missing symbols {missing}; "
+            "rebuild with __graft_entry__.build()")
     L.pdhg_last_error.restype = ctypes.c_char_p
     L.pdhg_last_error.argtypes = []
     L.pdhg_abi_version.restype = i32
@@ -111,26 +129,18 @@ def lib():
     L.pdhg_spmv.argtypes = [_vp, _dp, _dp]
     L.pdhg_spmv_t.restype = i32
     L.pdhg_spmv_t.argtypes = [_vp, _dp, _dp]
-    L.pdhg_dist_trial_begin.restype = i32
-    L.pdhg_dist_trial_begin.argtypes = [_vp, d, d, d]
-    L.pdhg_dist_parts.restype = i32
-    L.pdhg_dist_parts.argtypes = [_vp, i32, _ip]
-    L.pdhg_dist_trial_begin_part.restype = i32
-    L.pdhg_dist_trial_begin_part.argtypes = [_vp, d, d, d, i32, i32]
-    L.pdhg_dist_trial_dual_begin_part.restype = i32
-    L.pdhg_dist_trial_dual_begin_part.argtypes = [_vp, d, d, d, i32, i32]
     L.pdhg_measure_triad.restype = i32
     L.pdhg_measure_triad.argtypes = [_vp, i64, i32, _dp]
-    L.pdhg_dist_trial_dual_begin.restype = i32
-    L.pdhg_dist_trial_dual_begin.argtypes = [_vp, d, d, d]
-    L.pdhg_dist_trial_end.restype = i32
-    L.pdhg_dist_trial_end.argtypes = [_vp, _dp]
-    L.pdhg_dist_exchange_ptr.restype = _vp
-    L.pdhg_dist_exchange_ptr.argtypes = [_vp]
-    L.pdhg_dist_dual_product_begin.restype = i32
-    L.pdhg_dist_dual_product_begin.argtypes = [_vp]
-    L.pdhg_dist_dual_product_end.restype = i32
-    L.pdhg_dist_dual_product_end.argtypes = [_vp]
+    L.pdhg_dist_get_unique_id.restype = i32
+    L.pdhg_dist_get_unique_id.argtypes = [_vp]
+    L.pdhg_create_dist.restype = i32
+    L.pdhg_create_dist.argtypes = [ctypes.POINTER(_vp), i64, i64, i64, _ip, _ip,
+                                   _dp, i32, _dp, _dp, _dp, _dp, i64, i32, _vp, _vp, i32, i32]
+    L.pdhg_create_multi.restype = i32
+    L.pdhg_create_multi.argtypes = [ctypes.POINTER(_vp), i64, i64, i64, _ip, _ip,
+                                    _dp, i32, _dp, _dp, _dp, _dp, i64, i32, ctypes.POINTER(i32)]
+    L.pdhg_dist_info.restype = i32
+    L.pdhg_dist_info.argtypes = [_vp, _ip]
     L.pdhg_profile_enable.restype = i32
     L.pdhg_profile_enable.argtypes = [_vp, i32]
     L.pdhg_profile_read.restype = i32
@@ -138,7 +148,7 @@ def lib():
     L.pdhg_kernel_algorithmic_bytes.restype = i64
     L.pdhg_kernel_algorithmic_bytes.argtypes = [_vp, i32]
     L.pdhg_kernel_name.restype = ctypes.c_char_p
-    L.pdhg_kernel_name.argtypes = [i32]
+    L.pdhg_kernel_name.argtypes = [_vp, i32]
     L.pdhg_layout_info.restype = i32
     L.pdhg_layout_info.argtypes = [_vp, _ip]
     L.pdhg_set_original_problem.restype = i32
@@ -163,10 +173,6 @@ def lib():
     L.pdhg_trust_region_bound.argtypes = [_vp, i32, d, d, d, i32, i32, _dp]
     _lib = L
     return L
-
-
-class PdhgHipError(RuntimeError):
-    pass
 
 
 def check(rc):

@@ -1,0 +1,310 @@
+// dist.hpp -- part of the single translation unit pdhg_hip.hip (included there, after struct pdhg_handle).
+// The row-partitioned multi-GPU form, owned by the library: shard group, the
+// collective back ends (RCCL over xGMI; direct peer kernels inside one process)
+// and the row partition itself.
+//
+// Form ("reduce-scatter -> slice -> all-gather"): rank p holds the
+// row block A_p (CSR for A_p*xbar, CSR of A_p' for A_p'*y), its rows of y, b,
+// sum_y, and OWNS the column slice [p*S, (p+1)*S) of every n-vector: x, x', c,
+// lb, ub, A'y, A'y', sum_x are updated on that slice only.  Per trial step:
+//   primal step on the slice -> all-gather xbar -> y'_p = prox(A_p xbar)
+//   -> t_p = A_p' y'_p (length n) -> reduce-scatter(sum) t_p: the slice of A'y'
+//   -> interaction/movement partial sums on the slice -> the 5 scalars of every
+//   rank are gathered and added IN RANK ORDER on every rank, so all ranks take
+//   bitwise identical accept/reject decisions whatever the collective algorithm.
+// Communication volume equals the all-reduce form's (one RS + one AG of n
+// doubles), vector work is 1/P per rank, and no rank needs a bitwise-consistent
+// replica of A'y.
+// The reference has no counterpart (single process); the arithmetic being
+// distributed is src/primal_dual_hybrid_gradient.jl:442-549.
+#pragma once
+
+#include <rccl/rccl.h>
+
+namespace {
+
+enum { COMM_RCCL = 0, COMM_P2P = 1 };
+constexpr int DIST_MAX_WORLD = 64;     // scalar exchange buffers are sized for this
+constexpr int P2P_MAX_WORLD = 16;      // peer-kernel back end (single process)
+constexpr int SCAL_MAX = 32;           // scalars one shard contributes per reduction
+
+#define NCCL_TRY(expr)                                                         \
+  do {                                                                         \
+    ncclResult_t _r = (expr);                                                  \
+    if (_r != ncclSuccess) {                                                   \
+      g_last_error = std::string(#expr) + ": " + ncclGetErrorString(_r);       \
+      return 2000 + (int)_r;                                                   \
+    }                                                                          \
+  } while (0)
+
+struct DistGroup {
+  int world = 1;
+  int backend = COMM_RCCL;
+  std::vector<pdhg_handle *> sh;        // local shards, ascending rank (multi-process: one)
+  std::vector<ncclComm_t> comm;         // per local shard (COMM_RCCL)
+  int64_t n = 0, m_global = 0, num_eq_global = 0;
+  int64_t S = 0;                        // slice stride: rank r owns columns [r*S, min(n, (r+1)*S))
+  std::vector<int64_t> row_lo;          // [world+1] global row range of every rank
+  std::vector<hipEvent_t> ev[2];        // cross-stream barrier of the peer back end
+  int flip = 0;
+  bool all_local() const { return (int)sh.size() == world; }
+};
+
+// ---- the shard list every entry point walks: the group's local shards, or the handle itself
+struct Shards {
+  pdhg_handle *const *p;
+  int count;
+  DistGroup *g;
+};
+inline Shards shards_of(pdhg_handle *h) {
+  if (h->grp) return Shards{h->grp->sh.data(), (int)h->grp->sh.size(), h->grp};
+  return Shards{&h->self, 1, nullptr};
+}
+#define FOR_SHARDS(L, s)                                                       \
+  for (int _si = 0; _si < (L).count; ++_si)                                     \
+    if (pdhg_handle *s = (L).p[_si])                                            \
+      if (hipSetDevice(s->device) == hipSuccess)
+
+// ---- peer back end: kernels that read the other shards' buffers directly
+struct PeerPtrs {
+  const double *p[P2P_MAX_WORLD];
+  int world;
+};
+// out[i] = op over ranks q = 0..world-1 (ascending: deterministic) of p[q][off + i]
+template <bool MAXOP>
+__global__ __launch_bounds__(TPB) void p2p_reduce_kernel(PeerPtrs pp, int64_t off, int64_t count, double *out) {
+  const int64_t stride = (int64_t)gridDim.x * TPB;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < count; i += stride) {
+    double v = pp.p[0][off + i];
+    for (int q = 1; q < pp.world; ++q) {
+      const double t = pp.p[q][off + i];
+      v = MAXOP ? fmax(v, t) : v + t;
+    }
+    out[i] = v;
+  }
+}
+
+// every local stream waits for everything queued so far on every other local stream
+int p2p_barrier(DistGroup &g) {
+  const int k = (int)g.sh.size();
+  if (k <= 1) return 0;
+  g.flip ^= 1;
+  std::vector<hipEvent_t> &ev = g.ev[g.flip];
+  for (int i = 0; i < k; ++i) {
+    HIP_TRY(hipSetDevice(g.sh[i]->device));
+    HIP_TRY(hipEventRecord(ev[i], g.sh[i]->stream));
+  }
+  for (int i = 0; i < k; ++i) {
+    HIP_TRY(hipSetDevice(g.sh[i]->device));
+    for (int q = 0; q < k; ++q)
+      if (q != i) HIP_TRY(hipStreamWaitEvent(g.sh[i]->stream, ev[q], 0));
+  }
+  return 0;
+}
+
+// A buffer selector: the same logical vector on every shard.
+typedef double *(*BufSel)(pdhg_handle *);
+
+// In-place all-gather: rank r contributes buf[r*S .. r*S+S), every rank ends with all of them.
+// The buffers hold world*S doubles.
+template <typename Sel>
+int dist_all_gather(DistGroup &g, Sel sel, int64_t S) {
+  if (g.world == 1 && g.backend == COMM_P2P) return 0;
+  if (g.backend == COMM_RCCL) {
+    NCCL_TRY(ncclGroupStart());
+    for (size_t i = 0; i < g.sh.size(); ++i) {
+      pdhg_handle *s = g.sh[i];
+      HIP_TRY(hipSetDevice(s->device));
+      double *b = sel(s);
+      NCCL_TRY(ncclAllGather(b + (int64_t)s->rank * S, b, (size_t)S, ncclDouble, g.comm[i], s->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+  }
+  int rc;
+  if ((rc = p2p_barrier(g))) return rc;
+  for (pdhg_handle *s : g.sh) {
+    HIP_TRY(hipSetDevice(s->device));
+    for (pdhg_handle *q : g.sh)
+      if (q != s)
+        HIP_TRY(hipMemcpyAsync(sel(s) + (int64_t)q->rank * S, sel(q) + (int64_t)q->rank * S,
+                               sizeof(double) * (size_t)S, hipMemcpyDeviceToDevice, s->stream));
+  }
+  return p2p_barrier(g);
+}
+
+// In-place reduce-scatter: rank r ends with op_q buf_q[r*S .. r*S+S) in ITS buf[r*S ..).
+template <typename Sel>
+int dist_reduce_scatter(DistGroup &g, Sel sel, int64_t S, bool maxop = false) {
+  if (g.world == 1 && g.backend == COMM_P2P) return 0;
+  if (g.backend == COMM_RCCL) {
+    NCCL_TRY(ncclGroupStart());
+    for (size_t i = 0; i < g.sh.size(); ++i) {
+      pdhg_handle *s = g.sh[i];
+      HIP_TRY(hipSetDevice(s->device));
+      double *b = sel(s);
+      NCCL_TRY(ncclReduceScatter(b, b + (int64_t)s->rank * S, (size_t)S, ncclDouble, maxop ? ncclMax : ncclSum,
+                                 g.comm[i], s->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+  }
+  int rc;
+  if ((rc = p2p_barrier(g))) return rc;
+  PeerPtrs pp{};
+  pp.world = g.world;
+  for (pdhg_handle *q : g.sh) pp.p[q->rank] = sel(q);
+  for (pdhg_handle *s : g.sh) {
+    HIP_TRY(hipSetDevice(s->device));
+    const int64_t off = (int64_t)s->rank * S;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + TPB - 1) / TPB, EW_MAX_BLOCKS));
+    if (maxop) hipLaunchKernelGGL(p2p_reduce_kernel<true>, dim3(grid), dim3(TPB), 0, s->stream, pp, off, S, sel(s) + off);
+    else hipLaunchKernelGGL(p2p_reduce_kernel<false>, dim3(grid), dim3(TPB), 0, s->stream, pp, off, S, sel(s) + off);
+    HIP_TRY(hipGetLastError());
+  }
+  return p2p_barrier(g);
+}
+
+// All-reduce as reduce-scatter + all-gather: every element is reduced once, at
+// its owner, and then copied -- all ranks hold the same bits whatever the order.
+template <typename Sel>
+int dist_all_reduce(DistGroup &g, Sel sel, int64_t S, bool maxop = false) {
+  int rc = dist_reduce_scatter(g, sel, S, maxop);
+  if (rc) return rc;
+  return dist_all_gather(g, sel, S);
+}
+
+// In-place all-gather of row-partitioned m-vectors: rank r contributes
+// buf[row_lo[r] .. row_lo[r+1]).  The buffers hold m_global doubles.
+template <typename Sel>
+int dist_all_gather_rows(DistGroup &g, Sel sel) {
+  if (g.world == 1 && g.backend == COMM_P2P) return 0;
+  if (g.backend == COMM_RCCL) {
+    NCCL_TRY(ncclGroupStart());
+    for (size_t i = 0; i < g.sh.size(); ++i) {
+      pdhg_handle *s = g.sh[i];
+      HIP_TRY(hipSetDevice(s->device));
+      double *b = sel(s);
+      for (int q = 0; q < g.world; ++q) {
+        const int64_t cnt = g.row_lo[q + 1] - g.row_lo[q];
+        if (cnt > 0)
+          NCCL_TRY(ncclBroadcast(b + g.row_lo[q], b + g.row_lo[q], (size_t)cnt, ncclDouble, q, g.comm[i], s->stream));
+      }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+  }
+  int rc;
+  if ((rc = p2p_barrier(g))) return rc;
+  for (pdhg_handle *s : g.sh) {
+    HIP_TRY(hipSetDevice(s->device));
+    for (pdhg_handle *q : g.sh) {
+      const int64_t cnt = g.row_lo[q->rank + 1] - g.row_lo[q->rank];
+      if (q != s && cnt > 0)
+        HIP_TRY(hipMemcpyAsync(sel(s) + g.row_lo[q->rank], sel(q) + g.row_lo[q->rank], sizeof(double) * (size_t)cnt,
+                               hipMemcpyDeviceToDevice, s->stream));
+    }
+  }
+  return p2p_barrier(g);
+}
+
+// The k scalars every shard left in its scal_dev, combined over ALL ranks in
+// rank order on the host: entries [0, nsum) are added, [nsum, k) are maxed.
+// Every rank computes the same bits.  Synchronises the streams.
+int combine_scalars(const Shards &L, int k, int nsum, double *out) {
+  if (k > SCAL_MAX) return fail(-1, "too many scalars in one reduction");
+  DistGroup *g = L.g;
+  if (!g || g->all_local()) {
+    for (int i = 0; i < L.count; ++i) {
+      pdhg_handle *s = L.p[i];
+      HIP_TRY(hipSetDevice(s->device));
+      HIP_TRY(hipMemcpyAsync(s->scal_host, s->scal_dev, sizeof(double) * k, hipMemcpyDeviceToHost, s->stream));
+    }
+    for (int i = 0; i < L.count; ++i) {
+      pdhg_handle *s = L.p[i];
+      HIP_TRY(hipSetDevice(s->device));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    for (int q = 0; q < k; ++q) {
+      double v = L.p[0]->scal_host[q];
+      for (int i = 1; i < L.count; ++i) {
+        const double t = L.p[i]->scal_host[q];
+        v = (q < nsum) ? v + t : std::fmax(v, t);
+      }
+      out[q] = v;
+    }
+    return 0;
+  }
+  // one local shard per process: gather everybody's scalars through RCCL
+  pdhg_handle *s = L.p[0];
+  HIP_TRY(hipSetDevice(s->device));
+  NCCL_TRY(ncclAllGather(s->scal_dev, s->scal_all, (size_t)SCAL_MAX, ncclDouble, g->comm[0], s->stream));
+  HIP_TRY(hipMemcpyAsync(s->scal_host, s->scal_all, sizeof(double) * SCAL_MAX * g->world, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  for (int q = 0; q < k; ++q) {
+    double v = s->scal_host[q];
+    for (int r = 1; r < g->world; ++r) {
+      const double t = s->scal_host[(size_t)r * SCAL_MAX + q];
+      v = (q < nsum) ? v + t : std::fmax(v, t);
+    }
+    out[q] = v;
+  }
+  return 0;
+}
+
+// ---- row partition (host) -----------------------------------------------------
+
+// Contiguous row ranges balanced by nonzeros; equalities-first order is kept
+// because the ranges are contiguous.  bounds[world+1].
+void partition_rows_by_nnz(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int base, int world,
+                           std::vector<int64_t> &bounds) {
+  const int64_t nnz = colptr[n] - base;
+  std::vector<int64_t> prefix((size_t)m + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int64_t r = rowval[k] - base;
+    if (r >= 0 && r < m) prefix[(size_t)r + 1] += 1;
+  }
+  for (int64_t i = 0; i < m; ++i) prefix[(size_t)i + 1] += prefix[(size_t)i];
+  bounds.assign((size_t)world + 1, 0);
+  for (int p = 1; p < world; ++p) {
+    // first row index r with prefix[r] >= nnz*p/world (exact rational compare)
+    const __int128 target_num = (__int128)nnz * p;     // target = target_num / world
+    int64_t lo = 0, hi = m;                            // search over prefix[0..m]
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) / 2;
+      if ((__int128)prefix[(size_t)mid] * world < target_num) lo = mid + 1; else hi = mid;
+    }
+    bounds[(size_t)p] = std::min<int64_t>(std::max<int64_t>(lo, bounds[(size_t)p - 1]), m);
+  }
+  bounds[(size_t)world] = m;
+}
+
+// CSC of rows [lo, hi) of a CSC matrix (row indices rebased to 0, 0-based output).
+void slice_csc_rows(int64_t n, const int64_t *colptr, const int64_t *rowval, const double *nzval, int base,
+                    int64_t lo, int64_t hi, std::vector<int64_t> &cp, std::vector<int64_t> &rv, std::vector<double> &nv) {
+  cp.assign((size_t)n + 1, 0);
+  parallel_ranges((int)std::min<int64_t>(n, INT32_MAX), 1 << 16, [&](int jb, int je) {
+    for (int64_t j = jb; j < je; ++j) {
+      int64_t cnt = 0;
+      for (int64_t k = colptr[j] - base; k < colptr[j + 1] - base; ++k) {
+        const int64_t r = rowval[k] - base;
+        cnt += (r >= lo && r < hi);
+      }
+      cp[(size_t)j + 1] = cnt;
+    }
+  });
+  for (int64_t j = 0; j < n; ++j) cp[(size_t)j + 1] += cp[(size_t)j];
+  rv.resize((size_t)cp[(size_t)n]);
+  nv.resize((size_t)cp[(size_t)n]);
+  parallel_ranges((int)std::min<int64_t>(n, INT32_MAX), 1 << 16, [&](int jb, int je) {
+    for (int64_t j = jb; j < je; ++j) {
+      int64_t pos = cp[(size_t)j];
+      for (int64_t k = colptr[j] - base; k < colptr[j + 1] - base; ++k) {
+        const int64_t r = rowval[k] - base;
+        if (r >= lo && r < hi) { rv[(size_t)pos] = r - lo; nv[(size_t)pos] = nzval[k]; ++pos; }
+      }
+    }
+  });
+}
+
+}  // namespace

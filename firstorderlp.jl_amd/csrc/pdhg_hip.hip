@@ -41,6 +41,8 @@
 #include "rescale_kernels.hpp"
 #include "layout.hpp"
 
+namespace { struct DistGroup; }
+
 struct pdhg_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -69,8 +71,6 @@ struct pdhg_handle {
   int pAt_stride = 0;
   int ew_grid_n = 1, ew_grid_m = 1, ew_grid_nm = 1;
 
-  double *h_out = nullptr;  // pinned, device-visible, 8 doubles
-  double *d_out = nullptr;
 
   // evaluation branch (N1), allocated on first use
   double *E = nullptr, *Dv = nullptr, *c_o = nullptr, *b_o = nullptr, *lb_o = nullptr, *ub_o = nullptr;
@@ -85,7 +85,11 @@ struct pdhg_handle {
   uint64_t state_version = 1;                      // bumped by everything that moves x, y, the sums or A
   uint64_t ev_cversion[2] = {0, 0}, avg_version = 0;
   double *tr_g = nullptr, *tr_dir = nullptr, *tr_thr = nullptr;  // n+m each
-  double *ev_partials = nullptr, *ev_out = nullptr, *ev_host = nullptr;
+  double *ev_partials = nullptr;
+  double *ev_xg = nullptr;                         // [n_alloc] full x at the evaluated point (group only)
+  // the point being evaluated and its products (set by point_products)
+  const double *pt_x = nullptr, *pt_y = nullptr;
+  double *pt_ax = nullptr, *pt_aty = nullptr, *pt_qx = nullptr;
   int ev_grid = 1;
   bool has_original = false;
 
@@ -93,11 +97,27 @@ struct pdhg_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int64_t prof_count[PDHG_K_COUNT] = {0};
   double prof_ms[PDHG_K_COUNT] = {0};
-  bool dist_pending = false;
-  std::vector<int> dist_part_wg;   // workgroup boundaries of the parts handed out by pdhg_dist_parts
+
+  // ---- row-partitioned form (dist.hpp).  A plain handle is rank 0 of 1: it owns
+  // every column and every row, and all of the fields below keep their defaults.
+  pdhg_handle *self = nullptr;     // == this (storage of the one-element shard list)
+  DistGroup *grp = nullptr;        // shared by the shards of a group
+  int rank = 0, world = 1;
+  int64_t clo = 0, cn = 0;         // owned column slice [clo, clo + cn) of the n-vectors
+  int64_t n_alloc = 0;             // length of the n-vectors that take part in collectives (world * S >= n)
+  int64_t row_lo = 0;              // first GLOBAL row of this shard (m is the local row count)
+  int64_t m_global = 0;
+  double *dn_buf = nullptr;        // [n_alloc] gather / partial buffer (group only)
+  double *dm_buf = nullptr;        // [m_global] row-gather buffer (group only)
+  // scalar results: scal_dev[SCAL_MAX] on the device, scal_all[world*SCAL_MAX] (RCCL gather), pinned scal_host
+  double *scal_dev = nullptr, *scal_all = nullptr, *scal_host = nullptr;
 };
 
+#include "dist.hpp"
+
 namespace {
+
+void destroy_shard(pdhg_handle *h);
 
 int ew_grid(int64_t len) {
   int64_t g = (len + TPB - 1) / TPB;
@@ -167,58 +187,34 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
   return 0;
 }
 
-// MODE_PLAIN product restricted to the tiled workgroups [g0, g1) (their rows are a
-// contiguous range of the output); `with_long` also runs the long-row path.
-// The kernel is the one launch_spmv uses: the per-wave / per-workgroup tables
-// are simply passed from offset g0 (row numbers and entry offsets are absolute).
-int launch_spmv_plain_part(pdhg_handle *h, const CsrDev &D, const double *xin, double *out,
-                           int g0, int g1, bool with_long) {
-  if (!D.tiled) return fail(-1, "partial launch needs the tiled layout");
-  EpiArgs e{};
-  e.out = out;
-  if (with_long && D.nlong > 0) {
-    hipLaunchKernelGGL(spmv_long_partial_kernel, dim3(D.nchunks), dim3(TPB), 0, h->stream,
-                       D.view(), xin, D.chunk_row, D.chunk_off, D.chunk_partial);
-    hipLaunchKernelGGL(spmv_long_final_kernel<MODE_PLAIN>, dim3(D.long_grid), dim3(TPB), 0, h->stream,
-                       D.long_row, D.long_chunk_ptr, D.nlong, D.chunk_partial, e, D.grid);
-  }
-  if (g1 > g0) {
-    const size_t lds = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_scratch ? TW_WPB * WAVE : 0));
-    const int w0 = g0 * TW_WPB;
-    if (D.tw_scratch) {
-      int rc = ensure_lds_limit(h, MODE_PLAIN, true, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, true>);
-      if (rc) return rc;
-      hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, true>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
-                         D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
-                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
-    } else {
-      int rc = ensure_lds_limit(h, MODE_PLAIN, false, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, false>);
-      if (rc) return rc;
-      hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, false>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
-                         D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
-                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
-    }
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
+// K1+K2 on this shard's column slice (the whole vector for a plain handle).
+// QP: Q is replicated and acts on the full x (kept full on every shard).
 int launch_primal(pdhg_handle *h, double tau, double theta, bool write_xbar) {
   ProfScope ps(h, PDHG_K_PRIMAL);
-  const int n = (int)h->n;
   if (h->has_q) {
     EpiArgs e{};
     e.out = h->qx;
     int rc = launch_spmv<MODE_PLAIN>(h, h->Q, h->x, e);
     if (rc) return rc;
   }
-  const int grid = ew_grid((h->n + 1) / 2);
-#define PK(HQ, WX)                                                                  \
-  hipLaunchKernelGGL((primal_kernel<HQ, WX>), dim3(grid), dim3(TPB), 0, h->stream, n, \
-                     h->x, h->c, h->aty, h->qx, h->lb, h->ub, tau, theta, h->x_next, h->xbar)
+  const int n = (int)h->cn;
+  const int64_t o = h->clo;
+  const int grid = ew_grid((h->cn + 1) / 2);
+#define PK(HQ, WX)                                                                           \
+  hipLaunchKernelGGL((primal_kernel<HQ, WX>), dim3(grid), dim3(TPB), 0, h->stream, n,        \
+                     h->x + o, h->c + o, h->aty + o, h->has_q ? h->qx + o : nullptr, h->lb + o, h->ub + o, tau, theta, \
+                     h->x_next + o, h->xbar + o)
   if (h->has_q) { if (write_xbar) PK(true, true); else PK(true, false); }
   else          { if (write_xbar) PK(false, true); else PK(false, false); }
 #undef PK
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_xbar(pdhg_handle *h, double theta) {
+  const int64_t o = h->clo;
+  hipLaunchKernelGGL(xbar_kernel, dim3(ew_grid(h->cn)), dim3(TPB), 0, h->stream, (int)h->cn, h->x + o, h->x_next + o,
+                     theta, h->xbar + o);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -246,7 +242,7 @@ int launch_aty_plain(pdhg_handle *h, const double *yin, double *out) {
   return launch_spmv<MODE_PLAIN>(h, h->At, yin, e);
 }
 
-// 0.5 * dx' Q dx partials into pQ (QP only)
+// 0.5 * dx' Q dx partials into pQ (QP only; full vectors -- replicated in a group)
 int launch_q_interaction(pdhg_handle *h, int *count) {
   *count = 0;
   if (!h->has_q) return 0;
@@ -262,30 +258,122 @@ int launch_q_interaction(pdhg_handle *h, int *count) {
   return 0;
 }
 
-int finish_scalars(pdhg_handle *h, const double *p_int, int n_int, int stride_int,
-                   const double *p_dy, int n_dy, int q_count, double out[5]) {
-  {
-    ProfScope ps(h, PDHG_K_FINAL);
-    FinalSpec sp{};
-    sp.ptr[0] = p_int;                  sp.count[0] = n_int;
-    sp.ptr[1] = p_int + stride_int;     sp.count[1] = n_int;
-    sp.ptr[2] = p_dy;                   sp.count[2] = n_dy;
-    sp.ptr[3] = p_int + 2 * stride_int; sp.count[3] = n_int;
-    sp.ptr[4] = h->pQ;                  sp.count[4] = q_count;
-    sp.out = h->d_out;
-    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, sp);
-    HIP_TRY(hipGetLastError());
-  }
-  HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  for (int q = 0; q < 5; ++q) out[q] = h->h_out[q];
-  out[4] *= 0.5;
+// second-stage reduction of the trial's block partials into scal_dev[0..5)
+int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int, const double *p_dy, int n_dy,
+                 int q_count) {
+  ProfScope ps(h, PDHG_K_FINAL);
+  FinalSpec sp{};
+  sp.ptr[0] = p_int;                  sp.count[0] = n_int;
+  sp.ptr[1] = p_int + stride_int;     sp.count[1] = n_int;
+  sp.ptr[2] = p_dy;                   sp.count[2] = n_dy;
+  sp.ptr[3] = p_int + 2 * stride_int; sp.count[3] = n_int;
+  sp.ptr[4] = h->pQ;                  sp.count[4] = q_count;
+  sp.out = h->scal_dev;
+  hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, sp);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
 int check_handle(pdhg_handle *h) {
   if (!h) return fail(-1, "null handle");
   HIP_TRY(hipSetDevice(h->device));
+  return 0;
+}
+
+int sync_all(const Shards &L) {
+  FOR_SHARDS(L, s) HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+void bump_version(const Shards &L) {   // x, y, the running sums or A change: cached A*x / A'*y are stale
+  for (int i = 0; i < L.count; ++i) L.p[i]->state_version += 1;
+}
+
+// ---- moving distributed vectors -------------------------------------------------
+// "column vectors": n-vectors whose valid part on a shard is its own slice;
+// "row vectors": m-vectors, each shard holds its rows.
+
+// full copy of a column vector on every shard's device: dst[0..n) (dst holds n_alloc)
+template <typename Src, typename Dst>
+int gather_cols_device(const Shards &L, Src src, Dst dst) {
+  if (!L.g) {
+    pdhg_handle *s = L.p[0];
+    if (src(s) != dst(s))
+      HIP_TRY(hipMemcpyAsync(dst(s), src(s), sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, s->stream));
+    return 0;
+  }
+  FOR_SHARDS(L, s) {
+    if (src(s) != dst(s) && s->cn > 0)
+      HIP_TRY(hipMemcpyAsync(dst(s) + s->clo, src(s) + s->clo, sizeof(double) * (size_t)s->cn,
+                             hipMemcpyDeviceToDevice, s->stream));
+  }
+  return dist_all_gather(*L.g, dst, L.g->S);
+}
+
+// a column vector to a host array of length n (every process gets all of it); caller syncs
+template <typename Src>
+int cols_to_host(const Shards &L, Src src, double *host) {
+  if (!L.g || L.g->all_local()) {
+    FOR_SHARDS(L, s) {
+      if (s->cn > 0)
+        HIP_TRY(hipMemcpyAsync(host + s->clo, src(s) + s->clo, sizeof(double) * (size_t)s->cn, hipMemcpyDeviceToHost, s->stream));
+    }
+    return 0;
+  }
+  int rc = gather_cols_device(L, src, [](pdhg_handle *s) { return s->dn_buf; });
+  if (rc) return rc;
+  pdhg_handle *s = L.p[0];
+  HIP_TRY(hipMemcpyAsync(host, s->dn_buf, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost, s->stream));
+  return 0;
+}
+
+// a row vector to a host array of length m_global; caller syncs
+template <typename Src>
+int rows_to_host(const Shards &L, Src src, double *host) {
+  if (!L.g || L.g->all_local()) {
+    FOR_SHARDS(L, s) {
+      if (s->m > 0)
+        HIP_TRY(hipMemcpyAsync(host + s->row_lo, src(s), sizeof(double) * (size_t)s->m, hipMemcpyDeviceToHost, s->stream));
+    }
+    return 0;
+  }
+  pdhg_handle *s = L.p[0];
+  HIP_TRY(hipSetDevice(s->device));
+  if (s->m > 0)
+    HIP_TRY(hipMemcpyAsync(s->dm_buf + s->row_lo, src(s), sizeof(double) * (size_t)s->m, hipMemcpyDeviceToDevice, s->stream));
+  int rc = dist_all_gather_rows(*L.g, [](pdhg_handle *q) { return q->dm_buf; });
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(host, s->dm_buf, sizeof(double) * (size_t)s->m_global, hipMemcpyDeviceToHost, s->stream));
+  return 0;
+}
+
+// host arrays (global length) to the shards: column vectors are stored in full, row vectors by rows
+template <typename Dst>
+int cols_from_host(const Shards &L, const double *host, Dst dst) {
+  FOR_SHARDS(L, s) {
+    if (s->n > 0) HIP_TRY(hipMemcpyAsync(dst(s), host, sizeof(double) * (size_t)s->n, hipMemcpyHostToDevice, s->stream));
+  }
+  return 0;
+}
+template <typename Dst>
+int rows_from_host(const Shards &L, const double *host, Dst dst) {
+  FOR_SHARDS(L, s) {
+    if (s->m > 0)
+      HIP_TRY(hipMemcpyAsync(dst(s), host + s->row_lo, sizeof(double) * (size_t)s->m, hipMemcpyHostToDevice, s->stream));
+  }
+  return 0;
+}
+
+// A'y for a row vector y (each shard its rows) into the column vector `out`
+// (valid on the owned slice; out holds n_alloc in a group).
+template <typename Yin, typename Out>
+int dual_product(const Shards &L, Yin yin, Out out) {
+  int rc;
+  FOR_SHARDS(L, s) { if ((rc = launch_aty_plain(s, yin(s), out(s)))) return rc; }
+  if (L.g) {
+    ProfScope ps(L.p[0], PDHG_K_REDUCE_SCATTER);
+    if ((rc = dist_reduce_scatter(*L.g, out, L.g->S))) return rc;
+  }
   return 0;
 }
 
@@ -318,7 +406,28 @@ int choose_tile_shift(int64_t cols, int64_t nnz, int64_t rows) {
   return (big_vector && short_rows) ? shift : 0;
 }
 
-// CSC (any int64 base) -> int32 CSR of the transpose (direct) and CSR (counting sort).
+int host_threads() {
+  int threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char *ev = getenv("PDHG_HOST_THREADS")) threads = std::max(1, atoi(ev));
+  return threads;
+}
+
+template <typename F>
+void run_threads(int T, F f) {
+  if (T <= 1) { f(0); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < T; ++t) pool.emplace_back([=, &f] { f(t); });
+  for (std::thread &th : pool) th.join();
+}
+
+// CSC (any int64 base) -> int32 CSR of the transpose (direct) and CSR (stable sort by row).
+// The sort is a two-level bucket sort on host threads, O(nnz) work in total:
+// thread t scans ITS column range and appends every entry to the bucket of the
+// entry's row range (T buckets; per-(thread, bucket) output segments come from a
+// small T x T count table, so bucket b holds its entries in ascending column
+// order); thread b then counting-sorts bucket b by row.  Each row receives its
+// entries in ascending column order -- what the sequential loop produces -- and
+// the result does not depend on T.
 int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
                 const int64_t *rowval, const double *nzval, int base,
                 std::vector<int> &t_rowptr, std::vector<int> &t_col, std::vector<double> &t_val,
@@ -336,76 +445,85 @@ int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
   }
   t_col.resize(nnz);
   t_val.resize(nnz);
-  // CSR(A') is the CSC input itself (32-bit, 0-based); copied on host threads.
+  rowptr.assign(rows + 1, 0);
+  col.resize(nnz);
+  val.resize(nnz);
+  const int T = (nnz >= (1 << 22) && rows >= 1024 && cols >= 1024) ? host_threads() : 1;
   std::atomic<int> bad{0};
-  if (nnz > 0) parallel_ranges((int)std::min<int64_t>(nnz, 1 << 20), 1 << 15, [&](int cb, int ce) {
-    const int64_t chunks = std::min<int64_t>(nnz, 1 << 20);
-    const int64_t kb = nnz * cb / chunks, ke = nnz * ce / chunks;
-    for (int64_t k = kb; k < ke; ++k) {
+  if (T == 1) {
+    for (int64_t k = 0; k < nnz; ++k) {
+      const int64_t r = rowval[k] - base;
+      if (r < 0 || r >= rows) return fail(-1, "rowval out of range");
+      t_col[k] = (int)r;
+      t_val[k] = nzval[k];
+      rowptr[r + 1] += 1;
+    }
+    for (int64_t i = 0; i < rows; ++i) rowptr[i + 1] += rowptr[i];
+    std::vector<int> next(rowptr.begin(), rowptr.end() - 1);
+    for (int64_t j = 0; j < cols; ++j)
+      for (int k = t_rowptr[j]; k < t_rowptr[j + 1]; ++k) {
+        const int p = next[t_col[k]]++;
+        col[p] = (int)j;
+        val[p] = t_val[k];
+      }
+    return 0;
+  }
+  const int64_t rpb = (rows + T - 1) / T;                 // rows per bucket
+  auto col_begin = [&](int t) { return (int64_t)cols * t / T; };
+  std::vector<int64_t> cnt((size_t)T * T, 0);             // cnt[t*T + b]
+  // pass 1: CSR(A') = the CSC input narrowed to 32 bits; bucket counts
+  run_threads(T, [&](int t) {
+    int64_t *c = cnt.data() + (size_t)t * T;
+    for (int64_t k = t_rowptr[col_begin(t)]; k < t_rowptr[col_begin(t + 1)]; ++k) {
       const int64_t r = rowval[k] - base;
       if (r < 0 || r >= rows) { bad.store(1); return; }
       t_col[k] = (int)r;
       t_val[k] = nzval[k];
+      c[r / rpb] += 1;
     }
   });
   if (bad.load()) return fail(-1, "rowval out of range");
-  // CSR(A): a counting sort by row.  Every thread owns a contiguous range of ROWS
-  // and walks all columns in ascending order, counting and then placing only the
-  // entries of its rows -- so each row receives its entries in ascending column
-  // order (what the sequential loop produces) and the writes of a thread stay
-  // inside its own slice of col/val.
-  rowptr.assign(rows + 1, 0);
-  const int row_grain = nnz >= (1 << 22) ? 1 : INT32_MAX;   // below ~4M nonzeros one thread is faster
-  parallel_ranges((int)rows, row_grain, [&](int rb, int re) {
-    for (int64_t k = 0; k < nnz; ++k) {
-      const int r = t_col[k];
-      if (r >= rb && r < re) rowptr[r + 1] += 1;
-    }
-  });
-  for (int64_t i = 0; i < rows; ++i) rowptr[i + 1] += rowptr[i];
-  col.resize(nnz);
-  val.resize(nnz);
-  std::vector<int> next(rowptr.begin(), rowptr.end() - 1);
-  parallel_ranges((int)rows, row_grain, [&](int rb, int re) {
-    for (int64_t j = 0; j < cols; ++j) {
+  std::vector<int64_t> off((size_t)T * T), bstart((size_t)T + 1, 0);
+  for (int b = 0; b < T; ++b) {
+    int64_t run = bstart[b];
+    for (int t = 0; t < T; ++t) { off[(size_t)t * T + b] = run; run += cnt[(size_t)t * T + b]; }
+    bstart[b + 1] = run;
+  }
+  // pass 2: scatter (row, col, val) into the buckets
+  std::vector<int> brow((size_t)nnz), bcol((size_t)nnz);
+  std::vector<double> bval((size_t)nnz);
+  run_threads(T, [&](int t) {
+    int64_t *o = off.data() + (size_t)t * T;
+    for (int64_t j = col_begin(t); j < col_begin(t + 1); ++j)
       for (int k = t_rowptr[j]; k < t_rowptr[j + 1]; ++k) {
         const int r = t_col[k];
-        if (r >= rb && r < re) {
-          const int p = next[r]++;
-          col[p] = (int)j;
-          val[p] = t_val[k];
-        }
+        const int64_t p = o[r / rpb]++;
+        brow[p] = r; bcol[p] = (int)j; bval[p] = t_val[k];
       }
+  });
+  // pass 3: row counts (every bucket owns its rows), serial prefix, placement
+  run_threads(T, [&](int b) {
+    for (int64_t p = bstart[b]; p < bstart[b + 1]; ++p) rowptr[brow[p] + 1] += 1;
+  });
+  for (int64_t i = 0; i < rows; ++i) rowptr[i + 1] += rowptr[i];
+  run_threads(T, [&](int b) {
+    const int64_t r0 = std::min<int64_t>(rows, rpb * b), r1 = std::min<int64_t>(rows, rpb * (b + 1));
+    std::vector<int> next(rowptr.begin() + r0, rowptr.begin() + r1);
+    for (int64_t p = bstart[b]; p < bstart[b + 1]; ++p) {
+      const int q = next[brow[p] - r0]++;
+      col[q] = bcol[p];
+      val[q] = bval[p];
     }
   });
   return 0;
 }
 
-}  // namespace
-
-// ================================================================== C ABI
-
-extern "C" {
-
-const char *pdhg_last_error(void) { return g_last_error.c_str(); }
-int pdhg_abi_version(void) { return 4; }
-
-const char *pdhg_kernel_name(int kernel_id) {
-  switch (kernel_id) {
-    case PDHG_K_PRIMAL: return "primal_kernel";
-    case PDHG_K_SPMV_DUAL: return "spmv_stream_kernel<MODE_DUAL>";
-    case PDHG_K_SPMV_ATY: return "spmv_stream_kernel<MODE_ATY>";
-    case PDHG_K_FINAL: return "final_reduce_kernel";
-    case PDHG_K_ACCEPT: return "accept_kernel";
-    default: return "?";
-  }
-}
-
-int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
-                const int64_t *colptr, const int64_t *rowval, const double *nzval,
-                int index_base, const double *c, const double *b, const double *lb,
-                const double *ub, int64_t num_equalities, int device_id, void *stream) {
-  if (!out) return fail(-1, "out == NULL");
+// One shard: device layouts + vectors for the rows it is given.  n_alloc >= n is the
+// allocation length of the n-vectors that take part in collectives.
+int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
+                 const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                 int index_base, const double *c, const double *b, const double *lb,
+                 const double *ub, int64_t num_equalities, int device_id, void *stream, int64_t n_alloc) {
   *out = nullptr;
   if (index_base != 0 && index_base != 1) return fail(-1, "index_base must be 0 or 1");
   if (num_equalities < 0 || num_equalities > m) return fail(-1, "num_equalities out of range");
@@ -418,11 +536,12 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   if (dev < 0) HIP_TRY(hipGetDevice(&dev));
   if (dev >= ndev) return fail(-1, "device_id out of range");
   HIP_TRY(hipSetDevice(dev));
+  n_alloc = std::max(n_alloc, n);
 
   const bool verbose = getenv("PDHG_VERBOSE") != nullptr;   // phase timings of the set-up on stderr
   auto now = [] { return std::chrono::steady_clock::now(); };
-  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-    return std::chrono::duration<double>(b - a).count();
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+    return std::chrono::duration<double>(b2 - a).count();
   };
   const auto t_start = now();
   std::vector<int> t_rowptr, t_col, rowptr, col;
@@ -432,8 +551,10 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   const auto t_conv = now();
 
   pdhg_handle *h = new pdhg_handle();
+  h->self = h;
   h->device = dev;
   h->m = m; h->n = n; h->nnz = nnz; h->num_eq = num_equalities;
+  h->cn = n; h->n_alloc = n_alloc; h->m_global = m;
   const char *env = getenv("PDHG_XCD_REMAP");
   h->remap = !(env && env[0] == '0');
   if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
@@ -442,7 +563,7 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     if (e != hipSuccess) { delete h; return fail((int)e, "hipStreamCreate failed"); }
     h->own_stream = true;
   }
-#define CK(expr) do { int _rc = (expr); if (_rc) { pdhg_destroy(h); return _rc; } } while (0)
+#define CK(expr) do { int _rc = (expr); if (_rc) { destroy_shard(h); return _rc; } } while (0)
   CK(build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, choose_tile_shift(n, nnz, m)));
   const auto t_a = now();
   CK(build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, choose_tile_shift(m, nnz, n)));
@@ -457,22 +578,22 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     return 0;
   };
   CK(up(&h->c, c, n)); CK(up(&h->b, b, m)); CK(up(&h->lb, lb, n)); CK(up(&h->ub, ub, n));
-  CK(alloc_zero(&h->x, n)); CK(alloc_zero(&h->x_next, n)); CK(alloc_zero(&h->xbar, n));
+  CK(alloc_zero(&h->x, n_alloc)); CK(alloc_zero(&h->x_next, n_alloc)); CK(alloc_zero(&h->xbar, n_alloc));
   CK(alloc_zero(&h->y, m)); CK(alloc_zero(&h->y_next, m));
-  CK(alloc_zero(&h->aty, n + 1)); CK(alloc_zero(&h->aty_next, n + 1));
+  CK(alloc_zero(&h->aty, n_alloc + 1)); CK(alloc_zero(&h->aty_next, n_alloc + 1));
   CK(alloc_zero(&h->sum_x, n)); CK(alloc_zero(&h->sum_y, m));
-  CK(alloc_zero(&h->tmp_n, n)); CK(alloc_zero(&h->tmp_m, m));
+  CK(alloc_zero(&h->tmp_n, n_alloc)); CK(alloc_zero(&h->tmp_m, m));
   h->ew_grid_n = ew_grid(n); h->ew_grid_m = ew_grid(m); h->ew_grid_nm = ew_grid(std::max(n, m));
   h->pAt_stride = std::max(h->At.slots(), h->ew_grid_n);
   CK(alloc_zero(&h->pA, std::max(h->A.slots(), 1)));
   CK(alloc_zero(&h->pAt, 3 * (int64_t)std::max(h->pAt_stride, 1)));
   CK(alloc_zero(&h->pQ, h->ew_grid_n));
-  CK(alloc_zero(&h->d_out, 8));
+  CK(alloc_zero(&h->scal_dev, SCAL_MAX));
   {
-    hipError_t e = hipHostMalloc((void **)&h->h_out, 8 * sizeof(double), hipHostMallocDefault);
-    if (e != hipSuccess) { pdhg_destroy(h); return fail((int)e, "hipHostMalloc failed"); }
+    hipError_t e = hipHostMalloc((void **)&h->scal_host, sizeof(double) * SCAL_MAX * DIST_MAX_WORLD, hipHostMallocDefault);
+    if (e != hipSuccess) { destroy_shard(h); return fail((int)e, "hipHostMalloc failed"); }
     e = hipEventCreate(&h->ev0); if (e == hipSuccess) e = hipEventCreate(&h->ev1);
-    if (e != hipSuccess) { pdhg_destroy(h); return fail((int)e, "hipEventCreate failed"); }
+    if (e != hipSuccess) { destroy_shard(h); return fail((int)e, "hipEventCreate failed"); }
   }
 #undef CK
   HIP_TRY(hipDeviceSynchronize());
@@ -480,106 +601,392 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   return 0;
 }
 
-int pdhg_set_objective_matrix(pdhg_handle *h, int64_t q_nnz, const int64_t *q_colptr,
-                              const int64_t *q_rowval, const double *q_nzval, int index_base) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
-  if (h->has_q) { free_csr_dev(h->Q); free_csr_dev(h->Qt); h->has_q = false; }
-  bool all_zero = true;
-  for (int64_t k = 0; k < q_nnz; ++k) if (q_nzval[k] != 0.0) all_zero = false;
-  if (all_zero) return 0;  // iszero(objective_matrix): LP path (pdhg.jl:536)
-  std::vector<int> t_rowptr, t_col, rowptr, col;
-  std::vector<double> t_val, val;
-  rc = csc_to_both(h->n, h->n, q_nnz, q_colptr, q_rowval, q_nzval, index_base, t_rowptr, t_col, t_val, rowptr, col, val);
-  if (rc) return rc;
-  if ((rc = build_csr_dev(h->Q, (int)h->n, (int)h->n, rowptr, col, val, h->remap))) return rc;
-  if ((rc = build_csr_dev(h->Qt, (int)h->n, (int)h->n, t_rowptr, t_col, t_val, h->remap))) return rc;
-  if (!h->qx) { if ((rc = alloc_zero(&h->qx, h->n))) return rc; }
-  if (!h->tmp_n2) { if ((rc = alloc_zero(&h->tmp_n2, h->n))) return rc; }
-  h->has_q = true;
-  return 0;
-}
-
-void pdhg_destroy(pdhg_handle *h) {
+void destroy_shard(pdhg_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   free_csr_dev(h->A); free_csr_dev(h->At); free_csr_dev(h->Q); free_csr_dev(h->Qt);
   double *bufs[] = {h->c, h->b, h->lb, h->ub, h->x, h->x_next, h->xbar, h->y, h->y_next,
                     h->aty, h->aty_next, h->sum_x, h->sum_y, h->qx, h->tmp_n, h->tmp_n2,
-                    h->tmp_m, h->pA, h->pAt, h->pQ, h->d_out, h->E, h->Dv, h->c_o, h->b_o, h->lb_o,
+                    h->tmp_m, h->pA, h->pAt, h->pQ, h->scal_dev, h->scal_all, h->dn_buf, h->dm_buf,
+                    h->E, h->Dv, h->c_o, h->b_o, h->lb_o,
                     h->ub_o, h->x_r, h->y_r, h->px_avg, h->py_avg, h->ev_ax, h->ev_aty, h->tr_g,
-                    h->tr_dir, h->tr_thr, h->ev_partials, h->ev_out, h->ev_cax[0], h->ev_cax[1],
-                    h->ev_caty[0], h->ev_caty[1], h->ev_cqx[0], h->ev_cqx[1], h->ev_qx};
+                    h->tr_dir, h->tr_thr, h->ev_partials, h->ev_cax[0], h->ev_cax[1],
+                    h->ev_caty[0], h->ev_caty[1], h->ev_cqx[0], h->ev_cqx[1], h->ev_qx, h->ev_xg};
   for (double *p : bufs) if (p) (void)hipFree(p);
-  if (h->h_out) (void)hipHostFree(h->h_out);
-  if (h->ev_host) (void)hipHostFree(h->ev_host);
+  if (h->scal_host) (void)hipHostFree(h->scal_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
-int pdhg_trial_primal(pdhg_handle *h, double step_size, double primal_weight) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  return launch_primal(h, step_size / primal_weight, 0.0, false);
+void destroy_group(DistGroup *g) {
+  if (!g) return;
+  for (size_t i = 0; i < g->sh.size(); ++i) {
+    (void)hipSetDevice(g->sh[i]->device);
+    (void)hipStreamSynchronize(g->sh[i]->stream);
+  }
+  for (ncclComm_t c : g->comm) if (c) (void)ncclCommDestroy(c);
+  for (int f = 0; f < 2; ++f)
+    for (size_t i = 0; i < g->ev[f].size(); ++i) {
+      (void)hipSetDevice(g->sh[i]->device);
+      if (g->ev[f][i]) (void)hipEventDestroy(g->ev[f][i]);
+    }
+  for (pdhg_handle *s : g->sh) destroy_shard(s);
+  delete g;
 }
 
-static int trial_dual_from(pdhg_handle *h, double step_size, double primal_weight, double out[5]) {
+// Build rank `rank`'s shard of the GLOBAL problem: rows row_lo[rank]..row_lo[rank+1), all columns.
+int create_rank_shard(DistGroup *g, int rank, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                      const double *nzval, int base, const double *c, const double *b, const double *lb,
+                      const double *ub, int device_id, void *stream, pdhg_handle **out) {
+  const int64_t lo = g->row_lo[(size_t)rank], hi = g->row_lo[(size_t)rank + 1];
+  std::vector<int64_t> cp, rv;
+  std::vector<double> nv;
+  slice_csc_rows(n, colptr, rowval, nzval, base, lo, hi, cp, rv, nv);
+  const int64_t ne = std::min<int64_t>(std::max<int64_t>(g->num_eq_global - lo, 0), hi - lo);
+  pdhg_handle *s = nullptr;
+  int rc = create_shard(&s, hi - lo, n, cp[(size_t)n], cp.data(), rv.data(), nv.data(), 0, c, b ? b + lo : nullptr,
+                        lb, ub, ne, device_id, stream, g->world * g->S);
+  if (rc) return rc;
+  s->grp = g;
+  s->rank = rank;
+  s->world = g->world;
+  s->row_lo = lo;
+  s->m_global = g->m_global;
+  s->clo = std::min<int64_t>(n, (int64_t)rank * g->S);
+  s->cn = std::min<int64_t>(n, (int64_t)(rank + 1) * g->S) - s->clo;
+  if ((rc = alloc_zero(&s->dn_buf, s->n_alloc))) { destroy_shard(s); return rc; }
+  if ((rc = alloc_zero(&s->dm_buf, g->m_global))) { destroy_shard(s); return rc; }
+  if ((rc = alloc_zero(&s->scal_all, (int64_t)SCAL_MAX * g->world))) { destroy_shard(s); return rc; }
+  *out = s;
+  return 0;
+}
+
+int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int base,
+                        int64_t num_equalities, int world) {
+  if (world < 1 || world > DIST_MAX_WORLD) return fail(-1, "world size out of range (1..64)");
+  if (!colptr) return fail(-1, "null input array");
+  g->world = world;
+  g->n = n;
+  g->m_global = m;
+  g->num_eq_global = num_equalities;
+  const int64_t per = (n + world - 1) / world;
+  g->S = std::max<int64_t>(16, (per + 15) / 16 * 16);      // slice stride: whole 128-byte lines
+  partition_rows_by_nnz(m, n, colptr, rowval, base, world, g->row_lo);
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+
+extern "C" {
+
+const char *pdhg_last_error(void) { return g_last_error.c_str(); }
+int pdhg_abi_version(void) { return 5; }
+
+const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id) {
+  const bool fused = !(h && h->grp);
+  switch (kernel_id) {
+    case PDHG_K_PRIMAL: return "primal_kernel";
+    case PDHG_K_SPMV_DUAL: return (h && h->A.tiled) ? "spmv_tiled_kernel<MODE_DUAL>" : "spmv_stream_kernel<MODE_DUAL>";
+    case PDHG_K_SPMV_ATY:
+      if (h && h->At.tiled) return fused ? "spmv_tiled_kernel<MODE_ATY>" : "spmv_tiled_kernel<MODE_PLAIN>";
+      return fused ? "spmv_stream_kernel<MODE_ATY>" : "spmv_stream_kernel<MODE_PLAIN>";
+    case PDHG_K_FINAL: return "final_reduce_kernel";
+    case PDHG_K_ACCEPT: return "accept_kernel";
+    case PDHG_K_ALLGATHER: return "all_gather(xbar)";
+    case PDHG_K_REDUCE_SCATTER: return "reduce_scatter(A_p'y_p)";
+    case PDHG_K_INTERACTION: return "interaction_kernel";
+    default: return "?";
+  }
+}
+
+int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
+                const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                int index_base, const double *c, const double *b, const double *lb,
+                const double *ub, int64_t num_equalities, int device_id, void *stream) {
+  if (!out) return fail(-1, "out == NULL");
+  return create_shard(out, m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities,
+                      device_id, stream, n);
+}
+
+// ---- row-partitioned multi-GPU handles -------------------------------------------
+
+int pdhg_dist_get_unique_id(void *id) {
+  if (!id) return fail(-1, "id == NULL");
+  static_assert(sizeof(ncclUniqueId) <= PDHG_UNIQUE_ID_BYTES, "unique id does not fit the ABI's buffer");
+  ncclUniqueId u;
+  NCCL_TRY(ncclGetUniqueId(&u));
+  memset(id, 0, PDHG_UNIQUE_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+int pdhg_create_dist(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
+                     const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                     int index_base, const double *c, const double *b, const double *lb,
+                     const double *ub, int64_t num_equalities, int device_id, void *stream,
+                     const void *unique_id, int rank, int world) {
+  if (!out) return fail(-1, "out == NULL");
+  *out = nullptr;
+  if (!unique_id) return fail(-1, "unique_id == NULL");
+  if (rank < 0 || rank >= world) return fail(-1, "rank out of range");
+  if (index_base != 0 && index_base != 1) return fail(-1, "index_base must be 0 or 1");
+  if (num_equalities < 0 || num_equalities > m) return fail(-1, "num_equalities out of range");
+  if (!colptr || (nnz > 0 && (!rowval || !nzval))) return fail(-1, "null input array");
+  if (colptr[0] != index_base || colptr[n] - index_base != nnz) return fail(-1, "colptr does not match nnz / index_base");
+  DistGroup *g = new DistGroup();
+  int rc = init_group_geometry(g, m, n, colptr, rowval, index_base, num_equalities, world);
+  if (rc) { delete g; return rc; }
+  g->backend = COMM_RCCL;
+  pdhg_handle *s = nullptr;
+  rc = create_rank_shard(g, rank, n, colptr, rowval, nzval, index_base, c, b, lb, ub, device_id, stream, &s);
+  if (rc) { delete g; return rc; }
+  g->sh.push_back(s);
+  g->comm.assign(1, nullptr);
+  ncclUniqueId u;
+  memcpy(&u, unique_id, sizeof(u));
+  ncclResult_t nr = ncclCommInitRank(&g->comm[0], world, u, rank);
+  if (nr != ncclSuccess) {
+    g_last_error = std::string("ncclCommInitRank: ") + ncclGetErrorString(nr);
+    destroy_group(g);
+    return 2000 + (int)nr;
+  }
+  *out = s;
+  return 0;
+}
+
+int pdhg_create_multi(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
+                      const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                      int index_base, const double *c, const double *b, const double *lb,
+                      const double *ub, int64_t num_equalities, int n_devices, const int *device_ids) {
+  if (!out) return fail(-1, "out == NULL");
+  *out = nullptr;
+  if (n_devices < 1 || !device_ids) return fail(-1, "n_devices < 1 or device_ids == NULL");
+  if (index_base != 0 && index_base != 1) return fail(-1, "index_base must be 0 or 1");
+  if (num_equalities < 0 || num_equalities > m) return fail(-1, "num_equalities out of range");
+  if (!colptr || (nnz > 0 && (!rowval || !nzval))) return fail(-1, "null input array");
+  if (colptr[0] != index_base || colptr[n] - index_base != nnz) return fail(-1, "colptr does not match nnz / index_base");
+  DistGroup *g = new DistGroup();
+  int rc = init_group_geometry(g, m, n, colptr, rowval, index_base, num_equalities, n_devices);
+  if (rc) { delete g; return rc; }
+  // Back end: RCCL (ncclCommInitAll) when every shard has its own device; direct peer
+  // kernels when devices repeat (several shards on one GPU: tests, oversubscription)
+  // or when PDHG_COMM=p2p asks for them.
+  bool distinct = true;
+  for (int i = 0; i < n_devices; ++i)
+    for (int j = 0; j < i; ++j) if (device_ids[i] == device_ids[j]) distinct = false;
+  const char *cm = getenv("PDHG_COMM");
+  g->backend = (!distinct || (cm && !strcmp(cm, "p2p"))) ? COMM_P2P : COMM_RCCL;
+  if (g->backend == COMM_P2P && n_devices > P2P_MAX_WORLD) { delete g; return fail(-1, "peer back end supports at most 16 shards"); }
+  for (int r = 0; r < n_devices; ++r) {
+    pdhg_handle *s = nullptr;
+    rc = create_rank_shard(g, r, n, colptr, rowval, nzval, index_base, c, b, lb, ub, device_ids[r], nullptr, &s);
+    if (rc) { destroy_group(g); return rc; }
+    g->sh.push_back(s);
+  }
+  if (g->backend == COMM_RCCL) {
+    g->comm.assign((size_t)n_devices, nullptr);
+    ncclResult_t nr = ncclCommInitAll(g->comm.data(), n_devices, device_ids);
+    if (nr != ncclSuccess) {
+      g_last_error = std::string("ncclCommInitAll: ") + ncclGetErrorString(nr);
+      destroy_group(g);
+      return 2000 + (int)nr;
+    }
+  } else {
+    for (int f = 0; f < 2; ++f) g->ev[f].assign((size_t)n_devices, nullptr);
+    for (int i = 0; i < n_devices; ++i) {
+      (void)hipSetDevice(device_ids[i]);
+      for (int j = 0; j < n_devices; ++j)
+        if (device_ids[j] != device_ids[i]) {
+          hipError_t e = hipDeviceEnablePeerAccess(device_ids[j], 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+            destroy_group(g);
+            return fail((int)e, "hipDeviceEnablePeerAccess failed");
+          }
+          (void)hipGetLastError();
+        }
+      for (int f = 0; f < 2; ++f)
+        if (hipEventCreateWithFlags(&g->ev[f][(size_t)i], hipEventDisableTiming) != hipSuccess) {
+          destroy_group(g);
+          return fail(999, "hipEventCreate failed");
+        }
+    }
+  }
+  *out = g->sh[0];
+  return 0;
+}
+
+int pdhg_dist_info(pdhg_handle *h, int64_t info[8]) {
+  if (!h || !info) return fail(-1, "null argument");
+  info[0] = h->world;
+  info[1] = h->grp ? (int64_t)h->grp->sh.size() : 1;
+  info[2] = h->rank;
+  info[3] = h->grp ? h->grp->backend : -1;
+  info[4] = h->row_lo;
+  info[5] = h->row_lo + h->m;
+  info[6] = h->clo;
+  info[7] = h->clo + h->cn;
+  return 0;
+}
+
+int pdhg_set_objective_matrix(pdhg_handle *h0, int64_t q_nnz, const int64_t *q_colptr,
+                              const int64_t *q_rowval, const double *q_nzval, int index_base) {
+  int rc = check_handle(h0);
+  if (rc) return rc;
+  const Shards L = shards_of(h0);
+  bump_version(L);
+  bool all_zero = true;
+  for (int64_t k = 0; k < q_nnz; ++k) if (q_nzval[k] != 0.0) all_zero = false;
+  std::vector<int> t_rowptr, t_col, rowptr, col;
+  std::vector<double> t_val, val;
+  if (!all_zero) {
+    rc = csc_to_both(h0->n, h0->n, q_nnz, q_colptr, q_rowval, q_nzval, index_base, t_rowptr, t_col, t_val, rowptr, col, val);
+    if (rc) return rc;
+  }
+  FOR_SHARDS(L, h) {   // the objective matrix is replicated on every shard (it acts on full n-vectors)
+    if (h->has_q) { free_csr_dev(h->Q); free_csr_dev(h->Qt); h->has_q = false; }
+    if (all_zero) continue;  // iszero(objective_matrix): LP path (pdhg.jl:536)
+    if ((rc = build_csr_dev(h->Q, (int)h->n, (int)h->n, rowptr, col, val, h->remap))) return rc;
+    if ((rc = build_csr_dev(h->Qt, (int)h->n, (int)h->n, t_rowptr, t_col, t_val, h->remap))) return rc;
+    if (!h->qx) { if ((rc = alloc_zero(&h->qx, h->n))) return rc; }
+    if (!h->tmp_n2) { if ((rc = alloc_zero(&h->tmp_n2, h->n))) return rc; }
+    h->has_q = true;
+  }
+  return 0;
+}
+
+void pdhg_destroy(pdhg_handle *h) {
+  if (!h) return;
+  if (h->grp) destroy_group(h->grp);
+  else destroy_shard(h);
+}
+
+// ---- the trial step -----------------------------------------------------------------
+
+// Single GPU: K1+K2, K3+K4, K5+K6 (fused epilogues), second-stage reduction.
+static int trial_dual_single(pdhg_handle *h, double step_size, double primal_weight, double out[5]) {
   int rc;
   if ((rc = launch_dual(h, primal_weight * step_size))) return rc;
   if ((rc = launch_aty_fused(h))) return rc;
   int qcount = 0;
   if ((rc = launch_q_interaction(h, &qcount))) return rc;
-  return finish_scalars(h, h->pAt, h->At.slots(), h->pAt_stride, h->pA, h->A.slots(), qcount, out);
+  if ((rc = launch_final(h, h->pAt, h->At.slots(), h->pAt_stride, h->pA, h->A.slots(), qcount))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->scal_host, h->scal_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int q = 0; q < 5; ++q) out[q] = h->scal_host[q];
+  out[4] *= 0.5;
+  return 0;
+}
+
+// Row-partitioned group: the dual half of a trial.  xbar's owned slices are ready.
+static int trial_dual_group(const Shards &L, double step_size, double primal_weight, double out[5]) {
+  DistGroup &g = *L.g;
+  pdhg_handle *lead = L.p[0];
+  int rc;
+  {
+    ProfScope ps(lead, PDHG_K_ALLGATHER);
+    if ((rc = dist_all_gather(g, [](pdhg_handle *s) { return s->xbar; }, g.S))) return rc;
+    // QP: Q acts on full vectors, so x' is kept full as well (x becomes x' at accept)
+    if (lead->has_q && (rc = dist_all_gather(g, [](pdhg_handle *s) { return s->x_next; }, g.S))) return rc;
+  }
+  FOR_SHARDS(L, s) {
+    if ((rc = launch_dual(s, primal_weight * step_size))) return rc;
+    if ((rc = launch_aty_plain(s, s->y_next, s->aty_next))) return rc;      // t_p = A_p' y'_p, all n columns
+  }
+  {
+    ProfScope ps(lead, PDHG_K_REDUCE_SCATTER);
+    if ((rc = dist_reduce_scatter(g, [](pdhg_handle *s) { return s->aty_next; }, g.S))) return rc;
+  }
+  FOR_SHARDS(L, s) {
+    {
+      ProfScope ps(s, PDHG_K_INTERACTION);
+      const int64_t o = s->clo;
+      hipLaunchKernelGGL(interaction_kernel, dim3(ew_grid(s->cn)), dim3(TPB), 0, s->stream, (int)s->cn, s->x + o,
+                         s->x_next + o, s->aty + o, s->aty_next + o, s->pAt, s->pAt_stride);
+      HIP_TRY(hipGetLastError());
+    }
+    int qcount = 0;
+    if ((rc = launch_q_interaction(s, &qcount))) return rc;   // replicated: identical on every shard
+    if ((rc = launch_final(s, s->pAt, ew_grid(s->cn), s->pAt_stride, s->pA, s->A.slots(), qcount))) return rc;
+  }
+  double r[5];
+  if ((rc = combine_scalars(L, 5, 5, r))) return rc;
+  for (int q = 0; q < 4; ++q) out[q] = r[q];
+  out[4] = 0.5 * (r[4] / (double)g.world);   // every rank contributed the same replicated value
+  if (lead->has_q) {
+    // exact: take rank 0's value instead of sum/world (the division can round)
+    out[4] = 0.5 * (g.all_local() ? L.p[0]->scal_host[4] : L.p[0]->scal_host[4]);
+  }
+  return 0;
+}
+
+int pdhg_trial_primal(pdhg_handle *h, double step_size, double primal_weight) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  const Shards L = shards_of(h);
+  FOR_SHARDS(L, s) { if ((rc = launch_primal(s, step_size / primal_weight, 0.0, false))) return rc; }
+  return 0;
 }
 
 int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight, double theta, double out[5]) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
-  hipLaunchKernelGGL(xbar_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->x, h->x_next, theta, h->xbar);
-  HIP_TRY(hipGetLastError());
-  return trial_dual_from(h, step_size, primal_weight, out);
+  const Shards L = shards_of(h);
+  FOR_SHARDS(L, s) { if ((rc = launch_xbar(s, theta))) return rc; }
+  if (L.g) return trial_dual_group(L, step_size, primal_weight, out);
+  return trial_dual_single(h, step_size, primal_weight, out);
 }
 
 int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, double theta, double out[5]) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
-  if ((rc = launch_primal(h, step_size / primal_weight, theta, true))) return rc;
-  return trial_dual_from(h, step_size, primal_weight, out);
+  const Shards L = shards_of(h);
+  FOR_SHARDS(L, s) { if ((rc = launch_primal(s, step_size / primal_weight, theta, true))) return rc; }
+  if (L.g) return trial_dual_group(L, step_size, primal_weight, out);
+  return trial_dual_single(h, step_size, primal_weight, out);
 }
 
-int pdhg_accept(pdhg_handle *h, double avg_weight) {
-  int rc = check_handle(h);
+int pdhg_accept(pdhg_handle *h0, double avg_weight) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
-  {
-    ProfScope ps(h, PDHG_K_ACCEPT);
-    hipLaunchKernelGGL(accept_kernel, dim3(h->ew_grid_nm), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m,
-                       avg_weight, h->x_next, h->sum_x, h->y_next, h->sum_y);
-    HIP_TRY(hipGetLastError());
+  const Shards L = shards_of(h0);
+  bump_version(L);
+  FOR_SHARDS(L, h) {
+    {
+      ProfScope ps(h, PDHG_K_ACCEPT);
+      const int64_t o = h->clo;
+      hipLaunchKernelGGL(accept_kernel, dim3(ew_grid(std::max(h->cn, h->m))), dim3(TPB), 0, h->stream, (int)h->cn,
+                         (int)h->m, avg_weight, h->x_next + o, h->sum_x + o, h->y_next, h->sum_y);
+      HIP_TRY(hipGetLastError());
+    }
+    std::swap(h->x, h->x_next);
+    std::swap(h->y, h->y_next);
+    std::swap(h->aty, h->aty_next);
+    h->sum_x_count += 1; h->sum_y_count += 1;
+    h->sum_x_weights += avg_weight; h->sum_y_weights += avg_weight;
   }
-  std::swap(h->x, h->x_next);
-  std::swap(h->y, h->y_next);
-  std::swap(h->aty, h->aty_next);
-  h->sum_x_count += 1; h->sum_y_count += 1;
-  h->sum_x_weights += avg_weight; h->sum_y_weights += avg_weight;
   return 0;
 }
 
-int pdhg_add_current_primal_to_average(pdhg_handle *h, double weight) {
-  int rc = check_handle(h);
+int pdhg_add_current_primal_to_average(pdhg_handle *h0, double weight) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
-  hipLaunchKernelGGL(accept_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, 0, weight,
-                     h->x, h->sum_x, h->y, h->sum_y);
-  HIP_TRY(hipGetLastError());
-  h->sum_x_count += 1;
-  h->sum_x_weights += weight;
+  const Shards L = shards_of(h0);
+  bump_version(L);
+  FOR_SHARDS(L, h) {
+    const int64_t o = h->clo;
+    hipLaunchKernelGGL(accept_kernel, dim3(ew_grid(h->cn)), dim3(TPB), 0, h->stream, (int)h->cn, 0, weight,
+                       h->x + o, h->sum_x + o, h->y, h->sum_y);
+    HIP_TRY(hipGetLastError());
+    h->sum_x_count += 1;
+    h->sum_x_weights += weight;
+  }
   return 0;
 }
 
@@ -590,224 +997,121 @@ int pdhg_get_average_info(pdhg_handle *h, int64_t counts[2], double weights[2]) 
   return 0;
 }
 
-int pdhg_get_average(pdhg_handle *h, double *x_avg, double *y_avg) {
-  int rc = check_handle(h);
+int pdhg_get_average(pdhg_handle *h0, double *x_avg, double *y_avg) {
+  int rc = check_handle(h0);
   if (rc) return rc;
+  const Shards L = shards_of(h0);
   if (x_avg) {
-    hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->sum_x, h->sum_x_weights, h->tmp_n);
-    HIP_TRY(hipMemcpyAsync(x_avg, h->tmp_n, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    FOR_SHARDS(L, h) {
+      const int64_t o = h->clo;
+      hipLaunchKernelGGL(div_kernel, dim3(ew_grid(h->cn)), dim3(TPB), 0, h->stream, (int)h->cn, h->sum_x + o,
+                         h->sum_x_weights, h->tmp_n + o);
+      HIP_TRY(hipGetLastError());
+    }
+    if ((rc = cols_to_host(L, [](pdhg_handle *s) { return s->tmp_n; }, x_avg))) return rc;
   }
   if (y_avg) {
-    hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, (int)h->m, h->sum_y, h->sum_y_weights, h->tmp_m);
-    HIP_TRY(hipMemcpyAsync(y_avg, h->tmp_m, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
+    FOR_SHARDS(L, h) {
+      hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, (int)h->m, h->sum_y, h->sum_y_weights, h->tmp_m);
+      HIP_TRY(hipGetLastError());
+    }
+    if ((rc = rows_to_host(L, [](pdhg_handle *s) { return s->tmp_m; }, y_avg))) return rc;
   }
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  return sync_all(L);
+}
+
+int pdhg_reset_average(pdhg_handle *h0) {
+  int rc = check_handle(h0);
+  if (rc) return rc;
+  const Shards L = shards_of(h0);
+  bump_version(L);
+  FOR_SHARDS(L, h) {
+    HIP_TRY(hipMemsetAsync(h->sum_x, 0, sizeof(double) * (size_t)std::max<int64_t>(h->n, 1), h->stream));
+    HIP_TRY(hipMemsetAsync(h->sum_y, 0, sizeof(double) * (size_t)std::max<int64_t>(h->m, 1), h->stream));
+    h->sum_x_count = h->sum_y_count = 0;
+    h->sum_x_weights = h->sum_y_weights = 0.0;
+  }
   return 0;
 }
 
-int pdhg_reset_average(pdhg_handle *h) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
-  HIP_TRY(hipMemsetAsync(h->sum_x, 0, sizeof(double) * (size_t)std::max<int64_t>(h->n, 1), h->stream));
-  HIP_TRY(hipMemsetAsync(h->sum_y, 0, sizeof(double) * (size_t)std::max<int64_t>(h->m, 1), h->stream));
-  h->sum_x_count = h->sum_y_count = 0;
-  h->sum_x_weights = h->sum_y_weights = 0.0;
-  return 0;
+// after x (owned slices) changed outside a trial: QP groups keep x full on every shard
+static int refresh_full_x(const Shards &L) {
+  if (!L.g || !L.p[0]->has_q) return 0;
+  return dist_all_gather(*L.g, [](pdhg_handle *s) { return s->x; }, L.g->S);
 }
 
-int pdhg_restart_to_average(pdhg_handle *h) {
-  int rc = check_handle(h);
+int pdhg_restart_to_average(pdhg_handle *h0) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
-  if (h->sum_x_count == 0 || h->sum_y_count == 0) return fail(-1, "average is empty");
-  hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->sum_x, h->sum_x_weights, h->x);
-  hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, (int)h->m, h->sum_y, h->sum_y_weights, h->y);
-  HIP_TRY(hipGetLastError());
-  return launch_aty_plain(h, h->y, h->aty);
+  const Shards L = shards_of(h0);
+  bump_version(L);
+  if (h0->sum_x_count == 0 || h0->sum_y_count == 0) return fail(-1, "average is empty");
+  FOR_SHARDS(L, h) {
+    const int64_t o = h->clo;
+    hipLaunchKernelGGL(div_kernel, dim3(ew_grid(h->cn)), dim3(TPB), 0, h->stream, (int)h->cn, h->sum_x + o, h->sum_x_weights, h->x + o);
+    hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, (int)h->m, h->sum_y, h->sum_y_weights, h->y);
+    HIP_TRY(hipGetLastError());
+  }
+  if ((rc = refresh_full_x(L))) return rc;
+  return dual_product(L, [](pdhg_handle *s) { return (const double *)s->y; }, [](pdhg_handle *s) { return s->aty; });
 }
 
-int pdhg_get_current(pdhg_handle *h, double *x, double *y, double *aty) {
-  int rc = check_handle(h);
+int pdhg_get_current(pdhg_handle *h0, double *x, double *y, double *aty) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  if (x) HIP_TRY(hipMemcpyAsync(x, h->x, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  if (y) HIP_TRY(hipMemcpyAsync(y, h->y, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
-  if (aty) HIP_TRY(hipMemcpyAsync(aty, h->aty, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return 0;
+  const Shards L = shards_of(h0);
+  if (x && (rc = cols_to_host(L, [](pdhg_handle *s) { return s->x; }, x))) return rc;
+  if (y && (rc = rows_to_host(L, [](pdhg_handle *s) { return s->y; }, y))) return rc;
+  if (aty && (rc = cols_to_host(L, [](pdhg_handle *s) { return s->aty; }, aty))) return rc;
+  return sync_all(L);
 }
 
-int pdhg_get_trial(pdhg_handle *h, double *x_next, double *y_next, double *aty_next) {
-  int rc = check_handle(h);
+int pdhg_get_trial(pdhg_handle *h0, double *x_next, double *y_next, double *aty_next) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  if (x_next) HIP_TRY(hipMemcpyAsync(x_next, h->x_next, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  if (y_next) HIP_TRY(hipMemcpyAsync(y_next, h->y_next, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
-  if (aty_next) HIP_TRY(hipMemcpyAsync(aty_next, h->aty_next, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return 0;
+  const Shards L = shards_of(h0);
+  if (x_next && (rc = cols_to_host(L, [](pdhg_handle *s) { return s->x_next; }, x_next))) return rc;
+  if (y_next && (rc = rows_to_host(L, [](pdhg_handle *s) { return s->y_next; }, y_next))) return rc;
+  if (aty_next && (rc = cols_to_host(L, [](pdhg_handle *s) { return s->aty_next; }, aty_next))) return rc;
+  return sync_all(L);
 }
 
-int pdhg_set_current(pdhg_handle *h, const double *x, const double *y) {
-  int rc = check_handle(h);
+int pdhg_set_current(pdhg_handle *h0, const double *x, const double *y) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
-  if (x) HIP_TRY(hipMemcpyAsync(h->x, x, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
-  if (y) HIP_TRY(hipMemcpyAsync(h->y, y, sizeof(double) * (size_t)h->m, hipMemcpyHostToDevice, h->stream));
-  rc = launch_aty_plain(h, h->y, h->aty);
-  if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return 0;
+  const Shards L = shards_of(h0);
+  bump_version(L);
+  if (x && (rc = cols_from_host(L, x, [](pdhg_handle *s) { return s->x; }))) return rc;
+  if (y && (rc = rows_from_host(L, y, [](pdhg_handle *s) { return s->y; }))) return rc;
+  if ((rc = dual_product(L, [](pdhg_handle *s) { return (const double *)s->y; }, [](pdhg_handle *s) { return s->aty; }))) return rc;
+  return sync_all(L);
 }
 
-int pdhg_spmv(pdhg_handle *h, const double *x, double *out) {
-  int rc = check_handle(h);
+int pdhg_spmv(pdhg_handle *h0, const double *x, double *out) {
+  int rc = check_handle(h0);
   if (rc) return rc;
   if (!x || !out) return fail(-1, "null vector");
-  HIP_TRY(hipMemcpyAsync(h->tmp_n, x, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
-  EpiArgs e{};
-  e.out = h->tmp_m;
-  if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, h->tmp_n, e))) return rc;
-  HIP_TRY(hipMemcpyAsync(out, h->tmp_m, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return 0;
+  const Shards L = shards_of(h0);
+  if ((rc = cols_from_host(L, x, [](pdhg_handle *s) { return s->tmp_n; }))) return rc;
+  FOR_SHARDS(L, h) {
+    EpiArgs e{};
+    e.out = h->tmp_m;
+    if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, h->tmp_n, e))) return rc;
+  }
+  if ((rc = rows_to_host(L, [](pdhg_handle *s) { return s->tmp_m; }, out))) return rc;
+  return sync_all(L);
 }
 
-int pdhg_spmv_t(pdhg_handle *h, const double *y, double *out) {
-  int rc = check_handle(h);
+int pdhg_spmv_t(pdhg_handle *h0, const double *y, double *out) {
+  int rc = check_handle(h0);
   if (rc) return rc;
   if (!y || !out) return fail(-1, "null vector");
-  HIP_TRY(hipMemcpyAsync(h->tmp_m, y, sizeof(double) * (size_t)h->m, hipMemcpyHostToDevice, h->stream));
-  EpiArgs e{};
-  e.out = h->tmp_n;
-  if ((rc = launch_spmv<MODE_PLAIN>(h, h->At, h->tmp_m, e))) return rc;
-  HIP_TRY(hipMemcpyAsync(out, h->tmp_n, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return 0;
-}
-
-// ---- row-partitioned form ---------------------------------------------------
-
-int pdhg_dist_trial_begin(pdhg_handle *h, double step_size, double primal_weight, double theta) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if ((rc = launch_primal(h, step_size / primal_weight, theta, true))) return rc;   // Q (if any) is replicated
-  if ((rc = launch_dual(h, primal_weight * step_size))) return rc;
-  if ((rc = launch_aty_plain(h, h->y_next, h->aty_next))) return rc;
-  hipLaunchKernelGGL(final_to_slot_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->pA, h->A.slots(), h->aty_next + h->n);
-  HIP_TRY(hipGetLastError());
-  h->dist_pending = true;
-  return 0;
-}
-
-int pdhg_dist_trial_dual_begin(pdhg_handle *h, double step_size, double primal_weight, double theta) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  hipLaunchKernelGGL(xbar_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->x, h->x_next, theta, h->xbar);
-  HIP_TRY(hipGetLastError());
-  if ((rc = launch_dual(h, primal_weight * step_size))) return rc;
-  if ((rc = launch_aty_plain(h, h->y_next, h->aty_next))) return rc;
-  hipLaunchKernelGGL(final_to_slot_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->pA, h->A.slots(), h->aty_next + h->n);
-  HIP_TRY(hipGetLastError());
-  h->dist_pending = true;
-  return 0;
-}
-
-// ---- the same trial in parts, so that the caller can all-reduce finished column
-// ranges of the exchange buffer while later ones are still being computed --------
-
-int pdhg_dist_parts(pdhg_handle *h, int max_parts, int64_t *bounds) {
-  int rc = check_handle(h);
-  if (rc) return rc < 0 ? rc : -rc;
-  if (max_parts < 1 || !bounds) return fail(-1, "max_parts < 1 or bounds == NULL");
-  const CsrDev &D = h->At;
-  // A part is a whole number of residency rounds (256 CUs x 2 workgroups): a
-  // smaller launch would leave CUs idle and cost more than the overlap buys.
-  const char *rw = getenv("PDHG_DIST_ROUND_WGS");   // tests use a finer granule on small problems
-  const int round_wgs = rw ? std::max(1, atoi(rw)) : 256 * 2;
-  const int rounds = D.tiled ? D.grid / round_wgs : 0;
-  const int parts = std::max(1, std::min(max_parts, rounds));
-  h->dist_part_wg.assign((size_t)parts + 1, 0);
-  for (int k = 0; k <= parts; ++k) {
-    const int g = (k == parts) ? D.grid : round_wgs * (int)(((int64_t)rounds * k) / parts);
-    h->dist_part_wg[k] = D.tiled ? g : 0;
-    bounds[k] = (k == 0) ? 0 : (k == parts ? h->n : (int64_t)D.wg_first_row[g]);
-  }
-  h->dist_part_wg[parts] = D.tiled ? D.grid : 0;
-  return parts;
-}
-
-static int dist_part_common(pdhg_handle *h, int part, int nparts) {
-  if (nparts != (int)h->dist_part_wg.size() - 1) return fail(-1, "nparts does not match pdhg_dist_parts");
-  if (part < 0 || part >= nparts) return fail(-1, "part out of range");
-  int rc;
-  if (nparts == 1) {
-    if ((rc = launch_aty_plain(h, h->y_next, h->aty_next))) return rc;
-  } else {
-    ProfScope ps(h, PDHG_K_SPMV_ATY);
-    if ((rc = launch_spmv_plain_part(h, h->At, h->y_next, h->aty_next, h->dist_part_wg[part],
-                                     h->dist_part_wg[part + 1], part == 0))) return rc;
-  }
-  if (part == nparts - 1) {
-    hipLaunchKernelGGL(final_to_slot_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->pA, h->A.slots(), h->aty_next + h->n);
-    HIP_TRY(hipGetLastError());
-    h->dist_pending = true;
-  }
-  return 0;
-}
-
-int pdhg_dist_trial_begin_part(pdhg_handle *h, double step_size, double primal_weight, double theta,
-                               int part, int nparts) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if (part == 0) {
-    if ((rc = launch_primal(h, step_size / primal_weight, theta, true))) return rc;
-    if ((rc = launch_dual(h, primal_weight * step_size))) return rc;
-  }
-  return dist_part_common(h, part, nparts);
-}
-
-int pdhg_dist_trial_dual_begin_part(pdhg_handle *h, double step_size, double primal_weight, double theta,
-                                    int part, int nparts) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if (part == 0) {
-    hipLaunchKernelGGL(xbar_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->x, h->x_next, theta, h->xbar);
-    HIP_TRY(hipGetLastError());
-    if ((rc = launch_dual(h, primal_weight * step_size))) return rc;
-  }
-  return dist_part_common(h, part, nparts);
-}
-
-void *pdhg_dist_exchange_ptr(pdhg_handle *h) { return h ? (void *)h->aty_next : nullptr; }
-
-int pdhg_dist_trial_end(pdhg_handle *h, double out[5]) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if (!h->dist_pending) return fail(-1, "pdhg_dist_trial_end without begin");
-  h->dist_pending = false;
-  hipLaunchKernelGGL(interaction_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->x, h->x_next,
-                     h->aty, h->aty_next, h->pAt, h->pAt_stride);
-  HIP_TRY(hipGetLastError());
-  int qcount = 0;
-  if ((rc = launch_q_interaction(h, &qcount))) return rc;   // 0.5 dx'Q dx on the replicated vectors (QP)
-  return finish_scalars(h, h->pAt, h->ew_grid_n, h->pAt_stride, h->aty_next + h->n, 1, qcount, out);
-}
-
-// A'y recompute in two halves: local partial into the exchange buffer
-// (aty_next, since aty may still be needed), then adopt it after all-reduce.
-int pdhg_dist_dual_product_begin(pdhg_handle *h) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if ((rc = launch_aty_plain(h, h->y, h->aty_next))) return rc;
-  HIP_TRY(hipMemsetAsync(h->aty_next + h->n, 0, sizeof(double), h->stream));
-  return 0;
-}
-int pdhg_dist_dual_product_end(pdhg_handle *h) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
-  std::swap(h->aty, h->aty_next);
-  return 0;
+  const Shards L = shards_of(h0);
+  if ((rc = rows_from_host(L, y, [](pdhg_handle *s) { return s->tmp_m; }))) return rc;
+  // the partial products go through tmp_n (n_alloc long); a group's gather-to-host then uses dn_buf
+  if ((rc = dual_product(L, [](pdhg_handle *s) { return (const double *)s->tmp_m; }, [](pdhg_handle *s) { return s->tmp_n; }))) return rc;
+  if ((rc = cols_to_host(L, [](pdhg_handle *s) { return s->tmp_n; }, out))) return rc;
+  return sync_all(L);
 }
 
 // ---- evaluation branch on the device (N1) -----------------------------------
@@ -817,14 +1121,13 @@ static int ev_alloc(pdhg_handle *h) {
   int rc;
   h->ev_grid = ew_grid(std::max(h->n, h->m) + 1);
   if ((rc = alloc_zero(&h->ev_partials, (int64_t)EV_MAXQ * h->ev_grid))) return rc;
-  if ((rc = alloc_zero(&h->ev_out, EV_MAXQ))) return rc;
-  HIP_TRY(hipHostMalloc((void **)&h->ev_host, EV_MAXQ * sizeof(double), hipHostMallocDefault));
   if ((rc = alloc_zero(&h->ev_ax, h->m))) return rc;
-  if ((rc = alloc_zero(&h->ev_aty, h->n))) return rc;
+  if ((rc = alloc_zero(&h->ev_aty, h->n_alloc))) return rc;
   for (int k = 0; k < 2; ++k) {
     if ((rc = alloc_zero(&h->ev_cax[k], h->m))) return rc;
-    if ((rc = alloc_zero(&h->ev_caty[k], h->n))) return rc;
+    if ((rc = alloc_zero(&h->ev_caty[k], h->n_alloc))) return rc;
   }
+  if (h->grp && (rc = alloc_zero(&h->ev_xg, h->n_alloc))) return rc;
   if ((rc = alloc_zero(&h->px_avg, h->n))) return rc;
   if ((rc = alloc_zero(&h->py_avg, h->m))) return rc;
   if ((rc = alloc_zero(&h->x_r, h->n))) return rc;   // zeros == the initial restart point (pdhg.jl:869)
@@ -832,16 +1135,18 @@ static int ev_alloc(pdhg_handle *h) {
   return 0;
 }
 
-static int ev_finish(pdhg_handle *h, int ns, int nm, double *out) {
-  hipLaunchKernelGGL(multi_final_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->ev_partials, h->ev_grid,
-                     h->ev_grid, ns, nm, h->ev_out);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(h->ev_host, h->ev_out, (ns + nm) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  for (int q = 0; q < ns + nm; ++q) out[q] = h->ev_host[q];
-  return 0;
+// second stage of every shard's block partials (ns sums then nm maxes), then the
+// combination over ranks in rank order
+static int ev_finish(const Shards &L, int ns, int nm, double *out) {
+  FOR_SHARDS(L, h) {
+    hipLaunchKernelGGL(multi_final_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->ev_partials, h->ev_grid,
+                       h->ev_grid, ns, nm, h->scal_dev);
+    HIP_TRY(hipGetLastError());
+  }
+  return combine_scalars(L, ns + nm, ns, out);
 }
 
+// px: column vector (valid on the owned slice), py: this shard's rows
 static int select_point(pdhg_handle *h, int point, const double **px, const double **py) {
   int rc = ev_alloc(h);
   if (rc) return rc;
@@ -850,7 +1155,8 @@ static int select_point(pdhg_handle *h, int point, const double **px, const doub
   if (point == PDHG_POINT_AVERAGE) {
     if (h->sum_x_count == 0 || h->sum_y_count == 0) return fail(-1, "average is empty");
     if (h->avg_version != h->state_version) {
-      hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, h->sum_x, h->sum_x_weights, h->px_avg);
+      const int64_t o = h->clo;
+      hipLaunchKernelGGL(div_kernel, dim3(ew_grid(h->cn)), dim3(TPB), 0, h->stream, (int)h->cn, h->sum_x + o, h->sum_x_weights, h->px_avg + o);
       hipLaunchKernelGGL(div_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, (int)h->m, h->sum_y, h->sum_y_weights, h->py_avg);
       HIP_TRY(hipGetLastError());
       h->avg_version = h->state_version;
@@ -861,147 +1167,174 @@ static int select_point(pdhg_handle *h, int point, const double **px, const doub
   return fail(-1, "unknown point selector");
 }
 
-// A*x, A'*y and (QP) Q*x at a point selected by select_point (cached for CURRENT / AVERAGE).
-static int point_products(pdhg_handle *h, int point, const double *px, const double *py,
-                          const double **ax, const double **aty, const double **qx) {
+// A*x (this shard's rows), A'*y (owned slice) and, for a QP, Q*x (full) at `point`
+// on every shard; cached for CURRENT / AVERAGE until the state changes.  Results in
+// h->pt_ax / pt_aty / pt_qx together with the point itself in h->pt_x / pt_y.
+static int point_products(const Shards &L, int point) {
   int rc;
-  double *dax = h->ev_ax, *daty = h->ev_aty;
-  double **dqx = &h->ev_qx;
   static const bool cache_off = getenv("PDHG_NO_EVAL_CACHE") != nullptr;   // debugging aid
   const bool cached = !cache_off && (point == PDHG_POINT_CURRENT || point == PDHG_POINT_AVERAGE);
   bool fresh = true;
-  if (cached) {
-    const int k = point == PDHG_POINT_CURRENT ? 0 : 1;
-    dax = h->ev_cax[k]; daty = h->ev_caty[k]; dqx = &h->ev_cqx[k];
-    fresh = h->ev_cversion[k] != h->state_version;
-    h->ev_cversion[k] = h->state_version;
+  FOR_SHARDS(L, h) {
+    if ((rc = select_point(h, point, &h->pt_x, &h->pt_y))) return rc;
+    h->pt_ax = h->ev_ax; h->pt_aty = h->ev_aty;
+    double **dqx = &h->ev_qx;
+    bool f = true;
+    if (cached) {
+      const int k = point == PDHG_POINT_CURRENT ? 0 : 1;
+      h->pt_ax = h->ev_cax[k]; h->pt_aty = h->ev_caty[k]; dqx = &h->ev_cqx[k];
+      f = h->ev_cversion[k] != h->state_version;
+      h->ev_cversion[k] = h->state_version;
+    }
+    if (h->has_q && !*dqx) {
+      if ((rc = alloc_zero(dqx, h->n))) return rc;
+      f = true;
+    }
+    h->pt_qx = h->has_q ? *dqx : nullptr;
+    fresh = f;              // shards move in lock step: the same answer on all of them
   }
-  if (h->has_q && !*dqx) {
-    if ((rc = alloc_zero(dqx, h->n))) return rc;
-    fresh = true;
+  if (!fresh) return 0;
+  // full x at the point on every shard (a plain handle's vectors are full already)
+  if (L.g) {
+    if ((rc = gather_cols_device(L, [](pdhg_handle *s) { return s->pt_x; }, [](pdhg_handle *s) { return s->ev_xg; }))) return rc;
   }
-  if (fresh) {
+  FOR_SHARDS(L, h) {
+    const double *xfull = L.g ? h->ev_xg : h->pt_x;
     EpiArgs e{};
-    e.out = dax;
-    if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, px, e))) return rc;
-    e.out = daty;
-    if ((rc = launch_spmv<MODE_PLAIN>(h, h->At, py, e))) return rc;
+    e.out = h->pt_ax;
+    if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, xfull, e))) return rc;
     if (h->has_q) {
-      e.out = *dqx;
-      if ((rc = launch_spmv<MODE_PLAIN>(h, h->Q, px, e))) return rc;
+      e.out = h->pt_qx;
+      if ((rc = launch_spmv<MODE_PLAIN>(h, h->Q, xfull, e))) return rc;
     }
   }
-  *ax = dax; *aty = daty;
-  *qx = h->has_q ? *dqx : nullptr;
+  return dual_product(L, [](pdhg_handle *s) { return s->pt_y; }, [](pdhg_handle *s) { return s->pt_aty; });
+}
+
+int pdhg_set_original_problem(pdhg_handle *h0, const double *constraint_rescaling,
+                              const double *variable_rescaling, const double *c_o, const double *b_o,
+                              const double *lb_o, const double *ub_o) {
+  int rc = check_handle(h0);
+  if (rc) return rc;
+  if (!constraint_rescaling || !variable_rescaling || !c_o || !lb_o || !ub_o || (h0->m_global > 0 && !b_o))
+    return fail(-1, "null input array");
+  const Shards L = shards_of(h0);
+  FOR_SHARDS(L, h) {
+    auto up = [&](double **dst, const double *src, int64_t len) -> int {
+      if (!*dst) { int r2 = alloc_zero(dst, len); if (r2) return r2; }
+      if (len > 0) HIP_TRY(hipMemcpy(*dst, src, sizeof(double) * (size_t)len, hipMemcpyHostToDevice));
+      return 0;
+    };
+    // row vectors arrive with their GLOBAL length: a shard keeps its rows
+    if ((rc = up(&h->E, constraint_rescaling + h->row_lo, h->m))) return rc;
+    if ((rc = up(&h->b_o, b_o ? b_o + h->row_lo : nullptr, h->m))) return rc;
+    if ((rc = up(&h->Dv, variable_rescaling, h->n))) return rc;
+    if ((rc = up(&h->c_o, c_o, h->n))) return rc;
+    if ((rc = up(&h->lb_o, lb_o, h->n))) return rc;
+    if ((rc = up(&h->ub_o, ub_o, h->n))) return rc;
+    h->has_original = true;
+    if ((rc = ev_alloc(h))) return rc;
+  }
   return 0;
 }
 
-int pdhg_set_original_problem(pdhg_handle *h, const double *constraint_rescaling,
-                              const double *variable_rescaling, const double *c_o, const double *b_o,
-                              const double *lb_o, const double *ub_o) {
-  int rc = check_handle(h);
+int pdhg_eval_point(pdhg_handle *h0, int point, double out[24]) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  if (!constraint_rescaling || !variable_rescaling || !c_o || !lb_o || !ub_o || (h->m > 0 && !b_o))
-    return fail(-1, "null input array");
-  auto up = [&](double **dst, const double *src, int64_t len) -> int {
-    if (!*dst) { int r2 = alloc_zero(dst, len); if (r2) return r2; }
-    if (len > 0) HIP_TRY(hipMemcpy(*dst, src, sizeof(double) * (size_t)len, hipMemcpyHostToDevice));
-    return 0;
-  };
-  if ((rc = up(&h->E, constraint_rescaling, h->m))) return rc;
-  if ((rc = up(&h->Dv, variable_rescaling, h->n))) return rc;
-  if ((rc = up(&h->c_o, c_o, h->n))) return rc;
-  if ((rc = up(&h->b_o, b_o, h->m))) return rc;
-  if ((rc = up(&h->lb_o, lb_o, h->n))) return rc;
-  if ((rc = up(&h->ub_o, ub_o, h->n))) return rc;
-  h->has_original = true;
-  return ev_alloc(h);
-}
-
-int pdhg_eval_point(pdhg_handle *h, int point, double out[24]) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  if (!h->has_original) return fail(-1, "pdhg_set_original_problem has not been called");
-  const double *px, *py;
-  if ((rc = select_point(h, point, &px, &py))) return rc;
-  const double *ax, *aty, *qx;
-  if ((rc = point_products(h, point, px, py, &ax, &aty, &qx))) return rc;
-  hipLaunchKernelGGL(eval_rows_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->m, (int)h->num_eq,
-                     ax, py, h->E, h->b_o, h->ev_partials, h->ev_grid);
-  if ((rc = ev_finish(h, 4, 4, out))) return rc;
-  hipLaunchKernelGGL(eval_cols_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, aty, qx, px,
-                     h->Dv, h->c_o, h->lb_o, h->ub_o, h->ev_partials, h->ev_grid);
+  if (!h0->has_original) return fail(-1, "pdhg_set_original_problem has not been called");
+  const Shards L = shards_of(h0);
+  if ((rc = point_products(L, point))) return rc;
+  FOR_SHARDS(L, h) {
+    hipLaunchKernelGGL(eval_rows_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->m, (int)h->num_eq,
+                       h->pt_ax, h->pt_y, h->E, h->b_o, h->ev_partials, h->ev_grid);
+    HIP_TRY(hipGetLastError());
+  }
+  if ((rc = ev_finish(L, 4, 4, out))) return rc;
+  FOR_SHARDS(L, h) {
+    const int64_t o = h->clo;
+    hipLaunchKernelGGL(eval_cols_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, h->pt_aty + o,
+                       h->pt_qx ? h->pt_qx + o : nullptr, h->pt_x + o, h->Dv + o, h->c_o + o, h->lb_o + o,
+                       h->ub_o + o, h->ev_partials, h->ev_grid);
+    HIP_TRY(hipGetLastError());
+  }
   double r[14];
-  if ((rc = ev_finish(h, 7, 7, r))) return rc;
+  if ((rc = ev_finish(L, 7, 7, r))) return rc;
   for (int q = 0; q < 6; ++q) { out[8 + q] = r[q]; out[14 + q] = r[7 + q]; }
   out[20] = r[6]; out[21] = r[13]; out[22] = out[23] = 0.0;
   return 0;
 }
 
-int pdhg_save_restart_point(pdhg_handle *h) {
-  int rc = check_handle(h);
+int pdhg_save_restart_point(pdhg_handle *h0) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  if ((rc = ev_alloc(h))) return rc;
-  HIP_TRY(hipMemcpyAsync(h->x_r, h->x, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->y_r, h->y, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToDevice, h->stream));
+  const Shards L = shards_of(h0);
+  FOR_SHARDS(L, h) {
+    if ((rc = ev_alloc(h))) return rc;
+    if (h->cn > 0)
+      HIP_TRY(hipMemcpyAsync(h->x_r + h->clo, h->x + h->clo, sizeof(double) * (size_t)h->cn, hipMemcpyDeviceToDevice, h->stream));
+    if (h->m > 0)
+      HIP_TRY(hipMemcpyAsync(h->y_r, h->y, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToDevice, h->stream));
+  }
   return 0;
 }
 
-int pdhg_distance_to_restart(pdhg_handle *h, int point, double out[2]) {
-  int rc = check_handle(h);
+static int dist2_common(pdhg_handle *h0, int point, bool to_restart, double out[2]) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  const double *px, *py;
-  if ((rc = select_point(h, point, &px, &py))) return rc;
-  hipLaunchKernelGGL(dist2_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m, px, h->x_r,
-                     py, h->y_r, h->ev_partials, h->ev_grid);
-  return ev_finish(h, 2, 0, out);
+  const Shards L = shards_of(h0);
+  FOR_SHARDS(L, h) {
+    const double *px, *py;
+    if ((rc = select_point(h, point, &px, &py))) return rc;
+    const int64_t o = h->clo;
+    hipLaunchKernelGGL(dist2_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)h->m, px + o,
+                       to_restart ? (const double *)(h->x_r + o) : (const double *)nullptr, py,
+                       to_restart ? (const double *)h->y_r : (const double *)nullptr, h->ev_partials, h->ev_grid);
+    HIP_TRY(hipGetLastError());
+  }
+  return ev_finish(L, 2, 0, out);
 }
 
-int pdhg_point_sumsq(pdhg_handle *h, int point, double out[2]) {
-  int rc = check_handle(h);
-  if (rc) return rc;
-  const double *px, *py;
-  if ((rc = select_point(h, point, &px, &py))) return rc;
-  hipLaunchKernelGGL(dist2_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m, px,
-                     (const double *)nullptr, py, (const double *)nullptr, h->ev_partials, h->ev_grid);
-  return ev_finish(h, 2, 0, out);
-}
+int pdhg_distance_to_restart(pdhg_handle *h, int point, double out[2]) { return dist2_common(h, point, true, out); }
+int pdhg_point_sumsq(pdhg_handle *h, int point, double out[2]) { return dist2_common(h, point, false, out); }
 
-int pdhg_get_point(pdhg_handle *h, int point, double *x, double *y) {
-  int rc = check_handle(h);
+int pdhg_get_point(pdhg_handle *h0, int point, double *x, double *y) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  const double *px, *py;
-  if ((rc = select_point(h, point, &px, &py))) return rc;
-  if (x) HIP_TRY(hipMemcpyAsync(x, px, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  if (y) HIP_TRY(hipMemcpyAsync(y, py, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return 0;
+  const Shards L = shards_of(h0);
+  FOR_SHARDS(L, h) { if ((rc = select_point(h, point, &h->pt_x, &h->pt_y))) return rc; }
+  if (x && (rc = cols_to_host(L, [](pdhg_handle *s) { return s->pt_x; }, x))) return rc;
+  if (y && (rc = rows_to_host(L, [](pdhg_handle *s) { return s->pt_y; }, y))) return rc;
+  return sync_all(L);
 }
 
 static inline uint64_t d2bits(double v) { uint64_t b; memcpy(&b, &v, 8); return b; }
 static inline double bits2d(uint64_t b) { double v; memcpy(&v, &b, 8); return v; }
 
-int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm, double dual_weight_norm,
+int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_norm, double dual_weight_norm,
                             double radius, int range, int approximate, double out[8]) {
-  int rc = check_handle(h);
+  int rc = check_handle(h0);
   if (rc) return rc;
   if (range < 0 || range > 2) return fail(-1, "range must be 0, 1 or 2");
-  const double *px, *py;
-  if ((rc = select_point(h, point, &px, &py))) return rc;
-  const int64_t total = h->n + h->m;
-  if (!h->tr_g) {
-    if ((rc = alloc_zero(&h->tr_g, total))) return rc;
-    if ((rc = alloc_zero(&h->tr_dir, total))) return rc;
-    if ((rc = alloc_zero(&h->tr_thr, total))) return rc;
-  }
+  const Shards L = shards_of(h0);
   const double wp = primal_weight_norm, wd = dual_weight_norm;
-  const double *ax, *aty, *qx;
-  if ((rc = point_products(h, point, px, py, &ax, &aty, &qx))) return rc;
-  hipLaunchKernelGGL(tr_setup_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m,
-                     (int)h->num_eq, px, py, aty, qx, ax, h->c, h->b, h->lb, h->ub, wp, wd, range,
-                     h->tr_g, h->tr_dir, h->tr_thr, h->ev_partials, h->ev_grid);
+  if ((rc = point_products(L, point))) return rc;
+  // every shard works on the concatenation [its column slice ; its rows]
+  FOR_SHARDS(L, h) {
+    if (!h->tr_g) {
+      const int64_t total = h->n + h->m;
+      if ((rc = alloc_zero(&h->tr_g, total))) return rc;
+      if ((rc = alloc_zero(&h->tr_dir, total))) return rc;
+      if ((rc = alloc_zero(&h->tr_thr, total))) return rc;
+    }
+    const int64_t o = h->clo;
+    hipLaunchKernelGGL(tr_setup_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)h->m,
+                       (int)h->num_eq, h->pt_x + o, h->pt_y, h->pt_aty + o, h->pt_qx ? h->pt_qx + o : nullptr, h->pt_ax,
+                       h->c + o, h->b, h->lb + o, h->ub + o, wp, wd, range,
+                       h->tr_g, h->tr_dir, h->tr_thr, h->ev_partials, h->ev_grid);
+    HIP_TRY(hipGetLastError());
+  }
   double r[EV_MAXQ];
-  if ((rc = ev_finish(h, 11, 1, r))) return rc;
+  if ((rc = ev_finish(L, 11, 1, r))) return rc;
   // compute_lagrangian_value (saddle_point.jl:1109-1120) without objective_constant
   out[0] = 0.5 * r[10] + r[0] - r[1] + r[2];
   out[1] = out[2] = 0.0;
@@ -1023,9 +1356,12 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
   // breakpoint] until no breakpoint lies strictly inside the bracket, then the
   // same closed form (trust_region_utils.jl:167-175).
   auto probe = [&](const TrProbes &pr, double *lowhigh) -> int {
-    hipLaunchKernelGGL(tr_probe_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)total,
-                       h->tr_dir, h->tr_thr, wp, wd, pr, h->ev_partials, h->ev_grid);
-    return ev_finish(h, 2 * TR_K, 0, lowhigh);
+    FOR_SHARDS(L, h) {
+      hipLaunchKernelGGL(tr_probe_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)(h->cn + h->m),
+                         h->tr_dir, h->tr_thr, wp, wd, pr, h->ev_partials, h->ev_grid);
+      HIP_TRY(hipGetLastError());
+    }
+    return ev_finish(L, 2 * TR_K, 0, lowhigh);
   };
   double lh[2 * TR_K];
   TrProbes pr;
@@ -1085,10 +1421,15 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
       tstar = high_lo > 0.0 ? sqrt(fmax(r2 - low_lo, 0.0) / high_lo) : bits2d(lo);
     }
   }
-  hipLaunchKernelGGL(tr_value_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->n, (int)h->m,
-                     (int)h->num_eq, px, py, h->lb, h->ub, h->tr_g, h->tr_dir, tstar, h->ev_partials, h->ev_grid);
+  FOR_SHARDS(L, h) {
+    const int64_t o = h->clo;
+    hipLaunchKernelGGL(tr_value_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)h->m,
+                       (int)h->num_eq, h->pt_x + o, h->pt_y, h->lb + o, h->ub + o, h->tr_g, h->tr_dir, tstar,
+                       h->ev_partials, h->ev_grid);
+    HIP_TRY(hipGetLastError());
+  }
   double vv[2];
-  if ((rc = ev_finish(h, 2, 0, vv))) return rc;
+  if ((rc = ev_finish(L, 2, 0, vv))) return rc;
   out[1] = vv[0]; out[2] = vv[1]; out[5] = tstar; out[6] = (double)passes;
   return 0;
 }
@@ -1097,127 +1438,187 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
 
 static int row_grid(int rows) { return std::max(1, (rows + (TPB / WAVE) - 1) / (TPB / WAVE)); }
 
-// one scale_problem step on every resident layout + the vectors
-static int apply_scaling(pdhg_handle *h, double *ev, double *dv, double *inv_e, double *inv_d,
-                         double *cum_e, double *cum_d) {
+// scratch vectors of one pdhg_rescale call, per shard: row factors have the
+// shard's m entries, column factors all n (n_alloc: they are reduced over ranks)
+struct RescaleTmp {
+  double *ev = nullptr, *dv = nullptr, *inv_e = nullptr, *inv_d = nullptr, *cum_e = nullptr, *cum_d = nullptr;
+  double *tmp_e = nullptr, *tmp_d = nullptr;
+};
+
+// one scale_problem step on every resident layout + the vectors of one shard
+static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
   const int n = (int)h->n, m = (int)h->m;
-  hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, ev, inv_e, 0);
-  hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv, inv_d, 0);
-  CsrDev *L[2] = {&h->A, &h->At};
-  for (int t = 0; t < 2; ++t) {
-    CsrDev &D = *L[t];
+  hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, t.ev, t.inv_e, 0);
+  hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.dv, t.inv_d, 0);
+  CsrDev *Ls[2] = {&h->A, &h->At};
+  for (int k = 0; k < 2; ++k) {
+    CsrDev &D = *Ls[k];
     if (D.nnz == 0) continue;
     hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, D.rowptr,
-                       D.col, D.val, inv_e, inv_d, t);
+                       D.col, D.val, t.inv_e, t.inv_d, k);
     if (D.tiled && D.nwaves > 0)
       hipLaunchKernelGGL(scale_tiled_kernel, dim3(row_grid(D.nwaves)), dim3(TPB), 0, h->stream, D.wave_rows,
                          D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves, D.tile_shift,
-                         D.pk, D.tv, inv_e, inv_d, t);
+                         D.pk, D.tv, t.inv_e, t.inv_d, k);
   }
   if (h->has_q) {
     // objective_matrix = (D^-1 Q) D^-1 (preprocess.jl:562-564); Qt holds Q' entry by entry, so the
     // "transposed" order reproduces the same two roundings on it
     hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Q.rows)), dim3(TPB), 0, h->stream, h->Q.rows, h->Q.rowptr,
-                       h->Q.col, h->Q.val, inv_d, inv_d, 0);
+                       h->Q.col, h->Q.val, t.inv_d, t.inv_d, 0);
     hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Qt.rows)), dim3(TPB), 0, h->stream, h->Qt.rows, h->Qt.rowptr,
-                       h->Qt.col, h->Qt.val, inv_d, inv_d, 1);
+                       h->Qt.col, h->Qt.val, t.inv_d, t.inv_d, 1);
   }
-  hipLaunchKernelGGL(resc_apply_vectors_kernel, dim3(h->ew_grid_nm), dim3(TPB), 0, h->stream, n, m, dv, ev,
-                     h->c, h->lb, h->ub, h->b, cum_d, cum_e);
+  hipLaunchKernelGGL(resc_apply_vectors_kernel, dim3(h->ew_grid_nm), dim3(TPB), 0, h->stream, n, m, t.dv, t.ev,
+                     h->c, h->lb, h->ub, h->b, t.cum_d, t.cum_e);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
-int pdhg_rescale(pdhg_handle *h, int l_inf_ruiz_iterations, int l2_norm_rescaling,
+int pdhg_rescale(pdhg_handle *h0, int l_inf_ruiz_iterations, int l2_norm_rescaling,
                  int use_pock_chambolle, double pock_chambolle_alpha,
                  double *constraint_rescaling_out, double *variable_rescaling_out) {
-  int rc = check_handle(h);
+  int rc = check_handle(h0);
   if (rc) return rc;
-  h->state_version += 1;   // x, y, the running sums or A change: cached A*x / A'*y are stale
   if (use_pock_chambolle && !(pock_chambolle_alpha >= 0.0 && pock_chambolle_alpha <= 2.0))
     return fail(-1, "pock_chambolle_alpha must be in [0, 2]");
-  const int n = (int)h->n, m = (int)h->m;
-  double *ev = nullptr, *dv = nullptr, *inv_e = nullptr, *inv_d = nullptr, *cum_e = nullptr, *cum_d = nullptr;
-  double *tmp_e = nullptr, *tmp_d = nullptr;
-  auto cleanup = [&]() { for (double *p : {ev, dv, inv_e, inv_d, cum_e, cum_d, tmp_e, tmp_d}) if (p) (void)hipFree(p); };
+  const Shards L = shards_of(h0);
+  bump_version(L);
+  std::vector<RescaleTmp> T((size_t)L.count);
+  auto cleanup = [&]() {
+    for (int i = 0; i < L.count; ++i) {
+      (void)hipSetDevice(L.p[i]->device);
+      RescaleTmp &t = T[(size_t)i];
+      for (double *p : {t.ev, t.dv, t.inv_e, t.inv_d, t.cum_e, t.cum_d, t.tmp_e, t.tmp_d}) if (p) (void)hipFree(p);
+    }
+  };
 #define RS(expr) do { int _r = (expr); if (_r) { cleanup(); return _r; } } while (0)
-  RS(alloc_zero(&ev, m)); RS(alloc_zero(&dv, n)); RS(alloc_zero(&inv_e, m)); RS(alloc_zero(&inv_d, n));
-  RS(alloc_zero(&cum_e, m)); RS(alloc_zero(&cum_d, n)); RS(alloc_zero(&tmp_e, m)); RS(alloc_zero(&tmp_d, n));
-  hipLaunchKernelGGL(fill_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, 1.0, cum_e);
-  hipLaunchKernelGGL(fill_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, 1.0, cum_d);
-  const CsrView Av = h->A.view(), Atv = h->At.view();
+#define EACH(h, t) for (int _i = 0; _i < L.count; ++_i) if (pdhg_handle *h = L.p[_i]) if (hipSetDevice(h->device) == hipSuccess) if (RescaleTmp *_tp = &T[(size_t)_i]) if (RescaleTmp &t = *_tp; true)
+  EACH(h, t) {
+    RS(alloc_zero(&t.ev, h->m)); RS(alloc_zero(&t.dv, h->n_alloc)); RS(alloc_zero(&t.inv_e, h->m)); RS(alloc_zero(&t.inv_d, h->n));
+    RS(alloc_zero(&t.cum_e, h->m)); RS(alloc_zero(&t.cum_d, h->n)); RS(alloc_zero(&t.tmp_e, h->m)); RS(alloc_zero(&t.tmp_d, h->n_alloc));
+    hipLaunchKernelGGL(fill_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, (int)h->m, 1.0, t.cum_e);
+    hipLaunchKernelGGL(fill_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, (int)h->n, 1.0, t.cum_d);
+  }
+  // Column statistics of A are reductions over the row shards: every shard reduces its
+  // rows, then max / sum over ranks (reduce-scatter + all-gather: the same bits everywhere).
+  // Row statistics are complete on the shard that owns the row.
+  auto reduce_cols = [&](bool use_tmp, bool maxop) -> int {
+    if (!L.g) return 0;
+    std::vector<double *> ptr((size_t)L.g->world, nullptr);
+    for (int i = 0; i < L.count; ++i) ptr[(size_t)L.p[i]->rank] = use_tmp ? T[(size_t)i].tmp_d : T[(size_t)i].dv;
+    return dist_all_reduce(*L.g, [&](pdhg_handle *s) { return ptr[(size_t)s->rank]; }, L.g->S, maxop);
+  };
   // ruiz_rescaling, p = Inf (preprocess.jl:412-477): sqrt of the row / column max |a|, zeros -> 1
   for (int it = 0; it < l_inf_ruiz_iterations; ++it) {
-    hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, Atv, m, 0.0, (const double *)nullptr, dv);
-    hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, Av, n, 0.0, (const double *)nullptr, ev);
-    if (h->has_q) {   // QP: column max over the constraint AND the objective matrix (preprocess.jl:425-433)
-      hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->Qt.view(), n, 0.0, (const double *)nullptr, tmp_d);
-      hipLaunchKernelGGL(resc_max_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv, tmp_d);
+    EACH(h, t) {
+      const int n = (int)h->n, m = (int)h->m;
+      hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->At.view(), m, 0.0, (const double *)nullptr, t.dv);
+      hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, h->A.view(), n, 0.0, (const double *)nullptr, t.ev);
     }
-    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv);
-    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, ev);
-    RS(apply_scaling(h, ev, dv, inv_e, inv_d, cum_e, cum_d));
+    RS(reduce_cols(false, true));
+    EACH(h, t) {
+      const int n = (int)h->n, m = (int)h->m;
+      if (h->has_q) {   // QP: column max over the constraint AND the objective matrix (preprocess.jl:425-433)
+        hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->Qt.view(), n, 0.0, (const double *)nullptr, t.tmp_d);
+        hipLaunchKernelGGL(resc_max_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.dv, t.tmp_d);
+      }
+      hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.dv);
+      hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, t.ev);
+      RS(apply_scaling(h, t));
+    }
   }
   // l2_norm_rescaling (preprocess.jl:358-372): sqrt of the row / column L2 norms, zeros -> 1
   if (l2_norm_rescaling) {
-    hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, Atv, m, 0.0, (const double *)nullptr, tmp_d);
-    hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, Av, n, 0.0, (const double *)nullptr, tmp_e);
-    hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, tmp_d, inv_d, 1);
-    hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, tmp_e, inv_e, 1);
-    hipLaunchKernelGGL(row_op_kernel<ROP_SUMSQ_SCALED>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, Atv, m, 0.0, inv_d, dv);
-    hipLaunchKernelGGL(row_op_kernel<ROP_SUMSQ_SCALED>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, Av, n, 0.0, inv_e, ev);
-    hipLaunchKernelGGL(resc_l2norm_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, tmp_d, dv);
-    hipLaunchKernelGGL(resc_l2norm_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, tmp_e, ev);
-    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv);   // norm 0 -> sqrt 0 -> 1
-    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, ev);
-    RS(apply_scaling(h, ev, dv, inv_e, inv_d, cum_e, cum_d));
+    EACH(h, t) {
+      const int n = (int)h->n, m = (int)h->m;
+      hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->At.view(), m, 0.0, (const double *)nullptr, t.tmp_d);
+      hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, h->A.view(), n, 0.0, (const double *)nullptr, t.tmp_e);
+    }
+    RS(reduce_cols(true, true));
+    EACH(h, t) {
+      const int n = (int)h->n, m = (int)h->m;
+      hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.tmp_d, t.inv_d, 1);
+      hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, t.tmp_e, t.inv_e, 1);
+      hipLaunchKernelGGL(row_op_kernel<ROP_SUMSQ_SCALED>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->At.view(), m, 0.0, t.inv_d, t.dv);
+      hipLaunchKernelGGL(row_op_kernel<ROP_SUMSQ_SCALED>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, h->A.view(), n, 0.0, t.inv_e, t.ev);
+    }
+    RS(reduce_cols(false, false));
+    EACH(h, t) {
+      const int n = (int)h->n, m = (int)h->m;
+      hipLaunchKernelGGL(resc_l2norm_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.tmp_d, t.dv);
+      hipLaunchKernelGGL(resc_l2norm_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, t.tmp_e, t.ev);
+      hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.dv);   // norm 0 -> sqrt 0 -> 1
+      hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, t.ev);
+      RS(apply_scaling(h, t));
+    }
   }
   // pock_chambolle_rescaling (preprocess.jl:508-539)
   if (use_pock_chambolle) {
-    hipLaunchKernelGGL(row_op_kernel<ROP_SUMPOW>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, Atv, m, 2.0 - pock_chambolle_alpha, (const double *)nullptr, dv);
-    hipLaunchKernelGGL(row_op_kernel<ROP_SUMPOW>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, Av, n, pock_chambolle_alpha, (const double *)nullptr, ev);
-    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, dv);
-    hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, ev);
-    RS(apply_scaling(h, ev, dv, inv_e, inv_d, cum_e, cum_d));
+    EACH(h, t) {
+      const int n = (int)h->n, m = (int)h->m;
+      hipLaunchKernelGGL(row_op_kernel<ROP_SUMPOW>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->At.view(), m, 2.0 - pock_chambolle_alpha, (const double *)nullptr, t.dv);
+      hipLaunchKernelGGL(row_op_kernel<ROP_SUMPOW>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, h->A.view(), n, pock_chambolle_alpha, (const double *)nullptr, t.ev);
+    }
+    RS(reduce_cols(false, false));
+    EACH(h, t) {
+      const int n = (int)h->n, m = (int)h->m;
+      hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.dv);
+      hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, t.ev);
+      RS(apply_scaling(h, t));
+    }
   }
-  hipError_t e1 = hipGetLastError();
-  if (e1 != hipSuccess) { cleanup(); return fail((int)e1, hipGetErrorString(e1)); }
-  if (constraint_rescaling_out && m > 0)
-    (void)hipMemcpyAsync(constraint_rescaling_out, cum_e, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream);
-  if (variable_rescaling_out && n > 0)
-    (void)hipMemcpyAsync(variable_rescaling_out, cum_d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream);
-  hipError_t e2 = hipStreamSynchronize(h->stream);
+  EACH(h, t) {
+    (void)t;
+    hipError_t e1 = hipGetLastError();
+    if (e1 != hipSuccess) { cleanup(); return fail((int)e1, hipGetErrorString(e1)); }
+  }
+  if (constraint_rescaling_out && h0->m_global > 0) {
+    std::vector<double *> ptr((size_t)h0->world, nullptr);
+    for (int i = 0; i < L.count; ++i) ptr[(size_t)L.p[i]->rank] = T[(size_t)i].cum_e;
+    RS(rows_to_host(L, [&](pdhg_handle *s) { return ptr[(size_t)s->rank]; }, constraint_rescaling_out));
+  }
+  if (variable_rescaling_out && h0->n > 0) {
+    (void)hipSetDevice(h0->device);
+    (void)hipMemcpyAsync(variable_rescaling_out, T[0].cum_d, sizeof(double) * (size_t)h0->n, hipMemcpyDeviceToHost, h0->stream);
+  }
+  rc = sync_all(L);
   cleanup();
 #undef RS
-  if (e2 != hipSuccess) return fail((int)e2, hipGetErrorString(e2));
-  return 0;
+#undef EACH
+  return rc;
 }
 
-int pdhg_get_problem_vectors(pdhg_handle *h, double *c, double *b, double *lb, double *ub) {
-  int rc = check_handle(h);
+int pdhg_get_problem_vectors(pdhg_handle *h0, double *c, double *b, double *lb, double *ub) {
+  int rc = check_handle(h0);
   if (rc) return rc;
+  const Shards L = shards_of(h0);
+  pdhg_handle *h = h0;   // column vectors of the problem are stored in full on every shard
   if (c) HIP_TRY(hipMemcpyAsync(c, h->c, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  if (b) HIP_TRY(hipMemcpyAsync(b, h->b, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
   if (lb) HIP_TRY(hipMemcpyAsync(lb, h->lb, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
   if (ub) HIP_TRY(hipMemcpyAsync(ub, h->ub, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return 0;
+  if (b && (rc = rows_to_host(L, [](pdhg_handle *s) { return s->b; }, b))) return rc;
+  return sync_all(L);
 }
 
-int pdhg_matrix_max_abs(pdhg_handle *h, double *out) {
-  int rc = check_handle(h);
+int pdhg_matrix_max_abs(pdhg_handle *h0, double *out) {
+  int rc = check_handle(h0);
   if (rc) return rc;
-  if ((rc = ev_alloc(h))) return rc;
-  hipLaunchKernelGGL(maxabs_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int64_t)h->At.nnz, h->At.val,
-                     h->ev_partials, h->ev_grid);
-  return ev_finish(h, 0, 1, out);
+  const Shards L = shards_of(h0);
+  FOR_SHARDS(L, h) {
+    if ((rc = ev_alloc(h))) return rc;
+    hipLaunchKernelGGL(maxabs_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int64_t)h->At.nnz, h->At.val,
+                       h->ev_partials, h->ev_grid);
+    HIP_TRY(hipGetLastError());
+  }
+  return ev_finish(L, 0, 1, out);
 }
 
 // ---- measurement ------------------------------------------------------------
 
 int pdhg_profile_enable(pdhg_handle *h, int enable) {
   if (!h) return fail(-1, "null handle");
-  h->profile = enable != 0;
+  h->profile = enable != 0;     // a group is profiled through its first local shard
   if (enable) for (int k = 0; k < PDHG_K_COUNT; ++k) { h->prof_count[k] = 0; h->prof_ms[k] = 0.0; }
   return 0;
 }
@@ -1231,25 +1632,38 @@ int pdhg_profile_read(pdhg_handle *h, int kernel_id, int64_t *launches, double *
 
 int64_t pdhg_kernel_algorithmic_bytes(pdhg_handle *h, int kernel_id) {
   if (!h) return -1;
-  const int64_t m = h->m, n = h->n, nnz = h->nnz;
+  // sizes of THIS shard: m rows, nnz nonzeros, cn owned columns of n
+  const int64_t m = h->m, n = h->n, nnz = h->nnz, cn = h->cn;
+  const bool group = h->grp != nullptr;
   switch (kernel_id) {
-    case PDHG_K_PRIMAL: return 8 * 7 * n;                               // r: x,c,aty,lb,ub  w: x',xbar
+    case PDHG_K_PRIMAL: return 8 * 7 * cn;                              // r: x,c,aty,lb,ub  w: x',xbar
     case PDHG_K_SPMV_DUAL: return nnz * 12 + (m + 1) * 4 + n * 8 + 3 * m * 8;  // + r: y,b  w: y'
-    case PDHG_K_SPMV_ATY: return nnz * 12 + (n + 1) * 4 + m * 8 + 4 * n * 8;   // + r: x,x',aty  w: aty'
+    case PDHG_K_SPMV_ATY:                                                // fused: + r: x,x',aty  w: aty'
+      return nnz * 12 + (n + 1) * 4 + m * 8 + (group ? 1 : 4) * n * 8;
     case PDHG_K_FINAL: return 8 * (int64_t)(3 * h->At.slots() + h->A.slots());
-    case PDHG_K_ACCEPT: return 8 * 3 * (n + m);
+    case PDHG_K_ACCEPT: return 8 * 3 * (cn + m);
+    case PDHG_K_ALLGATHER: return group ? 8 * (h->n_alloc - h->grp->S) : 0;        // bytes received per rank
+    case PDHG_K_REDUCE_SCATTER: return group ? 8 * (h->n_alloc - h->grp->S) : 0;
+    case PDHG_K_INTERACTION: return group ? 8 * 4 * cn : 0;
     default: return -1;
   }
 }
 
 namespace {
-__global__ __launch_bounds__(TPB) void triad_kernel(int64_t len2, const double2 *__restrict__ b,
-                                                    const double2 *__restrict__ c, double s,
-                                                    double2 *__restrict__ a) {
+// a[i] = b[i] + s*c[i], 32 bytes per lane and pass (two 16-byte loads per stream in
+// flight), one workgroup of 256 threads per 8 KiB of each stream: the access shape
+// that reaches the chip's streaming rate (MI355X_MICROARCH.md: float4 copy 6.29 TB/s).
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(TPB) void triad_kernel(int64_t len4, const dbl2_t *__restrict__ b,
+                                                    const dbl2_t *__restrict__ c, double s,
+                                                    dbl2_t *__restrict__ a) {
   const int64_t stride = (int64_t)gridDim.x * TPB;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < len2; i += stride) {
-    const double2 bv = b[i], cv = c[i];
-    a[i] = make_double2(bv.x + s * cv.x, bv.y + s * cv.y);
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < len4; i += stride) {
+    const int64_t k = 2 * i;
+    const dbl2_t b0 = __builtin_nontemporal_load(b + k), b1 = __builtin_nontemporal_load(b + k + 1);
+    const dbl2_t c0 = __builtin_nontemporal_load(c + k), c1 = __builtin_nontemporal_load(c + k + 1);
+    __builtin_nontemporal_store(b0 + s * c0, a + k);
+    __builtin_nontemporal_store(b1 + s * c1, a + k + 1);
   }
 }
 }  // namespace
@@ -1257,7 +1671,7 @@ __global__ __launch_bounds__(TPB) void triad_kernel(int64_t len2, const double2 
 int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps) {
   int rc = check_handle(h);
   if (rc) return rc;
-  if (len <= 0 || (len & 1) || reps <= 0 || !gbps) return fail(-1, "bad triad arguments (len must be even)");
+  if (len <= 0 || (len & 3) || reps <= 0 || !gbps) return fail(-1, "bad triad arguments (len must be a multiple of 4)");
   double *buf = nullptr;
   HIP_TRY(hipMalloc((void **)&buf, sizeof(double) * 3 * (size_t)len));
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1265,14 +1679,16 @@ int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps) {
   hipError_t err = hipMemsetAsync(buf, 0, sizeof(double) * 3 * (size_t)len, h->stream);
   if (err == hipSuccess) err = hipEventCreate(&e0);
   if (err == hipSuccess) err = hipEventCreate(&e1);
-  const int64_t len2 = len / 2;
-  const int grids[3] = {256 * 8, 256 * 16, 256 * 64};   // grid-stride; keep the best shape
-  for (int g = 0; g < 3 && err == hipSuccess; ++g) {
+  const int64_t len4 = len / 4;
+  const int64_t full = (len4 + TPB - 1) / TPB;                 // one pass per thread
+  const int64_t grids[4] = {full, std::max<int64_t>(1, full / 2), 256 * 32, 256 * 64};
+  for (int g = 0; g < 4 && err == hipSuccess; ++g) {
+    const int grid = (int)std::min<int64_t>(grids[g], 1 << 30);
     for (int r = 0; r <= reps && err == hipSuccess; ++r) {   // pass 0 warms up
       (void)hipEventRecord(e0, h->stream);
-      hipLaunchKernelGGL(triad_kernel, dim3(grids[g]), dim3(TPB), 0, h->stream, len2,
-                         reinterpret_cast<const double2 *>(buf + len), reinterpret_cast<const double2 *>(buf + 2 * len),
-                         0.5, reinterpret_cast<double2 *>(buf));
+      hipLaunchKernelGGL(triad_kernel, dim3(grid), dim3(TPB), 0, h->stream, len4,
+                         reinterpret_cast<const dbl2_t *>(buf + len), reinterpret_cast<const dbl2_t *>(buf + 2 * len),
+                         0.5, reinterpret_cast<dbl2_t *>(buf));
       (void)hipEventRecord(e1, h->stream);
       err = hipEventSynchronize(e1);
       float ms = 0.f;
@@ -1284,7 +1700,7 @@ int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps) {
   if (e1) (void)hipEventDestroy(e1);
   (void)hipFree(buf);
   HIP_TRY(err);
-  *gbps = 24.0 * (double)(2 * len2) / ((double)best * 1e-3) / 1e9;
+  *gbps = 24.0 * (double)(4 * len4) / ((double)best * 1e-3) / 1e9;
   return 0;
 }
 

@@ -1,19 +1,24 @@
-"""1-D row partition of the constraint matrix across the GPUs of one node:
-one process per GPU, ``torch.distributed`` (backend "nccl" == RCCL over xGMI)
-for the single exchange step per trial.
+"""1-D row partition of the constraint matrix across the GPUs of one node.
 
-Rank p holds the contiguous row block A_p (balanced by nnz, equalities-first
-order preserved), its slices of y / b / sum_y, and a full replica of the
-n-vectors.  Per trial step (see include/pdhg_hip.h, "row-partitioned form"):
+PRODUCT PATH: the exchange lives inside the HIP library (csrc/dist.hpp: RCCL
+reduce-scatter / all-gather over xGMI, or direct peer kernels inside one
+process).  ``make_row_partitioned_hip_engine`` only hands the library a
+communicator id; the engine it returns is an ordinary ``HipPdhgEngine`` whose
+every method keeps global vector lengths.  No torch.distributed call is on the
+iteration path.
 
-    begin : x', xbar (replicated, identical on every rank), y'_p, and the
-            local partial A_p' y'_p  -> exchange buffer [0..n), sum dy_p^2 -> [n]
-    all_reduce(sum) of the n+1 doubles                      <- the only collective
-    end   : dx.(A'y'-A'y), |dx|^2, |A'y'-A'y|^2 on the replicated vectors
+    one process per GPU :  HipPdhgEngine(..., unique_id=, rank=, world=)   pdhg_create_dist
+    one process, N GPUs :  HipPdhgEngine(..., device_ids=[0, 1, ...])      pdhg_create_multi
 
-Every rank ends with bitwise-identical A'y' (the all-reduce delivers one
-result to all ranks) and therefore takes identical accept/reject decisions.
-The reference has no counterpart (single process, single thread).
+HOST MIRROR (``RowPartitionedEngine``): the same algorithm -- row shards,
+owned column slices, rank-ordered sums, scalars combined in rank order --
+restated in numpy over a local engine object and a small collective interface,
+so that the world_size > 1 logic can be exercised on a box without GPUs
+(tests/test_distributed_gloo.py: gloo, the CPU oracle injected as the local
+engine).  It mirrors csrc/dist.hpp step by step and is not used on GPUs.
+
+The reference has no counterpart (single process, single thread); the
+arithmetic being distributed is src/primal_dual_hybrid_gradient.jl:442-549.
 """
 import os
 
@@ -23,7 +28,8 @@ from .quadratic_programming import as_csc
 
 
 def partition_rows(constraint_matrix, world_size):
-    """Contiguous row ranges [(lo, hi)] * world_size balanced by nonzeros."""
+    """Contiguous row ranges [(lo, hi)] * world_size balanced by nonzeros
+    (the same rule as partition_rows_by_nnz in csrc/dist.hpp)."""
     csr_indptr = np.zeros(constraint_matrix.shape[0] + 1, dtype=np.int64)
     np.add.at(csr_indptr, constraint_matrix.indices + 1, 1)
     np.cumsum(csr_indptr, out=csr_indptr)
@@ -31,12 +37,19 @@ def partition_rows(constraint_matrix, world_size):
     nnz = int(csr_indptr[-1])
     bounds = [0]
     for p in range(1, world_size):
-        target = nnz * p / world_size
-        r = int(np.searchsorted(csr_indptr, target, side="left"))
+        # first r with prefix[r] * world >= nnz * p  (exact integer compare)
+        r = int(np.searchsorted(csr_indptr * world_size, nnz * p, side="left"))
         r = min(max(r, bounds[-1]), m)
         bounds.append(r)
     bounds.append(m)
     return [(bounds[p], bounds[p + 1]) for p in range(world_size)]
+
+
+def slice_stride(n, world_size):
+    """Column-slice stride S: rank r owns columns [r*S, min(n, (r+1)*S))
+    (init_group_geometry in csrc/pdhg_hip.hip)."""
+    per = (n + world_size - 1) // world_size
+    return max(16, (per + 15) // 16 * 16)
 
 
 def shard_rows(problem, lo, hi):
@@ -54,8 +67,67 @@ def shard_rows(problem, lo, hi):
     )
 
 
+# ---- product path -----------------------------------------------------------------
+
+def broadcast_unique_id(rank, group=None):
+    """Rank 0 creates the RCCL id inside the library; the 128 bytes travel over
+    whatever process group the host already has (gloo is enough)."""
+    import torch
+    import torch.distributed as dist
+    from .engine import HipPdhgEngine
+    from . import _lib
+    buf = torch.zeros(_lib.UNIQUE_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        buf = torch.frombuffer(bytearray(HipPdhgEngine.dist_unique_id()), dtype=torch.uint8).clone()
+    backend = dist.get_backend(group)
+    if backend == "nccl":
+        buf = buf.cuda()
+    dist.broadcast(buf, src=0, group=group)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def make_row_partitioned_hip_engine(problem, device_id=None, group=None):
+    """One process per GPU: this rank's shard of ``problem`` behind an ordinary
+    HipPdhgEngine (pdhg_create_dist).  Needs an initialised torch.distributed
+    group only to hand out the communicator id."""
+    import torch.distributed as dist
+    from .engine import HipPdhgEngine
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if device_id is None:
+        device_id = int(os.environ.get("LOCAL_RANK", rank))
+    uid = broadcast_unique_id(rank, group)
+    return HipPdhgEngine.from_problem(problem, device_id=device_id, unique_id=uid,
+                                      rank=rank, world=world)
+
+
+def make_multi_device_hip_engine(problem, device_ids):
+    """One process driving several GPUs (pdhg_create_multi)."""
+    from .engine import HipPdhgEngine
+    return HipPdhgEngine.from_problem(problem, device_ids=list(device_ids))
+
+
+def multi_device_factory(device_ids):
+    """``optimize(params, problem, multi_device_factory([0, 1, ...]))``: the engine is
+    built from the ORIGINAL problem and rescaled on the devices."""
+    def factory(problem):
+        return make_multi_device_hip_engine(problem, device_ids)
+    factory.takes_original_problem = True
+    return factory
+
+
+def row_partitioned_factory(group=None):
+    """The same for one process per GPU (torch.distributed group for the id hand-out)."""
+    def factory(problem):
+        return make_row_partitioned_hip_engine(problem, group=group)
+    factory.takes_original_problem = True
+    return factory
+
+
+# ---- host mirror (CPU tests) ----------------------------------------------------------
+
 class TorchComm:
-    """torch.distributed collectives (RCCL on GPU, gloo in the CPU tests)."""
+    """The collectives the mirror needs, on host numpy arrays over
+    torch.distributed (gloo in the CPU tests)."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -63,72 +135,29 @@ class TorchComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
-        self.backend = dist.get_backend(group)
 
-    def all_reduce_sum(self, tensor):
-        self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
-
-    def all_reduce_sum_async(self, tensor):
-        """Start the all-reduce and return its work handle: with RCCL the collective
-        is ordered after what the current stream has queued so far and runs on the
-        communicator's stream, so kernels launched next overlap it; ``wait()`` orders
-        the current stream after it."""
-        return self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group,
-                                    async_op=True)
-
-    def all_reduce_min_host(self, arr):
-        """Element-wise minimum of a small int64 numpy vector over ranks (set-up only)."""
+    def all_gather(self, arr):
+        """[world_size, len(arr)] float64: every rank's ``arr`` (equal lengths)."""
         import torch
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
-        return t.cpu().numpy()
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+        outs = [torch.empty_like(t) for _ in range(self.world_size)]
+        self.dist.all_gather(outs, t, group=self.group)
+        return np.stack([o.numpy() for o in outs])
 
-    def all_reduce_host(self, arr):
-        """Sum a float64 numpy vector over ranks (evaluation cadence only)."""
-        import torch
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy()
-
-    def all_gather_host(self, arr, sizes):
-        """Concatenate per-rank float64 numpy slices (evaluation cadence only)."""
-        import torch
-        dev = "cuda" if self.backend == "nccl" else "cpu"
+    def all_gather_rows(self, arr, sizes):
+        """Concatenate per-rank slices of different lengths (row vectors)."""
         width = max(max(sizes), 1)
-        buf = torch.zeros(width, dtype=torch.float64, device=dev)
-        buf[:len(arr)] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
-        outs = [torch.empty_like(buf) for _ in range(self.world_size)]
-        self.dist.all_gather(outs, buf, group=self.group)
-        return np.concatenate([o[:s].cpu().numpy() for o, s in zip(outs, sizes)])
-
-
-class _DeviceBuffer:
-    """Zero-copy view of library-owned device memory for torch.as_tensor."""
-
-    def __init__(self, ptr, length):
-        self.__cuda_array_interface__ = {
-            "shape": (int(length),), "typestr": "<f8", "data": (int(ptr), False),
-            "version": 2, "strides": None}
-
-
-def hip_exchange_tensor(engine, cache):
-    """torch view of the HIP engine's current exchange buffer (n+1 doubles)."""
-    import torch
-    ptr = engine.dist_exchange_ptr()
-    t = cache.get(ptr)
-    if t is None:
-        t = torch.as_tensor(_DeviceBuffer(ptr, engine.n + 1), device="cuda")
-        assert t.data_ptr() == ptr, "torch copied the exchange buffer"
-        cache[ptr] = t
-    return t
+        buf = np.zeros(width)
+        buf[:len(arr)] = arr
+        parts = self.all_gather(buf)
+        return np.concatenate([parts[r, :s] for r, s in enumerate(sizes)])
 
 
 class RowPartitionedEngine:
-    """Presents the ``HipPdhgEngine`` interface the host driver uses, over a
-    local row-shard engine plus the all-reduce.  ``local`` must provide the
-    dist_* methods and ``exchange_tensor()``."""
+    """numpy mirror of csrc/dist.hpp over a local engine that offers the shard
+    primitives (tests/oracle_engine.OracleEngine): ``dist_trial_begin`` /
+    ``dist_trial_dual_begin`` (x', xbar, y'_p and the partial t_p = A_p' y'_p),
+    ``exchange_array()`` (t_p, n doubles, in place), ``dist_trial_end_slice``."""
 
     def __init__(self, local, comm, row_ranges):
         self.local = local
@@ -139,75 +168,60 @@ class RowPartitionedEngine:
         self.n = local.n
         self.m = self.row_ranges[-1][1]
         assert local.m == self.hi - self.lo
-        self._bounds = None
+        self.S = slice_stride(self.n, comm.world_size)
+        self.clo = min(self.n, comm.rank * self.S)
+        self.chi = min(self.n, (comm.rank + 1) * self.S)
+
+    # ---- the exchange: reduce-scatter (rank-order sum on the owned slice), then
+    # all-gather of the slices (the local engine keeps full-length vectors)
+    def _reduce_scatter_all_gather(self, partial):
+        world, S, n = self.comm.world_size, self.S, self.n
+        padded = np.zeros(world * S)
+        padded[:n] = partial
+        parts = self.comm.all_gather(padded)                       # [world, world*S]
+        own = parts[0, self.comm.rank * S:(self.comm.rank + 1) * S].copy()
+        for r in range(1, world):                                  # ranks ascending: p2p_reduce_kernel
+            own = own + parts[r, self.comm.rank * S:(self.comm.rank + 1) * S]
+        slices = self.comm.all_gather(own)                         # [world, S]
+        partial[:] = slices.reshape(-1)[:n]
+
+    def _combine(self, raw_local):
+        """Scalars of all ranks added in rank order on every rank (combine_scalars);
+        the replicated QP term [4] is taken once."""
+        raws = self.comm.all_gather(np.asarray(raw_local, dtype=np.float64))
+        out = raws[0].copy()
+        for r in range(1, self.comm.world_size):
+            out[:4] = out[:4] + raws[r, :4]
+            out[4] = max(out[4], raws[r, 4])
+        return out
+
+    def _finish_trial(self):
+        self._reduce_scatter_all_gather(self.local.exchange_array())
+        return self._combine(self.local.dist_trial_end_slice(self.clo, self.chi))
 
     # ---- hot path ----
-    def _parts(self):
-        """Column ranges of the exchange buffer, agreed by all ranks once.  Every
-        rank cuts its own A_p' by ITS workgroups (pdhg_dist_parts), so the local
-        limits differ from rank to rank; a range may be exchanged once every rank
-        has finished it, hence the element-wise minimum of the limits -- and no
-        cutting at all unless every rank can cut into the same number of parts."""
-        if self._bounds is None:
-            want = int(os.environ.get("PDHG_DIST_PARTS", "4"))
-            useful = self.comm.world_size > 1 or "PDHG_DIST_PARTS" in os.environ   # nothing to overlap alone
-            local = list(self.local.dist_parts(want)) if (want > 1 and useful) else [0, self.n]
-            k = len(local) - 1
-            kmin, neg_kmax = self.comm.all_reduce_min_host(np.array([k, -k]))
-            if kmin != -neg_kmax or kmin < 2:
-                if k > 1:
-                    self.local.dist_parts(1)         # the library launches what it handed out last
-                self._bounds = [0, self.n]
-            else:
-                agreed = self.comm.all_reduce_min_host(np.array(local))
-                self._bounds = [0] + [int(b) for b in agreed[1:-1]] + [self.n]
-        return self._bounds
-
-    def _exchange_in_parts(self, begin_part, step_size, primal_weight, theta):
-        """Part k's columns are all-reduced while part k+1 is still being computed
-        (A_p'y'_p is produced range by range); one collective per part, the last
-        one also carries slot [n]."""
-        bounds = self._parts()
-        nparts = len(bounds) - 1
-        works = []
-        for k in range(nparts):
-            begin_part(step_size, primal_weight, theta, k, nparts)
-            t = self.local.exchange_tensor()
-            hi = bounds[k + 1] + (1 if k == nparts - 1 else 0)
-            works.append(self.comm.all_reduce_sum_async(t[bounds[k]:hi]))
-        for w in works:
-            w.wait()
-
     def trial_step(self, step_size, primal_weight, theta=1.0):
-        if len(self._parts()) > 2:
-            self._exchange_in_parts(self.local.dist_trial_begin_part, step_size, primal_weight, theta)
-        else:
-            self.local.dist_trial_begin(step_size, primal_weight, theta)
-            self.comm.all_reduce_sum(self.local.exchange_tensor())
-        return self.local.dist_trial_end()
+        self.local.dist_trial_begin(step_size, primal_weight, theta)
+        return self._finish_trial()
 
     def accept(self, avg_weight):
         self.local.accept(avg_weight)
 
-    # Malitsky-Pock (pdhg.jl:555-647): the primal half is rank-local, every
-    # linesearch iteration costs one all-reduce like an adaptive trial.
+    # Malitsky-Pock (pdhg.jl:555-647): the primal half is slice-local, every
+    # linesearch iteration costs one exchange like an adaptive trial.
     def trial_primal(self, step_size, primal_weight):
         self.local.trial_primal(step_size, primal_weight)
 
     def trial_dual(self, step_size, primal_weight, theta):
-        if len(self._parts()) > 2:
-            self._exchange_in_parts(self.local.dist_trial_dual_begin_part, step_size, primal_weight, theta)
-        else:
-            self.local.dist_trial_dual_begin(step_size, primal_weight, theta)
-            self.comm.all_reduce_sum(self.local.exchange_tensor())
-        return self.local.dist_trial_end()
+        self.local.dist_trial_dual_begin(step_size, primal_weight, theta)
+        return self._finish_trial()
 
     def add_current_primal_to_average(self, weight):
         self.local.add_current_primal_to_average(weight)
 
     def _refresh_dual_product(self):
         self.local.dist_dual_product_begin()
-        self.comm.all_reduce_sum(self.local.exchange_tensor())
+        self._reduce_scatter_all_gather(self.local.exchange_array())
         self.local.dist_dual_product_end()
 
     # ---- average / restart ----
@@ -216,7 +230,7 @@ class RowPartitionedEngine:
 
     def get_average(self):
         xa, ya = self.local.get_average()
-        return xa, self.comm.all_gather_host(ya, self.sizes)
+        return xa, self.comm.all_gather_rows(ya, self.sizes)
 
     def reset_average(self):
         self.local.reset_average()
@@ -228,7 +242,7 @@ class RowPartitionedEngine:
     # ---- iterate I/O ----
     def get_current(self):
         x, y = self.local.get_current()
-        return x, self.comm.all_gather_host(y, self.sizes)
+        return x, self.comm.all_gather_rows(y, self.sizes)
 
     def get_dual_product(self):
         return self.local.get_dual_product()
@@ -237,51 +251,16 @@ class RowPartitionedEngine:
         self.local.set_current(x, None if y is None else y[self.lo:self.hi])
         self._refresh_dual_product()
 
-    # ---- standalone mat-vecs for the evaluation branch (host vectors) ----
+    # ---- standalone mat-vecs for the host evaluation branch ----
     def spmv(self, x):
         """A*x: every rank multiplies its row block, slices are concatenated."""
-        return self.comm.all_gather_host(self.local.spmv(x), self.sizes)
+        return self.comm.all_gather_rows(self.local.spmv(x), self.sizes)
 
     def spmv_t(self, y):
-        """A'*y = sum_p A_p' y_p: local partial, then a sum over ranks."""
-        return self.comm.all_reduce_host(self.local.spmv_t(y[self.lo:self.hi]))
+        """A'*y = sum_p A_p' y_p: local partial, then the rank-ordered sum."""
+        partial = np.array(self.local.spmv_t(y[self.lo:self.hi]), dtype=np.float64)
+        self._reduce_scatter_all_gather(partial)
+        return partial
 
     def close(self):
         self.local.close()
-
-
-class HipRowShardEngine:
-    """HipPdhgEngine + torch view of its exchange buffer, on torch's current
-    stream so RCCL and the kernels are ordered by the stream."""
-
-    def __init__(self, problem, lo, hi, device_id):
-        import torch
-        from .engine import HipPdhgEngine
-        torch.cuda.set_device(device_id)
-        # A dedicated (non-null) torch stream, made current: the library runs
-        # on it and torch.distributed orders RCCL against it.
-        self._stream = torch.cuda.Stream(device=device_id)
-        torch.cuda.set_stream(self._stream)
-        self._eng = HipPdhgEngine(device_id=device_id,
-                                  stream=self._stream.cuda_stream,
-                                  **shard_rows(problem, lo, hi))
-        self._cache = {}
-        self.n, self.m = self._eng.n, self._eng.m
-
-    def exchange_tensor(self):
-        return hip_exchange_tensor(self._eng, self._cache)
-
-    def __getattr__(self, name):
-        return getattr(self._eng, name)
-
-
-def make_row_partitioned_hip_engine(problem, device_id=None, group=None):
-    """Build this rank's shard on its GPU (LOCAL_RANK) and wrap it."""
-    import os
-    comm = TorchComm(group)
-    ranges = partition_rows(problem.constraint_matrix, comm.world_size)
-    if device_id is None:
-        device_id = int(os.environ.get("LOCAL_RANK", comm.rank))
-    lo, hi = ranges[comm.rank]
-    local = HipRowShardEngine(problem, lo, hi, device_id)
-    return RowPartitionedEngine(local, comm, ranges)

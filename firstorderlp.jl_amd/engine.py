@@ -40,7 +40,16 @@ class HipPdhgEngine:
 
     def __init__(self, constraint_matrix, objective_vector, right_hand_side,
                  variable_lower_bound, variable_upper_bound, num_equalities,
-                 objective_matrix=None, device_id=-1, stream=None):
+                 objective_matrix=None, device_id=-1, stream=None,
+                 device_ids=None, unique_id=None, rank=None, world=None):
+        """One GPU by default.  Row-partitioned over several GPUs, inside the
+        library (include/pdhg_hip.h, "row-partitioned multi-GPU form"):
+
+        * ``device_ids=[...]``: this process drives all of them (``pdhg_create_multi``);
+        * ``unique_id, rank, world``: one process per GPU (``pdhg_create_dist``),
+          ``unique_id`` from ``dist_unique_id()`` on rank 0, sent to all ranks by the host.
+
+        Every rank passes the GLOBAL problem; all methods keep global vector lengths."""
         self._L = _lib.lib()
         A = constraint_matrix
         self.m, self.n = int(A.shape[0]), int(A.shape[1])
@@ -51,17 +60,40 @@ class HipPdhgEngine:
                 or b.shape != (self.m,):
             raise ValueError("vector lengths do not match the constraint matrix")
         h = ctypes.c_void_p()
-        _lib.check(self._L.pdhg_create(
-            ctypes.byref(h), self.m, self.n, len(nzval), _pi(colptr),
-            _pi(rowval), _pd(nzval), 0, _pd(c), _pd(b), _pd(lb), _pd(ub),
-            int(num_equalities), int(device_id),
-            ctypes.c_void_p(stream) if stream else None))
+        common = (self.m, self.n, len(nzval), _pi(colptr), _pi(rowval), _pd(nzval), 0,
+                  _pd(c), _pd(b), _pd(lb), _pd(ub), int(num_equalities))
+        if device_ids is not None:
+            ids = (ctypes.c_int * len(device_ids))(*[int(d) for d in device_ids])
+            _lib.check(self._L.pdhg_create_multi(ctypes.byref(h), *common, len(device_ids), ids))
+        elif unique_id is not None:
+            uid = ctypes.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES)
+            _lib.check(self._L.pdhg_create_dist(
+                ctypes.byref(h), *common, int(device_id),
+                ctypes.c_void_p(stream) if stream else None, uid, int(rank), int(world)))
+        else:
+            _lib.check(self._L.pdhg_create(
+                ctypes.byref(h), *common, int(device_id),
+                ctypes.c_void_p(stream) if stream else None))
         self._h = h
         if objective_matrix is not None and objective_matrix.nnz > 0:
             Q = objective_matrix
             qc, qr, qv = _i(Q.indptr), _i(Q.indices), _d(Q.data)
             _lib.check(self._L.pdhg_set_objective_matrix(
                 self._h, len(qv), _pi(qc), _pi(qr), _pd(qv), 0))
+
+    @staticmethod
+    def dist_unique_id():
+        """128 opaque bytes identifying a new RCCL communicator (rank 0 calls this
+        and sends the bytes to the other ranks)."""
+        buf = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        _lib.check(_lib.lib().pdhg_dist_get_unique_id(buf))
+        return buf.raw
+
+    def dist_info(self):
+        info = np.zeros(8, dtype=np.int64)
+        _lib.check(self._L.pdhg_dist_info(self._h, _pi(info)))
+        keys = ["world", "local_ranks", "rank", "backend", "row_lo", "row_hi", "col_lo", "col_hi"]
+        return dict(zip(keys, info.tolist()))
 
     @classmethod
     def from_problem(cls, problem, **kw):
@@ -225,45 +257,6 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_measure_triad(self._h, int(length), int(reps), ctypes.byref(out)))
         return out.value
 
-    # ---- row-partitioned form --------------------------------------------------
-    def dist_trial_begin(self, step_size, primal_weight, theta=1.0):
-        _lib.check(self._L.pdhg_dist_trial_begin(self._h, step_size,
-                                                 primal_weight, theta))
-
-    def dist_trial_dual_begin(self, step_size, primal_weight, theta):
-        _lib.check(self._L.pdhg_dist_trial_dual_begin(self._h, step_size,
-                                                      primal_weight, theta))
-
-    def dist_parts(self, max_parts):
-        """Column ranges in which the partial A_p'y'_p can be produced and exchanged."""
-        bounds = np.zeros(int(max_parts) + 1, dtype=np.int64)
-        parts = self._L.pdhg_dist_parts(self._h, int(max_parts), _pi(bounds))
-        if parts < 1:
-            _lib.check(parts if parts else -1)
-        return [int(b) for b in bounds[:parts + 1]]
-
-    def dist_trial_begin_part(self, step_size, primal_weight, theta, part, nparts):
-        _lib.check(self._L.pdhg_dist_trial_begin_part(self._h, step_size, primal_weight,
-                                                      theta, int(part), int(nparts)))
-
-    def dist_trial_dual_begin_part(self, step_size, primal_weight, theta, part, nparts):
-        _lib.check(self._L.pdhg_dist_trial_dual_begin_part(self._h, step_size, primal_weight,
-                                                           theta, int(part), int(nparts)))
-
-    def dist_trial_end(self):
-        out = np.empty(5)
-        _lib.check(self._L.pdhg_dist_trial_end(self._h, _pd(out)))
-        return out
-
-    def dist_exchange_ptr(self):
-        return int(self._L.pdhg_dist_exchange_ptr(self._h))
-
-    def dist_dual_product_begin(self):
-        _lib.check(self._L.pdhg_dist_dual_product_begin(self._h))
-
-    def dist_dual_product_end(self):
-        _lib.check(self._L.pdhg_dist_dual_product_end(self._h))
-
     # ---- measurement -------------------------------------------------------------
     def profile_enable(self, enable=True):
         _lib.check(self._L.pdhg_profile_enable(self._h, int(bool(enable))))
@@ -279,12 +272,7 @@ class HipPdhgEngine:
         return int(self._L.pdhg_kernel_algorithmic_bytes(self._h, kernel_id))
 
     def kernel_name(self, kernel_id):
-        name = self._L.pdhg_kernel_name(kernel_id).decode()
-        info = self.layout_info()
-        if (kernel_id == _lib.K_SPMV_DUAL and info["A_tiled_waves"]) or \
-                (kernel_id == _lib.K_SPMV_ATY and info["At_tiled_waves"]):
-            name = name.replace("spmv_stream_kernel", "spmv_tiled_kernel")
-        return name
+        return self._L.pdhg_kernel_name(self._h, kernel_id).decode()
 
     def layout_info(self):
         info = np.zeros(12, dtype=np.int64)

@@ -306,13 +306,14 @@ def _optimize(params, original_problem, engine_factory, created):
         raise ValueError("primal_importance must be positive and finite")
     is_lp_original = is_linear_programming_problem(original_problem)
     engine = None
-    if engine_factory is None and os.environ.get("PDHG_HOST_RESCALE", "0") != "1":
+    device_rescale = engine_factory is None or getattr(engine_factory, "takes_original_problem", False)
+    if device_rescale and os.environ.get("PDHG_HOST_RESCALE", "0") != "1":
         # Product path: upload the ORIGINAL problem and rescale on the device
         # (pdhg_rescale); only the n-/m-length vectors come back.  The scaled
         # constraint (and objective) matrix lives on the device only.
         from .quadratic_programming import QuadraticProgrammingProblem, ScaledQpProblem
         import scipy.sparse as _sp
-        engine = _default_engine_factory(original_problem)
+        engine = (engine_factory or _default_engine_factory)(original_problem)
         created.append(engine)
         constraint_rescaling, variable_rescaling = engine.rescale(
             params.l_inf_ruiz_iterations, params.l2_norm_rescaling, params.pock_chambolle_alpha)

@@ -124,51 +124,53 @@ int pdhg_spmv(pdhg_handle *h, const double *x, double *out);
 int pdhg_spmv_t(pdhg_handle *h, const double *y, double *out);
 
 /*
- * Row-partitioned multi-GPU form (one process per GPU; this handle holds the
- * row block A_p, its slice of y/b, and a full replica of the n-vectors).
- *   begin : x', xb, y'_p, and the LOCAL partial A_p' y'_p written to the
- *           exchange buffer; slot [n] of that buffer = local sum dy_p^2.
- *   (caller all-reduces(sum) the n+1 doubles at pdhg_dist_exchange_ptr over
- *    RCCL, e.g. torch.distributed.all_reduce on the same stream)
- *   end   : reductions on the replicated n-vectors; out[] as pdhg_trial_step.
- * QPs: the objective matrix is replicated on every rank (pdhg_set_objective_matrix
- * on each handle); Q x and 0.5 dx'Q dx are computed on the replicated vectors.
- * No reference counterpart (the reference is single-process).
+ * ---- row-partitioned multi-GPU form, owned by the library --------------------
+ * The constraint matrix is 1-D row-partitioned (contiguous row ranges balanced by
+ * nonzeros, equalities-first order kept) over `world` GPUs of one node; rank p
+ * holds A_p in both layouts, its rows of y / b / sum_y, and OWNS the column slice
+ * [p*S, (p+1)*S) of every n-vector.  Per trial step, inside the library:
+ *   primal step on the owned slice  ->  all-gather xbar (RCCL over xGMI)
+ *   -> y'_p = proj(y_p + sigma (b_p - A_p xbar))  ->  t_p = A_p' y'_p
+ *   -> reduce-scatter(sum) t_p = the owned slice of A'y'
+ *   -> interaction / movement partial sums on the slice; the scalars of all ranks
+ *      are gathered and added in rank order on every rank (identical decisions).
+ * Both creators take the GLOBAL problem, exactly like pdhg_create, on every rank;
+ * the library partitions the rows itself and keeps only its shard.  The handle
+ * they return is used with EVERY other entry point of this header unchanged, and
+ * all vector arguments keep their GLOBAL lengths (m, n): trial steps, accept,
+ * averages, restarts, evaluation, trust-region bounds and rescaling run sharded
+ * behind the same calls; only scalars (and, on request, whole solutions) cross
+ * the boundary.  QPs: the objective matrix is replicated (it acts on full
+ * n-vectors), so x' is all-gathered as well.
+ * No reference counterpart (the reference is single-process); the arithmetic
+ * being distributed is src/primal_dual_hybrid_gradient.jl:442-549.
  */
-int pdhg_dist_trial_begin(pdhg_handle *h, double step_size,
-                          double primal_weight, double theta);
-int pdhg_dist_trial_end(pdhg_handle *h, double out[5]);
-/*
- * Malitsky-Pock linesearch in the row-partitioned form (pdhg.jl:555-647):
- * pdhg_trial_primal is rank-local (x, A'y and c are replicated), then per
- * linesearch iteration dual_begin forms xb = x' + theta (x' - x), y'_p and the
- * local partial A_p' y'_p exactly like pdhg_dist_trial_begin; the caller
- * all-reduces the exchange buffer and calls pdhg_dist_trial_end.
- */
-int pdhg_dist_trial_dual_begin(pdhg_handle *h, double step_size,
-                               double primal_weight, double theta);
-/*
- * The same two calls in PARTS, to overlap the exchange with the product that
- * feeds it.  pdhg_dist_parts cuts the n columns of A_p' y'_p into at most
- * max_parts contiguous ranges aligned to the tiled layout's workgroups and
- * returns how many (1 when the layout cannot be cut); bounds[0..parts] are the
- * range limits (bounds[0] = 0, bounds[parts] = n).  Part 0 also runs x', xb and
- * y'_p; after part k returns (launches are asynchronous), columns
- * [bounds[k], bounds[k+1]) of the exchange buffer are final on the stream -- the
- * last part also fills slot [n] -- and the caller may start all-reducing that
- * range while the next part computes.  pdhg_dist_trial_end follows the last
- * all-reduce as before.
- */
-int pdhg_dist_parts(pdhg_handle *h, int max_parts, int64_t *bounds);
-int pdhg_dist_trial_begin_part(pdhg_handle *h, double step_size, double primal_weight,
-                               double theta, int part, int nparts);
-int pdhg_dist_trial_dual_begin_part(pdhg_handle *h, double step_size, double primal_weight,
-                                    double theta, int part, int nparts);
-/* Device pointer to the current exchange buffer (n+1 doubles). */
-void *pdhg_dist_exchange_ptr(pdhg_handle *h);
-/* Same split for A'y recompute after set_current/restart: partial then finish. */
-int pdhg_dist_dual_product_begin(pdhg_handle *h);
-int pdhg_dist_dual_product_end(pdhg_handle *h);
+#define PDHG_UNIQUE_ID_BYTES 128
+/* One process per GPU (torch.distributed.run, MPI, Julia Distributed ...): rank 0
+ * obtains an id, the host sends the 128 bytes to every rank by its own means, and
+ * every rank calls pdhg_create_dist with its rank and GPU.  Collective call. */
+int pdhg_dist_get_unique_id(void *id /* PDHG_UNIQUE_ID_BYTES */);
+int pdhg_create_dist(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
+                     const int64_t *colptr, const int64_t *rowval,
+                     const double *nzval, int index_base, const double *c,
+                     const double *b, const double *lb, const double *ub,
+                     int64_t num_equalities, int device_id, void *stream,
+                     const void *unique_id, int rank, int world);
+/* One process driving n_devices GPUs (what a single Julia process would use):
+ * all ranks live inside the returned handle; every call fans out over the
+ * devices (one stream and one RCCL communicator per device, ncclCommInitAll).
+ * When device ids repeat (several shards on one GPU) or PDHG_COMM=p2p is set,
+ * the exchange uses direct peer-memory kernels instead of RCCL (fixed rank-order
+ * sums). */
+int pdhg_create_multi(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
+                      const int64_t *colptr, const int64_t *rowval,
+                      const double *nzval, int index_base, const double *c,
+                      const double *b, const double *lb, const double *ub,
+                      int64_t num_equalities, int n_devices, const int *device_ids);
+/* info[0] world size, [1] ranks inside this handle, [2] rank of the handle's first
+ * shard, [3] exchange back end (0 RCCL, 1 peer kernels, -1 none), [4],[5] its row
+ * range, [6],[7] its owned column range. */
+int pdhg_dist_info(pdhg_handle *h, int64_t info[8]);
 
 /*
  * ---- evaluation branch on the device ("next" row N1) -----------------------
@@ -254,7 +256,10 @@ enum {
   PDHG_K_SPMV_ATY = 2,   /* CSR(A') SpMV + interaction epilogue        */
   PDHG_K_FINAL = 3,      /* second-stage reduction of block partials   */
   PDHG_K_ACCEPT = 4,     /* weighted-average AXPY                      */
-  PDHG_K_COUNT = 5
+  PDHG_K_ALLGATHER = 5,       /* group: all-gather of xbar (and x' for a QP)          */
+  PDHG_K_REDUCE_SCATTER = 6,  /* group: reduce-scatter of the partials A_p' y'_p       */
+  PDHG_K_INTERACTION = 7,     /* group: interaction/movement sums on the owned slice   */
+  PDHG_K_COUNT = 8
 };
 /* Bracket every launch of the hot kernels with hipEvents on the handle's
  * stream and accumulate per-kernel time (profiling mode serialises launches;
@@ -264,13 +269,15 @@ int pdhg_profile_read(pdhg_handle *h, int kernel_id, int64_t *launches,
                       double *total_ms);
 /* Algorithmic HBM bytes one launch of `kernel_id` must move. */
 int64_t pdhg_kernel_algorithmic_bytes(pdhg_handle *h, int kernel_id);
-const char *pdhg_kernel_name(int kernel_id);
+/* Name of the kernel `kernel_id` stands for ON THIS HANDLE (the SpMV layout is
+ * chosen per matrix at create).  h == NULL gives the stream-layout names. */
+const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id);
 /* Layout statistics (diagnostics): [0..3] CSR(A) {row blocks, long rows, long
  * chunks, max row nnz}, [4..7] same for CSR(A'), [8],[9] tiled-sweep waves of
  * A / A' (0 = stream layout), [10],[11] their log2(tile columns). */
 int pdhg_layout_info(pdhg_handle *h, int64_t info[12]);
 /* Measurement only: best-of-`reps` rate of a[i] = b[i] + s*c[i] over `len`
- * doubles on this handle's device and stream (24*len bytes per pass), in GB/s --
+ * doubles (len % 4 == 0) on this handle's device and stream (24*len bytes per pass), in GB/s --
  * the box's own streaming ceiling to put beside the 8 TB/s spec figure. */
 int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps);
 

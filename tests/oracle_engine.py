@@ -108,38 +108,28 @@ class OracleEngine:
         self._exchange[self.n] = raw[2]       # local sum dy_p^2
         self._dist_pending = (xn, yn)
 
-    # part-wise variants: the oracle produces everything in part 0 (the point of the
-    # parts is overlap on the GPU); the host logic still exchanges range by range.
-    def dist_parts(self, max_parts):
-        k = max(1, min(int(max_parts), self.n))
-        return [int(round(self.n * i / k)) for i in range(k + 1)]
-
-    def dist_trial_begin_part(self, step_size, primal_weight, theta, part, nparts):
-        if part == 0:
-            self.dist_trial_begin(step_size, primal_weight, theta)
-
-    def dist_trial_dual_begin_part(self, step_size, primal_weight, theta, part, nparts):
-        if part == 0:
-            self.dist_trial_dual_begin(step_size, primal_weight, theta)
-
     def dist_trial_dual_begin(self, step_size, primal_weight, theta):
         raw, xn, yn, an = self.st.trial_dual(step_size, primal_weight, theta)
         self._exchange[:self.n] = an
         self._exchange[self.n] = raw[2]
         self._dist_pending = (xn, yn)
 
-    def exchange_tensor(self):
-        import torch
-        return torch.from_numpy(self._exchange)
+    def exchange_array(self):
+        """t_p = A_p' y'_p, n doubles, reduced in place by the caller."""
+        return self._exchange[:self.n]
 
-    def dist_trial_end(self):
+    def dist_trial_end_slice(self, lo, hi):
+        """After the exchange: interaction/movement sums over the OWNED column
+        slice [lo, hi) plus this shard's rows (sum dy^2); the QP term acts on
+        the replicated full vectors and is identical on every rank."""
         xn, yn = self._dist_pending
         an = self._exchange[:self.n].copy()
         dx = xn - self.st.x
         dd = an - self.st.aty
         qterm = 0.5 * float(dx @ (self._Q @ dx)) if self._Q is not None else 0.0
-        raw = np.array([float(dx @ dd), float(dx @ dx), float(self._exchange[self.n]),
-                        float(dd @ dd), qterm])
+        sl = slice(lo, hi)
+        raw = np.array([float(dx[sl] @ dd[sl]), float(dx[sl] @ dx[sl]), float(self._exchange[self.n]),
+                        float(dd[sl] @ dd[sl]), qterm])
         self._trial = (xn, yn, an)
         return raw
 

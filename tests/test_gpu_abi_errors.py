@@ -55,8 +55,10 @@ def test_unsupported_and_misordered_calls(gpu_required):
         eng.restart_to_average()
     with pytest.raises(_lib.PdhgHipError, match="pdhg_set_original_problem"):
         eng.eval_point(_lib.POINT_CURRENT)
-    with pytest.raises(_lib.PdhgHipError, match="without begin"):
-        eng.dist_trial_end()
+    with pytest.raises(_lib.PdhgHipError, match="rank out of range"):
+        HipPdhgEngine.from_problem(H.example_lp(), unique_id=b"\0" * 128, rank=3, world=2)
+    with pytest.raises(_lib.PdhgHipError, match="device_id out of range"):
+        HipPdhgEngine.from_problem(H.example_lp(), device_ids=[0, 99])
     with pytest.raises(_lib.PdhgHipError, match="range"):
         eng.trust_region_bound(_lib.POINT_CURRENT, 1.0, 1.0, 1.0, 7)
     with pytest.raises(_lib.PdhgHipError, match="alpha"):

@@ -1,0 +1,255 @@
+"""The library-owned row-partitioned form (csrc/dist.hpp) on the ONE GPU of the
+test box.
+
+* several shards of one LP inside one process, all on cuda:0 (``device_ids=[0, 0]``,
+  ``[0, 0, 0]``): the exchange then runs through the peer-kernel back end -- the
+  complete reduce-scatter -> slice -> all-gather pipeline, rank-ordered sums, scalar
+  combination -- and is compared with the single-handle engine and scipy;
+* RCCL itself with one rank: ``device_ids=[0]`` (ncclCommInitAll) and
+  ``unique_id/rank/world`` (ncclCommInitRank), i.e. real ncclAllGather /
+  ncclReduceScatter / ncclBroadcast calls from the library (RCCL refuses two ranks
+  on one device, and multi-GPU boxes are only available to the driver);
+* the reference's 22 PDHG KATs (test/test_primal_dual_hybrid_gradient.jl:77-423)
+  through a two-shard and a three-shard group, stream and tiled layouts;
+* device evaluation, trust-region bounds, restarts and rescaling on a group.
+The world_size > 1 host logic on CPU is tests/test_distributed_gloo.py."""
+import numpy as np
+import pytest
+
+from firstorderlp_jl_amd import HipPdhgEngine
+from firstorderlp_jl_amd.generators import random_lp
+from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
+    AdaptiveStepsizeParams, MalitskyPockStepsizeParameters, PdhgSolverState, take_step)
+from tests import helpers as H
+from tests import kat_common
+
+pytestmark = pytest.mark.gpu
+
+ADAPTIVE = AdaptiveStepsizeParams(0.3, 0.6)
+
+
+def MP_PARAMS():
+    return MalitskyPockStepsizeParameters(downscaling_factor=0.7, breaking_factor=0.99,
+                                          interpolation_coefficient=1.0)
+
+
+def _run(eng, p, steps, mp_steps=0):
+    step, pw = H.initial_step_and_weight(p)
+    st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    decisions = []
+    for _ in range(steps):
+        before = st.total_number_iterations
+        take_step(ADAPTIVE, st)
+        decisions.append(st.total_number_iterations - before)
+    out = dict(decisions=decisions, step=st.step_size)
+    out["x"], out["y"] = eng.get_current()
+    out["xa"], out["ya"] = eng.get_average()
+    eng.restart_to_average()
+    out["aty"] = eng.get_dual_product()
+    out["ax"] = eng.spmv(out["x"])
+    if mp_steps:
+        ms = PdhgSolverState(eng, step_size=st.step_size, primal_weight=pw, ratio_step_sizes=1.0)
+        for _ in range(mp_steps):
+            take_step(MP_PARAMS(), ms)
+        out["xm"], out["ym"] = eng.get_current()
+        out["mp_iters"], out["mp_step"] = ms.total_number_iterations, ms.step_size
+    return out
+
+
+def _compare(g, s, p, tol=1e-9):
+    assert g["decisions"] == s["decisions"]
+    assert abs(g["step"] - s["step"]) <= 1e-9 * s["step"]
+    for k in ("x", "y", "xa", "ya"):
+        np.testing.assert_allclose(g[k], s[k], rtol=tol, atol=tol)
+    A = p.constraint_matrix
+    # A'y_avg refreshed after the restart (sharded dual product) and the sharded A*x, vs scipy
+    np.testing.assert_allclose(g["aty"], A.T @ g["ya"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(g["ax"], A @ g["x"], rtol=1e-11, atol=1e-11)
+    if "xm" in s:
+        assert g["mp_iters"] == s["mp_iters"]
+        assert abs(g["mp_step"] - s["mp_step"]) <= 1e-9 * s["mp_step"]
+        np.testing.assert_allclose(g["xm"], s["xm"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(g["ym"], s["ym"], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("device_ids", [[0, 0], [0, 0, 0], [0] * 8], ids=["2", "3", "8"])
+def test_shards_on_one_gpu_match_single_engine(gpu_required, device_ids):
+    p = random_lp(30000, 20000, 6, seed=21)
+    geng = HipPdhgEngine.from_problem(p, device_ids=device_ids)
+    info = geng.dist_info()
+    assert info["world"] == info["local_ranks"] == len(device_ids) and info["backend"] == 1
+    g = _run(geng, p, 60, 25)
+    s = _run(HipPdhgEngine.from_problem(p), p, 60, 25)
+    _compare(g, s, p)
+
+
+@pytest.mark.timeout(600)
+def test_two_tiled_shards_match_single_engine(gpu_required):
+    """Large enough that each shard's A_p (600k x 600k) and A_p' use the tiled layout."""
+    p = random_lp(1_200_000, 600_000, 5, seed=21)
+    geng = HipPdhgEngine.from_problem(p, device_ids=[0, 0])
+    assert geng.layout_info()["At_tiled_waves"] > 0
+    g = _run(geng, p, 40, 10)
+    s = _run(HipPdhgEngine.from_problem(p), p, 40, 10)
+    _compare(g, s, p)
+
+
+def test_row_partition_matches_the_host_rule(gpu_required):
+    from firstorderlp_jl_amd.distributed import partition_rows, slice_stride
+    p = H.skewed_lp(3000, 9000, seed=7, dense_rows=2, dense_cols=2)
+    ranges = partition_rows(p.constraint_matrix, 3)
+    eng = HipPdhgEngine.from_problem(p, device_ids=[0, 0, 0])
+    info = eng.dist_info()
+    assert (info["row_lo"], info["row_hi"]) == ranges[0]
+    S = slice_stride(p.constraint_matrix.shape[1], 3)
+    assert (info["col_lo"], info["col_hi"]) == (0, min(S, p.constraint_matrix.shape[1]))
+
+
+@pytest.mark.parametrize("how", ["init_all", "init_rank"])
+def test_rccl_world_1_matches_single_engine(gpu_required, how):
+    """Real RCCL calls from the library: all-gather, reduce-scatter, broadcast on a 1-rank communicator."""
+    p = random_lp(20000, 15000, 8, seed=9)
+    if how == "init_all":
+        geng = HipPdhgEngine.from_problem(p, device_ids=[0])
+    else:
+        uid = HipPdhgEngine.dist_unique_id()
+        assert len(uid) == 128
+        geng = HipPdhgEngine.from_problem(p, device_id=0, unique_id=uid, rank=0, world=1)
+    info = geng.dist_info()
+    assert info["world"] == 1 and info["backend"] == 0
+    g = _run(geng, p, 30, 10)
+    s = _run(HipPdhgEngine.from_problem(p), p, 30, 10)
+    _compare(g, s, p, tol=1e-10)
+    y_new = np.abs(np.random.default_rng(0).standard_normal(geng.m))
+    geng.set_current(None, y_new)
+    seng = HipPdhgEngine.from_problem(p)
+    seng.set_current(None, y_new)
+    assert np.array_equal(geng.get_dual_product(), seng.get_dual_product())
+    geng.close()
+
+
+def _qp_problem():
+    import scipy.sparse as sp
+    p = random_lp(6000, 5000, 6, seed=31)
+    B = sp.random(5000, 5000, density=0.001, random_state=6, format="csc")
+    p.objective_matrix = sp.csc_matrix(B.T @ B + sp.diags(np.random.default_rng(8).uniform(0.0, 1.0, 5000)))
+    return p
+
+
+@pytest.mark.parametrize("device_ids", [[0, 0], [0]], ids=["p2p2", "rccl1"])
+def test_qp_shards_match_single_engine(gpu_required, device_ids):
+    p = _qp_problem()
+    g = _run(HipPdhgEngine.from_problem(p, device_ids=device_ids), p, 40)
+    s = _run(HipPdhgEngine.from_problem(p), p, 40)
+    _compare(g, s, p)
+
+
+# ---- the reference's KATs on groups ------------------------------------------------
+
+def _group_factory(device_ids):
+    def factory(problem):
+        eng = HipPdhgEngine.from_problem(problem, device_ids=device_ids)
+        assert eng.dist_info()["world"] == len(device_ids)
+        return eng
+    return factory
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+@pytest.mark.parametrize("case", kat_common.CASES, ids=lambda c: c.__name__)
+def test_reference_kat_on_shard_group(gpu_required, case, shards):
+    case(_group_factory([0] * shards))
+
+
+@pytest.mark.parametrize("case", kat_common.CASES, ids=lambda c: c.__name__)
+def test_reference_kat_on_tiled_shard_group(gpu_required, monkeypatch, case):
+    monkeypatch.setenv("PDHG_SPMV", "tiled")
+    monkeypatch.setenv("PDHG_TILE_SHIFT", "8")
+    case(_group_factory([0, 0]))
+
+
+@pytest.mark.parametrize("case", kat_common.CASES[:6], ids=lambda c: c.__name__)
+def test_reference_kat_on_rccl_world_1(gpu_required, case):
+    case(_group_factory([0]))
+
+
+# ---- evaluation branch / rescaling on a group ---------------------------------------
+
+def test_group_device_evaluation_matches_single_engine(gpu_required):
+    from firstorderlp_jl_amd.evaluation import POINT_AVERAGE, POINT_CURRENT, POINT_RESTART
+    p = H.skewed_lp(2500, 6000, 5)
+    m, n = p.constraint_matrix.shape
+    rng = np.random.default_rng(4)
+    E, D = rng.uniform(0.5, 2.0, m), rng.uniform(0.5, 2.0, n)
+    engines = [HipPdhgEngine.from_problem(p), HipPdhgEngine.from_problem(p, device_ids=[0, 0, 0]),
+               HipPdhgEngine.from_problem(p, device_ids=[0])]
+    outs = []
+    for eng in engines:
+        eng.set_original_problem(E, D, p.objective_vector * D, p.right_hand_side * E,
+                                 p.variable_lower_bound / D, p.variable_upper_bound / D)
+        step, pw = H.initial_step_and_weight(p)
+        st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+        for _ in range(12):
+            take_step(ADAPTIVE, st)
+        eng.save_restart_point()
+        for _ in range(23):
+            take_step(ADAPTIVE, st)
+        rec = {}
+        for point in (POINT_CURRENT, POINT_AVERAGE, POINT_RESTART):
+            rec["eval", point] = eng.eval_point(point)
+            rec["dist", point] = np.array(eng.distance_to_restart(point))
+            rec["sumsq", point] = np.array(eng.point_sumsq(point))
+            for rng_ in (0, 1, 2):
+                rec["tr", point, rng_] = eng.trust_region_bound(point, 2.0, 0.5, 0.7, rng_)[:6]
+            rec["tra", point] = eng.trust_region_bound(point, 2.0, 0.5, 0.7, 0, True)[:5]
+            x, y = eng.get_point(point)
+            rec["pt", point] = np.concatenate([x, y])
+        rec["maxabs"] = np.array([eng.matrix_max_abs()])
+        outs.append(rec)
+    ref = outs[0]
+    for other in outs[1:]:
+        for key, val in ref.items():
+            np.testing.assert_allclose(other[key], val, rtol=1e-9, atol=1e-9, err_msg=str(key))
+
+
+@pytest.mark.parametrize("qp", [False, True], ids=["lp", "qp"])
+def test_group_rescale_matches_single_engine(gpu_required, qp):
+    p = _qp_problem() if qp else H.skewed_lp(3000, 5000, 11)
+    single = HipPdhgEngine.from_problem(p)
+    group = HipPdhgEngine.from_problem(p, device_ids=[0, 0, 0])
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(p.constraint_matrix.shape[1])
+    y = rng.standard_normal(p.constraint_matrix.shape[0])
+    # Ruiz: maxima are order-independent -> bit-identical factors, matrices and products
+    es, ds = single.rescale(10, False, None)
+    eg, dg = group.rescale(10, False, None)
+    assert np.array_equal(es, eg) and np.array_equal(ds, dg)
+    for a, b in zip(single.get_problem_vectors(), group.get_problem_vectors()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(single.spmv(x), group.spmv(x))
+    np.testing.assert_allclose(single.spmv_t(y), group.spmv_t(y), rtol=1e-12, atol=1e-12)
+    assert single.matrix_max_abs() == group.matrix_max_abs()
+    # L2 and Pock-Chambolle: column sums are added per shard, then over ranks
+    es, ds = single.rescale(0, True, 1.0)
+    eg, dg = group.rescale(0, True, 1.0)
+    np.testing.assert_allclose(eg, es, rtol=1e-12)
+    np.testing.assert_allclose(dg, ds, rtol=1e-12)
+    np.testing.assert_allclose(single.spmv(x), group.spmv(x), rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.timeout(900)
+def test_group_solve_matches_single_engine_solve(gpu_required):
+    """optimize() with solve_qp.jl's defaults, all on the device: three shards vs one handle."""
+    from firstorderlp_jl_amd.distributed import multi_device_factory
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import optimize
+    from tests.test_gpu_end_to_end import _params
+    tol = 1e-6
+    p = random_lp(12000, 10000, 8, seed=42)
+    one = optimize(_params(tol, 40000), p)
+    grp = optimize(_params(tol, 40000), p, multi_device_factory([0, 0, 0]))
+    assert one.termination_string == grp.termination_string == "OPTIMAL"
+    c1 = one.iteration_stats[-1].convergence_information[0]
+    c3 = grp.iteration_stats[-1].convergence_information[0]
+    scale = 1.0 + abs(c1.primal_objective)
+    assert abs(c3.primal_objective - c1.primal_objective) <= 50 * tol * scale
+    assert abs(c3.dual_objective - c1.dual_objective) <= 50 * tol * scale
+    assert 0.5 <= grp.iteration_count / one.iteration_count <= 2.0
