@@ -25,7 +25,7 @@ LINK_FLAGS = ["-L" + ROCM_LIB, "-lrccl", "-Wl,-rpath," + ROCM_LIB]
 EXPORTS = [
     "pdhg_last_error", "pdhg_abi_version", "pdhg_create",
     "pdhg_set_objective_matrix", "pdhg_destroy", "pdhg_trial_step",
-    "pdhg_trial_primal", "pdhg_trial_dual", "pdhg_accept",
+    "pdhg_trial_primal", "pdhg_trial_dual", "pdhg_accept", "pdhg_take_step_adaptive",
     "pdhg_add_current_primal_to_average", "pdhg_get_average_info",
     "pdhg_get_average", "pdhg_reset_average", "pdhg_restart_to_average",
     "pdhg_get_current", "pdhg_set_current", "pdhg_get_trial", "pdhg_spmv",
@@ -109,6 +109,8 @@ def lib():
     L.pdhg_trial_dual.argtypes = [_vp, d, d, d, _dp]
     L.pdhg_accept.restype = i32
     L.pdhg_accept.argtypes = [_vp, d]
+    L.pdhg_take_step_adaptive.restype = i32
+    L.pdhg_take_step_adaptive.argtypes = [_vp, d, d, _dp, d, _ip, _dp, ctypes.POINTER(i32)]
     L.pdhg_add_current_primal_to_average.restype = i32
     L.pdhg_add_current_primal_to_average.argtypes = [_vp, d]
     L.pdhg_get_average_info.restype = i32

@@ -74,10 +74,13 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
   // Geometry.  A CU holds 2 workgroups of 8 waves; the grid runs in rounds of
   // 256 CUs x 16 waves.  Rows per wave is chosen so that the rounds are full
   // (no tail round), within the LDS budget (160 KiB / 16 waves).
-  const int64_t slots = 256LL * 2 * TW_WPB;               // resident waves per round
+  // dev knobs (tools/tune_tiled.py): workgroups per CU the geometry is planned for, rows per wave cap
+  const char *wpc_env = getenv("PDHG_TW_WGS_PER_CU"), *mr_env = getenv("PDHG_TW_MAX_ROWS");
+  const int wgs_per_cu = wpc_env ? std::max(1, atoi(wpc_env)) : 2;
+  const int64_t slots = 256LL * wgs_per_cu * TW_WPB;      // resident waves per round
   // row_local must stay below all-ones in its bit field: {row_local << shift | col_local}
   // == TW_PAD (0xFFFFFFFF) would be taken for padding and dropped.
-  const int max_rows = std::min<int>(TW_MAX_ROWS, (1 << (32 - tile_shift)) - 1);
+  const int max_rows = std::min<int>(mr_env ? std::max(64, atoi(mr_env)) : TW_MAX_ROWS, (1 << (32 - tile_shift)) - 1);
   int TW_ROWS;
   {
     int64_t rounds = std::max<int64_t>(1, ((int64_t)rows + slots * max_rows - 1) / (slots * max_rows));

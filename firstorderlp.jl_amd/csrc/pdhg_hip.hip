@@ -111,6 +111,22 @@ struct pdhg_handle {
   double *dm_buf = nullptr;        // [m_global] row-gather buffer (group only)
   // scalar results: scal_dev[SCAL_MAX] on the device, scal_all[world*SCAL_MAX] (RCCL gather), pinned scal_host
   double *scal_dev = nullptr, *scal_all = nullptr, *scal_host = nullptr;
+
+  // ---- one trial step as ONE graph launch (small / medium problems: stream layouts,
+  // where the ~8 launches and the result copy cost as much as the kernels).  Two
+  // instances: the trial reads (x, y, A'y) and writes (x', y', A'y'), and accept swaps them.
+  struct TrialGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipGraphNode_t n_primal = nullptr, n_dual = nullptr, n_dual_long = nullptr;
+    const double *x = nullptr, *y = nullptr, *aty = nullptr;   // the buffers this instance was built for
+    double tau = 0.0, theta = 0.0, sigma = 0.0;                // scalars currently baked into the nodes
+  } tgraph[2];
+  int graph_mode = -1;                  // -1 undecided, 0 off, 1 on
+  hipStream_t graph_stream = nullptr;   // graphs launch here (== stream)
+  unsigned long long *seq_dev = nullptr;   // launch counter, incremented by the final kernel
+  volatile double *res_host = nullptr;     // pinned, coherent: 5 results + [7] = sequence number
+  unsigned long long seq_expected = 0;
 };
 
 #include "dist.hpp"
@@ -271,6 +287,213 @@ int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int,
   sp.out = h->scal_dev;
   hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, sp);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- the trial step as a HIP graph ---------------------------------------------------
+
+// second stage of the block partials straight into pinned host memory, then the launch's
+// sequence number: the host polls that word instead of a device-to-host copy + stream
+// synchronisation (the copy alone is a 4 us kernel on this runtime).
+__global__ __launch_bounds__(FINAL_TPB) void final_reduce_host_kernel(FinalSpec sp, unsigned long long *seq_dev,
+                                                                      volatile double *res_host) {
+  // quantity q is summed by waves 3q..3q+2 (192 threads, fixed order: strided per-thread
+  // sums, wave shuffle tree, then the three wave totals left to right)
+  __shared__ double wsum[16];
+  const int wid = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const int q = wid / 3, sub = wid % 3;
+  double acc = 0.0;
+  if (q < 5) {
+    const double *p = sp.ptr[q];
+    const int cnt = sp.count[q];
+    for (int i = sub * WAVE + lane; i < cnt; i += 3 * WAVE) acc += p[i];
+    acc = wave_sum(acc);
+    if (lane == 0) wsum[wid] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 5; ++k) res_host[k] = (wsum[3 * k] + wsum[3 * k + 1]) + wsum[3 * k + 2];
+    const unsigned long long s = *seq_dev + 1ull;
+    *seq_dev = s;
+    __threadfence_system();
+    res_host[7] = (double)s;      // exact up to 2^53 launches
+  }
+}
+
+template <typename... Args>
+hipError_t graph_add_kernel(hipGraph_t g, hipGraphNode_t *node, const std::vector<hipGraphNode_t> &deps,
+                            const void *func, dim3 grid, dim3 block, Args... args) {
+  void *params[] = {(void *)&args...};
+  hipKernelNodeParams p{};
+  p.func = const_cast<void *>(func);
+  p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0;
+  p.kernelParams = params; p.extra = nullptr;
+  return hipGraphAddKernelNode(node, g, deps.empty() ? nullptr : deps.data(), deps.size(), &p);
+}
+template <typename... Args>
+hipError_t graph_set_kernel(hipGraphExec_t exec, hipGraphNode_t node, const void *func, dim3 grid, dim3 block,
+                            Args... args) {
+  void *params[] = {(void *)&args...};
+  hipKernelNodeParams p{};
+  p.func = const_cast<void *>(func);
+  p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0;
+  p.kernelParams = params; p.extra = nullptr;
+  return hipGraphExecKernelNodeSetParams(exec, node, &p);
+}
+
+bool graph_eligible(pdhg_handle *h) {
+  if (h->graph_mode < 0) {
+    const char *ev = getenv("PDHG_GRAPH");
+    // stream layouts only: with the tiled sweep a trial runs for a millisecond and launch gaps are noise
+    bool on = !h->grp && !h->has_q && !h->A.tiled && !h->At.tiled && h->n > 0;
+    if (ev) on = on && ev[0] != '0';
+    h->graph_mode = on ? 1 : 0;
+  }
+  return h->graph_mode == 1 && !h->has_q && !h->profile;
+}
+
+void graph_destroy(pdhg_handle::TrialGraph &G) {
+  if (G.exec) (void)hipGraphExecDestroy(G.exec);
+  if (G.graph) (void)hipGraphDestroy(G.graph);
+  G = pdhg_handle::TrialGraph();
+}
+
+// the argument packs of the three nodes whose scalars change from trial to trial
+struct GraphArgs {
+  pdhg_handle *h;
+  int n;
+  dim3 primal_grid;
+  EpiArgs dual_epi;
+  GraphArgs(pdhg_handle *h_, double sigma) : h(h_), n((int)h_->n), primal_grid(ew_grid((h_->n + 1) / 2)) {
+    dual_epi = EpiArgs{};
+    dual_epi.y = h->y; dual_epi.b = h->b; dual_epi.y_next = h->y_next; dual_epi.sigma = sigma;
+    dual_epi.num_eq = (int)h->num_eq; dual_epi.partials = h->pA; dual_epi.stride = h->A.slots();
+  }
+};
+
+int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double theta, double sigma) {
+  graph_destroy(G);
+  if (!h->seq_dev) {
+    HIP_TRY(hipMalloc((void **)&h->seq_dev, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->seq_dev, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc((void **)&h->res_host, 8 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+    for (int q = 0; q < 8; ++q) h->res_host[q] = 0.0;
+  }
+  HIP_TRY(hipGraphCreate(&G.graph, 0));
+  GraphArgs a(h, sigma);
+  const double *nullq = nullptr;
+  // K1+K2
+  HIP_TRY(graph_add_kernel(G.graph, &G.n_primal, {}, (const void *)primal_kernel<false, true>, a.primal_grid, dim3(TPB),
+                           a.n, (const double *)h->x, (const double *)h->c, (const double *)h->aty, nullq,
+                           (const double *)h->lb, (const double *)h->ub, tau, theta, h->x_next, h->xbar));
+  // K3+K4 on CSR(A): the stream kernel and the long-row pair are independent branches
+  std::vector<hipGraphNode_t> dual_done;
+  const CsrDev &A = h->A;
+  if (A.grid > 0) {
+    HIP_TRY(graph_add_kernel(G.graph, &G.n_dual, {G.n_primal}, (const void *)spmv_stream_kernel<MODE_DUAL>, dim3(A.grid),
+                             dim3(TPB), A.view(), (const double *)h->xbar, (const int2 *)A.blks, A.nblk, A.per_xcd,
+                             h->remap ? 1 : 0, a.dual_epi));
+    dual_done.push_back(G.n_dual);
+  }
+  if (A.nlong > 0) {
+    hipGraphNode_t part = nullptr;
+    HIP_TRY(graph_add_kernel(G.graph, &part, {G.n_primal}, (const void *)spmv_long_partial_kernel, dim3(A.nchunks), dim3(TPB),
+                             A.view(), (const double *)h->xbar, (const int *)A.chunk_row, (const int *)A.chunk_off,
+                             A.chunk_partial));
+    HIP_TRY(graph_add_kernel(G.graph, &G.n_dual_long, {part}, (const void *)spmv_long_final_kernel<MODE_DUAL>,
+                             dim3(A.long_grid), dim3(TPB), (const int *)A.long_row, (const int *)A.long_chunk_ptr, A.nlong,
+                             (const double *)A.chunk_partial, a.dual_epi, A.grid));
+    dual_done.push_back(G.n_dual_long);
+  }
+  if (dual_done.empty()) dual_done.push_back(G.n_primal);
+  // K5+K6 on CSR(A')
+  const CsrDev &T = h->At;
+  EpiArgs te{};
+  te.x = h->x; te.x_next = h->x_next; te.aty = h->aty; te.aty_next = h->aty_next;
+  te.partials = h->pAt; te.stride = h->pAt_stride;
+  std::vector<hipGraphNode_t> aty_done;
+  if (T.grid > 0) {
+    hipGraphNode_t nd = nullptr;
+    HIP_TRY(graph_add_kernel(G.graph, &nd, dual_done, (const void *)spmv_stream_kernel<MODE_ATY>, dim3(T.grid), dim3(TPB),
+                             T.view(), (const double *)h->y_next, (const int2 *)T.blks, T.nblk, T.per_xcd,
+                             h->remap ? 1 : 0, te));
+    aty_done.push_back(nd);
+  }
+  if (T.nlong > 0) {
+    hipGraphNode_t part = nullptr, fin = nullptr;
+    HIP_TRY(graph_add_kernel(G.graph, &part, dual_done, (const void *)spmv_long_partial_kernel, dim3(T.nchunks), dim3(TPB),
+                             T.view(), (const double *)h->y_next, (const int *)T.chunk_row, (const int *)T.chunk_off,
+                             T.chunk_partial));
+    HIP_TRY(graph_add_kernel(G.graph, &fin, {part}, (const void *)spmv_long_final_kernel<MODE_ATY>, dim3(T.long_grid),
+                             dim3(TPB), (const int *)T.long_row, (const int *)T.long_chunk_ptr, T.nlong,
+                             (const double *)T.chunk_partial, te, T.grid));
+    aty_done.push_back(fin);
+  }
+  if (aty_done.empty()) aty_done = dual_done;
+  // K6b -> pinned host memory + sequence number
+  FinalSpec sp{};
+  sp.ptr[0] = h->pAt;                       sp.count[0] = T.slots();
+  sp.ptr[1] = h->pAt + h->pAt_stride;       sp.count[1] = T.slots();
+  sp.ptr[2] = h->pA;                        sp.count[2] = A.slots();
+  sp.ptr[3] = h->pAt + 2 * h->pAt_stride;   sp.count[3] = T.slots();
+  sp.ptr[4] = h->pQ;                        sp.count[4] = 0;
+  sp.out = nullptr;
+  hipGraphNode_t fin = nullptr;
+  HIP_TRY(graph_add_kernel(G.graph, &fin, aty_done, (const void *)final_reduce_host_kernel, dim3(1), dim3(FINAL_TPB), sp,
+                           h->seq_dev, h->res_host));
+  HIP_TRY(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
+  G.x = h->x; G.y = h->y; G.aty = h->aty;
+  G.tau = tau; G.theta = theta; G.sigma = sigma;
+  return 0;
+}
+
+int graph_trial(pdhg_handle *h, double step_size, double primal_weight, double theta, double out[5]) {
+  const double tau = step_size / primal_weight, sigma = primal_weight * step_size;
+  pdhg_handle::TrialGraph *G = nullptr;
+  for (int k = 0; k < 2; ++k)
+    if (h->tgraph[k].exec && h->tgraph[k].x == h->x && h->tgraph[k].y == h->y && h->tgraph[k].aty == h->aty)
+      G = &h->tgraph[k];
+  if (!G) {
+    G = !h->tgraph[0].exec ? &h->tgraph[0] : (!h->tgraph[1].exec ? &h->tgraph[1] : &h->tgraph[0]);
+    int rc = graph_build(h, *G, tau, theta, sigma);
+    if (rc) return rc;
+  } else {
+    GraphArgs a(h, sigma);
+    if (G->tau != tau || G->theta != theta) {
+      const double *nullq = nullptr;
+      HIP_TRY(graph_set_kernel(G->exec, G->n_primal, (const void *)primal_kernel<false, true>, a.primal_grid, dim3(TPB),
+                               a.n, (const double *)h->x, (const double *)h->c, (const double *)h->aty, nullq,
+                               (const double *)h->lb, (const double *)h->ub, tau, theta, h->x_next, h->xbar));
+      G->tau = tau; G->theta = theta;
+    }
+    if (G->sigma != sigma) {
+      const CsrDev &A = h->A;
+      if (G->n_dual)
+        HIP_TRY(graph_set_kernel(G->exec, G->n_dual, (const void *)spmv_stream_kernel<MODE_DUAL>, dim3(A.grid), dim3(TPB),
+                                 A.view(), (const double *)h->xbar, (const int2 *)A.blks, A.nblk, A.per_xcd,
+                                 h->remap ? 1 : 0, a.dual_epi));
+      if (G->n_dual_long)
+        HIP_TRY(graph_set_kernel(G->exec, G->n_dual_long, (const void *)spmv_long_final_kernel<MODE_DUAL>,
+                                 dim3(A.long_grid), dim3(TPB), (const int *)A.long_row, (const int *)A.long_chunk_ptr,
+                                 A.nlong, (const double *)A.chunk_partial, a.dual_epi, A.grid));
+      G->sigma = sigma;
+    }
+  }
+  h->seq_expected += 1;
+  HIP_TRY(hipGraphLaunch(G->exec, h->stream));
+  // wait for this launch's sequence number in pinned memory (bounded spin, then the stream)
+  const double want = (double)h->seq_expected;
+  bool seen = false;
+  for (long spin = 0; spin < 40000000L; ++spin) {
+    if (h->res_host[7] == want) { seen = true; break; }
+    if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+  }
+  if (!seen) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->res_host[7] != want) return fail(998, "trial graph finished without publishing its results");
+  }
+  for (int q = 0; q < 5; ++q) out[q] = h->res_host[q];
+  out[4] *= 0.5;
   return 0;
 }
 
@@ -614,6 +837,9 @@ void destroy_shard(pdhg_handle *h) {
                     h->tr_dir, h->tr_thr, h->ev_partials, h->ev_cax[0], h->ev_cax[1],
                     h->ev_caty[0], h->ev_caty[1], h->ev_cqx[0], h->ev_cqx[1], h->ev_qx, h->ev_xg};
   for (double *p : bufs) if (p) (void)hipFree(p);
+  graph_destroy(h->tgraph[0]); graph_destroy(h->tgraph[1]);
+  if (h->seq_dev) (void)hipFree(h->seq_dev);
+  if (h->res_host) (void)hipHostFree((void *)h->res_host);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -947,6 +1173,7 @@ int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, doub
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
+  if (!L.g && graph_eligible(h)) return graph_trial(h, step_size, primal_weight, theta, out);
   FOR_SHARDS(L, s) { if ((rc = launch_primal(s, step_size / primal_weight, theta, true))) return rc; }
   if (L.g) return trial_dual_group(L, step_size, primal_weight, out);
   return trial_dual_single(h, step_size, primal_weight, out);
@@ -971,6 +1198,48 @@ int pdhg_accept(pdhg_handle *h0, double avg_weight) {
     h->sum_x_count += 1; h->sum_y_count += 1;
     h->sum_x_weights += avg_weight; h->sum_y_weights += avg_weight;
   }
+  return 0;
+}
+
+/* take_step(::AdaptiveStepsizeParams, ...) -- src/primal_dual_hybrid_gradient.jl:653-731 --
+ * with its host part in C: the retry loop, compute_interaction_and_movement's scalar
+ * arithmetic (:527-549), the step-size rule (:713-729) and the accept.  The same
+ * statements as primal_dual_hybrid_gradient.py::take_step_adaptive (bitwise equal
+ * results; tests/test_gpu_native_take_step.py); what it removes is the host
+ * language's per-call overhead between the trial and the accept. */
+int pdhg_take_step_adaptive(pdhg_handle *h, double reduction_exponent, double growth_exponent,
+                            double *step_size_io, double primal_weight, int64_t *total_number_iterations_io,
+                            double *cumulative_kkt_passes_io, int *numerical_error_out) {
+  if (!h || !step_size_io || !total_number_iterations_io || !cumulative_kkt_passes_io || !numerical_error_out)
+    return fail(-1, "null argument");
+  const double step_on_entry = *step_size_io;
+  double step_size = step_on_entry;
+  *numerical_error_out = 0;
+  bool done = false;
+  while (!done) {
+    *total_number_iterations_io += 1;
+    double raw[5];
+    int rc = pdhg_trial_step(h, step_size, primal_weight, 1.0, raw);
+    if (rc) return rc;
+    const double interaction = fabs(raw[0]) + fabs(raw[4]);
+    const double nx = sqrt(raw[1]), ny = sqrt(raw[2]);
+    const double movement = 0.5 * primal_weight * (nx * nx) + (0.5 / primal_weight) * (ny * ny);
+    *cumulative_kkt_passes_io += 1;
+    if (movement == 0.0) {       // the algorithm terminates at the beginning of the next iteration
+      *numerical_error_out = 1;
+      break;
+    }
+    const double step_size_limit = interaction > 0 ? movement / interaction : INFINITY;
+    if (step_size <= step_size_limit) {
+      if ((rc = pdhg_accept(h, step_on_entry))) return rc;   // weight = step size on entry (pdhg.jl:512)
+      done = true;
+    }
+    const double k1 = (double)(*total_number_iterations_io + 1);
+    const double first_term = (1 - pow(k1, -reduction_exponent)) * step_size_limit;
+    const double second_term = (1 + pow(k1, -growth_exponent)) * step_size;
+    step_size = (second_term < first_term) ? second_term : first_term;
+  }
+  *step_size_io = step_size;
   return 0;
 }
 

@@ -119,13 +119,39 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
       const int ke = A.rowptr[r + 1] - k0;
       double s = 0.0;
       int k = ks;
-      // 8 LDS reads in flight, adds still strictly left to right (bit-exact
-      // order); a row of ~2K products is otherwise one LDS latency per add.
-      for (; k + 8 <= ke; k += 8) {
-        const double t0 = prod[k], t1 = prod[k + 1], t2 = prod[k + 2], t3 = prod[k + 3];
-        const double t4 = prod[k + 4], t5 = prod[k + 5], t6 = prod[k + 6], t7 = prod[k + 7];
-        s = s + t0; s = s + t1; s = s + t2; s = s + t3;
-        s = s + t4; s = s + t5; s = s + t6; s = s + t7;
+      // Adds strictly left to right (bit-exact order).  A row of hundreds of
+      // products (hub rows, dense feature columns) is one dependent chain on one
+      // lane, so its LDS reads are software-pipelined: the next 8 products are
+      // requested before the current 8 are added, which leaves the chain at the
+      // latency of the adds alone (L1-SVM A': 29.8 -> see profiles/r02).
+      if (k + 8 <= ke) {
+#define LD8(p, q) const double p##0 = prod[q], p##1 = prod[(q) + 1], p##2 = prod[(q) + 2], p##3 = prod[(q) + 3], \
+                               p##4 = prod[(q) + 4], p##5 = prod[(q) + 5], p##6 = prod[(q) + 6], p##7 = prod[(q) + 7]
+#define ADD8(p) s = s + p##0; s = s + p##1; s = s + p##2; s = s + p##3; s = s + p##4; s = s + p##5; s = s + p##6; s = s + p##7
+        double c0 = prod[k], c1 = prod[k + 1], c2 = prod[k + 2], c3 = prod[k + 3];
+        double c4 = prod[k + 4], c5 = prod[k + 5], c6 = prod[k + 6], c7 = prod[k + 7];
+        k += 8;
+        // two register sets alive at once (c: being added, b: in flight) and scheduling
+        // barriers: otherwise the compiler sinks the loads back behind the adds
+        for (; k + 16 <= ke; k += 16) {
+          LD8(b, k);
+          __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the adds they overlap
+          ADD8(c);
+          c0 = prod[k + 8]; c1 = prod[k + 9]; c2 = prod[k + 10]; c3 = prod[k + 11];
+          c4 = prod[k + 12]; c5 = prod[k + 13]; c6 = prod[k + 14]; c7 = prod[k + 15];
+          __builtin_amdgcn_sched_barrier(0);
+          ADD8(b);
+        }
+        if (k + 8 <= ke) {
+          LD8(b, k);
+          ADD8(c);
+          ADD8(b);
+          k += 8;
+        } else {
+          ADD8(c);
+        }
+#undef LD8
+#undef ADD8
       }
       for (; k < ke; ++k) s = s + prod[k];
       row_epilogue<MODE>(e, r, s, acc);

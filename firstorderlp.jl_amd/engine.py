@@ -132,6 +132,19 @@ class HipPdhgEngine:
     def accept(self, avg_weight):
         _lib.check(self._L.pdhg_accept(self._h, avg_weight))
 
+    def take_step_adaptive(self, reduction_exponent, growth_exponent, step_size, primal_weight,
+                           total_number_iterations, cumulative_kkt_passes):
+        """pdhg_take_step_adaptive: returns (step_size, total_number_iterations,
+        cumulative_kkt_passes, numerical_error)."""
+        ss = ctypes.c_double(step_size)
+        it = ctypes.c_int64(total_number_iterations)
+        kkt = ctypes.c_double(cumulative_kkt_passes)
+        err = ctypes.c_int(0)
+        _lib.check(self._L.pdhg_take_step_adaptive(
+            self._h, reduction_exponent, growth_exponent, ctypes.byref(ss), primal_weight,
+            ctypes.byref(it), ctypes.byref(kkt), ctypes.byref(err)))
+        return ss.value, it.value, kkt.value, bool(err.value)
+
     def add_current_primal_to_average(self, weight):
         _lib.check(self._L.pdhg_add_current_primal_to_average(self._h, weight))
 

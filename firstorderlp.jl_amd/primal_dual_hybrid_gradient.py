@@ -7,6 +7,7 @@ step-size rules of ``take_step`` (pdhg.jl:555-767), counters, and -- in
 ``optimize`` -- restarts, primal-weight updates and termination.
 """
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -76,8 +77,22 @@ def interaction_and_movement(raw, primal_weight):
 
 
 def take_step_adaptive(step_params, solver_state):
-    """take_step(::AdaptiveStepsizeParams, ...)  pdhg.jl:653-731."""
+    """take_step(::AdaptiveStepsizeParams, ...)  pdhg.jl:653-731.
+
+    With the HIP engine the same statements run inside the library
+    (pdhg_take_step_adaptive: one call per iteration instead of two with
+    Python in between; bitwise the same scalars).  PDHG_PY_TAKE_STEP=1 keeps
+    the loop below, which is also what every other engine uses."""
     eng = solver_state.engine
+    if hasattr(eng, "take_step_adaptive") and os.environ.get("PDHG_PY_TAKE_STEP", "0") != "1":
+        (solver_state.step_size, solver_state.total_number_iterations,
+         solver_state.cumulative_kkt_passes, err) = eng.take_step_adaptive(
+            step_params.reduction_exponent, step_params.growth_exponent, solver_state.step_size,
+            solver_state.primal_weight, solver_state.total_number_iterations,
+            solver_state.cumulative_kkt_passes)
+        if err:
+            solver_state.numerical_error = True
+        return
     step_size = solver_state.step_size
     done = False
     while not done:

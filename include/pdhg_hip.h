@@ -97,6 +97,21 @@ int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight,
  */
 int pdhg_accept(pdhg_handle *h, double avg_weight);
 
+/*
+ * take_step(::AdaptiveStepsizeParams, ...) (pdhg.jl:653-731) in one call: the retry
+ * loop around pdhg_trial_step, the scalar step-size rule (pdhg.jl:691-729, on the
+ * host, in C) and pdhg_accept.  In/out: *step_size, *total_number_iterations,
+ * *cumulative_kkt_passes (the solver-state scalars the reference updates);
+ * *numerical_error is set when movement == 0 (pdhg.jl:692-697).  Equivalent to
+ * driving pdhg_trial_step / pdhg_accept from the host language statement by statement
+ * (julia/FirstOrderLpHIP.jl does that); it exists because an interpreted host spends
+ * as long between two calls as a small LP's kernels take.
+ */
+int pdhg_take_step_adaptive(pdhg_handle *h, double reduction_exponent, double growth_exponent,
+                            double *step_size, double primal_weight,
+                            int64_t *total_number_iterations, double *cumulative_kkt_passes,
+                            int *numerical_error);
+
 /* add_to_primal_solution_weighted_average on the CURRENT x (pdhg.jl:621-627). */
 int pdhg_add_current_primal_to_average(pdhg_handle *h, double weight);
 

@@ -154,6 +154,21 @@ function average_info(s::HipSolverState)
   return counts[1], counts[2], weights[1], weights[2]
 end
 
+"""
+The whole adaptive take_step in one ccall (pdhg_take_step_adaptive: the same loop as the
+method below, with its scalar part in C).  Julia's ccall overhead is negligible, so the
+method below drives trial_step/accept itself; this binding is for hosts that prefer one call.
+"""
+function take_step_adaptive_native!(s::HipSolverState, reduction_exponent, growth_exponent)
+  step = Ref{Float64}(s.step_size); its = Ref{Int64}(s.total_number_iterations)
+  kkt = Ref{Float64}(s.cumulative_kkt_passes); err = Ref{Cint}(0)
+  check(ccall((:pdhg_take_step_adaptive, LIB), Cint,
+    (Ptr{Cvoid}, Float64, Float64, Ref{Float64}, Float64, Ref{Int64}, Ref{Float64}, Ref{Cint}),
+    s.handle, reduction_exponent, growth_exponent, step, s.primal_weight, its, kkt, err))
+  s.step_size = step[]; s.total_number_iterations = its[]; s.cumulative_kkt_passes = kkt[]
+  s.numerical_error = s.numerical_error || err[] != 0
+end
+
 "take_step(::AdaptiveStepsizeParams, ...) -- pdhg.jl:653-731 with the vector work on the GPU."
 function FirstOrderLp.take_step(step_params::FirstOrderLp.AdaptiveStepsizeParams,
                                 problem, s::HipSolverState)

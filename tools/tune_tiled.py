@@ -23,7 +23,8 @@ p = random_lp(a.m, a.n, a.k, 12345)
 A = p.constraint_matrix
 step0 = 1.0 / float(np.abs(A.data).max())
 pw0 = float(np.linalg.norm(p.objective_vector) / np.linalg.norm(p.right_hand_side))
-KEYS = ["PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TW_ROWS", "PDHG_TW_WPB", "PDHG_TW_FLAGS", "PDHG_XCD_REMAP"]
+KEYS = ["PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TW_ROWS", "PDHG_TW_WPB", "PDHG_TW_FLAGS", "PDHG_XCD_REMAP",
+        "PDHG_TW_MAX_ROWS", "PDHG_TW_WGS_PER_CU"]
 for rep in range(a.reps):
     for cfg in a.cfgs or [""]:
         for k in KEYS:
