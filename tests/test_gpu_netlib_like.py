@@ -56,6 +56,8 @@ def test_iterates_match_cpu_at_1e10_given_same_decisions(gpu_required, name, m, 
     vector path the CPU oracle's scalars drive BOTH runs here.  Bars: iterates
     at K = 1, 10, 100, 1000 accepted steps within 1e-10; every GPU scalar within
     1e-13 * sum|terms| of the oracle's (condition-aware, backward-stable bound)."""
+    print(f"SUBSTITUTE: {name} is a seeded LP with the shape of the Netlib instance, not the instance itself "
+          "(tests/test_gpu_netlib_real.py runs the real file when it is present)")
     p = netlib_like(m, n, nnz, ne, seed={"afiro_like": 27, "adlittle_like": 56}[name])
     assert p.constraint_matrix.nnz == nnz
     eng = HipPdhgEngine.from_problem(p)
