@@ -47,6 +47,11 @@ struct DistGroup {
   std::vector<int64_t> row_lo;          // [world+1] global row range of every rank
   std::vector<hipEvent_t> ev[2];        // cross-stream barrier of the peer back end
   int flip = 0;
+  // Exchange pattern of the trial's A_p'y_p: one reduce-scatter after the product, or P
+  // per-slice reductions issued as the product's slices complete (on the comm streams,
+  // overlapping the rest of the product).  Decided from (n, world, environment) only, so
+  // that every rank issues the same sequence of collectives.
+  bool overlap = false;
   bool all_local() const { return (int)sh.size() == world; }
 };
 
@@ -163,6 +168,58 @@ int dist_reduce_scatter(DistGroup &g, Sel sel, int64_t S, bool maxop = false) {
     HIP_TRY(hipGetLastError());
   }
   return p2p_barrier(g);
+}
+
+// Slice k of the partial vectors (S doubles at k*S) summed over ranks into its owner's
+// buffer, asynchronously on the comm streams, once every shard has recorded ev_part[k]
+// on its compute stream.  dist_join_comm() makes the compute streams wait for all of them.
+template <typename Sel>
+int dist_reduce_slice_async(DistGroup &g, Sel sel, int64_t S, int k) {
+  if (g.backend == COMM_RCCL) {
+    for (pdhg_handle *s : g.sh) {
+      HIP_TRY(hipSetDevice(s->device));
+      HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_part[(size_t)k], 0));
+    }
+    NCCL_TRY(ncclGroupStart());
+    for (size_t i = 0; i < g.sh.size(); ++i) {
+      pdhg_handle *s = g.sh[i];
+      HIP_TRY(hipSetDevice(s->device));
+      double *b = sel(s) + (int64_t)k * S;
+      NCCL_TRY(ncclReduce(b, b, (size_t)S, ncclDouble, ncclSum, k, g.comm[i], s->comm_stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return 0;
+  }
+  pdhg_handle *owner = nullptr;
+  PeerPtrs pp{};
+  pp.world = g.world;
+  for (pdhg_handle *q : g.sh) { pp.p[q->rank] = sel(q); if (q->rank == k) owner = q; }
+  if (!owner) return fail(-1, "peer back end needs every rank in this process");
+  HIP_TRY(hipSetDevice(owner->device));
+  for (pdhg_handle *q : g.sh) HIP_TRY(hipStreamWaitEvent(owner->comm_stream, q->ev_part[(size_t)k], 0));
+  const int64_t off = (int64_t)k * S;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + TPB - 1) / TPB, EW_MAX_BLOCKS));
+  hipLaunchKernelGGL(p2p_reduce_kernel<false>, dim3(grid), dim3(TPB), 0, owner->comm_stream, pp, off, S, sel(owner) + off);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int dist_join_comm(DistGroup &g) {
+  for (pdhg_handle *s : g.sh) {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventRecord(s->ev_comm, s->comm_stream));
+  }
+  for (pdhg_handle *s : g.sh) {
+    HIP_TRY(hipSetDevice(s->device));
+    if (g.backend == COMM_RCCL) {
+      HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_comm, 0));
+    } else {
+      // peer kernels read the OTHER shards' buffers: nobody may reuse its partial vector
+      // before every owner has finished reading
+      for (pdhg_handle *q : g.sh) HIP_TRY(hipStreamWaitEvent(s->stream, q->ev_comm, 0));
+    }
+  }
+  return 0;
 }
 
 // All-reduce as reduce-scatter + all-gather: every element is reduced once, at

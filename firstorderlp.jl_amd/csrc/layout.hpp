@@ -38,14 +38,21 @@ template <typename T>
 int upload(T **dst, const std::vector<T> &src) {
   const size_t bytes = sizeof(T) * std::max<size_t>(src.size(), 1);
   HIP_TRY(hipMalloc((void **)dst, bytes));
-  if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+  if (!src.empty()) {
+    HIP_TRY(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+  }
   return 0;
 }
 
 int alloc_zero(double **dst, int64_t len) {
   const size_t bytes = sizeof(double) * (size_t)std::max<int64_t>(len, 1);
   HIP_TRY(hipMalloc((void **)dst, bytes));
-  HIP_TRY(hipMemset(*dst, 0, bytes));
+  // the fill runs on the null stream, which does NOT order against the handles'
+  // non-blocking streams: wait for it, or a kernel launched next on such a stream
+  // can have its output zeroed by a late fill
+  HIP_TRY(hipMemsetAsync(*dst, 0, bytes, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   return 0;
 }
 

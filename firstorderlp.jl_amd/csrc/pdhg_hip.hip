@@ -107,6 +107,9 @@ struct pdhg_handle {
   int64_t n_alloc = 0;             // length of the n-vectors that take part in collectives (world * S >= n)
   int64_t row_lo = 0;              // first GLOBAL row of this shard (m is the local row count)
   int64_t m_global = 0;
+  hipStream_t comm_stream = nullptr;   // group: per-slice reductions run here, beside the product that feeds them
+  std::vector<hipEvent_t> ev_part;     // [world] "slice k of A_p'y_p is complete" on `stream`
+  hipEvent_t ev_comm = nullptr;        // "all of this shard's reductions are done" on `comm_stream`
   double *dn_buf = nullptr;        // [n_alloc] gather / partial buffer (group only)
   double *dm_buf = nullptr;        // [m_global] row-gather buffer (group only)
   // scalar results: scal_dev[SCAL_MAX] on the device, scal_all[world*SCAL_MAX] (RCCL gather), pinned scal_host
@@ -198,6 +201,42 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
                        D.view(), xin, D.chunk_row, D.chunk_off, D.chunk_partial);
     hipLaunchKernelGGL(spmv_long_final_kernel<MODE>, dim3(D.long_grid), dim3(TPB), 0, h->stream,
                        D.long_row, D.long_chunk_ptr, D.nlong, D.chunk_partial, e, D.grid);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// MODE_PLAIN product restricted to the tiled workgroups [g0, g1) (their rows are a
+// contiguous range of the output); `with_long` also runs the long-row path.
+// The kernel is the one launch_spmv uses: the per-wave / per-workgroup tables
+// are simply passed from offset g0 (row numbers and entry offsets are absolute).
+int launch_spmv_plain_part(pdhg_handle *h, const CsrDev &D, const double *xin, double *out,
+                           int g0, int g1, bool with_long) {
+  if (!D.tiled) return fail(-1, "partial launch needs the tiled layout");
+  EpiArgs e{};
+  e.out = out;
+  if (with_long && D.nlong > 0) {
+    hipLaunchKernelGGL(spmv_long_partial_kernel, dim3(D.nchunks), dim3(TPB), 0, h->stream,
+                       D.view(), xin, D.chunk_row, D.chunk_off, D.chunk_partial);
+    hipLaunchKernelGGL(spmv_long_final_kernel<MODE_PLAIN>, dim3(D.long_grid), dim3(TPB), 0, h->stream,
+                       D.long_row, D.long_chunk_ptr, D.nlong, D.chunk_partial, e, D.grid);
+  }
+  if (g1 > g0) {
+    const size_t lds = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_scratch ? TW_WPB * WAVE : 0));
+    const int w0 = g0 * TW_WPB;
+    if (D.tw_scratch) {
+      int rc = ensure_lds_limit(h, MODE_PLAIN, true, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, true>);
+      if (rc) return rc;
+      hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, true>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
+                         D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
+                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
+    } else {
+      int rc = ensure_lds_limit(h, MODE_PLAIN, false, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, false>);
+      if (rc) return rc;
+      hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, false>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
+                         D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
+                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
+    }
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -375,7 +414,8 @@ int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double t
   graph_destroy(G);
   if (!h->seq_dev) {
     HIP_TRY(hipMalloc((void **)&h->seq_dev, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->seq_dev, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(h->seq_dev, 0, sizeof(unsigned long long), nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));   // the null stream does not order against h->stream
     HIP_TRY(hipHostMalloc((void **)&h->res_host, 8 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     for (int q = 0; q < 8; ++q) h->res_host[q] = 0.0;
   }
@@ -797,7 +837,7 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   auto up = [&](double **dst, const double *src, int64_t len) -> int {
     int r2 = alloc_zero(dst, len);
     if (r2) return r2;
-    if (len > 0) HIP_TRY(hipMemcpy(*dst, src, sizeof(double) * (size_t)len, hipMemcpyHostToDevice));
+    if (len > 0) { HIP_TRY(hipMemcpy(*dst, src, sizeof(double) * (size_t)len, hipMemcpyHostToDevice)); HIP_TRY(hipStreamSynchronize(nullptr)); }
     return 0;
   };
   CK(up(&h->c, c, n)); CK(up(&h->b, b, m)); CK(up(&h->lb, lb, n)); CK(up(&h->ub, ub, n));
@@ -838,6 +878,9 @@ void destroy_shard(pdhg_handle *h) {
                     h->ev_caty[0], h->ev_caty[1], h->ev_cqx[0], h->ev_cqx[1], h->ev_qx, h->ev_xg};
   for (double *p : bufs) if (p) (void)hipFree(p);
   graph_destroy(h->tgraph[0]); graph_destroy(h->tgraph[1]);
+  if (h->comm_stream) { (void)hipStreamSynchronize(h->comm_stream); (void)hipStreamDestroy(h->comm_stream); }
+  for (hipEvent_t ev : h->ev_part) if (ev) (void)hipEventDestroy(ev);
+  if (h->ev_comm) (void)hipEventDestroy(h->ev_comm);
   if (h->seq_dev) (void)hipFree(h->seq_dev);
   if (h->res_host) (void)hipHostFree((void *)h->res_host);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
@@ -876,6 +919,17 @@ int create_rank_shard(DistGroup *g, int rank, int64_t n, const int64_t *colptr, 
   int rc = create_shard(&s, hi - lo, n, cp[(size_t)n], cp.data(), rv.data(), nv.data(), 0, c, b ? b + lo : nullptr,
                         lb, ub, ne, device_id, stream, g->world * g->S);
   if (rc) return rc;
+  if (hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming) != hipSuccess) {
+    destroy_shard(s);
+    return fail(999, "comm stream / event creation failed");
+  }
+  s->ev_part.assign((size_t)g->world, nullptr);
+  for (int k = 0; k < g->world; ++k)
+    if (hipEventCreateWithFlags(&s->ev_part[(size_t)k], hipEventDisableTiming) != hipSuccess) {
+      destroy_shard(s);
+      return fail(999, "event creation failed");
+    }
   s->grp = g;
   s->rank = rank;
   s->world = g->world;
@@ -901,6 +955,10 @@ int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colpt
   const int64_t per = (n + world - 1) / world;
   g->S = std::max<int64_t>(16, (per + 15) / 16 * 16);      // slice stride: whole 128-byte lines
   partition_rows_by_nnz(m, n, colptr, rowval, base, world, g->row_lo);
+  // per-slice reductions overlapped with the A_p' product: worth it when the exchanged
+  // vector is large (the same test that selects the tiled layout); PDHG_DIST_OVERLAP=0/1 forces
+  const char *ov = getenv("PDHG_DIST_OVERLAP");
+  g->overlap = ov ? (ov[0] != '0') : (world > 1 && n * 8 > (4LL << 20));
   return 0;
 }
 
@@ -1119,13 +1177,56 @@ static int trial_dual_group(const Shards &L, double step_size, double primal_wei
     // QP: Q acts on full vectors, so x' is kept full as well (x becomes x' at accept)
     if (lead->has_q && (rc = dist_all_gather(g, [](pdhg_handle *s) { return s->x_next; }, g.S))) return rc;
   }
-  FOR_SHARDS(L, s) {
-    if ((rc = launch_dual(s, primal_weight * step_size))) return rc;
-    if ((rc = launch_aty_plain(s, s->y_next, s->aty_next))) return rc;      // t_p = A_p' y'_p, all n columns
-  }
-  {
+  if (!g.overlap) {
+    FOR_SHARDS(L, s) {
+      if ((rc = launch_dual(s, primal_weight * step_size))) return rc;
+      if ((rc = launch_aty_plain(s, s->y_next, s->aty_next))) return rc;      // t_p = A_p' y'_p, all n columns
+    }
     ProfScope ps(lead, PDHG_K_REDUCE_SCATTER);
     if ((rc = dist_reduce_scatter(g, [](pdhg_handle *s) { return s->aty_next; }, g.S))) return rc;
+  } else {
+    // t_p in parts: a shard whose A_p' uses the tiled layout launches it one residency
+    // round at a time (256 CUs x 2 workgroups: a smaller launch would idle CUs for the whole
+    // sweep); as soon as the rows of slice k are complete, slice k is reduced to rank k on
+    // the comm stream while the next round computes.  The sequence of collectives (slice
+    // 0, 1, ..., P-1) is the same on every rank however the local product is cut.
+    FOR_SHARDS(L, s) { if ((rc = launch_dual(s, primal_weight * step_size))) return rc; }
+    const char *rw_env = getenv("PDHG_DIST_ROUND_WGS");            // tests use a finer granule on small problems
+    const int round_wgs = rw_env ? std::max(1, atoi(rw_env)) : 256 * 2;
+    std::vector<int> issued((size_t)L.count, 0), next_wg((size_t)L.count, 0);
+    int k_issued = 0;
+    while (k_issued < g.world) {
+      // every local shard advances until slice k_issued is complete on it
+      for (int i = 0; i < L.count; ++i) {
+        pdhg_handle *s = L.p[i];
+        HIP_TRY(hipSetDevice(s->device));
+        const CsrDev &T = s->At;
+        const int64_t need = std::min<int64_t>(s->n, (int64_t)(k_issued + 1) * g.S);   // rows [0, need) must be done
+        if (!T.tiled) {
+          if (issued[(size_t)i] == 0) {
+            if ((rc = launch_aty_plain(s, s->y_next, s->aty_next))) return rc;
+            issued[(size_t)i] = 1;
+          }
+        } else {
+          while (next_wg[(size_t)i] < T.grid || issued[(size_t)i] == 0) {
+            const int g0 = next_wg[(size_t)i];
+            const bool covered = g0 >= T.grid || (int64_t)T.wg_first_row[(size_t)g0] >= need;
+            if (covered && issued[(size_t)i] != 0) break;
+            int g1 = std::min(T.grid, g0 + round_wgs);
+            if (T.grid - g1 < round_wgs / 2) g1 = T.grid;       // no runt round at the end
+            ProfScope ps(s, PDHG_K_SPMV_ATY);
+            if ((rc = launch_spmv_plain_part(s, T, s->y_next, s->aty_next, g0, g1, issued[(size_t)i] == 0))) return rc;
+            issued[(size_t)i] = 1;
+            next_wg[(size_t)i] = g1;
+          }
+        }
+        HIP_TRY(hipEventRecord(s->ev_part[(size_t)k_issued], s->stream));
+      }
+      if ((rc = dist_reduce_slice_async(g, [](pdhg_handle *s) { return s->aty_next; }, g.S, k_issued))) return rc;
+      ++k_issued;
+    }
+    ProfScope ps(lead, PDHG_K_REDUCE_SCATTER);     // what is left of the exchange after the product
+    if ((rc = dist_join_comm(g))) return rc;
   }
   FOR_SHARDS(L, s) {
     {
@@ -1140,13 +1241,10 @@ static int trial_dual_group(const Shards &L, double step_size, double primal_wei
     if ((rc = launch_final(s, s->pAt, ew_grid(s->cn), s->pAt_stride, s->pA, s->A.slots(), qcount))) return rc;
   }
   double r[5];
-  if ((rc = combine_scalars(L, 5, 5, r))) return rc;
+  // [0..4) are added in rank order; [4] (dx'Q dx, replicated: the same value on every rank) is "maxed"
+  if ((rc = combine_scalars(L, 5, 4, r))) return rc;
   for (int q = 0; q < 4; ++q) out[q] = r[q];
-  out[4] = 0.5 * (r[4] / (double)g.world);   // every rank contributed the same replicated value
-  if (lead->has_q) {
-    // exact: take rank 0's value instead of sum/world (the division can round)
-    out[4] = 0.5 * (g.all_local() ? L.p[0]->scal_host[4] : L.p[0]->scal_host[4]);
-  }
+  out[4] = 0.5 * r[4];
   return 0;
 }
 
@@ -1491,7 +1589,7 @@ int pdhg_set_original_problem(pdhg_handle *h0, const double *constraint_rescalin
   FOR_SHARDS(L, h) {
     auto up = [&](double **dst, const double *src, int64_t len) -> int {
       if (!*dst) { int r2 = alloc_zero(dst, len); if (r2) return r2; }
-      if (len > 0) HIP_TRY(hipMemcpy(*dst, src, sizeof(double) * (size_t)len, hipMemcpyHostToDevice));
+      if (len > 0) { HIP_TRY(hipMemcpy(*dst, src, sizeof(double) * (size_t)len, hipMemcpyHostToDevice)); HIP_TRY(hipStreamSynchronize(nullptr)); }
       return 0;
     };
     // row vectors arrive with their GLOBAL length: a shard keeps its rows

@@ -72,8 +72,12 @@ def _compare(g, s, p, tol=1e-9):
         np.testing.assert_allclose(g["ym"], s["ym"], rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("overlap", ["0", "1"], ids=["reduce_scatter", "per_slice_reduce"])
 @pytest.mark.parametrize("device_ids", [[0, 0], [0, 0, 0], [0] * 8], ids=["2", "3", "8"])
-def test_shards_on_one_gpu_match_single_engine(gpu_required, device_ids):
+def test_shards_on_one_gpu_match_single_engine(gpu_required, monkeypatch, device_ids, overlap):
+    # overlap=1: the exchange of A_p'y_p as P per-slice reductions on the comm streams
+    # (these shards use the stream layout: the product is computed whole, then reduced slice by slice)
+    monkeypatch.setenv("PDHG_DIST_OVERLAP", overlap)
     p = random_lp(30000, 20000, 6, seed=21)
     geng = HipPdhgEngine.from_problem(p, device_ids=device_ids)
     info = geng.dist_info()
@@ -84,14 +88,41 @@ def test_shards_on_one_gpu_match_single_engine(gpu_required, device_ids):
 
 
 @pytest.mark.timeout(600)
-def test_two_tiled_shards_match_single_engine(gpu_required):
-    """Large enough that each shard's A_p (600k x 600k) and A_p' use the tiled layout."""
+@pytest.mark.parametrize("shards", [2, 3])
+def test_tiled_shards_match_single_engine_and_overlap_is_bitwise_neutral(gpu_required, monkeypatch, shards):
+    """Large enough that each shard's A_p and A_p' use the tiled layout: A_p' is then cut at
+    launched a residency round at a time and slice k is reduced to its owner as soon as its
+    rows are complete, while the next round computes (the default for vectors this long).  With the peer back end both exchange patterns add the
+    partials in rank order, so switching the overlap off must not change a single bit."""
+    monkeypatch.setenv("PDHG_DIST_ROUND_WGS", "64")     # default granule: a residency round of 512 workgroups
     p = random_lp(1_200_000, 600_000, 5, seed=21)
-    geng = HipPdhgEngine.from_problem(p, device_ids=[0, 0])
-    assert geng.layout_info()["At_tiled_waves"] > 0
-    g = _run(geng, p, 40, 10)
+    runs = {}
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("PDHG_DIST_OVERLAP", overlap)
+        geng = HipPdhgEngine.from_problem(p, device_ids=[0] * shards)
+        info = geng.layout_info()
+        # 2 shards: A_p' (600k x 600k) is tiled and launched in parts; 3 shards: its gathered
+        # vector (400k rows of y) fits an XCD's L2, so it streams and is computed whole
+        assert info["A_tiled_waves"] > 0 and (info["At_tiled_waves"] > 0) == (shards == 2)
+        runs[overlap] = _run(geng, p, 40, 10)
+        geng.close()
+    for key, val in runs["1"].items():
+        assert np.array_equal(np.asarray(val), np.asarray(runs["0"][key])), key
     s = _run(HipPdhgEngine.from_problem(p), p, 40, 10)
-    _compare(g, s, p)
+    _compare(runs["1"], s, p)
+
+
+@pytest.mark.timeout(600)
+def test_rccl_world_1_per_slice_reduce_on_tiled_layout(gpu_required, monkeypatch):
+    """ncclReduce on the comm stream behind the cut A_p' product, 1-rank communicator."""
+    monkeypatch.setenv("PDHG_DIST_OVERLAP", "1")
+    monkeypatch.setenv("PDHG_DIST_ROUND_WGS", "64")
+    p = random_lp(700_000, 600_000, 6, seed=9)
+    geng = HipPdhgEngine.from_problem(p, device_ids=[0])
+    assert geng.dist_info()["backend"] == 0 and geng.layout_info()["At_tiled_waves"] > 0
+    g = _run(geng, p, 30, 5)
+    s = _run(HipPdhgEngine.from_problem(p), p, 30, 5)
+    _compare(g, s, p, tol=1e-10)
 
 
 def test_row_partition_matches_the_host_rule(gpu_required):
