@@ -6,6 +6,17 @@ namespace {
 
 // ---------------------------------------------------------------- host side
 
+// One column slab of a stream-layout matrix: its own CSR (absolute column indices, rows
+// that are "long" in the full matrix left empty) and row blocks.
+struct SlabDev {
+  int *rowptr = nullptr, *col = nullptr;
+  double *val = nullptr;
+  int2 *blks = nullptr;
+  int nblk = 0, per_xcd = 0, grid = 0;
+  int64_t nnz = 0;
+  CsrView view(int rows) const { return CsrView{rows, rowptr, col, val}; }
+};
+
 struct CsrDev {
   int rows = 0, cols = 0;
   int64_t nnz = 0;
@@ -30,6 +41,10 @@ struct CsrDev {
   unsigned *pk = nullptr;
   double *tv = nullptr;
   std::vector<int> wg_first_row;  // host copy: first row of every tiled workgroup (+ rows), for partial launches
+  // column-slab passes (optional, stream layout only): when non-empty the product runs as one
+  // stream-kernel launch per slab and `grid` is the LAST slab's grid (its blocks write the partials)
+  std::vector<SlabDev> slabs;
+  double *slab_partial = nullptr;   // [rows] row sums between the passes
   int slots() const { return grid + long_grid; }
   CsrView view() const { return CsrView{rows, rowptr, col, val}; }
 };
@@ -235,6 +250,78 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
   return 0;
 }
 
+// Row blocks of one column slab: runs of consecutive rows with <= BLOCK_NNZ slab entries and
+// <= MAX_ROWS_PER_BLOCK rows.  Rows that are LONG in the full matrix belong to the long-row
+// path: no block may contain them (their epilogue must run exactly once, there).
+void make_row_blocks(int rows, const std::vector<int> &slab_rowptr, const std::vector<int> &full_rowptr,
+                     std::vector<int2> &blks) {
+  int r = 0;
+  while (r < rows) {
+    if (full_rowptr[r + 1] - full_rowptr[r] > BLOCK_NNZ) { ++r; continue; }
+    const int r0 = r;
+    int nn = 0;
+    while (r < rows && (r - r0) < MAX_ROWS_PER_BLOCK && full_rowptr[r + 1] - full_rowptr[r] <= BLOCK_NNZ) {
+      const int len = slab_rowptr[r + 1] - slab_rowptr[r];
+      if (len > BLOCK_NNZ - nn) break;
+      nn += len;
+      ++r;
+    }
+    blks.push_back(make_int2(r0, r));
+  }
+}
+
+// Column-slab copies for the stream layout (see spmv_stream_kernel).  Used when the
+// gathered vector is 1.25 .. 4 slabs long (slab = PDHG_SLAB_MB MiB, default 4 = one XCD's
+// L2); beyond that the tiled sweep is the tool.  PDHG_SLABS=0 disables.
+int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, const std::vector<int> &col,
+                const std::vector<double> &val, bool remap) {
+  const char *off = getenv("PDHG_SLABS");
+  if (off && off[0] == '0') return 0;
+  const char *mb = getenv("PDHG_SLAB_MB");
+  const double slab_bytes = (mb ? std::max(0.25, atof(mb)) : 4.0) * 1048576.0;
+  const double vec_bytes = 8.0 * (double)cols;
+  if (vec_bytes <= 1.25 * slab_bytes || D.nnz < (1 << 20)) return 0;
+  const int P = (int)std::ceil(vec_bytes / slab_bytes);
+  if (P < 2 || P > 4) return 0;
+  const int width = (cols + P - 1) / P;
+  int rc;
+  for (int p = 0; p < P; ++p) {
+    const int c0 = p * width, c1 = std::min(cols, (p + 1) * width);
+    std::vector<int> rp((size_t)rows + 1, 0);
+    for (int r = 0; r < rows; ++r) {
+      int cnt = 0;
+      if (rowptr[r + 1] - rowptr[r] <= BLOCK_NNZ)          // long rows stay with the long-row path
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) cnt += (col[k] >= c0 && col[k] < c1);
+      rp[(size_t)r + 1] = rp[(size_t)r] + cnt;
+    }
+    std::vector<int> sc((size_t)rp[(size_t)rows]);
+    std::vector<double> sv((size_t)rp[(size_t)rows]);
+    parallel_ranges(rows, 1 << 14, [&](int rb, int re) {
+      for (int r = rb; r < re; ++r) {
+        if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) continue;
+        int q = rp[(size_t)r];
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
+          if (col[k] >= c0 && col[k] < c1) { sc[(size_t)q] = col[k]; sv[(size_t)q] = val[k]; ++q; }
+      }
+    });
+    std::vector<int2> blks;
+    make_row_blocks(rows, rp, rowptr, blks);
+    SlabDev S;
+    S.nnz = rp[(size_t)rows];
+    S.nblk = (int)blks.size();
+    S.per_xcd = (S.nblk + NUM_XCD - 1) / NUM_XCD;
+    S.grid = remap ? S.per_xcd * NUM_XCD : S.nblk;
+    if ((rc = upload(&S.rowptr, rp))) return rc;
+    if ((rc = upload(&S.col, sc))) return rc;
+    if ((rc = upload(&S.val, sv))) return rc;
+    if ((rc = upload(&S.blks, blks))) return rc;
+    D.slabs.push_back(S);
+  }
+  if ((rc = alloc_zero(&D.slab_partial, rows))) return rc;
+  D.grid = D.slabs.back().grid;      // the last pass runs the epilogue and writes the block partials
+  return 0;
+}
+
 int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
                   const std::vector<int> &col, const std::vector<double> &val,
                   bool remap, int tile_shift = 0) {
@@ -289,6 +376,9 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
   if (tile_shift > 0) {
     if ((rc = build_tiled(D, rows, rowptr, col, val, tile_shift))) return rc;
   }
+  if (!D.tiled) {
+    if ((rc = build_slabs(D, rows, cols, rowptr, col, val, remap))) return rc;
+  }
   return 0;
 }
 
@@ -297,6 +387,11 @@ void free_csr_dev(CsrDev &D) {
                   D.chunk_row, D.chunk_off, D.chunk_partial, D.wave_rows, D.wave_ent, D.pk, D.tv,
                   D.wave_step_off, D.step_tile, D.wg_step_off};
   for (void *p : ptrs) if (p) (void)hipFree(p);
+  for (SlabDev &S : D.slabs) {
+    void *sp[] = {S.rowptr, S.col, S.val, S.blks};
+    for (void *p : sp) if (p) (void)hipFree(p);
+  }
+  if (D.slab_partial) (void)hipFree(D.slab_partial);
   D = CsrDev();
 }
 

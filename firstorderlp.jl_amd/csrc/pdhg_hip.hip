@@ -192,8 +192,30 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
                            D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
       }
     }
+  } else if (!D.slabs.empty()) {
+    // column-slab passes, ascending: partial row sums travel through slab_partial
+    const int P = (int)D.slabs.size(), rm = h->remap ? 1 : 0;
+    for (int p = 0; p < P; ++p) {
+      const SlabDev &S = D.slabs[(size_t)p];
+      if (p + 1 < P) {
+        EpiArgs pe{};
+        pe.out = D.slab_partial;
+        pe.init = D.slab_partial;
+        if (p == 0)
+          hipLaunchKernelGGL((spmv_stream_kernel<MODE_PLAIN, false>), dim3(S.grid), dim3(TPB), 0, h->stream,
+                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, pe);
+        else
+          hipLaunchKernelGGL((spmv_stream_kernel<MODE_PLAIN, true>), dim3(S.grid), dim3(TPB), 0, h->stream,
+                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, pe);
+      } else {
+        EpiArgs le = e;
+        le.init = D.slab_partial;
+        hipLaunchKernelGGL((spmv_stream_kernel<MODE, true>), dim3(S.grid), dim3(TPB), 0, h->stream,
+                           S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, le);
+      }
+    }
   } else if (D.grid > 0) {
-    hipLaunchKernelGGL(spmv_stream_kernel<MODE>, dim3(D.grid), dim3(TPB), 0, h->stream,
+    hipLaunchKernelGGL((spmv_stream_kernel<MODE, false>), dim3(D.grid), dim3(TPB), 0, h->stream,
                        D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, e);
   }
   if (D.nlong > 0) {
@@ -336,22 +358,11 @@ int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int,
 // synchronisation (the copy alone is a 4 us kernel on this runtime).
 __global__ __launch_bounds__(FINAL_TPB) void final_reduce_host_kernel(FinalSpec sp, unsigned long long *seq_dev,
                                                                       volatile double *res_host) {
-  // quantity q is summed by waves 3q..3q+2 (192 threads, fixed order: strided per-thread
-  // sums, wave shuffle tree, then the three wave totals left to right)
-  __shared__ double wsum[16];
-  const int wid = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  const int q = wid / 3, sub = wid % 3;
-  double acc = 0.0;
-  if (q < 5) {
-    const double *p = sp.ptr[q];
-    const int cnt = sp.count[q];
-    for (int i = sub * WAVE + lane; i < cnt; i += 3 * WAVE) acc += p[i];
-    acc = wave_sum(acc);
-    if (lane == 0) wsum[wid] = acc;
-  }
-  __syncthreads();
+  double res[5];
+  final_reduce_body(sp, res);
   if (threadIdx.x == 0) {
-    for (int k = 0; k < 5; ++k) res_host[k] = (wsum[3 * k] + wsum[3 * k + 1]) + wsum[3 * k + 2];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) res_host[k] = res[k];
     const unsigned long long s = *seq_dev + 1ull;
     *seq_dev = s;
     __threadfence_system();
@@ -410,6 +421,80 @@ struct GraphArgs {
   }
 };
 
+// nodes of one fused SpMV: stream kernel (one node) or its column-slab passes (a chain),
+// beside the long-row pair.  `done` receives the nodes the next stage must wait for;
+// main_node / long_node (optional) receive the nodes that carry the epilogue's scalars.
+template <int MODE>
+int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const double *xin, const EpiArgs &e,
+                   const std::vector<hipGraphNode_t> &deps, std::vector<hipGraphNode_t> &done,
+                   hipGraphNode_t *main_node, hipGraphNode_t *long_node) {
+  const int rm = h->remap ? 1 : 0;
+  if (!D.slabs.empty()) {
+    const int P = (int)D.slabs.size();
+    std::vector<hipGraphNode_t> prev = deps;
+    for (int p = 0; p < P; ++p) {
+      const SlabDev &S = D.slabs[(size_t)p];
+      hipGraphNode_t nd = nullptr;
+      if (p + 1 < P) {
+        EpiArgs pe{};
+        pe.out = D.slab_partial;
+        pe.init = D.slab_partial;
+        const void *fn = p == 0 ? (const void *)spmv_stream_kernel<MODE_PLAIN, false> : (const void *)spmv_stream_kernel<MODE_PLAIN, true>;
+        HIP_TRY(graph_add_kernel(graph, &nd, prev, fn, dim3(S.grid), dim3(TPB), S.view(D.rows), xin, (const int2 *)S.blks,
+                                 S.nblk, S.per_xcd, rm, pe));
+      } else {
+        EpiArgs le = e;
+        le.init = D.slab_partial;
+        HIP_TRY(graph_add_kernel(graph, &nd, prev, (const void *)spmv_stream_kernel<MODE, true>, dim3(S.grid), dim3(TPB),
+                                 S.view(D.rows), xin, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, le));
+        if (main_node) *main_node = nd;
+      }
+      prev.assign(1, nd);
+    }
+    done.push_back(prev[0]);
+  } else if (D.grid > 0) {
+    hipGraphNode_t nd = nullptr;
+    HIP_TRY(graph_add_kernel(graph, &nd, deps, (const void *)spmv_stream_kernel<MODE, false>, dim3(D.grid), dim3(TPB),
+                             D.view(), xin, (const int2 *)D.blks, D.nblk, D.per_xcd, rm, e));
+    if (main_node) *main_node = nd;
+    done.push_back(nd);
+  }
+  if (D.nlong > 0) {
+    hipGraphNode_t part = nullptr, fin = nullptr;
+    HIP_TRY(graph_add_kernel(graph, &part, deps, (const void *)spmv_long_partial_kernel, dim3(D.nchunks), dim3(TPB),
+                             D.view(), xin, (const int *)D.chunk_row, (const int *)D.chunk_off, D.chunk_partial));
+    HIP_TRY(graph_add_kernel(graph, &fin, {part}, (const void *)spmv_long_final_kernel<MODE>, dim3(D.long_grid), dim3(TPB),
+                             (const int *)D.long_row, (const int *)D.long_chunk_ptr, D.nlong,
+                             (const double *)D.chunk_partial, e, D.grid));
+    if (long_node) *long_node = fin;
+    done.push_back(fin);
+  }
+  return 0;
+}
+
+// the dual stream node's parameters again, with a new sigma
+int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &dual_epi) {
+  const CsrDev &A = h->A;
+  const int rm = h->remap ? 1 : 0;
+  if (G.n_dual) {
+    if (!A.slabs.empty()) {
+      const SlabDev &S = A.slabs.back();
+      EpiArgs le = dual_epi;
+      le.init = A.slab_partial;
+      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, true>, dim3(S.grid), dim3(TPB),
+                               S.view(A.rows), (const double *)h->xbar, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, le));
+    } else {
+      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, false>, dim3(A.grid), dim3(TPB),
+                               A.view(), (const double *)h->xbar, (const int2 *)A.blks, A.nblk, A.per_xcd, rm, dual_epi));
+    }
+  }
+  if (G.n_dual_long)
+    HIP_TRY(graph_set_kernel(G.exec, G.n_dual_long, (const void *)spmv_long_final_kernel<MODE_DUAL>,
+                             dim3(A.long_grid), dim3(TPB), (const int *)A.long_row, (const int *)A.long_chunk_ptr,
+                             A.nlong, (const double *)A.chunk_partial, dual_epi, A.grid));
+  return 0;
+}
+
 int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double theta, double sigma) {
   graph_destroy(G);
   if (!h->seq_dev) {
@@ -426,48 +511,22 @@ int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double t
   HIP_TRY(graph_add_kernel(G.graph, &G.n_primal, {}, (const void *)primal_kernel<false, true>, a.primal_grid, dim3(TPB),
                            a.n, (const double *)h->x, (const double *)h->c, (const double *)h->aty, nullq,
                            (const double *)h->lb, (const double *)h->ub, tau, theta, h->x_next, h->xbar));
-  // K3+K4 on CSR(A): the stream kernel and the long-row pair are independent branches
-  std::vector<hipGraphNode_t> dual_done;
-  const CsrDev &A = h->A;
-  if (A.grid > 0) {
-    HIP_TRY(graph_add_kernel(G.graph, &G.n_dual, {G.n_primal}, (const void *)spmv_stream_kernel<MODE_DUAL>, dim3(A.grid),
-                             dim3(TPB), A.view(), (const double *)h->xbar, (const int2 *)A.blks, A.nblk, A.per_xcd,
-                             h->remap ? 1 : 0, a.dual_epi));
-    dual_done.push_back(G.n_dual);
-  }
-  if (A.nlong > 0) {
-    hipGraphNode_t part = nullptr;
-    HIP_TRY(graph_add_kernel(G.graph, &part, {G.n_primal}, (const void *)spmv_long_partial_kernel, dim3(A.nchunks), dim3(TPB),
-                             A.view(), (const double *)h->xbar, (const int *)A.chunk_row, (const int *)A.chunk_off,
-                             A.chunk_partial));
-    HIP_TRY(graph_add_kernel(G.graph, &G.n_dual_long, {part}, (const void *)spmv_long_final_kernel<MODE_DUAL>,
-                             dim3(A.long_grid), dim3(TPB), (const int *)A.long_row, (const int *)A.long_chunk_ptr, A.nlong,
-                             (const double *)A.chunk_partial, a.dual_epi, A.grid));
-    dual_done.push_back(G.n_dual_long);
+  // K3+K4 on CSR(A), K5+K6 on CSR(A'): the stream kernel (or its column-slab passes, a
+  // chain) and the long-row pair are independent branches
+  std::vector<hipGraphNode_t> dual_done, aty_done;
+  {
+    int rc = graph_add_spmv<MODE_DUAL>(h, G.graph, h->A, h->xbar, a.dual_epi, {G.n_primal}, dual_done, &G.n_dual, &G.n_dual_long);
+    if (rc) return rc;
   }
   if (dual_done.empty()) dual_done.push_back(G.n_primal);
-  // K5+K6 on CSR(A')
+  const CsrDev &A = h->A;
   const CsrDev &T = h->At;
   EpiArgs te{};
   te.x = h->x; te.x_next = h->x_next; te.aty = h->aty; te.aty_next = h->aty_next;
   te.partials = h->pAt; te.stride = h->pAt_stride;
-  std::vector<hipGraphNode_t> aty_done;
-  if (T.grid > 0) {
-    hipGraphNode_t nd = nullptr;
-    HIP_TRY(graph_add_kernel(G.graph, &nd, dual_done, (const void *)spmv_stream_kernel<MODE_ATY>, dim3(T.grid), dim3(TPB),
-                             T.view(), (const double *)h->y_next, (const int2 *)T.blks, T.nblk, T.per_xcd,
-                             h->remap ? 1 : 0, te));
-    aty_done.push_back(nd);
-  }
-  if (T.nlong > 0) {
-    hipGraphNode_t part = nullptr, fin = nullptr;
-    HIP_TRY(graph_add_kernel(G.graph, &part, dual_done, (const void *)spmv_long_partial_kernel, dim3(T.nchunks), dim3(TPB),
-                             T.view(), (const double *)h->y_next, (const int *)T.chunk_row, (const int *)T.chunk_off,
-                             T.chunk_partial));
-    HIP_TRY(graph_add_kernel(G.graph, &fin, {part}, (const void *)spmv_long_final_kernel<MODE_ATY>, dim3(T.long_grid),
-                             dim3(TPB), (const int *)T.long_row, (const int *)T.long_chunk_ptr, T.nlong,
-                             (const double *)T.chunk_partial, te, T.grid));
-    aty_done.push_back(fin);
+  {
+    int rc = graph_add_spmv<MODE_ATY>(h, G.graph, T, h->y_next, te, dual_done, aty_done, nullptr, nullptr);
+    if (rc) return rc;
   }
   if (aty_done.empty()) aty_done = dual_done;
   // K6b -> pinned host memory + sequence number
@@ -507,15 +566,8 @@ int graph_trial(pdhg_handle *h, double step_size, double primal_weight, double t
       G->tau = tau; G->theta = theta;
     }
     if (G->sigma != sigma) {
-      const CsrDev &A = h->A;
-      if (G->n_dual)
-        HIP_TRY(graph_set_kernel(G->exec, G->n_dual, (const void *)spmv_stream_kernel<MODE_DUAL>, dim3(A.grid), dim3(TPB),
-                                 A.view(), (const double *)h->xbar, (const int2 *)A.blks, A.nblk, A.per_xcd,
-                                 h->remap ? 1 : 0, a.dual_epi));
-      if (G->n_dual_long)
-        HIP_TRY(graph_set_kernel(G->exec, G->n_dual_long, (const void *)spmv_long_final_kernel<MODE_DUAL>,
-                                 dim3(A.long_grid), dim3(TPB), (const int *)A.long_row, (const int *)A.long_chunk_ptr,
-                                 A.nlong, (const double *)A.chunk_partial, a.dual_epi, A.grid));
+      int rc = graph_set_dual(h, *G, a.dual_epi);
+      if (rc) return rc;
       G->sigma = sigma;
     }
   }
@@ -1827,6 +1879,10 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
       hipLaunchKernelGGL(scale_tiled_kernel, dim3(row_grid(D.nwaves)), dim3(TPB), 0, h->stream, D.wave_rows,
                          D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves, D.tile_shift,
                          D.pk, D.tv, t.inv_e, t.inv_d, k);
+    for (const SlabDev &S : D.slabs)
+      if (S.nnz > 0)
+        hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, S.rowptr,
+                           S.col, S.val, t.inv_e, t.inv_d, k);
   }
   if (h->has_q) {
     // objective_matrix = (D^-1 Q) D^-1 (preprocess.jl:562-564); Qt holds Q' entry by entry, so the
@@ -1835,6 +1891,14 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
                        h->Q.col, h->Q.val, t.inv_d, t.inv_d, 0);
     hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Qt.rows)), dim3(TPB), 0, h->stream, h->Qt.rows, h->Qt.rowptr,
                        h->Qt.col, h->Qt.val, t.inv_d, t.inv_d, 1);
+    for (const SlabDev &S : h->Q.slabs)
+      if (S.nnz > 0)
+        hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Q.rows)), dim3(TPB), 0, h->stream, h->Q.rows, S.rowptr,
+                           S.col, S.val, t.inv_d, t.inv_d, 0);
+    for (const SlabDev &S : h->Qt.slabs)
+      if (S.nnz > 0)
+        hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Qt.rows)), dim3(TPB), 0, h->stream, h->Qt.rows, S.rowptr,
+                           S.col, S.val, t.inv_d, t.inv_d, 1);
   }
   hipLaunchKernelGGL(resc_apply_vectors_kernel, dim3(h->ew_grid_nm), dim3(TPB), 0, h->stream, n, m, t.dv, t.ev,
                      h->c, h->lb, h->ub, h->b, t.cum_d, t.cum_e);
@@ -2071,8 +2135,9 @@ int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps) {
   return 0;
 }
 
-int pdhg_layout_info(pdhg_handle *h, int64_t info[12]) {
+int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   if (!h) return fail(-1, "null handle");
+  info[12] = (int64_t)h->A.slabs.size(); info[13] = (int64_t)h->At.slabs.size(); info[14] = info[15] = 0;
   info[0] = h->A.nblk; info[1] = h->A.nlong; info[2] = h->A.nchunks; info[3] = h->A.max_row_nnz;
   info[4] = h->At.nblk; info[5] = h->At.nlong; info[6] = h->At.nchunks; info[7] = h->At.max_row_nnz;
   info[8] = h->A.tiled ? h->A.nwaves : 0; info[9] = h->At.tiled ? h->At.nwaves : 0;

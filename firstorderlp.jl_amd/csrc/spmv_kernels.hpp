@@ -33,6 +33,8 @@ struct EpiArgs {
   // block partials: partials[q*stride + slot]
   double *partials;
   int stride;
+  // column-slab passes of the stream layout: the row sums so far (read when INIT)
+  const double *init;
 };
 
 template <int MODE>
@@ -77,7 +79,14 @@ struct ModeNQ { static constexpr int value = (MODE == MODE_PLAIN) ? 0 : (MODE ==
 // each XCD walks a contiguous eighth of the row blocks so its private 4 MiB
 // L2 sees a contiguous slice of the gathered vector for banded/local
 // matrices.
-template <int MODE>
+// INIT: the row sum starts from e.init[r] instead of 0 -- a later COLUMN-SLAB pass of
+// the same product.  When the gathered vector is a few times an XCD's L2 (4 MiB) the
+// matrix is also kept split by column slab, one launch per slab in ascending column
+// order: every workgroup of a launch then gathers from the same <= 4 MiB window, which
+// stays L2-resident on every XCD (the kernel boundary is the chip-wide synchronisation
+// the tiled sweep cannot afford), and the rows still receive their products strictly
+// left to right, so the result is bit-identical to the single pass.
+template <int MODE, bool INIT = false>
 __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
     CsrView A, const double *__restrict__ xin, const int2 *__restrict__ blks,
     int nblk, int per_xcd, int remap, EpiArgs e) {
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
     for (int r = r0 + tid; r < r1; r += TPB) {
       const int ks = A.rowptr[r] - k0;
       const int ke = A.rowptr[r + 1] - k0;
-      double s = 0.0;
+      double s = INIT ? e.init[r] : 0.0;
       int k = ks;
       // Adds strictly left to right (bit-exact order).  A row of hundreds of
       // products (hub rows, dense feature columns) is one dependent chain on one

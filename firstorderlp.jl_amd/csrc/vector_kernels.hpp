@@ -150,16 +150,35 @@ struct FinalSpec {
   int count[5];
   double *out;     // 5 doubles (host-mapped or device)
 };
-__global__ __launch_bounds__(FINAL_TPB) void final_reduce_kernel(FinalSpec sp) {
-  __shared__ double red[3][FINAL_TPB / WAVE];
-  for (int q = 0; q < 5; ++q) {
-    double acc[3] = {0.0, 0.0, 0.0};
+// The five sums in parallel: quantity q is summed by waves 3q..3q+2 (192 threads; fixed
+// order: strided per-thread sums, wave shuffle tree, then the three wave totals left to
+// right).  Thread 0 ends with all five in res[]; both final kernels (device result,
+// host-polled result of the trial graph) share it, so the two launch paths agree bitwise.
+__device__ __forceinline__ void final_reduce_body(const FinalSpec &sp, double (&res)[5]) {
+  __shared__ double wsum[16];
+  const int wid = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const int q = wid / 3, sub = wid % 3;
+  double acc = 0.0;
+  if (q < 5) {
     const double *p = sp.ptr[q];
     const int cnt = sp.count[q];
-    for (int i = threadIdx.x; i < cnt; i += FINAL_TPB) acc[0] += p[i];
-    block_sum<1, FINAL_TPB>(acc, red);
-    if (threadIdx.x == 0) sp.out[q] = acc[0];
-    __syncthreads();
+    for (int i = sub * WAVE + lane; i < cnt; i += 3 * WAVE) acc += p[i];
+    acc = wave_sum(acc);
+    if (lane == 0) wsum[wid] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) res[k] = (wsum[3 * k] + wsum[3 * k + 1]) + wsum[3 * k + 2];
+  }
+}
+
+__global__ __launch_bounds__(FINAL_TPB) void final_reduce_kernel(FinalSpec sp) {
+  double res[5];
+  final_reduce_body(sp, res);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sp.out[k] = res[k];
   }
 }
 

@@ -288,9 +288,10 @@ class HipPdhgEngine:
         return self._L.pdhg_kernel_name(self._h, kernel_id).decode()
 
     def layout_info(self):
-        info = np.zeros(12, dtype=np.int64)
+        info = np.zeros(16, dtype=np.int64)
         _lib.check(self._L.pdhg_layout_info(self._h, _pi(info)))
         keys = ["A_blocks", "A_long_rows", "A_long_chunks", "A_max_row_nnz",
                 "At_blocks", "At_long_rows", "At_long_chunks", "At_max_row_nnz",
-                "A_tiled_waves", "At_tiled_waves", "A_tile_shift", "At_tile_shift"]
+                "A_tiled_waves", "At_tiled_waves", "A_tile_shift", "At_tile_shift",
+                "A_slabs", "At_slabs"]
         return dict(zip(keys, info.tolist()))

@@ -771,7 +771,7 @@ kernel_name(s::HipSolverState, kernel_id) =
   unsafe_string(ccall((:pdhg_kernel_name, LIB), Cstring, (Ptr{Cvoid}, Cint), s.handle, kernel_id))
 
 function layout_info(s::HipSolverState)
-  info = zeros(Int64, 12)
+  info = zeros(Int64, 16)
   check(ccall((:pdhg_layout_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), s.handle, info))
   return info
 end

@@ -46,3 +46,12 @@ def gpu_required():
     """GPU tests must fail loudly (not skip) when selected without a GPU."""
     if not has_gpu():
         pytest.fail("test marked gpu but no GPU is visible")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Every GPU test gets a timeout (10 minutes unless it sets its own): a test that
+    hangs -- or a helper that quietly asks for a 150 GiB permutation -- must not burn
+    the GPU box's time."""
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(600))
