@@ -338,7 +338,7 @@ void partition_rows_by_nnz(int64_t m, int64_t n, const int64_t *colptr, const in
 
 // CSC of rows [lo, hi) of a CSC matrix (row indices rebased to 0, 0-based output).
 void slice_csc_rows(int64_t n, const int64_t *colptr, const int64_t *rowval, const double *nzval, int base,
-                    int64_t lo, int64_t hi, std::vector<int64_t> &cp, std::vector<int64_t> &rv, std::vector<double> &nv) {
+                    int64_t lo, int64_t hi, std::vector<int64_t> &cp, uvec<int64_t> &rv, dvec &nv) {
   cp.assign((size_t)n + 1, 0);
   parallel_ranges((int)std::min<int64_t>(n, INT32_MAX), 1 << 16, [&](int jb, int je) {
     for (int64_t j = jb; j < je; ++j) {

@@ -49,8 +49,24 @@ struct CsrDev {
   CsrView view() const { return CsrView{rows, rowptr, col, val}; }
 };
 
-template <typename T>
-int upload(T **dst, const std::vector<T> &src) {
+// Big host arrays (one element per nonzero) must not be value-initialised: the fill is
+// serial and, at a billion nonzeros, costs more than the threaded passes that then
+// overwrite every element (first touch happens in those passes, spread over the threads).
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U> struct rebind { using other = default_init_allocator<U>; };
+  template <class U, class... Args>
+  void construct(U *p, Args &&...args) {
+    if constexpr (sizeof...(args) == 0) ::new ((void *)p) U;
+    else ::new ((void *)p) U(std::forward<Args>(args)...);
+  }
+};
+template <class T> using uvec = std::vector<T, default_init_allocator<T>>;
+typedef uvec<int> ivec;
+typedef uvec<double> dvec;
+
+template <typename T, typename Alloc>
+int upload(T **dst, const std::vector<T, Alloc> &src) {
   const size_t bytes = sizeof(T) * std::max<size_t>(src.size(), 1);
   HIP_TRY(hipMalloc((void **)dst, bytes));
   if (!src.empty()) {
@@ -91,8 +107,8 @@ void parallel_ranges(int n, int grain, F f) {
 // Host-side construction of the tiled-sweep layout: wave row blocks (runs of
 // <= TW_ROWS consecutive non-long rows) and their entries counting-sorted by
 // column tile (stable, so (row, col) order is kept inside a tile).
-int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::vector<int> &col,
-                const std::vector<double> &val, int tile_shift) {
+int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec &col,
+                const dvec &val, int tile_shift) {
   // Geometry.  A CU holds 2 workgroups of 8 waves; the grid runs in rounds of
   // 256 CUs x 16 waves.  Rows per wave is chosen so that the rounds are full
   // (no tail round), within the LDS budget (160 KiB / 16 waves).
@@ -172,8 +188,8 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const std::
     }
   }
   if (step_ptr_len >= INT32_MAX) return fail(-2, "tiled layout: step table too large for 32-bit offsets");
-  std::vector<unsigned> pk((size_t)wave_base[nwaves]);
-  std::vector<double> tv((size_t)wave_base[nwaves]);
+  uvec<unsigned> pk((size_t)wave_base[nwaves]);
+  dvec tv((size_t)wave_base[nwaves]);
   std::vector<int> step_ptr((size_t)step_ptr_len), step_tile((size_t)wg_step_off[grid]);
   std::vector<int> max_run_of((size_t)std::max(grid, 1), 0);   // longest same-row run inside one tile, per workgroup
   // pass B: step lists, per-wave step offsets and the entries, tile-major (stable in (row, col))
@@ -273,8 +289,8 @@ void make_row_blocks(int rows, const std::vector<int> &slab_rowptr, const std::v
 // Column-slab copies for the stream layout (see spmv_stream_kernel).  Used when the
 // gathered vector is 1.25 .. 4 slabs long (slab = PDHG_SLAB_MB MiB, default 4 = one XCD's
 // L2); beyond that the tiled sweep is the tool.  PDHG_SLABS=0 disables.
-int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, const std::vector<int> &col,
-                const std::vector<double> &val, bool remap) {
+int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, const ivec &col,
+                const dvec &val, bool remap) {
   const char *off = getenv("PDHG_SLABS");
   if (off && off[0] == '0') return 0;
   const char *mb = getenv("PDHG_SLAB_MB");
@@ -294,8 +310,8 @@ int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, c
         for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) cnt += (col[k] >= c0 && col[k] < c1);
       rp[(size_t)r + 1] = rp[(size_t)r] + cnt;
     }
-    std::vector<int> sc((size_t)rp[(size_t)rows]);
-    std::vector<double> sv((size_t)rp[(size_t)rows]);
+    ivec sc((size_t)rp[(size_t)rows]);
+    dvec sv((size_t)rp[(size_t)rows]);
     parallel_ranges(rows, 1 << 14, [&](int rb, int re) {
       for (int r = rb; r < re; ++r) {
         if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) continue;
@@ -323,7 +339,7 @@ int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, c
 }
 
 int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
-                  const std::vector<int> &col, const std::vector<double> &val,
+                  const ivec &col, const dvec &val,
                   bool remap, int tile_shift = 0) {
   D.rows = rows;
   D.cols = cols;

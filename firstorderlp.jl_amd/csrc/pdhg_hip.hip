@@ -745,8 +745,8 @@ void run_threads(int T, F f) {
 // the result does not depend on T.
 int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
                 const int64_t *rowval, const double *nzval, int base,
-                std::vector<int> &t_rowptr, std::vector<int> &t_col, std::vector<double> &t_val,
-                std::vector<int> &rowptr, std::vector<int> &col, std::vector<double> &val) {
+                std::vector<int> &t_rowptr, ivec &t_col, dvec &t_val,
+                std::vector<int> &rowptr, ivec &col, dvec &val) {
   if (rows < 0 || cols < 0 || nnz < 0) return fail(-1, "negative dimension");
   if (rows >= INT32_MAX || cols >= INT32_MAX || nnz >= INT32_MAX || rows + cols >= INT32_MAX)
     return fail(-2, "m, n, m + n or nnz >= 2^31 need the 64-bit index path (not built)");
@@ -805,8 +805,8 @@ int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
     bstart[b + 1] = run;
   }
   // pass 2: scatter (row, col, val) into the buckets
-  std::vector<int> brow((size_t)nnz), bcol((size_t)nnz);
-  std::vector<double> bval((size_t)nnz);
+  ivec brow((size_t)nnz), bcol((size_t)nnz);
+  dvec bval((size_t)nnz);
   run_threads(T, [&](int t) {
     int64_t *o = off.data() + (size_t)t * T;
     for (int64_t j = col_begin(t); j < col_begin(t + 1); ++j)
@@ -859,8 +859,9 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     return std::chrono::duration<double>(b2 - a).count();
   };
   const auto t_start = now();
-  std::vector<int> t_rowptr, t_col, rowptr, col;
-  std::vector<double> t_val, val;
+  std::vector<int> t_rowptr, rowptr;
+  ivec t_col, col;
+  dvec t_val, val;
   int rc = csc_to_both(m, n, nnz, colptr, rowval, nzval, index_base, t_rowptr, t_col, t_val, rowptr, col, val);
   if (rc) return rc;
   const auto t_conv = now();
@@ -963,8 +964,9 @@ int create_rank_shard(DistGroup *g, int rank, int64_t n, const int64_t *colptr, 
                       const double *nzval, int base, const double *c, const double *b, const double *lb,
                       const double *ub, int device_id, void *stream, pdhg_handle **out) {
   const int64_t lo = g->row_lo[(size_t)rank], hi = g->row_lo[(size_t)rank + 1];
-  std::vector<int64_t> cp, rv;
-  std::vector<double> nv;
+  std::vector<int64_t> cp;
+  uvec<int64_t> rv;
+  dvec nv;
   slice_csc_rows(n, colptr, rowval, nzval, base, lo, hi, cp, rv, nv);
   const int64_t ne = std::min<int64_t>(std::max<int64_t>(g->num_eq_global - lo, 0), hi - lo);
   pdhg_handle *s = nullptr;
@@ -1045,6 +1047,24 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
                 int index_base, const double *c, const double *b, const double *lb,
                 const double *ub, int64_t num_equalities, int device_id, void *stream) {
   if (!out) return fail(-1, "out == NULL");
+  // The device layouts index nonzeros with 32 bits.  The reference's matrices are
+  // SparseMatrixCSC{Float64,Int64} (quadratic_programming.jl:64): a matrix with more
+  // nonzeros than that is cut into row shards on this ONE device (the row-partitioned
+  // form with the peer-kernel exchange, dist.hpp), each below the limit.  m and n stay
+  // below 2^31.  PDHG_MAX_SHARD_NNZ lowers the limit (tests).
+  int64_t cap = (int64_t)INT32_MAX - 1;
+  if (const char *ev = getenv("PDHG_MAX_SHARD_NNZ")) cap = std::max<int64_t>(1, atoll(ev));
+  if (nnz > cap && m > 1) {
+    *out = nullptr;
+    int dev = device_id;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    const int64_t target = std::max<int64_t>(1, (cap / 10) * 8);          // shards balanced by nnz: aim at 80 %
+    const int64_t shards = std::min<int64_t>(m, (nnz + target - 1) / target);
+    if (shards > P2P_MAX_WORLD) return fail(-2, "more than 16 x 2^31 nonzeros on one device are not supported");
+    std::vector<int> ids((size_t)shards, dev);
+    return pdhg_create_multi(out, m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities,
+                             (int)shards, ids.data());
+  }
   return create_shard(out, m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities,
                       device_id, stream, n);
 }
@@ -1177,8 +1197,9 @@ int pdhg_set_objective_matrix(pdhg_handle *h0, int64_t q_nnz, const int64_t *q_c
   bump_version(L);
   bool all_zero = true;
   for (int64_t k = 0; k < q_nnz; ++k) if (q_nzval[k] != 0.0) all_zero = false;
-  std::vector<int> t_rowptr, t_col, rowptr, col;
-  std::vector<double> t_val, val;
+  std::vector<int> t_rowptr, rowptr;
+  ivec t_col, col;
+  dvec t_val, val;
   if (!all_zero) {
     rc = csc_to_both(h0->n, h0->n, q_nnz, q_colptr, q_rowval, q_nzval, index_base, t_rowptr, t_col, t_val, rowptr, col, val);
     if (rc) return rc;

@@ -50,6 +50,10 @@ int pdhg_abi_version(void);
  * (src/primal_dual_hybrid_gradient.jl:805-819).
  * `stream`: a hipStream_t to run on (e.g. the caller's torch stream), or NULL
  * for a private stream.  `device_id` < 0 keeps the current device.
+ * Sizes: m, n and m + n below 2^31.  nnz may exceed 2^31 - 1 (the reference's
+ * index type is Int64): the matrix is then cut into row shards of fewer nonzeros
+ * on the same device (the row-partitioned form below with its peer-kernel
+ * exchange; up to 16 shards), behind the same handle; `stream` is ignored then.
  */
 int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
                 const int64_t *colptr, const int64_t *rowval,

@@ -1,0 +1,84 @@
+"""nnz beyond the 32-bit layout limit: pdhg_create cuts the matrix into row shards on the
+one device (each below the limit) behind an ordinary handle.  The limit is lowered through
+PDHG_MAX_SHARD_NNZ so that the path runs on a small problem; RUN_HUGE_NNZ=1 additionally
+builds a real 2.2 G-nonzero matrix (tens of GB of host memory, minutes)."""
+import os
+
+import numpy as np
+import pytest
+
+from firstorderlp_jl_amd import HipPdhgEngine
+from firstorderlp_jl_amd.generators import random_lp
+from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (AdaptiveStepsizeParams, PdhgSolverState,
+                                                             take_step)
+from oracle import oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_matrix_above_the_shard_limit_is_cut_on_one_device(gpu_required, monkeypatch):
+    p = random_lp(60_000, 50_000, 10, seed=12)           # 600k nonzeros
+    A = p.constraint_matrix
+    m, n = A.shape
+    monkeypatch.setenv("PDHG_MAX_SHARD_NNZ", "150000")
+    eng = HipPdhgEngine.from_problem(p)
+    info = eng.dist_info()
+    assert info["world"] == info["local_ranks"] == 5 and info["backend"] == 1     # 600k / (0.8 * 150k)
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    assert np.array_equal(eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x))     # rows are whole in a shard
+    np.testing.assert_allclose(eng.spmv_t(y), A.T @ y, rtol=1e-11, atol=1e-11)
+    monkeypatch.delenv("PDHG_MAX_SHARD_NNZ")
+    one = HipPdhgEngine.from_problem(p)
+    assert one.dist_info()["world"] == 1
+    outs = []
+    for e in (eng, one):
+        step, pw = H.initial_step_and_weight(p)
+        st = PdhgSolverState(e, step_size=step, primal_weight=pw)
+        for _ in range(50):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+        outs.append((*e.get_current(), st.total_number_iterations))
+    assert outs[0][2] == outs[1][2]
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.timeout(3000)
+@pytest.mark.skipif(os.environ.get("RUN_HUGE_NNZ", "0") != "1", reason="2.2 G nonzeros: set RUN_HUGE_NNZ=1")
+def test_2p2_billion_nonzeros(gpu_required):
+    """Layout construction and one product checksum at nnz > 2^31.  Structured matrix, built
+    directly in CSC: row i has 22 entries, at columns (7 i + 1000003 k) mod n with value
+    1/(k+1), so A*1 is the same known number in every row and A'*1 in every column."""
+    import time
+    n = m = 100_000_000
+    K = 22
+    inv7 = pow(7, -1, n)
+    indptr = np.arange(0, K * n + 1, K, dtype=np.int64)
+    indices = np.empty(K * n, dtype=np.int64)
+    data = np.empty(K * n, dtype=np.float64)
+    kk = np.arange(K, dtype=np.int64)
+    t0 = time.time()
+    for j0 in range(0, n, 5_000_000):
+        j = np.arange(j0, min(n, j0 + 5_000_000), dtype=np.int64)
+        rows = (((j[:, None] - 1000003 * kk[None, :]) % n) * inv7) % n      # 7 i = j - 1000003 k (mod n)
+        order = np.argsort(rows, axis=1)
+        indices[j0 * K:(j0 + len(j)) * K] = np.take_along_axis(rows, order, axis=1).reshape(-1)
+        data[j0 * K:(j0 + len(j)) * K] = (1.0 / (order + 1.0)).reshape(-1)
+    assert len(data) > 2 ** 31
+    print(f"generated {len(data)} nonzeros in {time.time() - t0:.0f} s", flush=True)
+
+    class Csc:            # what HipPdhgEngine reads of a scipy CSC matrix
+        shape = (m, n)
+        nnz = len(data)
+    Csc.indptr, Csc.indices, Csc.data = indptr, indices, data
+    t0 = time.time()
+    eng = HipPdhgEngine(Csc, np.ones(n), np.ones(m), np.zeros(n), np.full(n, np.inf), 0)
+    print(f"pdhg_create: {time.time() - t0:.0f} s, {eng.dist_info()}, {eng.layout_info()}", flush=True)
+    assert eng.dist_info()["world"] >= 2
+    want = float(np.sum(1.0 / (kk + 1.0)))
+    np.testing.assert_allclose(eng.spmv(np.ones(n)), np.full(m, want), rtol=1e-12)
+    np.testing.assert_allclose(eng.spmv_t(np.ones(m)), np.full(n, want), rtol=1e-12)
+    raw = eng.trial_step(0.1, 1.0, 1.0)
+    assert np.all(np.isfinite(raw))
+    eng.close()
