@@ -52,7 +52,12 @@ struct DistGroup {
   // overlapping the rest of the product).  Decided from (n, world, environment) only, so
   // that every rank issues the same sequence of collectives.
   bool overlap = false;
-  bool all_local() const { return (int)sh.size() == world; }
+  // true: every rank lives in this process (scalars and vectors can be collected shard by
+  // shard).  false: one rank per process -- everything other ranks hold arrives through RCCL.
+  // PDHG_DIST_FORCE_REMOTE=1 takes the second route even when all ranks are local, so that
+  // its collectives run (and are tested) on a 1-GPU box.
+  bool force_remote = false;
+  bool all_local() const { return (int)sh.size() == world && !(force_remote && backend == COMM_RCCL); }
 };
 
 // ---- the shard list every entry point walks: the group's local shards, or the handle itself

@@ -1011,6 +1011,8 @@ int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colpt
   partition_rows_by_nnz(m, n, colptr, rowval, base, world, g->row_lo);
   // per-slice reductions overlapped with the A_p' product: worth it when the exchanged
   // vector is large (the same test that selects the tiled layout); PDHG_DIST_OVERLAP=0/1 forces
+  const char *fr = getenv("PDHG_DIST_FORCE_REMOTE");
+  g->force_remote = fr && fr[0] == '1';
   const char *ov = getenv("PDHG_DIST_OVERLAP");
   g->overlap = ov ? (ov[0] != '0') : (world > 1 && n * 8 > (4LL << 20));
   return 0;

@@ -13,6 +13,8 @@ test box.
   through a two-shard and a three-shard group, stream and tiled layouts;
 * device evaluation, trust-region bounds, restarts and rescaling on a group.
 The world_size > 1 host logic on CPU is tests/test_distributed_gloo.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -136,9 +138,14 @@ def test_row_partition_matches_the_host_rule(gpu_required):
     assert (info["col_lo"], info["col_hi"]) == (0, min(S, p.constraint_matrix.shape[1]))
 
 
-@pytest.mark.parametrize("how", ["init_all", "init_rank"])
-def test_rccl_world_1_matches_single_engine(gpu_required, how):
-    """Real RCCL calls from the library: all-gather, reduce-scatter, broadcast on a 1-rank communicator."""
+@pytest.mark.parametrize("how", ["init_all", "init_rank", "init_rank_remote_route"])
+def test_rccl_world_1_matches_single_engine(gpu_required, monkeypatch, how):
+    """Real RCCL calls from the library: all-gather, reduce-scatter, broadcast on a 1-rank
+    communicator.  "remote_route": the one-rank-per-process code paths (scalars of all ranks
+    through ncclAllGather, vectors to the host through all-gather / grouped broadcasts) are
+    taken although the only rank is local -- the routes `bench.py --gpus N` uses."""
+    if how == "init_rank_remote_route":
+        monkeypatch.setenv("PDHG_DIST_FORCE_REMOTE", "1")
     p = random_lp(20000, 15000, 8, seed=9)
     if how == "init_all":
         geng = HipPdhgEngine.from_problem(p, device_ids=[0])
@@ -198,8 +205,10 @@ def test_reference_kat_on_tiled_shard_group(gpu_required, monkeypatch, case):
     case(_group_factory([0, 0]))
 
 
+@pytest.mark.parametrize("remote", ["0", "1"], ids=["local_route", "remote_route"])
 @pytest.mark.parametrize("case", kat_common.CASES[:6], ids=lambda c: c.__name__)
-def test_reference_kat_on_rccl_world_1(gpu_required, case):
+def test_reference_kat_on_rccl_world_1(gpu_required, monkeypatch, case, remote):
+    monkeypatch.setenv("PDHG_DIST_FORCE_REMOTE", remote)     # 1: the one-rank-per-process routes
     case(_group_factory([0]))
 
 
@@ -213,6 +222,11 @@ def test_group_device_evaluation_matches_single_engine(gpu_required):
     E, D = rng.uniform(0.5, 2.0, m), rng.uniform(0.5, 2.0, n)
     engines = [HipPdhgEngine.from_problem(p), HipPdhgEngine.from_problem(p, device_ids=[0, 0, 0]),
                HipPdhgEngine.from_problem(p, device_ids=[0])]
+    os.environ["PDHG_DIST_FORCE_REMOTE"] = "1"       # RCCL world 1 through the one-rank-per-process routes
+    try:
+        engines.append(HipPdhgEngine.from_problem(p, device_ids=[0]))
+    finally:
+        del os.environ["PDHG_DIST_FORCE_REMOTE"]
     outs = []
     for eng in engines:
         eng.set_original_problem(E, D, p.objective_vector * D, p.right_hand_side * E,
