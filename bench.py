@@ -261,9 +261,14 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         "whole_iteration_GBps": round(b_iter * (trials / steps) / (ms_per_step * 1e-3) / 1e9, 1),
         "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_socket": cpu_socket,
         "kernels": kernels,
-        "layout": {k: v for k, v in eng.layout_info().items() if "tiled" in k or "shift" in k or "slab" in k},
+        "layout": {k: v for k, v in eng.layout_info().items() if "tiled" in k or "shift" in k or "slab" in k or "graph" in k},
         "setup_sec": {"generate": round(t_gen, 1), "create_upload": round(t_create, 1)},
     }
+    if out["layout"].get("trial_graph"):
+        out["kernels_note"] = ("the timed region launches one trial as ONE HIP graph (long-row kernels on a parallel "
+                               "branch, no result copy); the per-kernel figures are HIP-event brackets around the plain "
+                               "launches of a separate profiling pass (launch latency included, branches serialised), so "
+                               "their sum can exceed ms_per_step")
     if cpu_baseline:
         out["speedup_vs_cpu_port"] = round(value / cpu_baseline["value"], 1)
     if cpu_socket and "value" in cpu_socket:

@@ -2160,7 +2160,8 @@ int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps) {
 
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   if (!h) return fail(-1, "null handle");
-  info[12] = (int64_t)h->A.slabs.size(); info[13] = (int64_t)h->At.slabs.size(); info[14] = info[15] = 0;
+  info[12] = (int64_t)h->A.slabs.size(); info[13] = (int64_t)h->At.slabs.size();
+  info[14] = graph_eligible(h) || (h->graph_mode == 1 && !h->has_q) ? 1 : 0; info[15] = 0;
   info[0] = h->A.nblk; info[1] = h->A.nlong; info[2] = h->A.nchunks; info[3] = h->A.max_row_nnz;
   info[4] = h->At.nblk; info[5] = h->At.nlong; info[6] = h->At.nchunks; info[7] = h->At.max_row_nnz;
   info[8] = h->A.tiled ? h->A.nwaves : 0; info[9] = h->At.tiled ? h->At.nwaves : 0;

@@ -293,5 +293,5 @@ class HipPdhgEngine:
         keys = ["A_blocks", "A_long_rows", "A_long_chunks", "A_max_row_nnz",
                 "At_blocks", "At_long_rows", "At_long_chunks", "At_max_row_nnz",
                 "A_tiled_waves", "At_tiled_waves", "A_tile_shift", "At_tile_shift",
-                "A_slabs", "At_slabs"]
+                "A_slabs", "At_slabs", "trial_graph"]
         return dict(zip(keys, info.tolist()))
