@@ -116,10 +116,6 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         from firstorderlp_jl_amd.distributed import make_row_partitioned_hip_engine
         eng = make_row_partitioned_hip_engine(problem, device_id=local_rank)
         parallelism = f"row-partition x{world}, RCCL reduce-scatter/all-gather inside the library"
-    elif ctx["force_dist"]:
-        uid = pkg.HipPdhgEngine.dist_unique_id()
-        eng = pkg.HipPdhgEngine.from_problem(problem, device_id=local_rank, unique_id=uid, rank=0, world=1)
-        parallelism = "row-partitioned form forced on 1 GPU (RCCL world 1)"
     elif args.shards > 0:
         eng = pkg.HipPdhgEngine.from_problem(problem, device_ids=[local_rank] * args.shards)
         parallelism = f"{args.shards} row shards inside one process on ONE GPU (peer-kernel back end; dev mode)"
@@ -180,7 +176,7 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
     # process; the figure is the committed result of `rocprofv3 --pmc` runs of THIS
     # command on the same workload and kernel (tools/pmc_traffic.sh), keyed by both.
     traffic, traffic_source = None, None
-    if dist is None and not ctx["force_dist"] and args.shards == 0:
+    if dist is None and args.shards == 0:
         try:
             with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as fh:
                 table = json.load(fh)
@@ -205,7 +201,7 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
 
     # ---- CPU baseline: the literal single-thread restatement, bounded sample
     cpu_baseline = cpu_socket = None
-    if rank == 0 and world == 1 and cpu_seconds > 0:
+    if rank == 0 and dist is None and cpu_seconds > 0:
         from oracle.oracle import OracleState
         st = OracleState(m, n, A.indptr, A.indices, A.data,
                          problem.objective_vector, problem.right_hand_side,
@@ -301,22 +297,21 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # PDHG_FORCE_DIST=1: take the N > 1 route of this script with ONE rank (gloo group of 1, id
+    # broadcast, pdhg_create_dist, 1-rank RCCL communicator) -- how that route is exercised on a
+    # 1-GPU box, e.g. under `python -m torch.distributed.run --nproc-per-node 1 ... bench.py`.
+    if world > 1 or os.environ.get("PDHG_FORCE_DIST", "0") == "1":
         # harness only (id hand-out, barriers, max over ranks): CPU tensors over gloo
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    # PDHG_FORCE_DIST=1: the row-partitioned form with a 1-rank RCCL communicator
-    # (how the N > 1 code path is exercised on a 1-GPU box).
-    ctx = {"pkg": pkg, "dist": dist, "rank": rank, "world": world, "local_rank": local_rank,
-           "force_dist": world == 1 and os.environ.get("PDHG_FORCE_DIST", "0") == "1"}
+    ctx = {"pkg": pkg, "dist": dist, "rank": rank, "world": world, "local_rank": local_rank}
 
     cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_baseline_seconds
     head = measure(args, args.workload, ctx, args.steps, args.warmup, cpu_s)
     others = []
-    if world == 1 and not args.no_other_configs and args.workload == "random" and args.shards == 0 \
-            and not ctx["force_dist"]:
+    if dist is None and not args.no_other_configs and args.workload == "random" and args.shards == 0:
         for wl in ("pagerank", "l1svm"):
             try:
                 r = measure(args, wl, ctx, max(args.steps, 200), max(args.warmup, 20), min(cpu_s, 3.0),
