@@ -1001,6 +1001,17 @@ int create_rank_shard(DistGroup *g, int rank, int64_t n, const int64_t *colptr, 
   return 0;
 }
 
+// One reduce-scatter after the product, or per-slice reductions overlapped with it
+// (DistGroup::overlap).  Decided from (n, world, back end, environment) only.  Default: on
+// for the peer back end when the exchanged vector is large (a slice is one small kernel of
+// its owner); OFF for RCCL, where P reductions to P roots cost P collective latencies and
+// may not reach the bandwidth of one reduce-scatter over all links -- the product they
+// could hide behind is 0.1 ms at P = 8.  PDHG_DIST_OVERLAP=0/1 forces.
+void choose_exchange_pattern(DistGroup *g) {
+  const char *ov = getenv("PDHG_DIST_OVERLAP");
+  g->overlap = ov ? (ov[0] != '0') : (g->backend == COMM_P2P && g->world > 1 && g->n * 8 > (4LL << 20));
+}
+
 int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int base,
                         int64_t num_equalities, int world) {
   if (world < 1 || world > DIST_MAX_WORLD) return fail(-1, "world size out of range (1..64)");
@@ -1012,12 +1023,8 @@ int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colpt
   const int64_t per = (n + world - 1) / world;
   g->S = std::max<int64_t>(16, (per + 15) / 16 * 16);      // slice stride: whole 128-byte lines
   partition_rows_by_nnz(m, n, colptr, rowval, base, world, g->row_lo);
-  // per-slice reductions overlapped with the A_p' product: worth it when the exchanged
-  // vector is large (the same test that selects the tiled layout); PDHG_DIST_OVERLAP=0/1 forces
   const char *fr = getenv("PDHG_DIST_FORCE_REMOTE");
   g->force_remote = fr && fr[0] == '1';
-  const char *ov = getenv("PDHG_DIST_OVERLAP");
-  g->overlap = ov ? (ov[0] != '0') : (world > 1 && n * 8 > (4LL << 20));
   return 0;
 }
 
@@ -1103,6 +1110,7 @@ int pdhg_create_dist(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   int rc = init_group_geometry(g, m, n, colptr, rowval, index_base, num_equalities, world);
   if (rc) { delete g; return rc; }
   g->backend = COMM_RCCL;
+  choose_exchange_pattern(g);
   pdhg_handle *s = nullptr;
   rc = create_rank_shard(g, rank, n, colptr, rowval, nzval, index_base, c, b, lb, ub, device_id, stream, &s);
   if (rc) { delete g; return rc; }
@@ -1143,6 +1151,7 @@ int pdhg_create_multi(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   const char *cm = getenv("PDHG_COMM");
   g->backend = (!distinct || (cm && !strcmp(cm, "p2p"))) ? COMM_P2P : COMM_RCCL;
   if (g->backend == COMM_P2P && n_devices > P2P_MAX_WORLD) { delete g; return fail(-1, "peer back end supports at most 16 shards"); }
+  choose_exchange_pattern(g);
   for (int r = 0; r < n_devices; ++r) {
     pdhg_handle *s = nullptr;
     rc = create_rank_shard(g, r, n, colptr, rowval, nzval, index_base, c, b, lb, ub, device_ids[r], nullptr, &s);
