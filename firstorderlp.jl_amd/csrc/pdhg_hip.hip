@@ -80,8 +80,11 @@ struct pdhg_handle {
   // The evaluation branch asks for the same products several times per check
   // (eval_point, then one or more trust-region bounds at the same point): keep
   // A*x and A'*y of the CURRENT and the AVERAGE point until the state changes.
-  double *ev_cax[2] = {nullptr, nullptr}, *ev_caty[2] = {nullptr, nullptr};
-  double *ev_cqx[2] = {nullptr, nullptr}, *ev_qx = nullptr;   // Q*x at those points (QP only)
+  // slot 0 CURRENT, 1 AVERAGE (valid for one state_version), 2 RESTART point (valid until the
+  // restart point or the matrix changes: every check asks for its products again)
+  double *ev_cax[3] = {nullptr, nullptr, nullptr}, *ev_caty[3] = {nullptr, nullptr, nullptr};
+  double *ev_cqx[3] = {nullptr, nullptr, nullptr}, *ev_qx = nullptr;   // Q*x at those points (QP only)
+  uint64_t restart_version = 1, matrix_version = 1, ev_rkey = 0;
   uint64_t state_version = 1;                      // bumped by everything that moves x, y, the sums or A
   uint64_t ev_cversion[2] = {0, 0}, avg_version = 0;
   double *tr_g = nullptr, *tr_dir = nullptr, *tr_thr = nullptr;  // n+m each
@@ -930,8 +933,9 @@ void destroy_shard(pdhg_handle *h) {
                     h->tmp_m, h->pA, h->pAt, h->pQ, h->scal_dev, h->scal_all, h->dn_buf, h->dm_buf,
                     h->E, h->Dv, h->c_o, h->b_o, h->lb_o,
                     h->ub_o, h->x_r, h->y_r, h->px_avg, h->py_avg, h->ev_ax, h->ev_aty, h->tr_g,
-                    h->tr_dir, h->tr_thr, h->ev_partials, h->ev_cax[0], h->ev_cax[1],
-                    h->ev_caty[0], h->ev_caty[1], h->ev_cqx[0], h->ev_cqx[1], h->ev_qx, h->ev_xg};
+                    h->tr_dir, h->tr_thr, h->ev_partials, h->ev_cax[0], h->ev_cax[1], h->ev_cax[2],
+                    h->ev_caty[0], h->ev_caty[1], h->ev_caty[2], h->ev_cqx[0], h->ev_cqx[1], h->ev_cqx[2],
+                    h->ev_qx, h->ev_xg};
   for (double *p : bufs) if (p) (void)hipFree(p);
   graph_destroy(h->tgraph[0]); graph_destroy(h->tgraph[1]);
   if (h->comm_stream) { (void)hipStreamSynchronize(h->comm_stream); (void)hipStreamDestroy(h->comm_stream); }
@@ -1218,6 +1222,7 @@ int pdhg_set_objective_matrix(pdhg_handle *h0, int64_t q_nnz, const int64_t *q_c
     rc = csc_to_both(h0->n, h0->n, q_nnz, q_colptr, q_rowval, q_nzval, index_base, t_rowptr, t_col, t_val, rowptr, col, val);
     if (rc) return rc;
   }
+  for (int i = 0; i < L.count; ++i) L.p[i]->matrix_version += 1;
   FOR_SHARDS(L, h) {   // the objective matrix is replicated on every shard (it acts on full n-vectors)
     if (h->has_q) { free_csr_dev(h->Q); free_csr_dev(h->Qt); h->has_q = false; }
     if (all_zero) continue;  // iszero(objective_matrix): LP path (pdhg.jl:536)
@@ -1577,7 +1582,7 @@ static int ev_alloc(pdhg_handle *h) {
   if ((rc = alloc_zero(&h->ev_partials, (int64_t)EV_MAXQ * h->ev_grid))) return rc;
   if ((rc = alloc_zero(&h->ev_ax, h->m))) return rc;
   if ((rc = alloc_zero(&h->ev_aty, h->n_alloc))) return rc;
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     if ((rc = alloc_zero(&h->ev_cax[k], h->m))) return rc;
     if ((rc = alloc_zero(&h->ev_caty[k], h->n_alloc))) return rc;
   }
@@ -1627,7 +1632,8 @@ static int select_point(pdhg_handle *h, int point, const double **px, const doub
 static int point_products(const Shards &L, int point) {
   int rc;
   static const bool cache_off = getenv("PDHG_NO_EVAL_CACHE") != nullptr;   // debugging aid
-  const bool cached = !cache_off && (point == PDHG_POINT_CURRENT || point == PDHG_POINT_AVERAGE);
+  const bool cached = !cache_off && (point == PDHG_POINT_CURRENT || point == PDHG_POINT_AVERAGE ||
+                                     point == PDHG_POINT_RESTART);
   bool fresh = true;
   FOR_SHARDS(L, h) {
     if ((rc = select_point(h, point, &h->pt_x, &h->pt_y))) return rc;
@@ -1635,10 +1641,16 @@ static int point_products(const Shards &L, int point) {
     double **dqx = &h->ev_qx;
     bool f = true;
     if (cached) {
-      const int k = point == PDHG_POINT_CURRENT ? 0 : 1;
+      const int k = point == PDHG_POINT_CURRENT ? 0 : (point == PDHG_POINT_AVERAGE ? 1 : 2);
       h->pt_ax = h->ev_cax[k]; h->pt_aty = h->ev_caty[k]; dqx = &h->ev_cqx[k];
-      f = h->ev_cversion[k] != h->state_version;
-      h->ev_cversion[k] = h->state_version;
+      if (k < 2) {
+        f = h->ev_cversion[k] != h->state_version;
+        h->ev_cversion[k] = h->state_version;
+      } else {
+        const uint64_t key = (h->matrix_version << 32) + h->restart_version;
+        f = h->ev_rkey != key;
+        h->ev_rkey = key;
+      }
     }
     if (h->has_q && !*dqx) {
       if ((rc = alloc_zero(dqx, h->n))) return rc;
@@ -1724,6 +1736,7 @@ int pdhg_save_restart_point(pdhg_handle *h0) {
   const Shards L = shards_of(h0);
   FOR_SHARDS(L, h) {
     if ((rc = ev_alloc(h))) return rc;
+    h->restart_version += 1;
     if (h->cn > 0)
       HIP_TRY(hipMemcpyAsync(h->x_r + h->clo, h->x + h->clo, sizeof(double) * (size_t)h->cn, hipMemcpyDeviceToDevice, h->stream));
     if (h->m > 0)
@@ -1950,6 +1963,7 @@ int pdhg_rescale(pdhg_handle *h0, int l_inf_ruiz_iterations, int l2_norm_rescali
     return fail(-1, "pock_chambolle_alpha must be in [0, 2]");
   const Shards L = shards_of(h0);
   bump_version(L);
+  for (int i = 0; i < L.count; ++i) L.p[i]->matrix_version += 1;
   std::vector<RescaleTmp> T((size_t)L.count);
   auto cleanup = [&]() {
     for (int i = 0; i < L.count; ++i) {
