@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_sq
 mkdir -p $O
 rocprofv3 --list-avail > $O/avail.txt 2>&1
-B="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --profile-steps 0"
+B="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --profile-steps 0"
 i=0
 for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" \
          "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
