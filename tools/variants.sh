@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p firstorderlp.jl_amd/csrc/variants
 while [ $# -ge 2 ]; do
   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -shared -fPIC -pthread $2 -I include \
-    -o firstorderlp.jl_amd/csrc/variants/libpdhg_$1.so firstorderlp.jl_amd/csrc/pdhg_hip.hip &
+    -o firstorderlp.jl_amd/csrc/variants/libpdhg_$1.so firstorderlp.jl_amd/csrc/pdhg_hip.hip -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib &
   shift 2
 done
 wait
