@@ -17,7 +17,10 @@ constexpr int FINAL_TPB = 1024;
 constexpr int TW_WPB = 8;              // waves per workgroup (512 threads), 2 workgroups per CU
 constexpr int TW_MAX_ROWS = 1272;      // rows owned by one wave: 2 x 8 x 1272 x 8 B fits the 160 KiB LDS
 constexpr unsigned TW_PAD = 0xFFFFFFFFu;
-constexpr int TW_U = 3;               // 64-entry chunks prefetched per wave per tile
+#ifndef TWD_U            // dev builds (tools/variants.sh) may override
+#define TWD_U 3
+#endif
+constexpr int TW_U = TWD_U;           // 64-entry chunks prefetched per wave per tile
 
 thread_local std::string g_last_error;
 
