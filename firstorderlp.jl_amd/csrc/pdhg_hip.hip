@@ -1912,6 +1912,21 @@ struct RescaleTmp {
   double *tmp_e = nullptr, *tmp_d = nullptr;
 };
 
+// a row statistic of one resident CSR: short rows one wave each, long rows chunk by chunk
+extern "C++" {
+template <int OP>
+static void launch_row_op(pdhg_handle *h, const CsrDev &D, int cols, double pexp, const double *inv_scale, double *out) {
+  hipLaunchKernelGGL(row_op_kernel<OP>, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.view(), cols, pexp, inv_scale, out);
+  if (D.nlong > 0) {
+    hipLaunchKernelGGL(row_op_long_partial_kernel<OP>, dim3(D.nchunks), dim3(TPB), 0, h->stream, D.view(),
+                       (const int *)D.chunk_row, (const int *)D.chunk_off, pexp, inv_scale, D.chunk_partial);
+    hipLaunchKernelGGL(row_op_long_final_kernel<OP>, dim3(D.long_grid), dim3(TPB), 0, h->stream, D.view(),
+                       (const int *)D.long_row, (const int *)D.long_chunk_ptr, D.nlong,
+                       (const double *)D.chunk_partial, cols, pexp, out);
+  }
+}
+}  // extern "C++"
+
 // one scale_problem step on every resident layout + the vectors of one shard
 static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
   const int n = (int)h->n, m = (int)h->m;
@@ -1922,7 +1937,11 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
     CsrDev &D = *Ls[k];
     if (D.nnz == 0) continue;
     hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, D.rowptr,
-                       D.col, D.val, t.inv_e, t.inv_d, k);
+                       D.col, D.val, t.inv_e, t.inv_d, k, 1);
+    if (D.nlong > 0)
+      hipLaunchKernelGGL(scale_long_kernel, dim3(D.nchunks), dim3(TPB), 0, h->stream, (const int *)D.rowptr,
+                         (const int *)D.col, D.val, (const int *)D.chunk_row, (const int *)D.chunk_off,
+                         (const double *)t.inv_e, (const double *)t.inv_d, k);
     if (D.tiled && D.nwaves > 0)
       hipLaunchKernelGGL(scale_tiled_kernel, dim3(row_grid(D.nwaves)), dim3(TPB), 0, h->stream, D.wave_rows,
                          D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves, D.tile_shift,
@@ -1930,23 +1949,23 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
     for (const SlabDev &S : D.slabs)
       if (S.nnz > 0)
         hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, S.rowptr,
-                           S.col, S.val, t.inv_e, t.inv_d, k);
+                           S.col, S.val, t.inv_e, t.inv_d, k, 0);
   }
   if (h->has_q) {
     // objective_matrix = (D^-1 Q) D^-1 (preprocess.jl:562-564); Qt holds Q' entry by entry, so the
     // "transposed" order reproduces the same two roundings on it
     hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Q.rows)), dim3(TPB), 0, h->stream, h->Q.rows, h->Q.rowptr,
-                       h->Q.col, h->Q.val, t.inv_d, t.inv_d, 0);
+                       h->Q.col, h->Q.val, t.inv_d, t.inv_d, 0, 0);
     hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Qt.rows)), dim3(TPB), 0, h->stream, h->Qt.rows, h->Qt.rowptr,
-                       h->Qt.col, h->Qt.val, t.inv_d, t.inv_d, 1);
+                       h->Qt.col, h->Qt.val, t.inv_d, t.inv_d, 1, 0);
     for (const SlabDev &S : h->Q.slabs)
       if (S.nnz > 0)
         hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Q.rows)), dim3(TPB), 0, h->stream, h->Q.rows, S.rowptr,
-                           S.col, S.val, t.inv_d, t.inv_d, 0);
+                           S.col, S.val, t.inv_d, t.inv_d, 0, 0);
     for (const SlabDev &S : h->Qt.slabs)
       if (S.nnz > 0)
         hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Qt.rows)), dim3(TPB), 0, h->stream, h->Qt.rows, S.rowptr,
-                           S.col, S.val, t.inv_d, t.inv_d, 1);
+                           S.col, S.val, t.inv_d, t.inv_d, 1, 0);
   }
   hipLaunchKernelGGL(resc_apply_vectors_kernel, dim3(h->ew_grid_nm), dim3(TPB), 0, h->stream, n, m, t.dv, t.ev,
                      h->c, h->lb, h->ub, h->b, t.cum_d, t.cum_e);
@@ -1993,14 +2012,14 @@ int pdhg_rescale(pdhg_handle *h0, int l_inf_ruiz_iterations, int l2_norm_rescali
   for (int it = 0; it < l_inf_ruiz_iterations; ++it) {
     EACH(h, t) {
       const int n = (int)h->n, m = (int)h->m;
-      hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->At.view(), m, 0.0, (const double *)nullptr, t.dv);
-      hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, h->A.view(), n, 0.0, (const double *)nullptr, t.ev);
+      launch_row_op<ROP_MAXABS>(h, h->At, m, 0.0, (const double *)nullptr, t.dv);
+      launch_row_op<ROP_MAXABS>(h, h->A, n, 0.0, (const double *)nullptr, t.ev);
     }
     RS(reduce_cols(false, true));
     EACH(h, t) {
       const int n = (int)h->n, m = (int)h->m;
       if (h->has_q) {   // QP: column max over the constraint AND the objective matrix (preprocess.jl:425-433)
-        hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->Qt.view(), n, 0.0, (const double *)nullptr, t.tmp_d);
+        launch_row_op<ROP_MAXABS>(h, h->Qt, n, 0.0, (const double *)nullptr, t.tmp_d);
         hipLaunchKernelGGL(resc_max_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.dv, t.tmp_d);
       }
       hipLaunchKernelGGL(resc_sqrt_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.dv);
@@ -2012,16 +2031,16 @@ int pdhg_rescale(pdhg_handle *h0, int l_inf_ruiz_iterations, int l2_norm_rescali
   if (l2_norm_rescaling) {
     EACH(h, t) {
       const int n = (int)h->n, m = (int)h->m;
-      hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->At.view(), m, 0.0, (const double *)nullptr, t.tmp_d);
-      hipLaunchKernelGGL(row_op_kernel<ROP_MAXABS>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, h->A.view(), n, 0.0, (const double *)nullptr, t.tmp_e);
+      launch_row_op<ROP_MAXABS>(h, h->At, m, 0.0, (const double *)nullptr, t.tmp_d);
+      launch_row_op<ROP_MAXABS>(h, h->A, n, 0.0, (const double *)nullptr, t.tmp_e);
     }
     RS(reduce_cols(true, true));
     EACH(h, t) {
       const int n = (int)h->n, m = (int)h->m;
       hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.tmp_d, t.inv_d, 1);
       hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, t.tmp_e, t.inv_e, 1);
-      hipLaunchKernelGGL(row_op_kernel<ROP_SUMSQ_SCALED>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->At.view(), m, 0.0, t.inv_d, t.dv);
-      hipLaunchKernelGGL(row_op_kernel<ROP_SUMSQ_SCALED>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, h->A.view(), n, 0.0, t.inv_e, t.ev);
+      launch_row_op<ROP_SUMSQ_SCALED>(h, h->At, m, 0.0, t.inv_d, t.dv);
+      launch_row_op<ROP_SUMSQ_SCALED>(h, h->A, n, 0.0, t.inv_e, t.ev);
     }
     RS(reduce_cols(false, false));
     EACH(h, t) {
@@ -2037,8 +2056,8 @@ int pdhg_rescale(pdhg_handle *h0, int l_inf_ruiz_iterations, int l2_norm_rescali
   if (use_pock_chambolle) {
     EACH(h, t) {
       const int n = (int)h->n, m = (int)h->m;
-      hipLaunchKernelGGL(row_op_kernel<ROP_SUMPOW>, dim3(row_grid(n)), dim3(TPB), 0, h->stream, h->At.view(), m, 2.0 - pock_chambolle_alpha, (const double *)nullptr, t.dv);
-      hipLaunchKernelGGL(row_op_kernel<ROP_SUMPOW>, dim3(row_grid(m)), dim3(TPB), 0, h->stream, h->A.view(), n, pock_chambolle_alpha, (const double *)nullptr, t.ev);
+      launch_row_op<ROP_SUMPOW>(h, h->At, m, 2.0 - pock_chambolle_alpha, (const double *)nullptr, t.dv);
+      launch_row_op<ROP_SUMPOW>(h, h->A, n, pock_chambolle_alpha, (const double *)nullptr, t.ev);
     }
     RS(reduce_cols(false, false));
     EACH(h, t) {

@@ -19,6 +19,7 @@ __global__ __launch_bounds__(TPB) void row_op_kernel(CsrView A, int cols, double
   const int r = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
   if (r >= A.rows) return;
   const int k0 = A.rowptr[r], k1 = A.rowptr[r + 1];
+  if (k1 - k0 > BLOCK_NNZ) return;        // long rows: row_op_long_* below (one workgroup per 8192-entry chunk)
   const double sc = (OP == ROP_SUMSQ_SCALED) ? inv_scale[r] : 1.0;
   double acc = 0.0;
   for (int k = k0 + lane; k < k1; k += WAVE) {
@@ -41,17 +42,81 @@ __global__ __launch_bounds__(TPB) void row_op_kernel(CsrView A, int cols, double
 __global__ __launch_bounds__(TPB) void scale_csr_kernel(int rows, const int *__restrict__ rowptr,
                                                         const int *__restrict__ col, double *__restrict__ val,
                                                         const double *__restrict__ inv_e,
-                                                        const double *__restrict__ inv_d, int transposed) {
+                                                        const double *__restrict__ inv_d, int transposed,
+                                                        int skip_long) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int r = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
   if (r >= rows) return;
   const int k0 = rowptr[r], k1 = rowptr[r + 1];
+  if (skip_long && k1 - k0 > BLOCK_NNZ) return;      // scale_long_kernel does them chunk by chunk
   for (int k = k0 + lane; k < k1; k += WAVE) {
     const int c = col[k];
     const double ie = transposed ? inv_e[c] : inv_e[r];
     const double id = transposed ? inv_d[r] : inv_d[c];
     val[k] = (val[k] * ie) * id;
   }
+}
+
+// Rows longer than BLOCK_NNZ (a dense equality row, an intercept column: up to n entries)
+// would keep one wave busy for milliseconds per pass: one workgroup per LONG_CHUNK entries.
+__global__ __launch_bounds__(TPB) void scale_long_kernel(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                         double *__restrict__ val, const int *__restrict__ chunk_row,
+                                                         const int *__restrict__ chunk_off,
+                                                         const double *__restrict__ inv_e,
+                                                         const double *__restrict__ inv_d, int transposed) {
+  const int r = chunk_row[blockIdx.x];
+  const int kb = rowptr[r] + chunk_off[blockIdx.x];
+  const int ke = min(kb + LONG_CHUNK, rowptr[r + 1]);
+  for (int k = kb + threadIdx.x; k < ke; k += TPB) {
+    const int c = col[k];
+    const double ie = transposed ? inv_e[c] : inv_e[r];
+    const double id = transposed ? inv_d[r] : inv_d[c];
+    val[k] = (val[k] * ie) * id;
+  }
+}
+
+// chunk partial of a long row's statistic (same three operations as row_op_kernel)
+template <int OP>
+__global__ __launch_bounds__(TPB) void row_op_long_partial_kernel(CsrView A, const int *__restrict__ chunk_row,
+                                                                  const int *__restrict__ chunk_off, double pexp,
+                                                                  const double *__restrict__ inv_scale,
+                                                                  double *__restrict__ chunk_partial) {
+  __shared__ double red[TPB / WAVE];
+  const int r = chunk_row[blockIdx.x];
+  const int kb = A.rowptr[r] + chunk_off[blockIdx.x];
+  const int ke = min(kb + LONG_CHUNK, A.rowptr[r + 1]);
+  const double sc = (OP == ROP_SUMSQ_SCALED) ? inv_scale[r] : 1.0;
+  double acc = 0.0;
+  for (int k = kb + threadIdx.x; k < ke; k += TPB) {
+    const double a = A.val[k];
+    if (OP == ROP_MAXABS) acc = fmax(acc, fabs(a));
+    else if (OP == ROP_SUMPOW) acc += pow(fabs(a), pexp);
+    else { const double t = a * sc; acc += t * t; }
+  }
+  acc = (OP == ROP_MAXABS) ? wave_max(acc) : wave_sum(acc);
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  if (lane == 0) red[wid] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = red[0];
+    for (int w = 1; w < TPB / WAVE; ++w) t = (OP == ROP_MAXABS) ? fmax(t, red[w]) : t + red[w];
+    chunk_partial[blockIdx.x] = t;
+  }
+}
+// one lane per long row: combine its chunk partials in order (+ the structural zeros of 0^0)
+template <int OP>
+__global__ __launch_bounds__(TPB) void row_op_long_final_kernel(CsrView A, const int *__restrict__ long_row,
+                                                                const int *__restrict__ long_chunk_ptr, int nlong,
+                                                                const double *__restrict__ chunk_partial, int cols,
+                                                                double pexp, double *__restrict__ out) {
+  const int l = blockIdx.x * TPB + threadIdx.x;
+  if (l >= nlong) return;
+  const int r = long_row[l];
+  double t = 0.0;
+  for (int c = long_chunk_ptr[l]; c < long_chunk_ptr[l + 1]; ++c)
+    t = (OP == ROP_MAXABS) ? fmax(t, chunk_partial[c]) : t + chunk_partial[c];
+  if (OP == ROP_SUMPOW && pexp == 0.0) t += (double)(cols - (A.rowptr[r + 1] - A.rowptr[r]));
+  out[r] = t;
 }
 
 // same for the tiled-sweep copy: one wave per wave-row-block, walking its steps
