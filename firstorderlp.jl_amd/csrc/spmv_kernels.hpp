@@ -412,8 +412,16 @@ __global__ __launch_bounds__(TPB) void spmv_long_final_kernel(
   const int l = blockIdx.x * TPB + threadIdx.x;
   if (l < nlong) {
     double s = 0.0;
-    for (int c = long_chunk_ptr[l]; c < long_chunk_ptr[l + 1]; ++c)
-      s = s + chunk_partial[c];
+    int c = long_chunk_ptr[l];
+    const int c1 = long_chunk_ptr[l + 1];
+    // the chunk partials are added in chunk order (a fixed order: reproducible); 8 loads in
+    // flight at a time -- one lane owns the row, and a 1M-entry row has over a hundred chunks
+    for (; c + 8 <= c1; c += 8) {
+      const double t0 = chunk_partial[c], t1 = chunk_partial[c + 1], t2 = chunk_partial[c + 2], t3 = chunk_partial[c + 3];
+      const double t4 = chunk_partial[c + 4], t5 = chunk_partial[c + 5], t6 = chunk_partial[c + 6], t7 = chunk_partial[c + 7];
+      s = s + t0; s = s + t1; s = s + t2; s = s + t3; s = s + t4; s = s + t5; s = s + t6; s = s + t7;
+    }
+    for (; c < c1; ++c) s = s + chunk_partial[c];
     row_epilogue<MODE>(e, long_row[l], s, acc);
   }
   constexpr int NQ = ModeNQ<MODE>::value;
