@@ -270,3 +270,27 @@ def evaluate_unscaled_iteration_stats(scaled_problem, qp_cache,
         iteration - 1, cumulative_kkt_passes, cumulative_time,
         eps_optimal_absolute, eps_optimal_relative, step_size, primal_weight,
         candidate_type, original_ops)
+
+
+def print_to_screen_this_iteration(termination_reason, iteration, verbosity,
+                                   termination_evaluation_frequency):
+    """Whether the stats row of this evaluation is printed
+    (iteration_stats_utils.jl:459-490): always when terminating, otherwise every
+    display_frequency evaluations, the frequency falling as verbosity rises."""
+    if verbosity < 2:
+        return False
+    if termination_reason is not False:
+        return True
+    if verbosity >= 9:
+        display_frequency = 1
+    elif verbosity >= 6:
+        display_frequency = 3
+    elif verbosity >= 5:
+        display_frequency = 10
+    elif verbosity >= 4:
+        display_frequency = 20
+    elif verbosity >= 3:
+        display_frequency = 50
+    else:
+        return iteration == 1
+    return math.fmod((iteration - 1) / termination_evaluation_frequency, display_frequency) == 0

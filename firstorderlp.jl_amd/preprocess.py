@@ -351,3 +351,18 @@ def undo_presolve(presolve_info, primal_solution, dual_solution):
     dual = recover_original_solution(dual_solution, presolve_info.empty_rows,
                                      presolve_info.original_dual_size)
     return primal, dual
+
+
+def row_permute_in_place(matrix, old_row_to_new):
+    """Rows of a CSC matrix moved by the map ``old_row_to_new`` (0-based) without
+    building a second matrix (preprocess.jl:598-622): the index and value arrays
+    are rewritten column by column, rows ascending inside each column.  Not
+    checked: that the map is a permutation."""
+    assert sp.isspmatrix_csc(matrix)
+    old_row_to_new = np.asarray(old_row_to_new)
+    new_rows = old_row_to_new[matrix.indices]
+    column_of = np.repeat(np.arange(matrix.shape[1]), np.diff(matrix.indptr))
+    order = np.lexsort((new_rows, column_of))      # stable: by column, then by new row
+    matrix.indices[:] = new_rows[order]
+    matrix.data[:] = matrix.data[order]
+    matrix.has_sorted_indices = True

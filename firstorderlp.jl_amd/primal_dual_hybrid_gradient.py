@@ -188,6 +188,7 @@ import time as _time
 
 from .evaluation import (POINT_AVERAGE, POINT_CURRENT, DeviceEvaluator,
                          HostEvaluator)
+from .iteration_stats_utils import print_to_screen_this_iteration
 from .preprocess import rescale_problem, validate
 from .quadratic_programming import is_linear_programming_problem
 from .saddle_point import (RestartParameters, compute_new_primal_weight,
@@ -442,7 +443,8 @@ def _optimize(params, original_problem, engine_factory, created):
             if params.record_iteration_stats or termination_reason is not False:
                 iteration_stats.append(current_iteration_stats)
 
-            if params.verbosity >= 4 or (params.verbosity >= 2 and termination_reason is not False):
+            if print_to_screen_this_iteration(termination_reason, iteration, params.verbosity,
+                                              termination_evaluation_frequency):
                 _display_iteration_stats(current_iteration_stats)
 
             if termination_reason is not False:

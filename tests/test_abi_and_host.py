@@ -47,6 +47,13 @@ def test_select_initial_primal_weight():
     lp.objective_vector = np.zeros(4)
     assert select_initial_primal_weight(lp, np.ones(4), np.ones(3), 1.0, 0) == 1.0
     assert select_initial_primal_weight(lp, np.ones(4), np.ones(3), 2.5, 0) == 2.5
+    # the reference's own three cases, primal_importance 1.3 (:33-63)
+    lp1 = H.example_lp()
+    want = 1.3 * np.linalg.norm([5.0, 2.0, 1.0, 1.0]) / np.linalg.norm([12.0, 7.0, 1.0])
+    assert abs(select_initial_primal_weight(lp1, np.ones(4), np.ones(3), 1.3, 0) - want) <= 1e-16
+    lp3 = H.example_lp()
+    lp3.right_hand_side = np.zeros(3)
+    assert select_initial_primal_weight(lp3, np.ones(4), np.ones(3), 1.3, 0) == 1.3
 
 
 def test_compute_lagrangian_value():
@@ -55,6 +62,9 @@ def test_compute_lagrangian_value():
     assert compute_lagrangian_value(lp, np.zeros(4), np.zeros(3)) == -14.0
     qp = H.example_qp()
     assert compute_lagrangian_value(qp, np.zeros(2), np.zeros(1)) == 0.0
+    assert compute_lagrangian_value(qp, np.array([1.0, 1.0]), np.array([0.0])) == 0.5      # :70-73
+    assert compute_lagrangian_value(qp, np.array([1.0, 1.0]), np.array([1.0])) == 1.5
+    assert compute_lagrangian_value(qp, np.array([0.25, 0.0]), np.array([0.0])) == -0.125
     # L(x,y) = c'x - y'(Ax) + b'y + const at the LP optimum equals the optimum value
     x, y = np.array([1.0, 0.0, 6.0, 2.0]), np.array([0.5, 4.0, 0.0])
     assert abs(compute_lagrangian_value(lp, x, y) - (-1.0)) < 1e-14

@@ -104,3 +104,52 @@ def test_device_rescale_qp(gpu_required, ruiz, l2, alpha):
         np.testing.assert_allclose(ra, rb, rtol=1e-9)
         for u, v in zip(ta, tb):
             np.testing.assert_allclose(u, v, rtol=1e-10, atol=1e-12)
+
+
+# ---- the reference's own exact-value cases (test/test_qp_processing.jl) through pdhg_rescale ----
+def _ref_lp(A, b, lb=(0.0, 0.0)):
+    from firstorderlp_jl_amd import linear_programming_problem
+    return linear_programming_problem(list(lb), [1.0, 2.0], [1.0, 2.0], 0.0, A, b, 1)
+
+
+S = np.sqrt
+REFERENCE_CASES = {
+    # name: (A, rhs, lb, (ruiz, l2, alpha), constraint_rescaling, variable_rescaling)
+    "l2 :234": ([[1.0, 1.0], [1.0, -1.0], [1.0, 0.0]], [1.0, 1.0, 2.0], (0.0, 0.0), (0, True, None),
+                [2 ** 0.25, 2 ** 0.25, 1.0], [3 ** 0.25, 2 ** 0.25]),
+    "l2 empty row :269": ([[1.0, 1.0], [1.0, -1.0], [0.0, 0.0]], [1.0, 1.0, 0.0], (0.0, 0.0), (0, True, None),
+                          [2 ** 0.25, 2 ** 0.25, 1.0], [2 ** 0.25, 2 ** 0.25]),
+    "l2 empty column :304": ([[1.0, 0.0], [1.0, 0.0], [2.0, 0.0]], [1.0, 1.0, 2.0], (0.0, 0.0), (0, True, None),
+                             [1.0, 1.0, S(2)], [6 ** 0.25, 1.0]),
+    "pock-chambolle 0 :339": ([[1.0, 1.0], [2.0, -1.0], [1.0, 0.0]], [1.0, 1.0, 2.0], (-1.0, -1.0), (0, False, 0.0),
+                              [S(2), S(2), S(2)], [S(6), S(2)]),
+    "pock-chambolle 1 :359": ([[1.0, 1.0], [2.0, -1.0], [1.0, 0.0]], [1.0, 1.0, 2.0], (-1.0, -1.0), (0, False, 1.0),
+                              [S(2), S(3), S(1)], [S(4), S(2)]),
+    "pock-chambolle 2 :379": ([[1.0, 1.0], [2.0, -1.0], [1.0, 0.0]], [1.0, 1.0, 2.0], (-1.0, -1.0), (0, False, 2.0),
+                              [S(2), S(5), S(1)], [S(3), S(3)]),
+    "ruiz :399": ([[1.0, 3.0], [1.0, -2.0], [2.0, 0.0]], [1.0, 1.0, 2.0], (0.0, 0.0), (1, False, None),
+                  [S(3), S(2), S(2)], [S(2), S(3)]),
+    "ruiz empty row and column :442": ([[2.0, 0.0], [0.0, 0.0]], [1.0, 1.0], (-1.0, -1.0), (1, False, None),
+                                       [S(2), 1.0], [S(2), 1.0]),
+}
+
+
+@pytest.mark.parametrize("shards", [1, 2])
+@pytest.mark.parametrize("name", sorted(REFERENCE_CASES))
+def test_device_rescale_reference_values(gpu_required, name, shards):
+    """The values the reference's tests hold for the cumulative rescaling vectors, and
+    b / E, c / D, bounds * D for the scaled vectors (preprocess.jl scale_problem)."""
+    A, b, lb, (ruiz, l2, alpha), con, var = REFERENCE_CASES[name]
+    p = _ref_lp(A, b, lb)
+    eng = HipPdhgEngine.from_problem(p, device_ids=[0] * shards) if shards > 1 else HipPdhgEngine.from_problem(p)
+    E, D = eng.rescale(ruiz, l2, alpha)
+    np.testing.assert_allclose(E, con, rtol=1e-14)
+    np.testing.assert_allclose(D, var, rtol=1e-14)
+    c, rhs, lo, hi = eng.get_problem_vectors()
+    np.testing.assert_allclose(c, np.array([1.0, 2.0]) / var, rtol=1e-14)
+    np.testing.assert_allclose(rhs, np.array(b) / con, rtol=1e-14)
+    np.testing.assert_allclose(lo, np.array(lb) * var, rtol=1e-14)
+    np.testing.assert_allclose(hi, np.array([1.0, 2.0]) * var, rtol=1e-14)
+    want = np.array(A) / np.outer(con, var)
+    for j in range(2):
+        np.testing.assert_allclose(eng.spmv(np.eye(2)[j]), want[:, j], rtol=1e-14, atol=0)

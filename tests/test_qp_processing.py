@@ -116,3 +116,163 @@ def test_remove_empty_rows_and_columns_and_presolve():      # :22-232
     bad2 = _lp([0.0], [1.0], [1.0], [[1.0], [0.0]], [1.0, 1.0], 1)  # empty inequality row with rhs > 0
     with pytest.raises(ValueError):
         P.remove_empty_rows(bad2)
+
+
+# ---- the remaining testsets of test/test_qp_processing.jl, one function per testset ----
+
+def test_remove_empty_rows_inequality():             # :22-52
+    p = _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[2.0, 0.0], [1.0, 0.0], [0.0, 0.0]], [1.0, 1.0, -1.0], 1)
+    P.remove_empty_rows(p)
+    _same(p, _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[2.0, 0.0], [1.0, 0.0]], [1.0, 1.0], 1), tol=0)
+
+
+def test_remove_empty_rows_equality():               # :54-84
+    p = _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[0.0, 0.0], [1.0, 0.0], [1.0, 0.0]], [0.0, 1.0, 0.0], 1)
+    P.remove_empty_rows(p)
+    _same(p, _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[1.0, 0.0], [1.0, 0.0]], [1.0, 0.0], 0), tol=0)
+
+
+def test_remove_empty_rows_errors_on_positive_inequality_rhs():   # :86-102
+    p = _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[1.0, 0.0], [1.0, 0.0], [0.0, 0.0]], [1.0, 1.0, 1.0], 1)
+    with pytest.raises(ValueError):
+        P.remove_empty_rows(p)
+
+
+def test_remove_empty_rows_errors_on_nonzero_equality_rhs():      # :104-120
+    p = _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]], [1.0, 1.0, 1.0], 1)
+    with pytest.raises(ValueError):
+        P.remove_empty_rows(p)
+
+
+@pytest.mark.parametrize("c0,constant", [(3.0, -3.0), (-3.0, -6.0)])   # :122-148 lower bound, :150-176 upper
+def test_remove_empty_columns(c0, constant):
+    p = _lp([-1.0, -1.0], [2.0, 2.0], [c0, 2.0], [[0.0, 1.0], [0.0, -1.0]], [1.0, 1.0], 0)
+    P.remove_empty_columns(p)
+    q = linear_programming_problem([-1.0], [2.0], [2.0], constant, [[1.0], [-1.0]], [1.0, 1.0], 0)
+    _same(p, q, tol=0)
+
+
+def test_recover_original_solution():                # :178-188 (1-based [1, 4] there)
+    out = P.recover_original_solution(np.array([1.0, 1.0, 1.0, 5.0]), np.array([0, 3]), 5)
+    assert list(out) == [0.0, 1.0, 1.0, 0.0, 1.0]
+
+
+def test_presolve_then_undo():                       # :190-209
+    p = _lp([0.0, 0.0, 1.0], [1.0, 2.0, 2.0], [1.0, 2.0, 0.0],
+            [[1.0, 1.0, 0.0], [1.0, -1.0, 0.0], [0.0, 0.0, 0.0]], [1.0, 1.0, 0.0], 1)
+    info = P.presolve(p, verbosity=0)
+    x, y = P.undo_presolve(info, np.array([1.0, 0.0]), np.array([1.0, 1.0]))
+    assert list(x) == [1.0, 0.0, 1.0]                # the removed variable lands on its lower bound
+    assert list(y) == [1.0, 1.0, 0.0]
+
+
+def test_presolve_keeps_empty_columns_of_a_qp():     # :211-232
+    p = QuadraticProgrammingProblem([0.0, 0.0, 0.0], [1.0, 2.0, 1.0],
+                                    [[4.0, 2.0, 0.0], [2.0, 1.0, 0.0], [0.0, 0.0, 1.0]], [1.0, 2.0, 1.0], 0.0,
+                                    [[1.0, 1.0, 0.0], [1.0, -1.0, 0.0], [1.0, 0.0, 0.0]], [1.0, 1.0, 2.0], 1)
+    P.presolve(p, verbosity=0)
+    assert p.constraint_matrix.shape == (3, 3)
+
+
+def test_l2_norm_rescaling_with_empty_rows():        # :269-302
+    p = _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[1.0, 1.0], [1.0, -1.0], [0.0, 0.0]], [1.0, 1.0, 0.0], 1)
+    P.l2_norm_rescaling(p)
+    r = 2 ** 0.25
+    q = _lp([0.0, 0.0], [r, 2.0 * r], [1.0 / r, 2.0 / r],
+            [[4 ** -0.25, 4 ** -0.25], [4 ** -0.25, -(4 ** -0.25)], [0.0, 0.0]], [1 / r, 1 / r, 0.0], 1)
+    _same(p, q)
+
+
+def test_l2_norm_rescaling_with_empty_columns():     # :304-337
+    p = _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[1.0, 0.0], [1.0, 0.0], [2.0, 0.0]], [1.0, 1.0, 2.0], 1)
+    P.l2_norm_rescaling(p)
+    q = _lp([0.0, 0.0], [6 ** 0.25, 2.0], [6 ** -0.25, 2.0],
+            [[6 ** -0.25, 0.0], [6 ** -0.25, 0.0], [24 ** -0.25 * 2.0, 0.0]], [1.0, 1.0, 2.0 / S(2)], 1)
+    _same(p, q)
+
+
+def _qp_case(lb0):
+    return QuadraticProgrammingProblem([lb0, -2.0], [1.0, 2.0], [[4.0, 2.0], [2.0, 1.0]], [1.0, 2.0], 0.0,
+                                       [[1.0, 3.0], [1.0, -2.0], [2.0, 0.0]], [1.0, 1.0, 2.0], 1)
+
+
+def test_ruiz_qp_exact_values():                     # :549-592
+    p = _qp_case(-np.inf)
+    cr, vr = P.ruiz_rescaling(p, 1)
+    np.testing.assert_allclose(vr, [2.0, S(3)], rtol=1e-14)
+    np.testing.assert_allclose(cr, [S(3), S(2), S(2)], rtol=1e-14)
+    q = QuadraticProgrammingProblem([-np.inf, -2 * S(3)], [2.0, 2 * S(3)],
+                                    [[1.0, 1 / S(3)], [1 / S(3), 1 / 3.0]], [0.5, 2 / S(3)], 0.0,
+                                    [[1 / (2 * S(3)), 1.0], [1 / (2 * S(2)), -S(2) / S(3)], [1 / S(2), 0.0]],
+                                    [1 / S(3), 1 / S(2), S(2)], 1)
+    _same(p, q)
+
+
+def test_ruiz_qp_converges():                        # :594-633
+    p = _qp_case(-1.0)
+    original = p.copy()
+    cr, vr = P.ruiz_rescaling(p, 30)
+    A, Q = np.abs(p.constraint_matrix.toarray()), np.abs(p.objective_matrix.toarray())
+    np.testing.assert_allclose(np.sqrt(np.maximum(A.max(axis=0), Q.max(axis=0))), 1.0, rtol=1e-7)
+    np.testing.assert_allclose(np.sqrt(A.max(axis=1)), 1.0, rtol=1e-7)
+    P.unscale_problem(p, cr, vr)
+    _same(p, original)
+
+
+def test_l2_ruiz_lp_one_iteration():                 # :635-671
+    p = _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[1.0, 3.0], [1.0, -2.0], [2.0, 0.0]], [1.0, 1.0, 3.0], 1)
+    cr, vr = P.ruiz_rescaling(p, 1, 2.0)
+    q = _lp([0.0, 0.0], [6 ** 0.25, 2 * 13 ** 0.25], [6 ** -0.25, 2 / 13 ** 0.25],
+            [[(6 * 15) ** -0.25, 3 / (13 * 15) ** 0.25], [(7.5 * 6) ** -0.25, -2 / (13 * 7.5) ** 0.25],
+             [2 / 36 ** 0.25, 0.0]], [15 ** -0.25, 7.5 ** -0.25, 3 / 6 ** 0.25], 1)
+    _same(p, q)
+    np.testing.assert_allclose(vr, [6 ** 0.25, 13 ** 0.25], rtol=1e-14)
+    np.testing.assert_allclose(cr, [15 ** 0.25, 7.5 ** 0.25, 6 ** 0.25], rtol=1e-14)
+
+
+def test_l2_ruiz_lp_converges():                     # :672-692
+    p = _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[1.0, 3.0], [1.0, -2.0], [2.0, 0.0]], [1.0, 1.0, 3.0], 1)
+    P.ruiz_rescaling(p, 60, 2.0)
+    np.testing.assert_allclose(P.l2_norm(p.constraint_matrix, 1), [1.0, 1.0], atol=1e-5)
+    np.testing.assert_allclose(P.l2_norm(p.constraint_matrix, 2), [S(2 / 3)] * 3, atol=1e-5)
+
+
+def test_l2_ruiz_qp_one_iteration():                 # :694-733
+    p = _qp_case(-np.inf)
+    cr, vr = P.ruiz_rescaling(p, 1, 2.0)
+    q = QuadraticProgrammingProblem(
+        [-np.inf, -2 * 18 ** 0.25], [26 ** 0.25, 2 * 18 ** 0.25],
+        [[4 / 26 ** 0.5, 2 / (26 * 18) ** 0.25], [2 / (26 * 18) ** 0.25, 1 / 18 ** 0.5]],
+        [26 ** -0.25, 2 / 18 ** 0.25], 0.0,
+        [[(25 * 26) ** -0.25, 3 / (18 * 25) ** 0.25], [(12.5 * 26) ** -0.25, -2 / (18 * 12.5) ** 0.25],
+         [2 / (10 * 26) ** 0.25, 0.0]], [25 ** -0.25, 12.5 ** -0.25, 2 / 10 ** 0.25], 1)
+    _same(p, q)
+    np.testing.assert_allclose(vr, [26 ** 0.25, 18 ** 0.25], rtol=1e-14)
+    np.testing.assert_allclose(cr, [25 ** 0.25, 12.5 ** 0.25, 10 ** 0.25], rtol=1e-14)
+
+
+def test_l2_ruiz_qp_converges():                     # :735-766
+    p = _qp_case(-1.0)
+    P.ruiz_rescaling(p, 100, 2.0)
+    cols = np.sqrt(np.sqrt(P.l2_norm(p.constraint_matrix, 1) ** 2 + P.l2_norm(p.objective_matrix, 1) ** 2))
+    np.testing.assert_allclose(cols, [1.0, 1.0], atol=1e-5)
+    np.testing.assert_allclose(P.l2_norm(p.constraint_matrix, 2), [S(2 / 5)] * 3, atol=1e-5)
+
+
+def test_l2_ruiz_closed_form():                      # :770-800
+    p = _lp([0.0, 0.0], [1.0, 2.0], [1.0, 2.0], [[1.0, 1.0], [1.0, -1.0], [1.0, 1.0]], [1.0, 1.0, 3.0], 1)
+    P.ruiz_rescaling(p, 10, 2.0)
+    r, t = 3 ** 0.25, 1 / S(3)
+    _same(p, _lp([0.0, 0.0], [r, 2 * r], [1 / r, 2 / r], [[t, t], [t, -t], [t, t]], [1 / r, 1 / r, 3 / r], 1))
+
+
+@pytest.mark.parametrize("before,perm,after", [                     # test_sparse_linalg.jl:16-20, 22-35
+    ([[1.0, 0.0], [0.0, 1.0]], [1, 0], [[0.0, 1.0], [1.0, 0.0]]),
+    ([[1.0, 0.0], [0.0, 1.0], [2.0, 3.0]], [2, 0, 1], [[0.0, 1.0], [2.0, 3.0], [1.0, 0.0]])])
+def test_row_permute_in_place(before, perm, after):
+    M = sp.csc_matrix(np.array(before))
+    data_buffer, index_buffer = M.data, M.indices
+    P.row_permute_in_place(M, perm)
+    assert M.data is data_buffer and M.indices is index_buffer      # in place
+    assert np.array_equal(M.toarray(), np.array(after))
+    assert np.all(np.diff(M.indices[M.indptr[1]:M.indptr[2]]) > 0)

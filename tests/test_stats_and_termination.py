@@ -105,3 +105,12 @@ def test_termination():                              # test_termination.jl:15-19
         tc.kkt_matrix_pass_limit = 40.0
         assert T.check_termination_criteria(tc, qp_cache, mk(no1)) == \
             TerminationReason.TERMINATION_REASON_KKT_MATRIX_PASS_LIMIT
+
+
+def test_print_to_screen_this_iteration():           # test_iteration_stats.jl:310-342
+    from firstorderlp_jl_amd.iteration_stats_utils import print_to_screen_this_iteration as f
+    assert f(False, 1, 2, 10)
+    assert f(False, 101, 5, 10)
+    assert not f(False, 31, 5, 10)
+    assert not f(False, 531, 5, 10)
+    assert f(True, 124, 5, 10)
