@@ -704,18 +704,29 @@ int dual_product(const Shards &L, Yin yin, Out out) {
 int choose_tile_shift(int64_t cols, int64_t nnz, int64_t rows) {
   const char *mode = getenv("PDHG_SPMV");
   const char *ts = getenv("PDHG_TILE_SHIFT");
-  int shift = ts ? atoi(ts) : 16;   // 64K columns = 512 KiB of the gathered vector (best of 14..19 on MI355X)
+  int shift = ts ? atoi(ts) : 16;
   if (!ts && rows > 0) {
-    // Few rows (a row shard of a multi-GPU run): a wave then owns few rows and a
-    // 64K-column tile gives it well under one 64-entry chunk per step.  128K-column
-    // tiles double the chunk fill (config S, 1/8 row shard: 0.200 -> 0.137 ms;
-    // 1/4 shard 0.242 -> 0.222 ms; full matrix and the transposes stay at 64K).
+    // One step of the sweep costs about the same for any cell of up to TW_U x 64
+    // entries, and a smaller tile keeps the gathered vector in L2 more reliably, so
+    // the tile is the smallest power of two that gives a wave ~80-140 entries per
+    // (wave, tile) cell: entries per wave / number of tiles.  Measured on MI355X
+    // (profiles/r02_tile_rule.txt), time per nonzero against entries per cell, same
+    // matrix: 40 -> +20 %, 48-64 -> +10-18 %, 80-128 -> best, 160 -> +15-20 %.
+    // Config S (10 per row, 10M columns) lands on 64K columns, 20 per row on 32K,
+    // a 1/8 row shard on 256K, 1M-4M square on 32K.  Tiles of 2 MiB are only used
+    // when the grid is a single residency round: with several rounds in flight
+    // workgroups of different rounds sit in different tiles and two 2 MiB tiles
+    // thrash the 4 MiB L2 (30M x 30M: 3.2 ms at 128K columns, 4.6 ms at 256K).
     const int64_t slots = 256LL * 2 * TW_WPB;
     const int64_t rounds = std::max<int64_t>(1, (rows + slots * TW_MAX_ROWS - 1) / (slots * TW_MAX_ROWS));
     const int64_t rpw = std::max<int64_t>(64, (rows + slots * rounds - 1) / (slots * rounds));
-    const int64_t ntiles16 = std::max<int64_t>(1, (cols + 65535) >> 16);
-    const double per_step = (double)nnz / (double)rows * (double)rpw / (double)ntiles16;
-    if (per_step < 48.0 && ntiles16 >= 4) shift = 17;
+    const double per_wave = (double)nnz / (double)rows * (double)rpw;
+    const int smax = rounds == 1 ? 18 : 17;
+    shift = smax;
+    for (int s = 13; s <= smax; ++s) {
+      const int64_t ntiles = std::max<int64_t>(1, (cols + (1LL << s) - 1) >> s);
+      if (per_wave / (double)ntiles >= 72.0) { shift = s; break; }
+    }
   }
   if (shift < 6) shift = 6;
   if (shift > 22) shift = 22;                            // leave >= 10 bits for row_local

@@ -17,14 +17,19 @@ ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--pagerank", type=int, default=0, help="PageRank LP with this many nodes instead of the random LP")
 ap.add_argument("cfgs", nargs="*")
 a = ap.parse_args()
-p = random_lp(a.m, a.n, a.k, 12345)
+if a.pagerank:
+    from firstorderlp_jl_amd.generators import pagerank_lp
+    p = pagerank_lp(a.pagerank, seed=1)
+else:
+    p = random_lp(a.m, a.n, a.k, 12345)
 A = p.constraint_matrix
 step0 = 1.0 / float(np.abs(A.data).max())
 pw0 = float(np.linalg.norm(p.objective_vector) / np.linalg.norm(p.right_hand_side))
 KEYS = ["PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TW_ROWS", "PDHG_TW_WPB", "PDHG_TW_FLAGS", "PDHG_XCD_REMAP",
-        "PDHG_TW_MAX_ROWS", "PDHG_TW_WGS_PER_CU"]
+        "PDHG_TW_MAX_ROWS", "PDHG_TW_WGS_PER_CU", "PDHG_SLABS", "PDHG_SLAB_MB", "PDHG_GRAPH"]
 for rep in range(a.reps):
     for cfg in a.cfgs or [""]:
         for k in KEYS:
