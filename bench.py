@@ -257,7 +257,7 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         "whole_iteration_GBps": round(b_iter * (trials / steps) / (ms_per_step * 1e-3) / 1e9, 1),
         "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_socket": cpu_socket,
         "kernels": kernels,
-        "layout": {k: v for k, v in eng.layout_info().items() if "tiled" in k or "shift" in k or "slab" in k or "graph" in k},
+        "layout": {k: v for k, v in eng.layout_info().items() if "tiled" in k or "tile_cols" in k or "slab" in k or "graph" in k},
         "setup_sec": {"generate": round(t_gen, 1), "create_upload": round(t_create, 1)},
     }
     if out["layout"].get("trial_graph"):

@@ -30,7 +30,7 @@ struct CsrDev {
   int64_t max_row_nnz = 0;
   // tiled-sweep layout (optional)
   bool tiled = false;
-  int tile_shift = 0, nwaves = 0, ntiles = 0, tw_rows = 0;
+  int tile_shift = 0, tile_cols = 0, nwaves = 0, ntiles = 0, tw_rows = 0;   // tile_cols <= 1 << tile_shift
   int2 *wave_rows = nullptr;
   int *wave_ent = nullptr;        // per-wave entry offsets, one per step of its workgroup (+1)
   int *wave_step_off = nullptr;   // [nwaves] start of a wave's offsets inside wave_ent
@@ -108,7 +108,12 @@ void parallel_ranges(int n, int grain, F f) {
 // <= TW_ROWS consecutive non-long rows) and their entries counting-sorted by
 // column tile (stable, so (row, col) order is kept inside a tile).
 int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec &col,
-                const dvec &val, int tile_shift) {
+                const dvec &val, int tile_cols) {
+  // the column field of an entry is wide enough for tile_cols (any width, not only powers of two)
+  int tile_shift = 1;
+  while ((1LL << tile_shift) < tile_cols) ++tile_shift;
+  const bool pow2 = (1LL << tile_shift) == tile_cols;
+  auto tile_of = [=](int c) { return pow2 ? (c >> tile_shift) : (c / tile_cols); };
   // Geometry.  A CU holds 2 workgroups of 8 waves; the grid runs in rounds of
   // 256 CUs x 16 waves.  Rows per wave is chosen so that the rounds are full
   // (no tail round), within the LDS budget (160 KiB / 16 waves).
@@ -127,8 +132,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   }
   if (const char *ev = getenv("PDHG_TW_ROWS")) TW_ROWS = std::max(1, std::min(atoi(ev), max_rows));
   D.tw_rows = TW_ROWS;
-  const int ntiles = std::max<int>(1, (int)((((int64_t)D.cols) + (1LL << tile_shift) - 1) >> tile_shift));
-  const unsigned cmask = (1u << tile_shift) - 1u;
+  const int ntiles = std::max<int>(1, (int)((((int64_t)D.cols) + tile_cols - 1) / tile_cols));
   const int WIN = TW_U * WAVE;  // entries a wave holds in registers per step
   // pass 1: wave row blocks.  A wave owns <= TW_ROWS rows AND <= nnz_cap
   // nonzeros: hub regions (PageRank's oldest nodes) would otherwise give one
@@ -160,7 +164,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     for (int w = w0; w < w1; ++w) {
       std::vector<int> &c = cnt[w - w0];
       std::fill(c.begin(), c.end(), 0);
-      for (int k = rowptr[wave_rows[w].x]; k < rowptr[wave_rows[w].y]; ++k) c[(col[k] >> tile_shift) + 1] += 1;
+      for (int k = rowptr[wave_rows[w].x]; k < rowptr[wave_rows[w].y]; ++k) c[tile_of(col[k]) + 1] += 1;
       for (int t = 0; t < ntiles; ++t) nsub[t] = std::max(nsub[t], (c[t + 1] + WIN - 1) / WIN);
       for (int t = 0; t < ntiles; ++t) c[t + 1] += c[t];   // prefix: cell start offsets
     }
@@ -220,12 +224,12 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
           const unsigned rl = (unsigned)(rr - r0) << tile_shift;
           int run = 0, run_tile = -1;
           for (int k = rowptr[rr]; k < rowptr[rr + 1]; ++k) {
-            const int tt = col[k] >> tile_shift;
+            const int tt = tile_of(col[k]);
             run = (tt == run_tile) ? run + 1 : 1;
             run_tile = tt;
             if (run > max_run) max_run = run;
             const int pos = next[tt]++;
-            pk[(size_t)base + pos] = rl | ((unsigned)col[k] & cmask);
+            pk[(size_t)base + pos] = rl | (unsigned)(col[k] - tt * tile_cols);
             tv[(size_t)base + pos] = val[k];
           }
         }
@@ -250,6 +254,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   D.wg_first_row[grid] = rows;
   D.tiled = true;
   D.tile_shift = tile_shift;
+  D.tile_cols = tile_cols;
   D.ntiles = ntiles;
   D.nwaves = nwaves;
   D.grid = grid;
@@ -340,7 +345,7 @@ int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, c
 
 int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
                   const ivec &col, const dvec &val,
-                  bool remap, int tile_shift = 0) {
+                  bool remap, int tile_cols = 0) {
   D.rows = rows;
   D.cols = cols;
   D.nnz = rowptr[rows];
@@ -389,8 +394,8 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
   if ((rc = upload(&D.chunk_row, chunk_row))) return rc;
   if ((rc = upload(&D.chunk_off, chunk_off))) return rc;
   if ((rc = alloc_zero(&D.chunk_partial, D.nchunks))) return rc;
-  if (tile_shift > 0) {
-    if ((rc = build_tiled(D, rows, rowptr, col, val, tile_shift))) return rc;
+  if (tile_cols > 0) {
+    if ((rc = build_tiled(D, rows, rowptr, col, val, tile_cols))) return rc;
   }
   if (!D.tiled) {
     if ((rc = build_slabs(D, rows, cols, rowptr, col, val, remap))) return rc;

@@ -187,12 +187,12 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
         if ((rc = ensure_lds_limit(h, MODE, true, lds, (const void *)spmv_tiled_kernel<MODE, true>))) return rc;
         hipLaunchKernelGGL((spmv_tiled_kernel<MODE, true>), dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
                            D.wave_rows, D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves,
-                           D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
+                           D.tile_shift, D.tile_cols, D.tw_rows, D.pk, D.tv, xin, e);
       } else {
         if ((rc = ensure_lds_limit(h, MODE, false, lds, (const void *)spmv_tiled_kernel<MODE, false>))) return rc;
         hipLaunchKernelGGL((spmv_tiled_kernel<MODE, false>), dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
                            D.wave_rows, D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves,
-                           D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
+                           D.tile_shift, D.tile_cols, D.tw_rows, D.pk, D.tv, xin, e);
       }
     }
   } else if (!D.slabs.empty()) {
@@ -254,13 +254,13 @@ int launch_spmv_plain_part(pdhg_handle *h, const CsrDev &D, const double *xin, d
       if (rc) return rc;
       hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, true>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
                          D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
-                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
+                         D.nwaves - w0, D.tile_shift, D.tile_cols, D.tw_rows, D.pk, D.tv, xin, e);
     } else {
       int rc = ensure_lds_limit(h, MODE_PLAIN, false, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, false>);
       if (rc) return rc;
       hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, false>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
                          D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
-                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
+                         D.nwaves - w0, D.tile_shift, D.tile_cols, D.tw_rows, D.pk, D.tv, xin, e);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -701,41 +701,38 @@ int dual_product(const Shards &L, Yin yin, Out out) {
 // Layout choice for one CSR: the tiled sweep pays off when the gathered vector
 // (cols doubles) is far larger than an XCD's 4 MiB L2 and rows are short.
 // PDHG_SPMV=stream|tiled forces a layout; PDHG_TILE_SHIFT sets log2(tile cols).
-int choose_tile_shift(int64_t cols, int64_t nnz, int64_t rows) {
+int choose_tile_cols(int64_t cols, int64_t nnz, int64_t rows) {
   const char *mode = getenv("PDHG_SPMV");
-  const char *ts = getenv("PDHG_TILE_SHIFT");
-  int shift = ts ? atoi(ts) : 16;
-  if (!ts && rows > 0) {
+  const char *ts = getenv("PDHG_TILE_SHIFT"), *tc = getenv("PDHG_TILE_COLS");
+  int64_t tile = tc ? atoll(tc) : (ts ? (1LL << std::min(22, std::max(6, atoi(ts)))) : 65536);
+  if (!ts && !tc && rows > 0) {
     // One step of the sweep costs about the same for any cell of up to TW_U x 64
     // entries, and a smaller tile keeps the gathered vector in L2 more reliably, so
-    // the tile is the smallest power of two that gives a wave ~80-140 entries per
-    // (wave, tile) cell: entries per wave / number of tiles.  Measured on MI355X
-    // (profiles/r02_tile_rule.txt), time per nonzero against entries per cell, same
-    // matrix: 40 -> +20 %, 48-64 -> +10-18 %, 80-128 -> best, 160 -> +15-20 %.
-    // Config S (10 per row, 10M columns) lands on 64K columns, 20 per row on 32K,
-    // a 1/8 row shard on 256K, 1M-4M square on 32K.  Tiles of 2 MiB are only used
-    // when the grid is a single residency round: with several rounds in flight
-    // workgroups of different rounds sit in different tiles and two 2 MiB tiles
-    // thrash the 4 MiB L2 (30M x 30M: 3.2 ms at 128K columns, 4.6 ms at 256K).
+    // the tile is as narrow as a cell of ~100-110 entries allows (entries per wave /
+    // number of tiles; tile widths are multiples of 4096 columns, not powers of two).
+    // Measured on MI355X (profiles/r02_tile_rule.txt), time per nonzero against
+    // entries per cell on the same matrix: 40 -> +20 %, 48-64 -> +10-18 %,
+    // 88-120 -> best, 160 -> +15-20 %.  The width is capped where the L2 stops
+    // holding the tile against the entry stream: 76K columns (608 KiB) when several
+    // residency rounds are in flight (config S: 0.73 ms at 72-80K, 0.96 ms at 96K;
+    // 16M x 16M: 1.33 ms at 80K, 1.58 ms at 96K), 144K columns for a single round
+    // (row shards of a multi-GPU run).
     const int64_t slots = 256LL * 2 * TW_WPB;
     const int64_t rounds = std::max<int64_t>(1, (rows + slots * TW_MAX_ROWS - 1) / (slots * TW_MAX_ROWS));
     const int64_t rpw = std::max<int64_t>(64, (rows + slots * rounds - 1) / (slots * rounds));
     const double per_wave = (double)nnz / (double)rows * (double)rpw;
-    const int smax = rounds == 1 ? 18 : 17;
-    shift = smax;
-    for (int s = 13; s <= smax; ++s) {
-      const int64_t ntiles = std::max<int64_t>(1, (cols + (1LL << s) - 1) >> s);
-      if (per_wave / (double)ntiles >= 72.0) { shift = s; break; }
-    }
+    const double target = getenv("PDHG_TILE_FILL") ? atof(getenv("PDHG_TILE_FILL")) : (rounds == 1 ? 110.0 : 100.0);
+    const int64_t cap = (rounds == 1 ? 144 : 76) * 1024, unit = 4096;
+    const int64_t want = (int64_t)((double)cols * target / std::max(per_wave, 1.0));
+    tile = std::min(cap, std::max<int64_t>(2 * unit, (want + unit / 2) / unit * unit));
   }
-  if (shift < 6) shift = 6;
-  if (shift > 22) shift = 22;                            // leave >= 10 bits for row_local
-  if (((cols + (1LL << shift) - 1) >> shift) > 65536) return 0;  // tile table would be huge
+  tile = std::min<int64_t>(std::max<int64_t>(tile, 64), 1LL << 22);   // leave >= 10 bits for row_local
+  if ((cols + tile - 1) / tile > 65536) return 0;        // tile table would be huge
   if (mode && !strcmp(mode, "stream")) return 0;
-  if (mode && !strcmp(mode, "tiled")) return shift;
+  if (mode && !strcmp(mode, "tiled")) return (int)tile;
   const bool big_vector = cols * 8 > (4LL << 20);        // larger than one XCD's 4 MiB L2
   const bool short_rows = rows > 0 && nnz / rows <= 64;
-  return (big_vector && short_rows) ? shift : 0;
+  return (big_vector && short_rows) ? (int)tile : 0;
 }
 
 int host_threads() {
@@ -897,9 +894,9 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     h->own_stream = true;
   }
 #define CK(expr) do { int _rc = (expr); if (_rc) { destroy_shard(h); return _rc; } } while (0)
-  CK(build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, choose_tile_shift(n, nnz, m)));
+  CK(build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, choose_tile_cols(n, nnz, m)));
   const auto t_a = now();
-  CK(build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, choose_tile_shift(m, nnz, n)));
+  CK(build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, choose_tile_cols(m, nnz, n)));
   const auto t_at = now();
   if (verbose)
     fprintf(stderr, "pdhg_create: CSC -> CSR(A), CSR(A') %.2fs; layouts + upload A %.2fs, A' %.2fs\n",
@@ -1956,7 +1953,7 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
     if (D.tiled && D.nwaves > 0)
       hipLaunchKernelGGL(scale_tiled_kernel, dim3(row_grid(D.nwaves)), dim3(TPB), 0, h->stream, D.wave_rows,
                          D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves, D.tile_shift,
-                         D.pk, D.tv, t.inv_e, t.inv_d, k);
+                         D.tile_cols, D.pk, D.tv, t.inv_e, t.inv_d, k);
     for (const SlabDev &S : D.slabs)
       if (S.nnz > 0)
         hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, S.rowptr,
@@ -2221,7 +2218,7 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   info[0] = h->A.nblk; info[1] = h->A.nlong; info[2] = h->A.nchunks; info[3] = h->A.max_row_nnz;
   info[4] = h->At.nblk; info[5] = h->At.nlong; info[6] = h->At.nchunks; info[7] = h->At.max_row_nnz;
   info[8] = h->A.tiled ? h->A.nwaves : 0; info[9] = h->At.tiled ? h->At.nwaves : 0;
-  info[10] = h->A.tiled ? h->A.tile_shift : 0; info[11] = h->At.tiled ? h->At.tile_shift : 0;
+  info[10] = h->A.tiled ? h->A.tile_cols : 0; info[11] = h->At.tiled ? h->At.tile_cols : 0;
   return 0;
 }
 

@@ -292,6 +292,9 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_layout_info(self._h, _pi(info)))
         keys = ["A_blocks", "A_long_rows", "A_long_chunks", "A_max_row_nnz",
                 "At_blocks", "At_long_rows", "At_long_chunks", "At_max_row_nnz",
-                "A_tiled_waves", "At_tiled_waves", "A_tile_shift", "At_tile_shift",
+                "A_tiled_waves", "At_tiled_waves", "A_tile_cols", "At_tile_cols",
                 "A_slabs", "At_slabs", "trial_graph"]
-        return dict(zip(keys, info.tolist()))
+        out = dict(zip(keys, info.tolist()))
+        for k in ("A", "At"):    # width in bits of an entry's column field
+            out[k + "_tile_shift"] = max(1, (out[k + "_tile_cols"] - 1).bit_length()) if out[k + "_tile_cols"] else 0
+        return out

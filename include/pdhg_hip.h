@@ -293,7 +293,7 @@ int64_t pdhg_kernel_algorithmic_bytes(pdhg_handle *h, int kernel_id);
 const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id);
 /* Layout statistics (diagnostics): [0..3] CSR(A) {row blocks, long rows, long
  * chunks, max row nnz}, [4..7] same for CSR(A'), [8],[9] tiled-sweep waves of
- * A / A' (0 = stream layout), [10],[11] their log2(tile columns), [12],[13]
+ * A / A' (0 = stream layout), [10],[11] their tile widths in columns, [12],[13]
  * column-slab passes of A / A' (0 = single pass), [14] 1 when pdhg_trial_step runs as one
  * graph launch (small / medium LPs; not while profiling), [15] reserved. */
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]);

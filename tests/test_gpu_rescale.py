@@ -53,9 +53,10 @@ def test_device_rescale_matches_host(gpu_required, name, ruiz, l2, alpha):
             np.testing.assert_allclose(got, wantv, rtol=1e-11, atol=1e-11 * np.abs(wantv).max())
 
 
-def test_device_rescale_tiled_layout(gpu_required, monkeypatch):
+@pytest.mark.parametrize("tile_env", [("PDHG_TILE_SHIFT", "9"), ("PDHG_TILE_COLS", "700")])
+def test_device_rescale_tiled_layout(gpu_required, monkeypatch, tile_env):
     monkeypatch.setenv("PDHG_SPMV", "tiled")
-    monkeypatch.setenv("PDHG_TILE_SHIFT", "9")
+    monkeypatch.setenv(*tile_env)
     p = random_lp(5000, 7000, 9, 11)
     host = rescale_problem(10, False, None, 0, p)
     eng = HipPdhgEngine.from_problem(p)

@@ -17,9 +17,15 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[8, 10, 13])
+@pytest.fixture(params=[8, 10, 13, "cols=1000", "cols=97"])
 def tiled_env(request, monkeypatch):
+    """Tile widths: powers of two (PDHG_TILE_SHIFT) and arbitrary widths (PDHG_TILE_COLS);
+    the value is the width of the column field of an entry in bits."""
     monkeypatch.setenv("PDHG_SPMV", "tiled")
+    if isinstance(request.param, str):
+        cols = int(request.param.split("=")[1])
+        monkeypatch.setenv("PDHG_TILE_COLS", str(cols))
+        return (cols - 1).bit_length()
     monkeypatch.setenv("PDHG_TILE_SHIFT", str(request.param))
     return request.param
 
