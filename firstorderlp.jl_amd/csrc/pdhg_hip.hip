@@ -63,6 +63,12 @@ struct pdhg_handle {
   double *sum_x = nullptr, *sum_y = nullptr;
   double *qx = nullptr, *tmp_n = nullptr, *tmp_n2 = nullptr, *tmp_m = nullptr;
   int64_t sum_x_count = 0, sum_y_count = 0;
+  // Lazy accept: pdhg_accept swaps the iterates and leaves K7 (sum += w * iterate) to the
+  // kernels of the next trial, which read x and y anyway (primal_kernel, the dual epilogue);
+  // every other entry point that reads or writes x, y or the sums settles it first
+  // (flush_pending).  pend_x / pend_y: the sums do not contain pend_w * (x | y) yet.
+  bool pend_x = false, pend_y = false, lazy_accept = true;
+  double pend_w = 0.0;
   double sum_x_weights = 0.0, sum_y_weights = 0.0;
 
   double *pA = nullptr;   // partials of the A kernel (1 quantity)
@@ -127,6 +133,8 @@ struct pdhg_handle {
     hipGraphNode_t n_primal = nullptr, n_dual = nullptr, n_dual_long = nullptr;
     const double *x = nullptr, *y = nullptr, *aty = nullptr;   // the buffers this instance was built for
     double tau = 0.0, theta = 0.0, sigma = 0.0;                // scalars currently baked into the nodes
+    bool add_x = false, add_y = false;                         // deferred K7 baked into the primal / dual nodes
+    double add_wx = 0.0, add_wy = 0.0;
   } tgraph[2];
   int graph_mode = -1;                  // -1 undecided, 0 off, 1 on
   hipStream_t graph_stream = nullptr;   // graphs launch here (== stream)
@@ -283,11 +291,12 @@ int launch_primal(pdhg_handle *h, double tau, double theta, bool write_xbar) {
 #define PK(HQ, WX)                                                                           \
   hipLaunchKernelGGL((primal_kernel<HQ, WX>), dim3(grid), dim3(TPB), 0, h->stream, n,        \
                      h->x + o, h->c + o, h->aty + o, h->has_q ? h->qx + o : nullptr, h->lb + o, h->ub + o, tau, theta, \
-                     h->x_next + o, h->xbar + o)
+                     h->x_next + o, h->xbar + o, h->pend_w, h->pend_x ? h->sum_x + o : nullptr)
   if (h->has_q) { if (write_xbar) PK(true, true); else PK(true, false); }
   else          { if (write_xbar) PK(false, true); else PK(false, false); }
 #undef PK
   HIP_TRY(hipGetLastError());
+  h->pend_x = false;
   return 0;
 }
 
@@ -304,7 +313,10 @@ int launch_dual(pdhg_handle *h, double sigma) {
   EpiArgs e{};
   e.y = h->y; e.b = h->b; e.y_next = h->y_next; e.sigma = sigma; e.num_eq = (int)h->num_eq;
   e.partials = h->pA; e.stride = h->A.slots();
-  return launch_spmv<MODE_DUAL>(h, h->A, h->xbar, e);
+  if (h->pend_y) { e.sum_y = h->sum_y; e.avg_w = h->pend_w; }
+  const int rc = launch_spmv<MODE_DUAL>(h, h->A, h->xbar, e);
+  if (!rc) h->pend_y = false;
+  return rc;
 }
 
 int launch_aty_fused(pdhg_handle *h) {
@@ -421,6 +433,7 @@ struct GraphArgs {
     dual_epi = EpiArgs{};
     dual_epi.y = h->y; dual_epi.b = h->b; dual_epi.y_next = h->y_next; dual_epi.sigma = sigma;
     dual_epi.num_eq = (int)h->num_eq; dual_epi.partials = h->pA; dual_epi.stride = h->A.slots();
+    if (h->pend_y) { dual_epi.sum_y = h->sum_y; dual_epi.avg_w = h->pend_w; }
   }
 };
 
@@ -513,7 +526,8 @@ int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double t
   // K1+K2
   HIP_TRY(graph_add_kernel(G.graph, &G.n_primal, {}, (const void *)primal_kernel<false, true>, a.primal_grid, dim3(TPB),
                            a.n, (const double *)h->x, (const double *)h->c, (const double *)h->aty, nullq,
-                           (const double *)h->lb, (const double *)h->ub, tau, theta, h->x_next, h->xbar));
+                           (const double *)h->lb, (const double *)h->ub, tau, theta, h->x_next, h->xbar,
+                           h->pend_w, h->pend_x ? h->sum_x : (double *)nullptr));
   // K3+K4 on CSR(A), K5+K6 on CSR(A'): the stream kernel (or its column-slab passes, a
   // chain) and the long-row pair are independent branches
   std::vector<hipGraphNode_t> dual_done, aty_done;
@@ -546,6 +560,8 @@ int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double t
   HIP_TRY(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
   G.x = h->x; G.y = h->y; G.aty = h->aty;
   G.tau = tau; G.theta = theta; G.sigma = sigma;
+  G.add_x = h->pend_x; G.add_wx = h->pend_w;
+  G.add_y = h->pend_y; G.add_wy = h->pend_w;
   return 0;
 }
 
@@ -561,21 +577,25 @@ int graph_trial(pdhg_handle *h, double step_size, double primal_weight, double t
     if (rc) return rc;
   } else {
     GraphArgs a(h, sigma);
-    if (G->tau != tau || G->theta != theta) {
+    if (G->tau != tau || G->theta != theta || G->add_x != h->pend_x || (h->pend_x && G->add_wx != h->pend_w)) {
       const double *nullq = nullptr;
       HIP_TRY(graph_set_kernel(G->exec, G->n_primal, (const void *)primal_kernel<false, true>, a.primal_grid, dim3(TPB),
                                a.n, (const double *)h->x, (const double *)h->c, (const double *)h->aty, nullq,
-                               (const double *)h->lb, (const double *)h->ub, tau, theta, h->x_next, h->xbar));
+                               (const double *)h->lb, (const double *)h->ub, tau, theta, h->x_next, h->xbar,
+                               h->pend_w, h->pend_x ? h->sum_x : (double *)nullptr));
       G->tau = tau; G->theta = theta;
+      G->add_x = h->pend_x; G->add_wx = h->pend_w;
     }
-    if (G->sigma != sigma) {
+    if (G->sigma != sigma || G->add_y != h->pend_y || (h->pend_y && G->add_wy != h->pend_w)) {
       int rc = graph_set_dual(h, *G, a.dual_epi);
       if (rc) return rc;
       G->sigma = sigma;
+      G->add_y = h->pend_y; G->add_wy = h->pend_w;
     }
   }
   h->seq_expected += 1;
   HIP_TRY(hipGraphLaunch(G->exec, h->stream));
+  h->pend_x = h->pend_y = false;     // the launch carries the deferred average update
   // wait for this launch's sequence number in pinned memory (bounded spin, then the stream)
   const double want = (double)h->seq_expected;
   bool seen = false;
@@ -603,6 +623,22 @@ int check_handle(pdhg_handle *h) {
 
 int sync_all(const Shards &L) {
   FOR_SHARDS(L, s) HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+// Settle a deferred K7 (lazy accept): sum_x += w * x and / or sum_y += w * y on the
+// iterate that is current now.  Called by every entry point other than the trial itself.
+int flush_pending(const Shards &L) {
+  FOR_SHARDS(L, h) {
+    if (!h->pend_x && !h->pend_y) continue;
+    ProfScope ps(h, PDHG_K_ACCEPT);
+    const int64_t o = h->clo;
+    const int nn = h->pend_x ? (int)h->cn : 0, mm = h->pend_y ? (int)h->m : 0;
+    hipLaunchKernelGGL(accept_kernel, dim3(ew_grid(std::max<int64_t>(std::max(nn, mm), 1))), dim3(TPB), 0, h->stream, nn, mm,
+                       h->pend_w, h->x + o, h->sum_x + o, h->y, h->sum_y);
+    HIP_TRY(hipGetLastError());
+    h->pend_x = h->pend_y = false;
+  }
   return 0;
 }
 
@@ -887,6 +923,8 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   h->cn = n; h->n_alloc = n_alloc; h->m_global = m;
   const char *env = getenv("PDHG_XCD_REMAP");
   h->remap = !(env && env[0] == '0');
+  env = getenv("PDHG_LAZY_ACCEPT");       // 0: pdhg_accept runs K7 itself (one more launch and n + m more words per iteration)
+  h->lazy_accept = !(env && env[0] == '0');
   if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
   else {
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -1381,9 +1419,13 @@ int pdhg_accept(pdhg_handle *h0, double avg_weight) {
   int rc = check_handle(h0);
   if (rc) return rc;
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;   // two accepts without a trial in between
   bump_version(L);
   FOR_SHARDS(L, h) {
-    {
+    if (h->lazy_accept) {
+      h->pend_x = h->pend_y = true;         // K7 rides on the next trial's kernels
+      h->pend_w = avg_weight;
+    } else {
       ProfScope ps(h, PDHG_K_ACCEPT);
       const int64_t o = h->clo;
       hipLaunchKernelGGL(accept_kernel, dim3(ew_grid(std::max(h->cn, h->m))), dim3(TPB), 0, h->stream, (int)h->cn,
@@ -1445,6 +1487,7 @@ int pdhg_add_current_primal_to_average(pdhg_handle *h0, double weight) {
   int rc = check_handle(h0);
   if (rc) return rc;
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;
   bump_version(L);
   FOR_SHARDS(L, h) {
     const int64_t o = h->clo;
@@ -1468,6 +1511,7 @@ int pdhg_get_average(pdhg_handle *h0, double *x_avg, double *y_avg) {
   int rc = check_handle(h0);
   if (rc) return rc;
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;
   if (x_avg) {
     FOR_SHARDS(L, h) {
       const int64_t o = h->clo;
@@ -1495,6 +1539,7 @@ int pdhg_reset_average(pdhg_handle *h0) {
   FOR_SHARDS(L, h) {
     HIP_TRY(hipMemsetAsync(h->sum_x, 0, sizeof(double) * (size_t)std::max<int64_t>(h->n, 1), h->stream));
     HIP_TRY(hipMemsetAsync(h->sum_y, 0, sizeof(double) * (size_t)std::max<int64_t>(h->m, 1), h->stream));
+    h->pend_x = h->pend_y = false;          // a deferred update belongs to the sums being discarded
     h->sum_x_count = h->sum_y_count = 0;
     h->sum_x_weights = h->sum_y_weights = 0.0;
   }
@@ -1511,6 +1556,7 @@ int pdhg_restart_to_average(pdhg_handle *h0) {
   int rc = check_handle(h0);
   if (rc) return rc;
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;
   bump_version(L);
   if (h0->sum_x_count == 0 || h0->sum_y_count == 0) return fail(-1, "average is empty");
   FOR_SHARDS(L, h) {
@@ -1547,6 +1593,7 @@ int pdhg_set_current(pdhg_handle *h0, const double *x, const double *y) {
   int rc = check_handle(h0);
   if (rc) return rc;
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;
   bump_version(L);
   if (x && (rc = cols_from_host(L, x, [](pdhg_handle *s) { return s->x; }))) return rc;
   if (y && (rc = rows_from_host(L, y, [](pdhg_handle *s) { return s->y; }))) return rc;
@@ -1717,6 +1764,7 @@ int pdhg_eval_point(pdhg_handle *h0, int point, double out[24]) {
   if (rc) return rc;
   if (!h0->has_original) return fail(-1, "pdhg_set_original_problem has not been called");
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;
   if ((rc = point_products(L, point))) return rc;
   FOR_SHARDS(L, h) {
     hipLaunchKernelGGL(eval_rows_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->m, (int)h->num_eq,
@@ -1742,6 +1790,7 @@ int pdhg_save_restart_point(pdhg_handle *h0) {
   int rc = check_handle(h0);
   if (rc) return rc;
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;
   FOR_SHARDS(L, h) {
     if ((rc = ev_alloc(h))) return rc;
     h->restart_version += 1;
@@ -1757,6 +1806,7 @@ static int dist2_common(pdhg_handle *h0, int point, bool to_restart, double out[
   int rc = check_handle(h0);
   if (rc) return rc;
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;
   FOR_SHARDS(L, h) {
     const double *px, *py;
     if ((rc = select_point(h, point, &px, &py))) return rc;
@@ -1776,6 +1826,7 @@ int pdhg_get_point(pdhg_handle *h0, int point, double *x, double *y) {
   int rc = check_handle(h0);
   if (rc) return rc;
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;
   FOR_SHARDS(L, h) { if ((rc = select_point(h, point, &h->pt_x, &h->pt_y))) return rc; }
   if (x && (rc = cols_to_host(L, [](pdhg_handle *s) { return s->pt_x; }, x))) return rc;
   if (y && (rc = rows_to_host(L, [](pdhg_handle *s) { return s->pt_y; }, y))) return rc;
@@ -1791,6 +1842,7 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
   if (rc) return rc;
   if (range < 0 || range > 2) return fail(-1, "range must be 0, 1 or 2");
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;
   const double wp = primal_weight_norm, wd = dual_weight_norm;
   if ((rc = point_products(L, point))) return rc;
   // every shard works on the concatenation [its column slice ; its rows]
@@ -1989,6 +2041,7 @@ int pdhg_rescale(pdhg_handle *h0, int l_inf_ruiz_iterations, int l2_norm_rescali
   if (use_pock_chambolle && !(pock_chambolle_alpha >= 0.0 && pock_chambolle_alpha <= 2.0))
     return fail(-1, "pock_chambolle_alpha must be in [0, 2]");
   const Shards L = shards_of(h0);
+  if ((rc = flush_pending(L))) return rc;
   bump_version(L);
   for (int i = 0; i < L.count; ++i) L.p[i]->matrix_version += 1;
   std::vector<RescaleTmp> T((size_t)L.count);
@@ -2143,8 +2196,10 @@ int64_t pdhg_kernel_algorithmic_bytes(pdhg_handle *h, int kernel_id) {
   const int64_t m = h->m, n = h->n, nnz = h->nnz, cn = h->cn;
   const bool group = h->grp != nullptr;
   switch (kernel_id) {
-    case PDHG_K_PRIMAL: return 8 * 7 * cn;                              // r: x,c,aty,lb,ub  w: x',xbar
-    case PDHG_K_SPMV_DUAL: return nnz * 12 + (m + 1) * 4 + n * 8 + 3 * m * 8;  // + r: y,b  w: y'
+    // lazy accept: K7's sums are read and written where x and y are read anyway
+    case PDHG_K_PRIMAL: return 8 * (7 + (h->lazy_accept ? 2 : 0)) * cn;         // r: x,c,aty,lb,ub  w: x',xbar  (+ r/w sum_x)
+    case PDHG_K_SPMV_DUAL:                                                      // + r: y,b  w: y'  (+ r/w sum_y)
+      return nnz * 12 + (m + 1) * 4 + n * 8 + (3 + (h->lazy_accept ? 2 : 0)) * m * 8;
     case PDHG_K_SPMV_ATY:                                                // fused: + r: x,x',aty  w: aty'
       return nnz * 12 + (n + 1) * 4 + m * 8 + (group ? 1 : 4) * n * 8;
     case PDHG_K_FINAL: return 8 * (int64_t)(3 * h->At.slots() + h->A.slots());

@@ -35,6 +35,9 @@ struct EpiArgs {
   int stride;
   // column-slab passes of the stream layout: the row sums so far (read when INIT)
   const double *init;
+  // MODE_DUAL: the deferred K7 of the previous accept, sum_y += avg_w * y (nullptr: none)
+  double *sum_y;
+  double avg_w;
 };
 
 template <int MODE>
@@ -45,6 +48,10 @@ __device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
   } else if (MODE == MODE_DUAL) {
     // compute_dual_gradient: b .- A*x              saddle_point.jl:1102-1107
     const double yo = e.y[r];
+    if (e.sum_y) {
+      const double t = yo * e.avg_w;
+      e.sum_y[r] = e.sum_y[r] + t;
+    }
     const double dg = e.b[r] - s;
     // next_dual = y .+ (pw*step) .* dual_gradient   pdhg.jl:489-490
     const double t = e.sigma * dg;

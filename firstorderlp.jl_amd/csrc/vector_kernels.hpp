@@ -35,11 +35,21 @@ __global__ __launch_bounds__(TPB) void primal_kernel(
     int n, const double *__restrict__ x, const double *__restrict__ c,
     const double *__restrict__ aty, const double *__restrict__ qx,
     const double *__restrict__ lb, const double *__restrict__ ub, double tau,
-    double theta, double *__restrict__ x_next, double *__restrict__ xbar) {
+    double theta, double *__restrict__ x_next, double *__restrict__ xbar,
+    double avg_w, double *__restrict__ sum_x) {
+  // sum_x != nullptr: the accept of the previous iteration left its K7 to this kernel
+  // (sum_x += avg_w * x, x being the iterate accepted then; same two roundings)
   const int npair = n >> 1;
   const int stride = gridDim.x * TPB;
   for (int p = blockIdx.x * TPB + threadIdx.x; p < npair; p += stride) {
     const double2 xv = reinterpret_cast<const double2 *>(x)[p];
+    if (sum_x) {
+      double2 sv = reinterpret_cast<double2 *>(sum_x)[p];
+      const double t0 = xv.x * avg_w, t1 = xv.y * avg_w;
+      sv.x = sv.x + t0;
+      sv.y = sv.y + t1;
+      reinterpret_cast<double2 *>(sum_x)[p] = sv;
+    }
     const double2 cv = reinterpret_cast<const double2 *>(c)[p];
     const double2 av = reinterpret_cast<const double2 *>(aty)[p];
     const double2 lv = reinterpret_cast<const double2 *>(lb)[p];
@@ -55,6 +65,10 @@ __global__ __launch_bounds__(TPB) void primal_kernel(
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int j = n - 1;
     double xn, xb;
+    if (sum_x) {
+      const double t = x[j] * avg_w;
+      sum_x[j] = sum_x[j] + t;
+    }
     primal_one<HAS_Q, WRITE_XBAR>(x[j], c[j], aty[j], HAS_Q ? qx[j] : 0.0, lb[j], ub[j], tau, theta, xn, xb);
     x_next[j] = xn;
     if (WRITE_XBAR) xbar[j] = xb;
