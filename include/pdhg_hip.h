@@ -98,6 +98,11 @@ int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight,
  * add_to_solution_weighted_average (saddle_point.jl:252-294).  The caller
  * passes the weight (reference quirk: it is solver_state.step_size on entry to
  * take_step, pdhg.jl:512).
+ * The two sums are updated lazily: the call itself launches nothing, the next
+ * trial's kernels add w*x and w*y where they read x and y anyway, and every other
+ * entry point that reads or changes x, y or the sums settles a pending update
+ * first -- observable state is always as if the update had happened here, bit for
+ * bit (PDHG_LAZY_ACCEPT=0: update in this call with its own kernel).
  */
 int pdhg_accept(pdhg_handle *h, double avg_weight);
 
