@@ -30,11 +30,12 @@ struct CsrDev {
   int64_t max_row_nnz = 0;
   // tiled-sweep layout (optional)
   bool tiled = false;
-  int tile_shift = 0, tile_cols = 0, nwaves = 0, ntiles = 0, tw_rows = 0;   // tile_cols <= 1 << tile_shift
+  int tile_shift = 0, tile_cols = 0, nwaves = 0, ntiles = 0, tw_rows = 0;   // tile widths <= 1 << tile_shift
+  bool var_tiles = false;          // equal-nonzero tiles of different widths (skewed columns); tile_cols is then the nominal width
   int2 *wave_rows = nullptr;
   int *wave_ent = nullptr;        // per-wave entry offsets, one per step of its workgroup (+1)
   int *wave_step_off = nullptr;   // [nwaves] start of a wave's offsets inside wave_ent
-  int *step_tile = nullptr;       // tile id of every step, workgroup after workgroup
+  int *step_tile = nullptr;       // first column of the tile of every step, workgroup after workgroup
   int *wg_step_off = nullptr;     // [grid+1] start of a workgroup's steps inside step_tile
   int64_t total_steps = 0;
   bool tw_scratch = false;        // long same-row runs: use the LDS-scratch chunk variant
@@ -104,16 +105,88 @@ void parallel_ranges(int n, int grain, F f) {
   for (std::thread &th : pool) th.join();
 }
 
+// Widest tile the L2 holds against the entry stream (measured, profiles/r02_tile_rule.txt):
+// 76K columns when several residency rounds of the sweep are in flight, 144K for one round.
+inline int tile_width_cap(int64_t rows) {
+  const int64_t slots = 256LL * 2 * TW_WPB;
+  const int64_t rounds = std::max<int64_t>(1, (rows + slots * TW_MAX_ROWS - 1) / (slots * TW_MAX_ROWS));
+  return (rounds == 1 ? 144 : 76) * 1024;
+}
+
 // Host-side construction of the tiled-sweep layout: wave row blocks (runs of
 // <= TW_ROWS consecutive non-long rows) and their entries counting-sorted by
 // column tile (stable, so (row, col) order is kept inside a tile).
 int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec &col,
                 const dvec &val, int tile_cols) {
-  // the column field of an entry is wide enough for tile_cols (any width, not only powers of two)
+  // Tile boundaries.  Uniform width tile_cols by default.  When the columns are skewed
+  // (hub columns: the fullest uniform tile holds more than 1.5x the average), the
+  // boundaries are moved so that every tile holds about the same number of entries
+  // (widths are multiples of 16 columns, at most the L2 cap): a hub region gets narrow
+  // tiles instead of cells cut into many barrier-separated sub-steps, and the entries a
+  // row has inside one tile -- summed by one lane, in order -- stay few.
+  std::vector<int> tstart;                  // [ntiles + 1] first column of every tile
+  std::vector<int> map16;                   // variable widths: tile of a 16-column group
+  {
+    const int nt0 = std::max<int>(1, (int)((((int64_t)D.cols) + tile_cols - 1) / tile_cols));
+    // entries per 16-column group, on host threads (integer counts: the result does not depend on the thread count)
+    const int groups = (D.cols + 15) / 16;
+    std::vector<int> cnt16((size_t)groups, 0);
+    {
+      std::mutex merge;
+      parallel_ranges(rows, 1 << 16, [&](int rb, int re) {
+        std::vector<int> mine((size_t)groups, 0);
+        for (int r = rb; r < re; ++r) {
+          if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) continue;    // long rows are not in the sweep
+          for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) mine[(size_t)(col[k] >> 4)] += 1;
+        }
+        std::lock_guard<std::mutex> lock(merge);
+        for (int g = 0; g < groups; ++g) cnt16[(size_t)g] += mine[(size_t)g];
+      });
+    }
+    std::vector<int64_t> hist((size_t)nt0, 0);
+    int64_t total = 0;
+    for (int g = 0; g < groups; ++g) {
+      // a group straddling two uniform tiles is counted with its first column's tile: a skew test, not a layout
+      hist[(size_t)(((int64_t)g * 16) / tile_cols)] += cnt16[(size_t)g];
+      total += cnt16[(size_t)g];
+    }
+    int64_t fullest = 0;
+    for (int64_t v : hist) fullest = std::max(fullest, v);
+    const char *vt = getenv("PDHG_VAR_TILES");                   // 0 / 1 force
+    bool variable = nt0 > 1 && (double)fullest > 1.5 * (double)total / (double)nt0;
+    if (vt) variable = vt[0] != '0' && nt0 > 1;
+    if (!variable) {
+      for (int t = 0; t <= nt0; ++t) tstart.push_back((int)std::min<int64_t>(D.cols, (int64_t)t * tile_cols));
+    } else {
+      const int64_t target = std::max<int64_t>(1, total / nt0);
+      const int wmax = std::max(16, std::min(tile_width_cap(rows), 2 * tile_cols) / 16 * 16);
+      map16.assign((size_t)groups, 0);
+      tstart.push_back(0);
+      int64_t have = 0;
+      int g0 = 0;
+      for (int g = 0; g < groups; ++g) {
+        map16[(size_t)g] = (int)tstart.size() - 1;
+        have += cnt16[(size_t)g];
+        const bool last = g + 1 == groups;
+        if (last || have >= target || (g + 1 - g0) * 16 >= wmax) {
+          tstart.push_back(last ? D.cols : (g + 1) * 16);
+          have = 0;
+          g0 = g + 1;
+        }
+      }
+      if ((int64_t)tstart.size() - 1 > 65536) return 0;          // absurdly many tiles: leave it to the stream layout
+    }
+  }
+  const int ntiles = (int)tstart.size() - 1;
+  int widest = 1;
+  for (int t = 0; t < ntiles; ++t) widest = std::max(widest, tstart[(size_t)t + 1] - tstart[(size_t)t]);
+  // the column field of an entry is wide enough for the widest tile (any width, not only powers of two)
   int tile_shift = 1;
-  while ((1LL << tile_shift) < tile_cols) ++tile_shift;
-  const bool pow2 = (1LL << tile_shift) == tile_cols;
-  auto tile_of = [=](int c) { return pow2 ? (c >> tile_shift) : (c / tile_cols); };
+  while ((1LL << tile_shift) < widest) ++tile_shift;
+  const bool uniform = map16.empty();
+  const bool pow2 = uniform && (1LL << tile_shift) == tile_cols;
+  const int *map16p = map16.data();
+  auto tile_of = [=](int c) { return !uniform ? map16p[c >> 4] : (pow2 ? (c >> tile_shift) : (c / tile_cols)); };
   // Geometry.  A CU holds 2 workgroups of 8 waves; the grid runs in rounds of
   // 256 CUs x 16 waves.  Rows per wave is chosen so that the rounds are full
   // (no tail round), within the LDS budget (160 KiB / 16 waves).
@@ -132,7 +205,6 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   }
   if (const char *ev = getenv("PDHG_TW_ROWS")) TW_ROWS = std::max(1, std::min(atoi(ev), max_rows));
   D.tw_rows = TW_ROWS;
-  const int ntiles = std::max<int>(1, (int)((((int64_t)D.cols) + tile_cols - 1) / tile_cols));
   const int WIN = TW_U * WAVE;  // entries a wave holds in registers per step
   // pass 1: wave row blocks.  A wave owns <= TW_ROWS rows AND <= nnz_cap
   // nonzeros: hub regions (PageRank's oldest nodes) would otherwise give one
@@ -205,7 +277,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
       count_cells(g, cnt, nsub);
       int *st = step_tile.data() + wg_step_off[g];
       for (int t = 0; t < ntiles; ++t)
-        for (int j = 0; j < nsub[t]; ++j) *st++ = t;
+        for (int j = 0; j < nsub[t]; ++j) *st++ = tstart[(size_t)t];     // the tile's first column
       int max_run = 0;
       for (int w = w0; w < w1; ++w) {
         std::vector<int> &c = cnt[w - w0];
@@ -229,7 +301,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
             run_tile = tt;
             if (run > max_run) max_run = run;
             const int pos = next[tt]++;
-            pk[(size_t)base + pos] = rl | (unsigned)(col[k] - tt * tile_cols);
+            pk[(size_t)base + pos] = rl | (unsigned)(col[k] - tstart[(size_t)tt]);
             tv[(size_t)base + pos] = val[k];
           }
         }
@@ -255,6 +327,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   D.tiled = true;
   D.tile_shift = tile_shift;
   D.tile_cols = tile_cols;
+  D.var_tiles = !uniform;
   D.ntiles = ntiles;
   D.nwaves = nwaves;
   D.grid = grid;

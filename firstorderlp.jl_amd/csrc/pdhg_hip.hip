@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -195,12 +196,12 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
         if ((rc = ensure_lds_limit(h, MODE, true, lds, (const void *)spmv_tiled_kernel<MODE, true>))) return rc;
         hipLaunchKernelGGL((spmv_tiled_kernel<MODE, true>), dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
                            D.wave_rows, D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves,
-                           D.tile_shift, D.tile_cols, D.tw_rows, D.pk, D.tv, xin, e);
+                           D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
       } else {
         if ((rc = ensure_lds_limit(h, MODE, false, lds, (const void *)spmv_tiled_kernel<MODE, false>))) return rc;
         hipLaunchKernelGGL((spmv_tiled_kernel<MODE, false>), dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
                            D.wave_rows, D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves,
-                           D.tile_shift, D.tile_cols, D.tw_rows, D.pk, D.tv, xin, e);
+                           D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
       }
     }
   } else if (!D.slabs.empty()) {
@@ -262,13 +263,13 @@ int launch_spmv_plain_part(pdhg_handle *h, const CsrDev &D, const double *xin, d
       if (rc) return rc;
       hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, true>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
                          D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
-                         D.nwaves - w0, D.tile_shift, D.tile_cols, D.tw_rows, D.pk, D.tv, xin, e);
+                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
     } else {
       int rc = ensure_lds_limit(h, MODE_PLAIN, false, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, false>);
       if (rc) return rc;
       hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, false>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
                          D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
-                         D.nwaves - w0, D.tile_shift, D.tile_cols, D.tw_rows, D.pk, D.tv, xin, e);
+                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -758,7 +759,7 @@ int choose_tile_cols(int64_t cols, int64_t nnz, int64_t rows) {
     const int64_t rpw = std::max<int64_t>(64, (rows + slots * rounds - 1) / (slots * rounds));
     const double per_wave = (double)nnz / (double)rows * (double)rpw;
     const double target = getenv("PDHG_TILE_FILL") ? atof(getenv("PDHG_TILE_FILL")) : (rounds == 1 ? 110.0 : 100.0);
-    const int64_t cap = (rounds == 1 ? 144 : 76) * 1024, unit = 4096;
+    const int64_t cap = tile_width_cap(rows), unit = 4096;
     const int64_t want = (int64_t)((double)cols * target / std::max(per_wave, 1.0));
     tile = std::min(cap, std::max<int64_t>(2 * unit, (want + unit / 2) / unit * unit));
   }
@@ -2005,7 +2006,7 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
     if (D.tiled && D.nwaves > 0)
       hipLaunchKernelGGL(scale_tiled_kernel, dim3(row_grid(D.nwaves)), dim3(TPB), 0, h->stream, D.wave_rows,
                          D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves, D.tile_shift,
-                         D.tile_cols, D.pk, D.tv, t.inv_e, t.inv_d, k);
+                         D.pk, D.tv, t.inv_e, t.inv_d, k);
     for (const SlabDev &S : D.slabs)
       if (S.nnz > 0)
         hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, S.rowptr,
@@ -2269,7 +2270,8 @@ int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps) {
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   if (!h) return fail(-1, "null handle");
   info[12] = (int64_t)h->A.slabs.size(); info[13] = (int64_t)h->At.slabs.size();
-  info[14] = graph_eligible(h) || (h->graph_mode == 1 && !h->has_q) ? 1 : 0; info[15] = 0;
+  info[14] = graph_eligible(h) || (h->graph_mode == 1 && !h->has_q) ? 1 : 0;
+  info[15] = (h->A.tiled && h->A.var_tiles ? 1 : 0) + (h->At.tiled && h->At.var_tiles ? 2 : 0);
   info[0] = h->A.nblk; info[1] = h->A.nlong; info[2] = h->A.nchunks; info[3] = h->A.max_row_nnz;
   info[4] = h->At.nblk; info[5] = h->At.nlong; info[6] = h->At.nchunks; info[7] = h->At.max_row_nnz;
   info[8] = h->A.tiled ? h->A.nwaves : 0; info[9] = h->At.tiled ? h->At.nwaves : 0;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(TPB) void scale_tiled_kernel(const int2 *__restrict
                                                           const int *__restrict__ wave_step_off,
                                                           const int *__restrict__ step_tile,
                                                           const int *__restrict__ wg_step_off, int nwaves,
-                                                          int tile_shift, int tile_cols, const unsigned *__restrict__ pk,
+                                                          int tile_shift, const unsigned *__restrict__ pk,
                                                           double *__restrict__ tv,
                                                           const double *__restrict__ inv_e,
                                                           const double *__restrict__ inv_d, int transposed) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(TPB) void scale_tiled_kernel(const int2 *__restrict
     for (int k = sp[st] + lane; k < sp[st + 1]; k += WAVE) {
       const unsigned p = pk[k];
       const int r = r0 + (int)(p >> tile_shift);
-      const int c = tile * tile_cols + (int)(p & cmask);
+      const int c = tile + (int)(p & cmask);      // step_tile holds the tile's first column
       const double ie = transposed ? inv_e[c] : inv_e[r];
       const double id = transposed ? inv_d[r] : inv_d[c];
       tv[k] = (tv[k] * ie) * id;

@@ -252,7 +252,7 @@ template <int MODE, bool SCR>
 __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
     const int2 *__restrict__ wave_rows, const int *__restrict__ step_ptr,
     const int *__restrict__ wave_step_off, const int *__restrict__ step_tile,
-    const int *__restrict__ wg_step_off, int nwaves, int tile_shift, int tile_cols, int TW_ROWS,
+    const int *__restrict__ wg_step_off, int nwaves, int tile_shift, int TW_ROWS,
     const unsigned *__restrict__ pk, const double *__restrict__ tv,
     const double *__restrict__ xin, EpiArgs e) {
   constexpr int TW_THREADS = TW_WPB * WAVE;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
 #ifdef TWD_ONE_TILE   // timing diagnostic, wrong results (tools/variants.sh): every gather hits tile 0
         const double *xt = xin;
 #else
-        const double *xt = xin + (size_t)tl[s] * (size_t)tile_cols;
+        const double *xt = xin + (size_t)tl[s];      // the step table holds the tile's first column
 #endif
         // 1. gathers for tile t (entries requested D steps ago).  Issued BEFORE
         //    the prefetch: a wave's loads return in order, so the L2-latency

@@ -293,7 +293,7 @@ class HipPdhgEngine:
         keys = ["A_blocks", "A_long_rows", "A_long_chunks", "A_max_row_nnz",
                 "At_blocks", "At_long_rows", "At_long_chunks", "At_max_row_nnz",
                 "A_tiled_waves", "At_tiled_waves", "A_tile_cols", "At_tile_cols",
-                "A_slabs", "At_slabs", "trial_graph"]
+                "A_slabs", "At_slabs", "trial_graph", "var_tiles"]   # var_tiles: bit 0 = A, bit 1 = A'
         out = dict(zip(keys, info.tolist()))
         for k in ("A", "At"):    # width in bits of an entry's column field
             out[k + "_tile_shift"] = max(1, (out[k + "_tile_cols"] - 1).bit_length()) if out[k + "_tile_cols"] else 0

@@ -300,7 +300,8 @@ const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id);
  * chunks, max row nnz}, [4..7] same for CSR(A'), [8],[9] tiled-sweep waves of
  * A / A' (0 = stream layout), [10],[11] their tile widths in columns, [12],[13]
  * column-slab passes of A / A' (0 = single pass), [14] 1 when pdhg_trial_step runs as one
- * graph launch (small / medium LPs; not while profiling), [15] reserved. */
+ * graph launch (small / medium LPs; not while profiling), [15] bit 0 / bit 1: A / A' use
+ * equal-nonzero tiles of different widths (skewed columns; [10],[11] are then nominal). */
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]);
 /* Measurement only: best-of-`reps` rate of a[i] = b[i] + s*c[i] over `len`
  * doubles (len % 4 == 0) on this handle's device and stream (24*len bytes per pass), in GB/s --

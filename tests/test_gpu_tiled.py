@@ -17,15 +17,19 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[8, 10, 13, "cols=1000", "cols=97"])
+@pytest.fixture(params=[8, 10, 13, "cols=1000", "cols=97", "var=256", "var=4096"])
 def tiled_env(request, monkeypatch):
-    """Tile widths: powers of two (PDHG_TILE_SHIFT) and arbitrary widths (PDHG_TILE_COLS);
-    the value is the width of the column field of an entry in bits."""
+    """Tile widths: powers of two (PDHG_TILE_SHIFT), arbitrary widths (PDHG_TILE_COLS), and
+    equal-nonzero tiles of different widths (PDHG_VAR_TILES=1 on top of a nominal width).
+    The value is the expected width of an entry's column field in bits (None: not fixed)."""
     monkeypatch.setenv("PDHG_SPMV", "tiled")
     if isinstance(request.param, str):
-        cols = int(request.param.split("=")[1])
-        monkeypatch.setenv("PDHG_TILE_COLS", str(cols))
-        return (cols - 1).bit_length()
+        kind, cols = request.param.split("=")
+        monkeypatch.setenv("PDHG_TILE_COLS", cols)
+        if kind == "var":
+            monkeypatch.setenv("PDHG_VAR_TILES", "1")
+            return None
+        return (int(cols) - 1).bit_length()
     monkeypatch.setenv("PDHG_TILE_SHIFT", str(request.param))
     return request.param
 
@@ -39,7 +43,10 @@ def test_tiled_spmv_bit_exact(gpu_required, tiled_env, m, n, k, seed):
     eng = HipPdhgEngine.from_problem(p)
     info = eng.layout_info()
     assert info["A_tiled_waves"] > 0 and info["At_tiled_waves"] > 0
-    assert info["A_tile_shift"] == tiled_env
+    if tiled_env is not None:
+        assert info["A_tile_shift"] == tiled_env
+    elif n > int(os.environ["PDHG_TILE_COLS"]):
+        assert info["var_tiles"] & 1
     rng = np.random.default_rng(seed)
     x, y = rng.standard_normal(n), rng.standard_normal(m)
     assert np.array_equal(eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x))
@@ -103,6 +110,41 @@ def test_tiled_trajectory_matches_stream_and_oracle(gpu_required, tiled_env, mon
     np.testing.assert_allclose(x1, st.x, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(y1, st.y, rtol=1e-9, atol=1e-9)
     assert s1.total_number_iterations == st.total_number_iterations
+
+
+def test_skewed_columns_get_equal_nonzero_tiles(gpu_required, monkeypatch):
+    """A PageRank LP (Barabasi-Albert graph: the oldest nodes are hub columns AND hub rows):
+    uniform tiles put most entries into the first tile; the layout notices (fullest tile
+    > 1.5x average) and moves the boundaries.  Products stay bit-exact, the device rescaling
+    walks the same tiles, and a trajectory matches the stream layout."""
+    from firstorderlp_jl_amd.generators import pagerank_lp
+    from firstorderlp_jl_amd.preprocess import rescale_problem
+    p = pagerank_lp(60000, seed=4)
+    A = p.constraint_matrix
+    m, n = A.shape
+    monkeypatch.setenv("PDHG_SPMV", "tiled")
+    monkeypatch.setenv("PDHG_TILE_COLS", "2048")
+    eng = HipPdhgEngine.from_problem(p)
+    info = eng.layout_info()
+    assert info["A_tiled_waves"] > 0 and info["var_tiles"] == 3
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    short = np.diff(A.tocsr().indptr) <= 2048
+    short_t = np.diff(A.indptr) <= 2048
+    assert np.array_equal(eng.spmv(x)[short], orc.spmv(m, n, A.indptr, A.indices, A.data, x)[short])
+    assert np.array_equal(eng.spmv_t(y)[short_t], orc.spmv_t(m, n, A.indptr, A.indices, A.data, y)[short_t])
+    # forcing uniform tiles gives the same products (short rows: bitwise)
+    monkeypatch.setenv("PDHG_VAR_TILES", "0")
+    uni = HipPdhgEngine.from_problem(p)
+    assert uni.layout_info()["var_tiles"] == 0
+    assert np.array_equal(uni.spmv(x)[short], eng.spmv(x)[short])
+    monkeypatch.delenv("PDHG_VAR_TILES")
+    # device rescaling over variable-width tiles == a fresh layout of the host-rescaled problem
+    host = rescale_problem(10, False, None, 0, p)
+    eng.rescale(10, False, None)
+    ref = HipPdhgEngine.from_problem(host.scaled_qp)
+    assert np.array_equal(eng.spmv(x)[short], ref.spmv(x)[short])
+    assert np.array_equal(eng.spmv_t(y)[short_t], ref.spmv_t(y)[short_t])
 
 
 def test_layout_construction_is_independent_of_host_threads(gpu_required, monkeypatch):

@@ -18,17 +18,28 @@ ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--pagerank", type=int, default=0, help="PageRank LP with this many nodes instead of the random LP")
+ap.add_argument("--colskew", action="store_true", help="random LP whose column popularity falls like 1/sqrt(index) (hub columns clustered at low indices, short rows)")
 ap.add_argument("cfgs", nargs="*")
 a = ap.parse_args()
 if a.pagerank:
     from firstorderlp_jl_amd.generators import pagerank_lp
     p = pagerank_lp(a.pagerank, seed=1)
+elif a.colskew:
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd import linear_programming_problem
+    rng = np.random.default_rng(5)
+    cols = np.minimum((rng.random(a.m * a.k) ** 2 * a.n).astype(np.int64), a.n - 1)     # density ~ 1/sqrt(index)
+    rows = np.repeat(np.arange(a.m), a.k)
+    M = sp.csr_matrix((rng.standard_normal(a.m * a.k), (rows, cols)), shape=(a.m, a.n))
+    M.sum_duplicates()
+    p = linear_programming_problem(np.zeros(a.n), np.full(a.n, 10.0), rng.standard_normal(a.n), 0.0,
+                                   M.tocsc(), rng.standard_normal(a.m), a.m // 2)
 else:
     p = random_lp(a.m, a.n, a.k, 12345)
 A = p.constraint_matrix
 step0 = 1.0 / float(np.abs(A.data).max())
 pw0 = float(np.linalg.norm(p.objective_vector) / np.linalg.norm(p.right_hand_side))
-KEYS = ["PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TILE_COLS", "PDHG_TILE_FILL", "PDHG_TW_ROWS", "PDHG_TW_WPB", "PDHG_TW_FLAGS", "PDHG_XCD_REMAP",
+KEYS = ["PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TILE_COLS", "PDHG_TILE_FILL", "PDHG_VAR_TILES", "PDHG_TW_ROWS", "PDHG_TW_WPB", "PDHG_TW_FLAGS", "PDHG_XCD_REMAP",
         "PDHG_TW_MAX_ROWS", "PDHG_TW_WGS_PER_CU", "PDHG_SLABS", "PDHG_SLAB_MB", "PDHG_GRAPH"]
 for rep in range(a.reps):
     for cfg in a.cfgs or [""]:
@@ -51,5 +62,5 @@ for rep in range(a.reps):
         by1 = eng.kernel_algorithmic_bytes(_lib.K_SPMV_DUAL)
         info = eng.layout_info()
         print(f"rep{rep} [{cfg:48s}] dual {m1/c1:.4f} ms ({by1/(m1/c1)/1e6:6.0f} GB/s)  aty {m2/c2:.4f} ms  "
-              f"waves={info['A_tiled_waves']} create={tc:.1f}s", flush=True)
+              f"waves={info['A_tiled_waves']} var={info['var_tiles']} create={tc:.1f}s", flush=True)
         eng.close()
