@@ -142,6 +142,9 @@ struct pdhg_handle {
   unsigned long long *seq_dev = nullptr;   // launch counter, incremented by the final kernel
   volatile double *res_host = nullptr;     // pinned, coherent: 5 results + [7] = sequence number
   unsigned long long seq_expected = 0;
+  // host-side breakdown of graph trials (PDHG_VERBOSE): seconds in node updates, in hipGraphLaunch, waiting
+  double t_set = 0.0, t_launch = 0.0, t_wait = 0.0;
+  long n_graph_trials = 0;
 };
 
 #include "dist.hpp"
@@ -577,6 +580,7 @@ int graph_trial(pdhg_handle *h, double step_size, double primal_weight, double t
     int rc = graph_build(h, *G, tau, theta, sigma);
     if (rc) return rc;
   } else {
+    const auto c0 = std::chrono::steady_clock::now();
     GraphArgs a(h, sigma);
     if (G->tau != tau || G->theta != theta || G->add_x != h->pend_x || (h->pend_x && G->add_wx != h->pend_w)) {
       const double *nullq = nullptr;
@@ -593,9 +597,14 @@ int graph_trial(pdhg_handle *h, double step_size, double primal_weight, double t
       G->sigma = sigma;
       G->add_y = h->pend_y; G->add_wy = h->pend_w;
     }
+    h->t_set += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
   }
   h->seq_expected += 1;
+  const auto c1 = std::chrono::steady_clock::now();
   HIP_TRY(hipGraphLaunch(G->exec, h->stream));
+  const auto c2 = std::chrono::steady_clock::now();
+  h->t_launch += std::chrono::duration<double>(c2 - c1).count();
+  h->n_graph_trials += 1;
   h->pend_x = h->pend_y = false;     // the launch carries the deferred average update
   // wait for this launch's sequence number in pinned memory (bounded spin, then the stream)
   const double want = (double)h->seq_expected;
@@ -611,6 +620,7 @@ int graph_trial(pdhg_handle *h, double step_size, double primal_weight, double t
       return fail(998, "trial graph finished without publishing its results");
     }
   }
+  h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
   for (int q = 0; q < 5; ++q) out[q] = h->res_host[q];
   out[4] *= 0.5;
   return 0;
@@ -974,6 +984,10 @@ void destroy_shard(pdhg_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->n_graph_trials > 0 && getenv("PDHG_VERBOSE"))
+    fprintf(stderr, "[pdhg_hip] %ld graph trials: host us per trial: node updates %.2f, hipGraphLaunch %.2f, wait for the result %.2f\n",
+            h->n_graph_trials, 1e6 * h->t_set / h->n_graph_trials, 1e6 * h->t_launch / h->n_graph_trials,
+            1e6 * h->t_wait / h->n_graph_trials);
   free_csr_dev(h->A); free_csr_dev(h->At); free_csr_dev(h->Q); free_csr_dev(h->Qt);
   double *bufs[] = {h->c, h->b, h->lb, h->ub, h->x, h->x_next, h->xbar, h->y, h->y_next,
                     h->aty, h->aty_next, h->sum_x, h->sum_y, h->qx, h->tmp_n, h->tmp_n2,
