@@ -200,6 +200,36 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
 // (tile-major order preserves it) => bit-identical to the sequential CPU
 // loops.  Entries of one row inside a tile are adjacent; the run head adds
 // them left to right via lane shuffles.
+#ifdef TWD_DPP
+// lane i <- lane i+1 (wave_shl:1) / lane i <- lane i-1 (wave_shr:1); lanes without a source get `fill`
+__device__ __forceinline__ unsigned dpp_from_next(unsigned v, unsigned fill) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned dpp_from_prev(unsigned v, unsigned fill) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, double xv,
+                                            int tile_shift, int lane) {
+  const bool valid = p != TW_PAD;
+  const unsigned row = valid ? (p >> tile_shift) : 0xFFFFFFFFu;
+  const double prod = v * xv;
+  const unsigned rowp = dpp_from_prev(row, 0xFFFFFFFEu);
+  const bool head = valid && rowp != row;
+  double s = head ? acc[row] : 0.0;
+  if (head) s = s + prod;
+  unsigned rj = row;
+  unsigned lo = (unsigned)__double2loint(prod), hi = (unsigned)__double2hiint(prod);
+  for (int j = 1; j < WAVE; ++j) {
+    rj = dpp_from_next(rj, 0xFFFFFFFFu);
+    lo = dpp_from_next(lo, 0u);
+    hi = dpp_from_next(hi, 0u);
+    const bool take = head && (rj == row);
+    if (!__any(take)) break;
+    if (take) s = s + __hiloint2double((int)hi, (int)lo);
+  }
+  if (head) acc[row] = s;
+}
+#else
 __device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, double xv,
                                             int tile_shift, int lane) {
   const bool valid = p != TW_PAD;
@@ -217,6 +247,7 @@ __device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, d
   }
   if (head) acc[row] = s;
 }
+#endif
 
 // Variant for matrices with long same-row runs inside a tile (rows with hundreds
 // of entries): run lengths from two ballots, followers' products handed to the
