@@ -2,7 +2,8 @@
 empty to dense, duplicated structure, +-Inf bounds, any number of equalities -- through
 every way the library can lay the matrix out (stream, tiled with tiny tiles, column-slab
 passes, 2- and 3-shard groups, with and without the one-graph-launch trial).  For each:
-the products A x and A'y and the vectors of one trial step (x', y', A'y') must be
+the products A x and A'y, the vectors of a trial step (x', y', A'y'), of a second trial after an
+accept, and the running average must be
 BIT-IDENTICAL to the CPU oracle (rows are far below the long-row threshold), and the
 five step scalars must agree to the condition-aware bound 1e-13 * sum|terms|."""
 import os
@@ -19,13 +20,14 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-LAYOUTS = ["default", "stream_nograph", "tiled6", "tiled8", "slabs", "shards2", "shards3", "shards2_tiled"]
+LAYOUTS = ["default", "stream_nograph", "tiled6", "tiled8", "tiled_cols96", "tiled_var", "slabs", "shards2", "shards3",
+           "shards2_tiled"]
 
 
 @st.composite
 def small_lps(draw):
     m = draw(st.integers(0, 70))
-    n = draw(st.integers(1, 70))
+    n = draw(st.integers(1, 200))
     density = draw(st.sampled_from([0.0, 0.03, 0.15, 0.5, 1.0]))
     seed = draw(st.integers(0, 2 ** 31 - 1))
     rng = np.random.default_rng(seed)
@@ -44,12 +46,16 @@ def small_lps(draw):
 
 
 def _engine(p, layout):
-    keys = ("PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_GRAPH", "PDHG_SLABS", "PDHG_SLAB_MB")
+    keys = ("PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TILE_COLS", "PDHG_VAR_TILES", "PDHG_GRAPH", "PDHG_SLABS", "PDHG_SLAB_MB")
     saved = {k: os.environ.pop(k, None) for k in keys}
     kw = {}
     try:
         if layout == "stream_nograph":
             os.environ.update(PDHG_SPMV="stream", PDHG_GRAPH="0")
+        elif layout == "tiled_cols96":       # a width that is not a power of two
+            os.environ.update(PDHG_SPMV="tiled", PDHG_TILE_COLS="96")
+        elif layout == "tiled_var":          # equal-nonzero tiles of different widths
+            os.environ.update(PDHG_SPMV="tiled", PDHG_TILE_COLS="64", PDHG_VAR_TILES="1")
         elif layout.startswith("tiled"):
             os.environ.update(PDHG_SPMV="tiled", PDHG_TILE_SHIFT=layout[5:])
         elif layout == "slabs":
@@ -105,6 +111,23 @@ def test_products_and_one_trial_are_bit_identical_to_the_oracle(gpu_required, ca
         for q in range(4):
             assert abs(raw[q] - exact[q]) <= 1e-13 * bounds[q] + 1e-300, (layout, q, raw[q], exact[q])
         assert raw[4] == 0.0
+        # accept (the running sums are updated lazily, by the next trial's kernels), a second
+        # trial from the accepted point, then the average
+        oracle.step_size = step
+        eng.accept(step)
+        oracle.accept(gx, gy, ga)
+        eng.trial_step(0.7 * step, pw, theta)
+        _, xn2, yn2, an2 = oracle.trial_step(0.7 * step, pw, theta)
+        gx2, gy2, ga2 = eng.get_trial()
+        assert np.array_equal(gx2, xn2), layout
+        assert np.array_equal(gy2, yn2), layout
+        if sharded:
+            np.testing.assert_allclose(ga2, an2, rtol=0, atol=1e-13 * (abs(A.T) @ np.abs(yn2)).max(initial=0) + 1e-300)
+        else:
+            assert np.array_equal(ga2, an2), layout
+        xa, ya = eng.get_average()
+        xo, yo = oracle.compute_average()
+        assert np.array_equal(xa, xo) and np.array_equal(ya, yo), layout
     finally:
         eng.close()
         oracle.close()
