@@ -210,7 +210,9 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   // nonzeros: hub regions (PageRank's oldest nodes) would otherwise give one
   // wave 100x the average work and the whole launch would wait for its workgroup.
   const int64_t est_waves = std::max<int64_t>(1, ((int64_t)rows + TW_ROWS - 1) / TW_ROWS);
-  const int64_t nnz_cap = std::max<int64_t>(4096, 2 * (D.nnz / est_waves));   // 2x the average wave
+  const double cap_factor = getenv("PDHG_TW_NNZ_CAP") ? std::max(1.0, atof(getenv("PDHG_TW_NNZ_CAP"))) : 2.0;   // dev knob
+  const int64_t nnz_cap = std::max<int64_t>(getenv("PDHG_TW_NNZ_CAP") ? 256 : 4096,
+                                            (int64_t)(cap_factor * (double)(D.nnz / est_waves)));   // 2x the average wave
   std::vector<int2> wave_rows;
   {
     int r = 0;
@@ -332,6 +334,14 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   D.nwaves = nwaves;
   D.grid = grid;
   D.total_steps = (int64_t)step_tile.size();
+  if (getenv("PDHG_VERBOSE")) {
+    int mx = 0;
+    for (int g = 0; g < grid; ++g) mx = std::max(mx, wg_nsteps[(size_t)g]);
+    fprintf(stderr, "[pdhg_hip] tiled layout %d x %d: %d tiles (widest %d columns%s), %d waves x <= %d rows in %d workgroups, "
+                    "steps per workgroup: mean %.1f, max %d; longest same-row run inside a tile %d\n",
+            rows, D.cols, ntiles, widest, uniform ? "" : ", equal-nonzero widths", nwaves, TW_ROWS, grid,
+            grid ? (double)D.total_steps / grid : 0.0, mx, max_run);
+  }
   D.tw_scratch = max_run > 8;
   int rc;
   if ((rc = upload(&D.wave_rows, wave_rows))) return rc;
