@@ -231,7 +231,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   // once the output offsets are known, so it runs on host threads in two passes
   // (A: sizes, serial prefix sums, B: fill).  The result does not depend on the
   // number of threads.
-  std::vector<int> wg_nsteps((size_t)std::max(grid, 1), 0);
+  std::vector<int> wg_nsteps((size_t)std::max(grid, 1), 0), wg_touched((size_t)std::max(grid, 1), 0);
   auto count_cells = [&](int g, std::vector<std::vector<int>> &cnt, std::vector<int> &nsub) {
     const int w0 = g * TW_WPB, w1 = std::min(nwaves, w0 + TW_WPB);
     std::fill(nsub.begin(), nsub.end(), 0);
@@ -249,11 +249,31 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     std::vector<int> nsub((size_t)ntiles);
     for (int g = g_begin; g < g_end; ++g) {
       count_cells(g, cnt, nsub);
-      int steps = 0;
-      for (int t = 0; t < ntiles; ++t) steps += nsub[t];
+      int steps = 0, touched = 0;
+      for (int t = 0; t < ntiles; ++t) { steps += nsub[t]; touched += nsub[t] > 0; }
       wg_nsteps[g] = steps;
+      wg_touched[g] = touched;
     }
   });
+  // Locality: the share of (workgroup, tile) cells that hold entries.  1.0 for a matrix whose
+  // rows scatter over all columns -- what the sweep is for.  A banded / block-local matrix
+  // touches a few tiles per workgroup: its gathers are L2-local in the stream layout anyway
+  // (contiguous row ranges per XCD), and the sweep only adds barriers.  Measured on MI355X
+  // (profiles/r02_locality.txt), 10M x 10M, 10 per row inside a band of +-w columns.
+  double touched_share = 1.0;
+  {
+    int64_t cells = 0;
+    for (int g = 0; g < grid; ++g) cells += wg_touched[(size_t)g];
+    if (grid > 0 && ntiles > 0) touched_share = (double)cells / ((double)grid * (double)ntiles);
+    const char *mode_env = getenv("PDHG_SPMV");
+    const bool forced = mode_env && !strcmp(mode_env, "tiled");
+    // stream wins below ~0.25 (4M columns, band +-500K: share 0.245, stream 0.43 ms / sweep 0.57 ms), the
+    // sweep above ~0.28 (10M columns, band +-1.5M: share 0.284, sweep 1.22 ms / stream 1.60 ms)
+    const double min_share = getenv("PDHG_TW_MIN_SHARE") ? atof(getenv("PDHG_TW_MIN_SHARE")) : 0.26;
+    if (getenv("PDHG_VERBOSE"))
+      fprintf(stderr, "[pdhg_hip] tiled layout %d x %d: %.3f of the (workgroup, tile) cells hold entries\n", rows, D.cols, touched_share);
+    if (!forced && touched_share < min_share) return 0;
+  }
   std::vector<int> wave_step_off((size_t)std::max(nwaves, 1), 0), wg_step_off((size_t)grid + 1, 0);
   std::vector<int64_t> wave_base((size_t)nwaves + 1, 0);
   int64_t step_ptr_len = 0;

@@ -171,3 +171,41 @@ def test_layout_construction_is_independent_of_host_threads(gpu_required, monkey
     m, n = A.shape
     assert np.array_equal(outs[0][1], orc.spmv(m, n, A.indptr, A.indices, A.data, x))
     assert np.array_equal(outs[0][2], orc.spmv_t(m, n, A.indptr, A.indices, A.data, y))
+
+
+def test_banded_matrix_keeps_the_stream_layout(gpu_required, monkeypatch):
+    """Layout choice by locality: a matrix whose rows stay inside a narrow band of columns
+    touches a few (workgroup, tile) cells only; its gathers are L2-local when streamed and
+    the sweep would only add barriers (profiles/r02_locality.txt: 2x slower at 10M columns).
+    The same shape with scattered columns gets the sweep.  Both layouts stay bit-exact."""
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd import linear_programming_problem
+    m = n = 600_000
+    rng = np.random.default_rng(8)
+    rows = np.repeat(np.arange(m), 4)
+
+    def lp(cols):
+        M = sp.csr_matrix((rng.standard_normal(4 * m), (rows, cols)), shape=(m, n))
+        M.sum_duplicates()
+        return linear_programming_problem(np.zeros(n), np.ones(n), rng.standard_normal(n), 0.0, M.tocsc(),
+                                          rng.standard_normal(m), m // 2)
+
+    banded = lp(np.clip(rows + rng.integers(-2000, 2001, 4 * m), 0, n - 1))
+    scattered = lp(rng.integers(0, n, 4 * m))
+    for k in ("PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TILE_COLS", "PDHG_VAR_TILES"):
+        monkeypatch.delenv(k, raising=False)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    for p, want_tiled in ((banded, False), (scattered, True)):
+        A = p.constraint_matrix
+        eng = HipPdhgEngine.from_problem(p)
+        info = eng.layout_info()
+        assert (info["A_tiled_waves"] > 0) == want_tiled and (info["At_tiled_waves"] > 0) == want_tiled
+        assert np.array_equal(eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x))
+        assert np.array_equal(eng.spmv_t(y), orc.spmv_t(m, n, A.indptr, A.indices, A.data, y))
+        eng.close()
+    monkeypatch.setenv("PDHG_SPMV", "tiled")          # forcing the sweep still works on the banded matrix
+    A = banded.constraint_matrix
+    eng = HipPdhgEngine.from_problem(banded)
+    assert eng.layout_info()["A_tiled_waves"] > 0
+    assert np.array_equal(eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x))
+    eng.close()

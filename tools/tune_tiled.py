@@ -19,11 +19,23 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--pagerank", type=int, default=0, help="PageRank LP with this many nodes instead of the random LP")
 ap.add_argument("--colskew", action="store_true", help="random LP whose column popularity falls like 1/sqrt(index) (hub columns clustered at low indices, short rows)")
+ap.add_argument("--banded", type=int, default=0, help="random LP whose row i has its k entries within +-BANDED columns of i*n/m (local / banded structure)")
 ap.add_argument("cfgs", nargs="*")
 a = ap.parse_args()
 if a.pagerank:
     from firstorderlp_jl_amd.generators import pagerank_lp
     p = pagerank_lp(a.pagerank, seed=1)
+elif a.banded:
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd import linear_programming_problem
+    rng = np.random.default_rng(6)
+    centre = (np.arange(a.m, dtype=np.int64) * a.n) // a.m
+    cols = np.clip(np.repeat(centre, a.k) + rng.integers(-a.banded, a.banded + 1, a.m * a.k), 0, a.n - 1)
+    rows = np.repeat(np.arange(a.m), a.k)
+    M = sp.csr_matrix((rng.standard_normal(a.m * a.k), (rows, cols)), shape=(a.m, a.n))
+    M.sum_duplicates()
+    p = linear_programming_problem(np.zeros(a.n), np.full(a.n, 10.0), rng.standard_normal(a.n), 0.0,
+                                   M.tocsc(), rng.standard_normal(a.m), a.m // 2)
 elif a.colskew:
     import scipy.sparse as sp
     from firstorderlp_jl_amd import linear_programming_problem
