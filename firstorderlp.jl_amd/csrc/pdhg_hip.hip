@@ -746,7 +746,7 @@ int dual_product(const Shards &L, Yin yin, Out out) {
 }
 
 // Layout choice for one CSR: the tiled sweep pays off when the gathered vector
-// (cols doubles) is far larger than an XCD's 4 MiB L2 and rows are short.
+// (cols doubles) is comparable to or larger than an XCD's 4 MiB L2.
 // PDHG_SPMV=stream|tiled forces a layout; PDHG_TILE_SHIFT sets log2(tile cols).
 int choose_tile_cols(int64_t cols, int64_t nnz, int64_t rows) {
   const char *mode = getenv("PDHG_SPMV");
@@ -777,9 +777,15 @@ int choose_tile_cols(int64_t cols, int64_t nnz, int64_t rows) {
   if ((cols + tile - 1) / tile > 65536) return 0;        // tile table would be huge
   if (mode && !strcmp(mode, "stream")) return 0;
   if (mode && !strcmp(mode, "tiled")) return (int)tile;
-  const bool big_vector = cols * 8 > (4LL << 20);        // larger than one XCD's 4 MiB L2
-  const bool short_rows = rows > 0 && nnz / rows <= 64;
-  return (big_vector && short_rows) ? (int)tile : 0;
+  // The sweep is tried whenever the gathered vector is beyond ~3 MiB; build_tiled() then
+  // declines for matrices it does not suit (a row with a long run inside one tile, rows
+  // that stay inside a band of columns) and the stream layout takes over.  Measured
+  // crossover on square 10-per-row LPs, whole iterations: 250K columns stream 13.9k / swept
+  // 13.3k it/s (the stream layout's trial is one graph launch), 500K columns 8.3k / 8.9k,
+  // 1M 4.6k / 5.6k.  Row length is no criterion: 100 per row (10M x 1M transposed) streams
+  // at 1.91 ms and sweeps at 0.62 ms; 1 000 per row 1.85 / 1.33 ms (profiles/r02_locality.txt).
+  const bool big_vector = cols * 8 > (3LL << 20);
+  return (big_vector && rows > 0) ? (int)tile : 0;
 }
 
 int host_threads() {

@@ -97,7 +97,7 @@ def test_tiled_shards_match_single_engine_and_overlap_is_bitwise_neutral(gpu_req
     rows are complete, while the next round computes (the default for vectors this long).  With the peer back end both exchange patterns add the
     partials in rank order, so switching the overlap off must not change a single bit."""
     monkeypatch.setenv("PDHG_DIST_ROUND_WGS", "64")     # default granule: a residency round of 512 workgroups
-    p = random_lp(1_200_000, 600_000, 5, seed=21)
+    p = random_lp(1_100_000, 600_000, 5, seed=21)
     runs = {}
     for overlap in ("1", "0"):
         monkeypatch.setenv("PDHG_DIST_OVERLAP", overlap)
