@@ -752,6 +752,7 @@ int choose_tile_cols(int64_t cols, int64_t nnz, int64_t rows) {
   const char *mode = getenv("PDHG_SPMV");
   const char *ts = getenv("PDHG_TILE_SHIFT"), *tc = getenv("PDHG_TILE_COLS");
   int64_t tile = tc ? atoll(tc) : (ts ? (1LL << std::min(22, std::max(6, atoi(ts)))) : 65536);
+  bool thin = false;
   if (!ts && !tc && rows > 0) {
     // One step of the sweep costs about the same for any cell of up to TW_U x 64
     // entries, and a smaller tile keeps the gathered vector in L2 more reliably, so
@@ -772,6 +773,10 @@ int choose_tile_cols(int64_t cols, int64_t nnz, int64_t rows) {
     const int64_t cap = tile_width_cap(rows), unit = 4096;
     const int64_t want = (int64_t)((double)cols * target / std::max(per_wave, 1.0));
     tile = std::min(cap, std::max<int64_t>(2 * unit, (want + unit / 2) / unit * unit));
+    // Few rows against a very long vector: even the widest tile leaves a wave a handful of
+    // entries per step and the sweep is all barriers (100K x 10M, 9 per cell: 0.081 ms swept,
+    // 0.029 ms streamed; 1M x 30M, 12 per cell: 0.248 / 0.220; 500K x 10M, 18 per cell: 0.099 / 0.109).
+    thin = per_wave * (double)tile / (double)std::max<int64_t>(cols, 1) < 15.0;
   }
   tile = std::min<int64_t>(std::max<int64_t>(tile, 64), 1LL << 22);   // leave >= 10 bits for row_local
   if ((cols + tile - 1) / tile > 65536) return 0;        // tile table would be huge
@@ -785,7 +790,7 @@ int choose_tile_cols(int64_t cols, int64_t nnz, int64_t rows) {
   // 1M 4.6k / 5.6k.  Row length is no criterion: 100 per row (10M x 1M transposed) streams
   // at 1.91 ms and sweeps at 0.62 ms; 1 000 per row 1.85 / 1.33 ms (profiles/r02_locality.txt).
   const bool big_vector = cols * 8 > (3LL << 20);
-  return (big_vector && rows > 0) ? (int)tile : 0;
+  return (big_vector && rows > 0 && !thin) ? (int)tile : 0;
 }
 
 int host_threads() {
