@@ -203,18 +203,24 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     int64_t rpw = ((int64_t)rows + slots * rounds - 1) / (slots * rounds);
     TW_ROWS = (int)std::max<int64_t>(64, std::min<int64_t>(max_rows, rpw));
   }
-  if (const char *ev = getenv("PDHG_TW_ROWS")) TW_ROWS = std::max(1, std::min(atoi(ev), max_rows));
-  D.tw_rows = TW_ROWS;
+  const bool rows_forced = getenv("PDHG_TW_ROWS") != nullptr;
+  if (rows_forced) TW_ROWS = std::max(1, std::min(atoi(getenv("PDHG_TW_ROWS")), max_rows));
   const int WIN = TW_U * WAVE;  // entries a wave holds in registers per step
   // pass 1: wave row blocks.  A wave owns <= TW_ROWS rows AND <= nnz_cap
   // nonzeros: hub regions (PageRank's oldest nodes) would otherwise give one
   // wave 100x the average work and the whole launch would wait for its workgroup.
-  const int64_t est_waves = std::max<int64_t>(1, ((int64_t)rows + TW_ROWS - 1) / TW_ROWS);
-  const double cap_factor = getenv("PDHG_TW_NNZ_CAP") ? std::max(1.0, atof(getenv("PDHG_TW_NNZ_CAP"))) : 2.0;   // dev knob
-  const int64_t nnz_cap = std::max<int64_t>(getenv("PDHG_TW_NNZ_CAP") ? 256 : 4096,
-                                            (int64_t)(cap_factor * (double)(D.nnz / est_waves)));   // 2x the average wave
+  // The entry cap (and skipped long rows) can leave a few waves more than fill the
+  // planned residency rounds; one workgroup beyond them runs a whole extra sweep by
+  // itself (measured: 8 195 waves instead of 8 192 cost +45 %).  Rows per wave are
+  // then raised, within the LDS budget (and, on a near miss, the entry cap a little),
+  // until the waves fit the rounds again.
+  double cap_factor = getenv("PDHG_TW_NNZ_CAP") ? std::max(1.0, atof(getenv("PDHG_TW_NNZ_CAP"))) : 2.0;   // dev knob
   std::vector<int2> wave_rows;
-  {
+  for (int attempt = 0;; ++attempt) {
+    const int64_t est_waves = std::max<int64_t>(1, ((int64_t)rows + TW_ROWS - 1) / TW_ROWS);
+    const int64_t nnz_cap = std::max<int64_t>(getenv("PDHG_TW_NNZ_CAP") ? 256 : 4096,
+                                              (int64_t)(cap_factor * (double)(D.nnz / est_waves)));   // 2x the average wave
+    wave_rows.clear();
     int r = 0;
     while (r < rows) {
       if (rowptr[r + 1] - rowptr[r] > BLOCK_NNZ) { ++r; continue; }  // long row: separate path
@@ -223,7 +229,13 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
              (r == r0 || (int64_t)rowptr[r + 1] - rowptr[r0] <= nnz_cap)) ++r;
       wave_rows.push_back(make_int2(r0, r));
     }
+    const int64_t planned = slots * std::max<int64_t>(1, ((int64_t)est_waves + slots - 1) / slots);
+    if (rows_forced || (int64_t)wave_rows.size() <= planned || attempt >= 16) break;
+    if (TW_ROWS < max_rows) TW_ROWS = std::min(max_rows, TW_ROWS + std::max(1, TW_ROWS / 128));
+    else if ((double)wave_rows.size() <= 1.03 * (double)planned && cap_factor < 4.0) cap_factor *= 1.2;   // a near miss: let hub waves grow a little
+    else break;
   }
+  D.tw_rows = TW_ROWS;
   const int nwaves = (int)wave_rows.size();
   const int grid = (nwaves + TW_WPB - 1) / TW_WPB;
   // The per-workgroup work below (count the cells, cut heavy ones into steps,

@@ -20,11 +20,42 @@ ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--pagerank", type=int, default=0, help="PageRank LP with this many nodes instead of the random LP")
 ap.add_argument("--colskew", action="store_true", help="random LP whose column popularity falls like 1/sqrt(index) (hub columns clustered at low indices, short rows)")
 ap.add_argument("--banded", type=int, default=0, help="random LP whose row i has its k entries within +-BANDED columns of i*n/m (local / banded structure)")
+ap.add_argument("--shape", default="", help="blockdiag | clustered | twodensity | arrowhead (structured test matrices, m x n, about k per row)")
 ap.add_argument("cfgs", nargs="*")
 a = ap.parse_args()
 if a.pagerank:
     from firstorderlp_jl_amd.generators import pagerank_lp
     p = pagerank_lp(a.pagerank, seed=1)
+elif a.shape:
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd import linear_programming_problem
+    rng = np.random.default_rng(7)
+    rows = np.repeat(np.arange(a.m, dtype=np.int64), a.k)
+    if a.shape == "blockdiag":            # 100 diagonal blocks, uniform inside a block
+        nb = 100
+        blk = rows * nb // a.m
+        w = a.n // nb
+        cols = blk * w + rng.integers(0, w, a.m * a.k)
+    elif a.shape == "clustered":          # every row: k entries within +-500 columns of a random centre
+        centre = np.repeat(rng.integers(0, a.n, a.m), a.k)
+        cols = np.clip(centre + rng.integers(-500, 501, a.m * a.k), 0, a.n - 1)
+    elif a.shape == "twodensity":         # alternating rows of k/3 and 5k/3 entries
+        lens = np.where(np.arange(a.m) % 2 == 0, max(1, a.k // 3), 5 * a.k // 3)
+        rows = np.repeat(np.arange(a.m, dtype=np.int64), lens)
+        cols = rng.integers(0, a.n, rows.size)
+    elif a.shape == "arrowhead":          # uniform + 5 dense rows + 5 dense columns
+        cols = rng.integers(0, a.n, a.m * a.k)
+        dr = np.repeat(np.arange(5, dtype=np.int64) * (a.m // 5), a.n // 4)
+        dc = np.tile(rng.choice(a.n, a.n // 4, replace=False), 5)
+        er = rng.choice(a.m, a.m // 4, replace=False)
+        rows = np.concatenate([rows, dr, np.tile(er, 5)])
+        cols = np.concatenate([cols, dc, np.repeat(np.arange(5, dtype=np.int64) * (a.n // 5) + 1, er.size)])
+    else:
+        raise SystemExit("unknown shape")
+    M = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(a.m, a.n))
+    M.sum_duplicates()
+    p = linear_programming_problem(np.zeros(a.n), np.full(a.n, 10.0), rng.standard_normal(a.n), 0.0,
+                                   M.tocsc(), rng.standard_normal(a.m), a.m // 2)
 elif a.banded:
     import scipy.sparse as sp
     from firstorderlp_jl_amd import linear_programming_problem
