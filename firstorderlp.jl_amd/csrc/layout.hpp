@@ -31,6 +31,7 @@ struct CsrDev {
   // tiled-sweep layout (optional)
   bool tiled = false;
   int tile_shift = 0, tile_cols = 0, nwaves = 0, ntiles = 0, tw_rows = 0;   // tile widths <= 1 << tile_shift
+  size_t tw_lds_floor = 0;         // dynamic LDS is padded to this: keeps a third workgroup off the CU
   bool var_tiles = false;          // equal-nonzero tiles of different widths (skewed columns); tile_cols is then the nominal width
   int2 *wave_rows = nullptr;
   int *wave_ent = nullptr;        // per-wave entry offsets, one per step of its workgroup (+1)
@@ -362,6 +363,10 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   D.tile_shift = tile_shift;
   D.tile_cols = tile_cols;
   D.var_tiles = !uniform;
+  {
+    const char *ev = getenv("PDHG_TW_MIN_LDS_KB");
+    D.tw_lds_floor = (size_t)(ev ? std::max(0, atoi(ev)) : 55) * 1024;
+  }
   D.ntiles = ntiles;
   D.nwaves = nwaves;
   D.grid = grid;

@@ -189,11 +189,22 @@ int ensure_lds_limit(pdhg_handle *h, int mode, bool scratch, size_t lds, const v
   return 0;
 }
 
+// Dynamic LDS of one sweep workgroup: the accumulators -- padded to just over a third of the
+// CU's 160 KiB, so that never more than the two workgroups per CU the layout plans for become
+// resident.  Without the padding a problem with <= ~830 rows per wave gets three (the
+// accumulators need < 53 KiB): the residency rounds no longer match the geometry and 24 waves
+// per CU gather from more tiles at once -- 10M-nnz-per-million-rows LPs of 5.3M-6.5M rows ran
+// at 10 ps per nonzero, against 7.0 at 5M and 7.7 at 7M (profiles/r02_locality.txt).
+size_t tiled_lds_bytes(const CsrDev &D) {
+  const size_t need = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_scratch ? TW_WPB * WAVE : 0));
+  return std::max(need, D.tw_lds_floor);
+}
+
 template <int MODE>
 int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
   if (D.tiled) {
     if (D.grid > 0) {
-      const size_t lds = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_scratch ? TW_WPB * WAVE : 0));
+      const size_t lds = tiled_lds_bytes(D);
       int rc;
       if (D.tw_scratch) {
         if ((rc = ensure_lds_limit(h, MODE, true, lds, (const void *)spmv_tiled_kernel<MODE, true>))) return rc;
@@ -259,7 +270,7 @@ int launch_spmv_plain_part(pdhg_handle *h, const CsrDev &D, const double *xin, d
                        D.long_row, D.long_chunk_ptr, D.nlong, D.chunk_partial, e, D.grid);
   }
   if (g1 > g0) {
-    const size_t lds = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_scratch ? TW_WPB * WAVE : 0));
+    const size_t lds = tiled_lds_bytes(D);
     const int w0 = g0 * TW_WPB;
     if (D.tw_scratch) {
       int rc = ensure_lds_limit(h, MODE_PLAIN, true, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, true>);

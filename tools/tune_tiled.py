@@ -82,7 +82,7 @@ else:
 A = p.constraint_matrix
 step0 = 1.0 / float(np.abs(A.data).max())
 pw0 = float(np.linalg.norm(p.objective_vector) / np.linalg.norm(p.right_hand_side))
-KEYS = ["PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TILE_COLS", "PDHG_TILE_FILL", "PDHG_VAR_TILES", "PDHG_TW_NNZ_CAP", "PDHG_HOST_THREADS", "PDHG_TW_ROWS", "PDHG_TW_WPB", "PDHG_TW_FLAGS", "PDHG_XCD_REMAP",
+KEYS = ["PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TILE_COLS", "PDHG_TILE_FILL", "PDHG_VAR_TILES", "PDHG_TW_NNZ_CAP", "PDHG_HOST_THREADS", "PDHG_TW_MIN_LDS_KB", "PDHG_TW_ROWS", "PDHG_TW_WPB", "PDHG_TW_FLAGS", "PDHG_XCD_REMAP",
         "PDHG_TW_MAX_ROWS", "PDHG_TW_WGS_PER_CU", "PDHG_SLABS", "PDHG_SLAB_MB", "PDHG_GRAPH"]
 for rep in range(a.reps):
     for cfg in a.cfgs or [""]:
