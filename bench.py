@@ -171,7 +171,9 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
                 "launches_per_trial": round(cnt / max(prof_trials, 1), 2)}
     eng.profile_enable(False)
     dom = max((_lib.K_SPMV_DUAL, _lib.K_SPMV_ATY), key=lambda k: eng.profile_read(k)[1])
-    dk = kernels[eng.kernel_name(dom)]
+    # --profile-steps 0 (counter passes, timeline traces): no per-kernel events, no roofline object
+    dk = kernels.get(eng.kernel_name(dom), {"achieved_GBps": 0.0, "avg_ms": None,
+                                            "algorithmic_bytes": eng.kernel_algorithmic_bytes(dom)})
     # HBM bytes per launch from hardware counters.  PMC passes cannot run inside this
     # process; the figure is the committed result of `rocprofv3 --pmc` runs of THIS
     # command on the same workload and kernel (tools/pmc_traffic.sh), keyed by both.

@@ -176,7 +176,19 @@ __device__ __forceinline__ void final_reduce_body(const FinalSpec &sp, double (&
   if (q < 5) {
     const double *p = sp.ptr[q];
     const int cnt = sp.count[q];
-    for (int i = sub * WAVE + lane; i < cnt; i += 3 * WAVE) acc += p[i];
+    // eight loads in flight per lane (the partials come from other CUs' stores: every one is a
+    // trip to memory), added in the same ascending order as a plain loop would
+    for (int i0 = sub * WAVE + lane; i0 < cnt; i0 += 8 * 3 * WAVE) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 3 * WAVE;
+        v[u] = i < cnt ? p[i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * 3 * WAVE < cnt) acc += v[u];
+    }
     acc = wave_sum(acc);
     if (lane == 0) wsum[wid] = acc;
   }
