@@ -209,3 +209,33 @@ def test_banded_matrix_keeps_the_stream_layout(gpu_required, monkeypatch):
     assert eng.layout_info()["A_tiled_waves"] > 0
     assert np.array_equal(eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x))
     eng.close()
+
+
+def test_layout_choice_long_rows_and_thin_cells(gpu_required, monkeypatch):
+    """The sweep is chosen by what it needs, not by row length: the transposed side of a tall LP
+    (rows of ~100 entries gathering from a long vector) is swept; a matrix with so few rows that
+    a wave would get a handful of entries per tile streams.  Products bit-exact either way."""
+    for k in ("PDHG_SPMV", "PDHG_TILE_SHIFT", "PDHG_TILE_COLS", "PDHG_VAR_TILES"):
+        monkeypatch.delenv(k, raising=False)
+    rng = np.random.default_rng(12)
+    tall = random_lp(2_000_000, 400_000, 5, seed=31)          # A': 400K rows x 25 entries over 2M columns
+    eng = HipPdhgEngine.from_problem(tall)
+    info = eng.layout_info()
+    assert info["At_tiled_waves"] > 0 and info["At_max_row_nnz"] > 25
+    assert info["A_tiled_waves"] > 0                            # 400K columns = 3.2 MB: just beyond the 3 MiB threshold
+    A = tall.constraint_matrix
+    m, n = A.shape
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    assert np.array_equal(eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x))
+    assert np.array_equal(eng.spmv_t(y), orc.spmv_t(m, n, A.indptr, A.indices, A.data, y))
+    eng.close()
+    wide = random_lp(20_000, 8_000_000, 10, seed=32)           # 200K entries against a 64 MB vector: ~12 per (wave, tile) cell
+    eng = HipPdhgEngine.from_problem(wide)
+    info = eng.layout_info()
+    assert info["A_tiled_waves"] == 0
+    A = wide.constraint_matrix
+    m, n = A.shape
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    assert np.array_equal(eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x))
+    assert np.array_equal(eng.spmv_t(y), orc.spmv_t(m, n, A.indptr, A.indices, A.data, y))
+    eng.close()
