@@ -781,7 +781,16 @@ int choose_tile_cols(int64_t cols, int64_t nnz, int64_t rows) {
     const int64_t rpw = std::max<int64_t>(64, (rows + slots * rounds - 1) / (slots * rounds));
     const double per_wave = (double)nnz / (double)rows * (double)rpw;
     const double target = getenv("PDHG_TILE_FILL") ? atof(getenv("PDHG_TILE_FILL")) : (rounds == 1 ? 110.0 : 100.0);
-    const int64_t cap = tile_width_cap(rows), unit = 4096;
+    // Many rounds (>= 5, i.e. beyond ~21M rows): the cells thin out at the 76K cap and the balance tips
+    // towards wider tiles -- 24M x 24M 2.51 ms at 76K columns / 2.39 at 96K, 30M x 30M 3.47 / 3.08 / 2.92 at
+    // 76K / 96K / 112K (128K: 3.46), 20M and below indifferent or worse -- so the cap stretches to what
+    // gives a cell ~45 entries, up to 112K.
+    const int64_t unit = 4096;
+    int64_t cap = tile_width_cap(rows);
+    if (rounds >= 2) {
+      const int64_t stretch = ((int64_t)((double)cols * 45.0 / std::max(per_wave, 1.0)) + unit - 1) / unit * unit;
+      cap = std::max(cap, std::min<int64_t>(112 * 1024, stretch));
+    }
     const int64_t want = (int64_t)((double)cols * target / std::max(per_wave, 1.0));
     tile = std::min(cap, std::max<int64_t>(2 * unit, (want + unit / 2) / unit * unit));
     // Few rows against a very long vector: even the widest tile leaves a wave a handful of
