@@ -231,8 +231,8 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
       wave_rows.push_back(make_int2(r0, r));
     }
     const int64_t planned = slots * std::max<int64_t>(1, ((int64_t)est_waves + slots - 1) / slots);
-    if (rows_forced || (int64_t)wave_rows.size() <= planned || attempt >= 16) break;
-    if (TW_ROWS < max_rows) TW_ROWS = std::min(max_rows, TW_ROWS + std::max(1, TW_ROWS / 128));
+    if (rows_forced || (int64_t)wave_rows.size() <= planned || attempt >= 40) break;
+    if (TW_ROWS < max_rows) TW_ROWS = std::min(max_rows, TW_ROWS + std::max(1, TW_ROWS / 48));
     else if ((double)wave_rows.size() <= 1.03 * (double)planned && cap_factor < 4.0) cap_factor *= 1.2;   // a near miss: let hub waves grow a little
     else break;
   }

@@ -239,3 +239,25 @@ def test_layout_choice_long_rows_and_thin_cells(gpu_required, monkeypatch):
     assert np.array_equal(eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x))
     assert np.array_equal(eng.spmv_t(y), orc.spmv_t(m, n, A.indptr, A.indices, A.data, y))
     eng.close()
+
+
+def test_hub_rows_do_not_spill_into_an_extra_round(gpu_required, monkeypatch):
+    """PageRank LP large enough that the per-wave entry cap makes more waves than one residency
+    round holds (4096): the builder raises the rows per wave until they fit again.  Products of
+    rows <= 2048 entries stay bit-exact with the widened waves."""
+    from firstorderlp_jl_amd.generators import pagerank_lp
+    p = pagerank_lp(400_000, seed=9)
+    A = p.constraint_matrix
+    m, n = A.shape
+    monkeypatch.setenv("PDHG_SPMV", "tiled")
+    monkeypatch.setenv("PDHG_TW_NNZ_CAP", "1.0")       # every hub region splits: well over 4096 waves at 98 rows per wave
+    eng = HipPdhgEngine.from_problem(p)
+    info = eng.layout_info()
+    assert 0 < info["A_tiled_waves"] <= 4096 and 0 < info["At_tiled_waves"] <= 4096
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    short = np.diff(A.tocsr().indptr) <= 2048
+    short_t = np.diff(A.indptr) <= 2048
+    assert np.array_equal(eng.spmv(x)[short], orc.spmv(m, n, A.indptr, A.indices, A.data, x)[short])
+    assert np.array_equal(eng.spmv_t(y)[short_t], orc.spmv_t(m, n, A.indptr, A.indices, A.data, y)[short_t])
+    eng.close()
