@@ -56,8 +56,11 @@ mutable struct HipSolverState
   ratio_step_sizes::Union{Float64,Nothing}
 end
 
-const CREATE_COMMON = (Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint,
-                       Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64)
+# NOTE: ccall's argument-type tuple must be a LITERAL tuple (a splatted constant does not
+# lower: `T...` is only legal as the trailing vararg marker), so the twelve common creator
+# arguments (m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities) are
+# spelled out in each of the three creators below; tests/test_julia_shim.py checks every
+# ccall's arity and C types against include/pdhg_hip.h.
 
 """
 Ingest a problem exactly as Julia stores it (SparseMatrixCSC{Float64,Int64},
@@ -75,7 +78,8 @@ function HipSolverState(problem::FirstOrderLp.QuadraticProgrammingProblem;
     if devices !== nothing
       ids = Cint.(collect(devices))
       check(ccall((:pdhg_create_multi, LIB), Cint,
-        (Ref{Ptr{Cvoid}}, CREATE_COMMON..., Cint, Ptr{Cint}),
+        (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint,
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Ptr{Cint}),
         h, m, n, length(A.nzval), A.colptr, A.rowval, A.nzval, 1,
         problem.objective_vector, problem.right_hand_side,
         problem.variable_lower_bound, problem.variable_upper_bound,
@@ -83,14 +87,16 @@ function HipSolverState(problem::FirstOrderLp.QuadraticProgrammingProblem;
     elseif dist !== nothing
       id, rank, world = dist
       check(ccall((:pdhg_create_dist, LIB), Cint,
-        (Ref{Ptr{Cvoid}}, CREATE_COMMON..., Cint, Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint),
+        (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint,
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint),
         h, m, n, length(A.nzval), A.colptr, A.rowval, A.nzval, 1,
         problem.objective_vector, problem.right_hand_side,
         problem.variable_lower_bound, problem.variable_upper_bound,
         problem.num_equalities, device_id, C_NULL, id, rank, world))
     else
       check(ccall((:pdhg_create, LIB), Cint,
-        (Ref{Ptr{Cvoid}}, CREATE_COMMON..., Cint, Ptr{Cvoid}),
+        (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint,
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Ptr{Cvoid}),
         h, m, n, length(A.nzval), A.colptr, A.rowval, A.nzval, 1,
         problem.objective_vector, problem.right_hand_side,
         problem.variable_lower_bound, problem.variable_upper_bound,

@@ -27,3 +27,166 @@ def test_julia_shim_defines_the_reference_methods():
     abi = int(re.search(r"const ABI_VERSION = (\d+)", shim).group(1))
     from firstorderlp_jl_amd import _lib
     assert abi == _lib.ABI_VERSION
+
+
+# ---- static check of every ccall against the C prototypes -------------------------------
+# No Julia here, so the shim is checked the way a reviewer would read it: each ccall's
+# argument-type tuple must be a LITERAL tuple of known Julia C-types (ccall is lowered
+# specially: a splatted constant `T...` or a variable in that tuple does not lower), its
+# arity must equal the prototype's in include/pdhg_hip.h and the number of values passed, and
+# each Julia type must be one the C type accepts.
+
+_C2JL = {
+    "int": {"Cint"},
+    "int64_t": {"Int64"},
+    "double": {"Float64", "Cdouble"},
+    "double*": {"Ptr{Float64}", "Ref{Float64}"},
+    "int64_t*": {"Ptr{Int64}", "Ref{Int64}"},
+    "int*": {"Ptr{Cint}", "Ref{Cint}"},
+    "pdhg_handle*": {"Ptr{Cvoid}"},
+    "pdhg_handle**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
+    "void*": {"Ptr{Cvoid}", "Ptr{UInt8}"},
+    "char*": {"Cstring", "Ptr{UInt8}"},
+    "void": {"Cvoid"},
+}
+
+
+def _split_top(s, sep=","):
+    """Split on `sep` at nesting depth 0 of (), {} and []."""
+    out, depth, cur = [], 0, []
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == sep and depth == 0:
+            out.append("".join(cur))
+            cur = []
+        else:
+            cur.append(ch)
+    tail = "".join(cur)
+    if tail.strip():
+        out.append(tail)
+    return [t.strip() for t in out]
+
+
+def _balanced(s, start):
+    """s[start] == '(' -> index one past its matching ')'."""
+    depth = 0
+    for k in range(start, len(s)):
+        if s[k] == "(":
+            depth += 1
+        elif s[k] == ")":
+            depth -= 1
+            if depth == 0:
+                return k + 1
+    raise AssertionError("unbalanced parenthesis")
+
+
+def _c_type(decl):
+    """'const double *x' / 'double out[5]' / 'pdhg_handle **out' -> canonical C type."""
+    decl = re.sub(r"/\*.*?\*/", "", decl, flags=re.S).strip()
+    array = "[" in decl
+    decl = re.sub(r"\[.*?\]", "", decl)
+    decl = re.sub(r"\bconst\b", "", decl)
+    stars = decl.count("*")
+    words = decl.replace("*", " ").split()
+    base = words[0] if len(words) == 1 or words[0] != "unsigned" else " ".join(words[:2])
+    return base + "*" * (stars + (1 if array else 0))
+
+
+def header_prototypes(header_text):
+    text = re.sub(r"/\*.*?\*/", "", header_text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = {}
+    for mt in re.finditer(r"([A-Za-z_][A-Za-z_0-9 \*]*?)\b(pdhg_[a-z_0-9]+)\s*\(", text):
+        name = mt.group(2)
+        end = _balanced(text, mt.end() - 1)
+        args = text[mt.end():end - 1].strip()
+        ret = _c_type(mt.group(1) + " r")
+        params = [] if args in ("", "void") else [_c_type(a) for a in _split_top(args)]
+        protos[name] = (ret, params)
+    return protos
+
+
+def julia_ccalls(shim_text):
+    calls = []
+    for mt in re.finditer(r"ccall\(", shim_text):
+        end = _balanced(shim_text, mt.end() - 1)
+        parts = _split_top(shim_text[mt.end():end - 1])
+        target = re.match(r"\(:(pdhg_[a-z_0-9]+), LIB\)$", parts[0])
+        assert target, f"unrecognised ccall target {parts[0]!r}"
+        assert parts[2].startswith("(") and parts[2].endswith(")"), \
+            f"{target.group(1)}: the argument-type tuple must be a literal tuple, got {parts[2]!r}"
+        types = _split_top(parts[2][1:-1])
+        calls.append((target.group(1), parts[1], types, parts[3:], shim_text.count("\n", 0, mt.start()) + 1))
+    return calls
+
+
+def check_ccalls(shim_text, header_text):
+    """Returns a list of problems (empty = the shim matches the header)."""
+    protos = header_prototypes(header_text)
+    known = set().union(*_C2JL.values())
+    problems = []
+    for name, ret, types, values, line in julia_ccalls(shim_text):
+        where = f"line {line}: ccall {name}"
+        if name not in protos:
+            problems.append(f"{where}: not declared in the header")
+            continue
+        c_ret, c_params = protos[name]
+        for t in types:
+            if "..." in t:
+                problems.append(f"{where}: '{t}' splats into the argument-type tuple (does not lower)")
+            elif t not in known:
+                problems.append(f"{where}: '{t}' is not a literal C type")
+        if ret not in _C2JL.get(c_ret, set()):
+            problems.append(f"{where}: return type {ret} does not match C '{c_ret}'")
+        if len(types) != len(c_params):
+            problems.append(f"{where}: {len(types)} argument types, the prototype has {len(c_params)}")
+        elif any("..." in t for t in types):
+            pass
+        else:
+            for k, (t, c) in enumerate(zip(types, c_params)):
+                if t not in _C2JL.get(c, set()):
+                    problems.append(f"{where}: argument {k + 1} is {t}, C wants '{c}'")
+        if len(values) != len(types):
+            problems.append(f"{where}: {len(values)} values passed for {len(types)} argument types")
+    return problems
+
+
+def _texts():
+    return (open(os.path.join(ROOT, "julia", "FirstOrderLpHIP.jl")).read(),
+            open(os.path.join(ROOT, "include", "pdhg_hip.h")).read())
+
+
+def test_header_parser_sees_every_export():
+    from firstorderlp_jl_amd import _lib
+    protos = header_prototypes(_texts()[1])
+    assert set(protos) == set(_lib.EXPORTS)
+    assert protos["pdhg_create"] == ("int", ["pdhg_handle**", "int64_t", "int64_t", "int64_t", "int64_t*", "int64_t*",
+                                             "double*", "int", "double*", "double*", "double*", "double*", "int64_t",
+                                             "int", "void*"])
+    assert protos["pdhg_last_error"] == ("char*", [])
+    assert protos["pdhg_trial_step"] == ("int", ["pdhg_handle*", "double", "double", "double", "double*"])
+
+
+def test_every_ccall_matches_its_c_prototype():
+    shim, header = _texts()
+    problems = check_ccalls(shim, header)
+    assert not problems, "\n".join(problems)
+
+
+def test_ccall_checker_rejects_a_splatted_type_tuple():
+    """Round 2's shim splatted a constant into three creators' type tuples; the checker must see that."""
+    shim, header = _texts()
+    lit = ("Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint,\n"
+           "         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64")
+    assert shim.count(lit) == 3
+    broken = shim.replace(lit, "CREATE_COMMON...")
+    problems = check_ccalls(broken, header)
+    assert sum("splats" in p for p in problems) == 3, problems
+    # and a wrong width / arity is caught too
+    wrong = shim.replace("(Ptr{Cvoid}, Float64, Float64, Float64, Ptr{Float64}),\n    s.handle, step_size, primal_weight, theta, out))",
+                         "(Ptr{Cvoid}, Float64, Float64, Ptr{Float64}),\n    s.handle, step_size, primal_weight, theta, out))", 1)
+    assert wrong != shim
+    assert any("argument types, the prototype has" in p for p in check_ccalls(wrong, header))
