@@ -88,11 +88,57 @@ def make_problem(args, workload):
             "damping=0.99 (BASELINE configs[2])")
     if workload == "l1svm":
         return l1_svm_rcv1_like_lp(seed=0), (
-            "L1-SVM LP (generate_l1_svm_lp.jl model) on synthetic rcv1.binary-shaped data "
-            "20242 x 47236, ~74 nnz/row, lambda=1 (BASELINE configs[3]; rcv1 itself is not available offline)")
+            "SUBSTITUTE for LIBSVM rcv1 (not available offline): L1-SVM LP (generate_l1_svm_lp.jl model) on SYNTHETIC "
+            "rcv1.binary-shaped data 20242 x 47236, ~74 nnz/row, lambda=1 (BASELINE configs[3])")
     p = random_lp(args.m, args.n, args.nnz_per_row, args.seed)
     A = p.constraint_matrix
     return p, f"random LP m={A.shape[0]} n={A.shape[1]} nnz={A.nnz} seed={args.seed} (BASELINE configs[4])"
+
+
+def initial_scalars(problem):
+    import numpy as np
+    step0 = 1.0 / float(np.abs(problem.constraint_matrix.data).max())          # pdhg.jl:823
+    cn = float(np.sqrt(np.sum(problem.objective_vector ** 2)))
+    bn = float(np.sqrt(np.sum(problem.right_hand_side ** 2)))
+    return step0, (cn / bn if cn > 0 and bn > 0 else 1.0)                      # saddle_point.jl:1049
+
+
+def shard_for_rank(args, workload, ctx):
+    """Rank 0 generates the LP, computes the row partition and writes one file per rank;
+    every rank then loads only its own rows.  Returns (shard dict for
+    make_row_shard_hip_engine, meta dict with the global sizes and start scalars)."""
+    import pickle
+    import tempfile
+    import numpy as np
+    from firstorderlp_jl_amd import HipPdhgEngine
+    from firstorderlp_jl_amd.distributed import row_shard_of
+    dist, rank, world = ctx["dist"], ctx["rank"], ctx["world"]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    tag = os.environ.get("MASTER_PORT", "0")
+    path = lambda r: os.path.join(base, f"pdhg_bench_{tag}_{workload}_rank{r}.pkl")   # noqa: E731
+    if rank == 0:
+        problem, wl = make_problem(args, workload)
+        A = problem.constraint_matrix
+        step0, pw0 = initial_scalars(problem)
+        meta = {"wl": wl, "m": A.shape[0], "n": A.shape[1], "nnz": int(A.nnz), "step0": step0, "pw0": pw0}
+        bounds = HipPdhgEngine.partition_rows(A, world)
+        problem.constraint_matrix = A.tocsr()            # one conversion; row slices are then cheap
+        for r in range(world):
+            with open(path(r) + ".tmp", "wb") as fh:
+                pickle.dump((row_shard_of(problem, bounds, r), meta), fh, protocol=pickle.HIGHEST_PROTOCOL)
+            os.replace(path(r) + ".tmp", path(r))
+        del problem
+    dist.barrier()
+    with open(path(rank), "rb") as fh:
+        shard, meta = pickle.load(fh)
+    dist.barrier()
+    if rank == 0:
+        for r in range(world):
+            try:
+                os.remove(path(r))
+            except OSError:
+                pass
+    return shard, meta
 
 
 def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
@@ -106,16 +152,27 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
     pkg, dist, rank, world, local_rank = ctx["pkg"], ctx["dist"], ctx["rank"], ctx["world"], ctx["local_rank"]
 
     t0 = time.time()
-    problem, wl = make_problem(args, workload)
-    A = problem.constraint_matrix
-    m, n, nnz = A.shape[0], A.shape[1], int(A.nnz)
+    problem = None
+    if dist is not None:
+        # N > 1: the LP is generated ONCE (rank 0), cut by the library's own row partition
+        # (pdhg_partition_rows) and every rank ingests only ITS rows (pdhg_create_dist_rows);
+        # the slices travel through files in shared memory
+        shard, meta = shard_for_rank(args, workload, ctx)
+        wl, m, n, nnz, step0, pw0 = (meta[k] for k in ("wl", "m", "n", "nnz", "step0", "pw0"))
+    else:
+        problem, wl = make_problem(args, workload)
+        A = problem.constraint_matrix
+        m, n, nnz = A.shape[0], A.shape[1], int(A.nnz)
+        step0, pw0 = initial_scalars(problem)
     t_gen = time.time() - t0
 
     t0 = time.time()
     if dist is not None:
-        from firstorderlp_jl_amd.distributed import make_row_partitioned_hip_engine
-        eng = make_row_partitioned_hip_engine(problem, device_id=local_rank)
-        parallelism = f"row-partition x{world}, RCCL reduce-scatter/all-gather inside the library"
+        from firstorderlp_jl_amd.distributed import make_row_shard_hip_engine
+        eng = make_row_shard_hip_engine(shard, device_id=local_rank)
+        del shard
+        parallelism = (f"row-partition x{world}, rank-local ingest, RCCL reduce-scatter/all-gather inside the library "
+                       f"({pkg.HipPdhgEngine.rccl_info()['path']})")
     elif args.shards > 0:
         eng = pkg.HipPdhgEngine.from_problem(problem, device_ids=[local_rank] * args.shards)
         parallelism = f"{args.shards} row shards inside one process on ONE GPU (peer-kernel back end; dev mode)"
@@ -124,10 +181,6 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         parallelism = "single GPU"
     t_create = time.time() - t0
 
-    step0 = 1.0 / float(np.abs(A.data).max())                      # pdhg.jl:823
-    cn = float(np.sqrt(np.sum(problem.objective_vector ** 2)))
-    bn = float(np.sqrt(np.sum(problem.right_hand_side ** 2)))
-    pw0 = cn / bn if cn > 0 and bn > 0 else 1.0                    # saddle_point.jl:1049
     state = PdhgSolverState(eng, step_size=step0, primal_weight=pw0)
     policy = AdaptiveStepsizeParams(0.3, 0.6)
 
@@ -152,6 +205,16 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / steps
     value = steps / elapsed
+
+    # host-side cost of a trial (groups: issuing threads; one-launch path: launch + wait), timed region + warm-up
+    issue_stats = None
+    try:
+        tr, t_issue, t_wait = eng.host_issue_stats()
+        if tr > 0:
+            issue_stats = {"trials": tr, "issue": round(1e6 * t_issue / tr, 2), "wait_for_result": round(1e6 * t_wait / tr, 2),
+                           "shard_threads": os.environ.get("PDHG_SHARD_THREADS", "1") != "0"}
+    except Exception:      # measurement extra
+        pass
 
     # ---- roofline of the dominant kernel: HIP events on the engine's stream
     kernels = {}
@@ -262,6 +325,8 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         "layout": {k: v for k, v in eng.layout_info().items() if "tiled" in k or "tile_cols" in k or "slab" in k or "graph" in k},
         "setup_sec": {"generate": round(t_gen, 1), "create_upload": round(t_create, 1)},
     }
+    if issue_stats is not None:
+        out["host_us_per_trial"] = issue_stats
     if out["layout"].get("trial_graph"):
         out["kernels_note"] = ("the timed region launches one trial as ONE HIP graph (long-row kernels on a parallel "
                                "branch, no result copy); the per-kernel figures are HIP-event brackets around the plain "

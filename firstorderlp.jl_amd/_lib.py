@@ -17,9 +17,9 @@ SRC_PATH = os.path.join(CSRC, "pdhg_hip.hip")
 
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off",
                "-std=c++17", "-shared", "-fPIC", "-pthread"]
-# RCCL: the library owns the multi-GPU exchange (csrc/dist.hpp)
-ROCM_LIB = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
-LINK_FLAGS = ["-L" + ROCM_LIB, "-lrccl", "-Wl,-rpath," + ROCM_LIB]
+# RCCL (the library owns the multi-GPU exchange, csrc/dist.hpp) is bound at RUN time by
+# csrc/rccl_loader.hpp: no link-time dependency, no rpath
+LINK_FLAGS = ["-ldl"]
 
 # every symbol include/pdhg_hip.h declares
 EXPORTS = [
@@ -35,9 +35,10 @@ EXPORTS = [
     "pdhg_set_original_problem", "pdhg_eval_point", "pdhg_save_restart_point",
     "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound",
     "pdhg_point_sumsq", "pdhg_rescale", "pdhg_get_problem_vectors", "pdhg_matrix_max_abs",
+    "pdhg_partition_rows", "pdhg_create_dist_rows", "pdhg_rccl_info", "pdhg_host_issue_stats",
 ]
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 UNIQUE_ID_BYTES = 128
 (K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_ALLGATHER, K_REDUCE_SCATTER,
  K_INTERACTION, K_COUNT) = range(9)
@@ -141,6 +142,15 @@ def lib():
     L.pdhg_create_multi.restype = i32
     L.pdhg_create_multi.argtypes = [ctypes.POINTER(_vp), i64, i64, i64, _ip, _ip,
                                     _dp, i32, _dp, _dp, _dp, _dp, i64, i32, ctypes.POINTER(i32)]
+    L.pdhg_partition_rows.restype = i32
+    L.pdhg_partition_rows.argtypes = [i64, i64, _ip, _ip, i32, i32, _ip]
+    L.pdhg_create_dist_rows.restype = i32
+    L.pdhg_create_dist_rows.argtypes = [ctypes.POINTER(_vp), i64, i64, _ip, i64, _ip, _ip, _dp, i32,
+                                        _dp, _dp, _dp, _dp, i64, i32, _vp, _vp, i32, i32]
+    L.pdhg_rccl_info.restype = i32
+    L.pdhg_rccl_info.argtypes = [ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.c_char_p, i32]
+    L.pdhg_host_issue_stats.restype = i32
+    L.pdhg_host_issue_stats.argtypes = [_vp, _ip, _dp, _dp]
     L.pdhg_dist_info.restype = i32
     L.pdhg_dist_info.argtypes = [_vp, _ip]
     L.pdhg_profile_enable.restype = i32

@@ -32,6 +32,11 @@ int fail(int code, const std::string &msg) {
   return code;
 }
 
+int fail_hip(hipError_t e, const char *what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return (int)e > 0 ? (int)e : 999;
+}
+
 #define HIP_TRY(expr)                                                        \
   do {                                                                       \
     hipError_t _e = (expr);                                                  \

@@ -19,7 +19,7 @@
 // distributed is src/primal_dual_hybrid_gradient.jl:442-549.
 #pragma once
 
-#include <rccl/rccl.h>
+#include "rccl_loader.hpp"
 
 namespace {
 
@@ -28,16 +28,112 @@ constexpr int DIST_MAX_WORLD = 64;     // scalar exchange buffers are sized for 
 constexpr int P2P_MAX_WORLD = 16;      // peer-kernel back end (single process)
 constexpr int SCAL_MAX = 32;           // scalars one shard contributes per reduction
 
+// the run-time bound RCCL entry points (rccl_loader.hpp); 2999: RCCL unavailable / refused
+#define RCCL_API(R)                                                            \
+  const RcclApi *R = rccl();                                                   \
+  if (!R) return 2999
+
 #define NCCL_TRY(expr)                                                         \
   do {                                                                         \
     ncclResult_t _r = (expr);                                                  \
     if (_r != ncclSuccess) {                                                   \
-      g_last_error = std::string(#expr) + ": " + ncclGetErrorString(_r);       \
+      g_last_error = std::string(#expr) + ": " + rccl_loader().api.GetErrorString(_r); \
       return 2000 + (int)_r;                                                   \
     }                                                                          \
   } while (0)
 
+// ---- host-side fan-out: one worker thread per local shard -------------------------------
+// pdhg_create_multi hands one process several GPUs.  Issued from the calling thread alone, a
+// trial is ~15 launches / event calls / collectives PER SHARD, one shard after the other:
+// at 8 shards that is ~0.5 ms of host calls against ~0.33 ms of kernels on config S
+// (DESIGN.md section 5).  With the pool every shard's sequence is issued by its own thread
+// (thread 0 is the caller), so the host cost per trial is that of ONE shard.  The threads
+// sleep on a condition variable between entry points and spin only briefly (the next trial
+// usually follows within microseconds).  PDHG_SHARD_THREADS=0 keeps the single-thread issue.
+struct ShardPool {
+  int n = 0;
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<uint64_t> gen{0};
+  std::atomic<int> pending{0};
+  std::atomic<bool> stop{false}, abort_job{false};
+  std::function<int(int)> job;
+  std::vector<int> rc;
+  std::vector<std::string> err;
+  // sense-reversing barrier among the n issuing threads (peer back end: "all events recorded")
+  std::atomic<int> bar_arrived{0};
+  std::atomic<uint64_t> bar_gen{0};
+
+  explicit ShardPool(int n_) : n(n_), rc((size_t)n_, 0), err((size_t)n_) {
+    for (int i = 1; i < n; ++i) th.emplace_back([this, i] { worker(i); });
+  }
+  ~ShardPool() {
+    { std::lock_guard<std::mutex> lk(mu); stop.store(true); }
+    cv.notify_all();
+    for (std::thread &t : th) t.join();
+  }
+  void run_one(int i) {
+    g_last_error.clear();
+    const int r = job(i);
+    rc[(size_t)i] = r;
+    if (r) { err[(size_t)i] = g_last_error; abort_job.store(true); }
+    pending.fetch_sub(1, std::memory_order_acq_rel);
+  }
+  void worker(int i) {
+    uint64_t seen = 0;
+    for (;;) {
+      // short spin (back-to-back trials), then sleep
+      bool got = false;
+      for (int spin = 0; spin < 20000; ++spin) {
+        if (gen.load(std::memory_order_acquire) != seen || stop.load(std::memory_order_relaxed)) { got = true; break; }
+        __builtin_ia32_pause();
+      }
+      if (!got) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen || stop.load(); });
+      }
+      if (stop.load()) return;
+      seen = gen.load(std::memory_order_acquire);
+      run_one(i);
+    }
+  }
+  // f(i) on n threads at once (i = 0 on the caller); returns the first nonzero code in shard order
+  int run(std::function<int(int)> f) {
+    job = std::move(f);
+    abort_job.store(false);
+    bar_arrived.store(0);        // a failed job may have left arrivals behind
+    pending.store(n, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk(mu); gen.fetch_add(1, std::memory_order_acq_rel); }
+    cv.notify_all();
+    run_one(0);
+    while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    for (int i = 0; i < n; ++i)
+      if (rc[(size_t)i]) { g_last_error = err[(size_t)i]; return rc[(size_t)i]; }
+    return 0;
+  }
+  // all n issuing threads meet; nonzero if a sibling failed (nobody may wait for it for ever)
+  int barrier() {
+    const uint64_t my = bar_gen.load(std::memory_order_acquire);
+    if (bar_arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+      bar_arrived.store(0, std::memory_order_relaxed);
+      bar_gen.fetch_add(1, std::memory_order_acq_rel);
+      return 0;
+    }
+    while (bar_gen.load(std::memory_order_acquire) == my) {
+      if (abort_job.load(std::memory_order_relaxed)) return fail(997, "a sibling shard failed while issuing");
+      __builtin_ia32_pause();
+    }
+    return 0;
+  }
+};
+
 struct DistGroup {
+  ShardPool *pool = nullptr;            // several local shards: one issuing thread each (trial steps)
+  // host-side cost of the trials issued so far: seconds until the last launch call returned
+  // (max over the issuing threads), seconds from then until the scalars were on the host
+  double t_issue = 0.0, t_wait = 0.0;
+  int64_t n_trials = 0;
   int world = 1;
   int backend = COMM_RCCL;
   std::vector<pdhg_handle *> sh;        // local shards, ascending rank (multi-process: one)
@@ -57,7 +153,9 @@ struct DistGroup {
   // PDHG_DIST_FORCE_REMOTE=1 takes the second route even when all ranks are local, so that
   // its collectives run (and are tested) on a 1-GPU box.
   bool force_remote = false;
-  bool all_local() const { return (int)sh.size() == world && !(force_remote && backend == COMM_RCCL); }
+  // (force_remote is honoured for a single local shard only: with several local RCCL shards the
+  // one-rank-per-process route would issue a collective on one of N communicators and hang)
+  bool all_local() const { return (int)sh.size() == world && !(force_remote && backend == COMM_RCCL && sh.size() == 1); }
 };
 
 // ---- the shard list every entry point walks: the group's local shards, or the handle itself
@@ -70,10 +168,17 @@ inline Shards shards_of(pdhg_handle *h) {
   if (h->grp) return Shards{h->grp->sh.data(), (int)h->grp->sh.size(), h->grp};
   return Shards{&h->self, 1, nullptr};
 }
+// Walks the local shards with the shard's device current.  A failing hipSetDevice is an
+// ERROR of the enclosing entry point (every user returns int): skipping the shard instead
+// would leave its kernel, accept or flush unissued and the call would still report success.
+// (the macro ends in `else`, so that the loop body is the else-branch: intended)
+#pragma clang diagnostic ignored "-Wdangling-else"
 #define FOR_SHARDS(L, s)                                                       \
   for (int _si = 0; _si < (L).count; ++_si)                                     \
     if (pdhg_handle *s = (L).p[_si])                                            \
-      if (hipSetDevice(s->device) == hipSuccess)
+      if (hipError_t _sde = hipSetDevice(s->device); _sde != hipSuccess)        \
+        return fail_hip(_sde, "hipSetDevice (shard loop)");                     \
+      else
 
 // ---- peer back end: kernels that read the other shards' buffers directly
 struct PeerPtrs {
@@ -149,14 +254,15 @@ template <typename Sel>
 int dist_all_gather(DistGroup &g, Sel sel, int64_t S) {
   if (g.world == 1 && g.backend == COMM_P2P) return 0;
   if (g.backend == COMM_RCCL) {
-    NCCL_TRY(ncclGroupStart());
+    RCCL_API(R);
+    NCCL_TRY(R->GroupStart());
     for (size_t i = 0; i < g.sh.size(); ++i) {
       pdhg_handle *s = g.sh[i];
       HIP_TRY(hipSetDevice(s->device));
       double *b = sel(s);
-      NCCL_TRY(ncclAllGather(b + (int64_t)s->rank * S, b, (size_t)S, ncclDouble, g.comm[i], s->stream));
+      NCCL_TRY(R->AllGather(b + (int64_t)s->rank * S, b, (size_t)S, ncclDouble, g.comm[i], s->stream));
     }
-    NCCL_TRY(ncclGroupEnd());
+    NCCL_TRY(R->GroupEnd());
     return 0;
   }
   int rc;
@@ -178,15 +284,16 @@ template <typename Sel>
 int dist_reduce_scatter(DistGroup &g, Sel sel, int64_t S, bool maxop = false) {
   if (g.world == 1 && g.backend == COMM_P2P) return 0;
   if (g.backend == COMM_RCCL) {
-    NCCL_TRY(ncclGroupStart());
+    RCCL_API(R);
+    NCCL_TRY(R->GroupStart());
     for (size_t i = 0; i < g.sh.size(); ++i) {
       pdhg_handle *s = g.sh[i];
       HIP_TRY(hipSetDevice(s->device));
       double *b = sel(s);
-      NCCL_TRY(ncclReduceScatter(b, b + (int64_t)s->rank * S, (size_t)S, ncclDouble, maxop ? ncclMax : ncclSum,
+      NCCL_TRY(R->ReduceScatter(b, b + (int64_t)s->rank * S, (size_t)S, ncclDouble, maxop ? ncclMax : ncclSum,
                                  g.comm[i], s->stream));
     }
-    NCCL_TRY(ncclGroupEnd());
+    NCCL_TRY(R->GroupEnd());
     return 0;
   }
   int rc;
@@ -211,18 +318,19 @@ int dist_reduce_scatter(DistGroup &g, Sel sel, int64_t S, bool maxop = false) {
 template <typename Sel>
 int dist_reduce_slice_async(DistGroup &g, Sel sel, int64_t S, int k) {
   if (g.backend == COMM_RCCL) {
+    RCCL_API(R);
     for (pdhg_handle *s : g.sh) {
       HIP_TRY(hipSetDevice(s->device));
       HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_part[(size_t)k], 0));
     }
-    NCCL_TRY(ncclGroupStart());
+    NCCL_TRY(R->GroupStart());
     for (size_t i = 0; i < g.sh.size(); ++i) {
       pdhg_handle *s = g.sh[i];
       HIP_TRY(hipSetDevice(s->device));
       double *b = sel(s) + (int64_t)k * S;
-      NCCL_TRY(ncclReduce(b, b, (size_t)S, ncclDouble, ncclSum, k, g.comm[i], s->comm_stream));
+      NCCL_TRY(R->Reduce(b, b, (size_t)S, ncclDouble, ncclSum, k, g.comm[i], s->comm_stream));
     }
-    NCCL_TRY(ncclGroupEnd());
+    NCCL_TRY(R->GroupEnd());
     return 0;
   }
   pdhg_handle *owner = nullptr;
@@ -257,6 +365,99 @@ int dist_join_comm(DistGroup &g) {
   return 0;
 }
 
+// ---- the same collectives issued PER SHARD, each by its own host thread (ShardPool) -------
+// `i` is the shard's index in g.sh, `s` the shard; every local shard's thread makes the same
+// sequence of calls.  RCCL: plain per-communicator calls (one thread per device needs no
+// group).  Peer back end: the cross-stream barrier becomes "record my event, meet the other
+// threads, wait for their events".
+
+int mt_stream_barrier(DistGroup &g, pdhg_handle *s, int i) {
+  const int k = (int)g.sh.size();
+  if (k <= 1) return 0;
+  s->mt_flip ^= 1;
+  std::vector<hipEvent_t> &ev = g.ev[s->mt_flip];
+  HIP_TRY(hipEventRecord(ev[(size_t)i], s->stream));
+  int rc = g.pool->barrier();
+  if (rc) return rc;
+  for (int q = 0; q < k; ++q)
+    if (q != i) HIP_TRY(hipStreamWaitEvent(s->stream, ev[(size_t)q], 0));
+  return 0;
+}
+
+inline PeerPtrs peer_ptrs(DistGroup &g, BufSel sel) {
+  PeerPtrs pp{};
+  pp.world = g.world;
+  for (pdhg_handle *q : g.sh) pp.p[q->rank] = sel(q);
+  return pp;
+}
+
+int mt_all_gather(DistGroup &g, pdhg_handle *s, int i, BufSel sel, int64_t S) {
+  if (g.world == 1 && g.backend == COMM_P2P) return 0;
+  if (g.backend == COMM_RCCL) {
+    RCCL_API(R);
+    double *b = sel(s);
+    NCCL_TRY(R->AllGather(b + (int64_t)s->rank * S, b, (size_t)S, ncclDouble, g.comm[(size_t)i], s->stream));
+    return 0;
+  }
+  int rc;
+  if ((rc = mt_stream_barrier(g, s, i))) return rc;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + TPB - 1) / TPB, EW_MAX_BLOCKS));
+  hipLaunchKernelGGL(p2p_gather_kernel, dim3(grid), dim3(TPB), 0, s->stream, peer_ptrs(g, sel), s->rank, S, sel(s));
+  HIP_TRY(hipGetLastError());
+  return mt_stream_barrier(g, s, i);
+}
+
+int mt_reduce_scatter(DistGroup &g, pdhg_handle *s, int i, BufSel sel, int64_t S) {
+  if (g.world == 1 && g.backend == COMM_P2P) return 0;
+  if (g.backend == COMM_RCCL) {
+    RCCL_API(R);
+    double *b = sel(s);
+    NCCL_TRY(R->ReduceScatter(b, b + (int64_t)s->rank * S, (size_t)S, ncclDouble, ncclSum, g.comm[(size_t)i], s->stream));
+    return 0;
+  }
+  int rc;
+  if ((rc = mt_stream_barrier(g, s, i))) return rc;
+  const int64_t off = (int64_t)s->rank * S;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + TPB - 1) / TPB, EW_MAX_BLOCKS));
+  hipLaunchKernelGGL(p2p_reduce_kernel<false>, dim3(grid), dim3(TPB), 0, s->stream, peer_ptrs(g, sel), off, S, sel(s) + off);
+  HIP_TRY(hipGetLastError());
+  return mt_stream_barrier(g, s, i);
+}
+
+// slice k of the partial vectors to its owner, on the comm streams, after every shard has
+// recorded ev_part[k] on its compute stream (the caller did so for `s` just before)
+int mt_reduce_slice_async(DistGroup &g, pdhg_handle *s, int i, BufSel sel, int64_t S, int k) {
+  if (g.backend == COMM_RCCL) {
+    RCCL_API(R);
+    HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_part[(size_t)k], 0));
+    double *b = sel(s) + (int64_t)k * S;
+    NCCL_TRY(R->Reduce(b, b, (size_t)S, ncclDouble, ncclSum, k, g.comm[(size_t)i], s->comm_stream));
+    return 0;
+  }
+  int rc = g.pool->barrier();            // everybody's ev_part[k] is recorded
+  if (rc) return rc;
+  if (s->rank != k) return 0;
+  for (pdhg_handle *q : g.sh) HIP_TRY(hipStreamWaitEvent(s->comm_stream, q->ev_part[(size_t)k], 0));
+  const int64_t off = (int64_t)k * S;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + TPB - 1) / TPB, EW_MAX_BLOCKS));
+  hipLaunchKernelGGL(p2p_reduce_kernel<false>, dim3(grid), dim3(TPB), 0, s->comm_stream, peer_ptrs(g, sel), off, S, sel(s) + off);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int mt_join_comm(DistGroup &g, pdhg_handle *s, int i) {
+  (void)i;
+  HIP_TRY(hipEventRecord(s->ev_comm, s->comm_stream));
+  if (g.backend == COMM_RCCL) {
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_comm, 0));
+    return 0;
+  }
+  int rc = g.pool->barrier();            // every owner's ev_comm is recorded
+  if (rc) return rc;
+  for (pdhg_handle *q : g.sh) HIP_TRY(hipStreamWaitEvent(s->stream, q->ev_comm, 0));
+  return 0;
+}
+
 // All-reduce as reduce-scatter + all-gather: every element is reduced once, at
 // its owner, and then copied -- all ranks hold the same bits whatever the order.
 template <typename Sel>
@@ -272,7 +473,8 @@ template <typename Sel>
 int dist_all_gather_rows(DistGroup &g, Sel sel) {
   if (g.world == 1 && g.backend == COMM_P2P) return 0;
   if (g.backend == COMM_RCCL) {
-    NCCL_TRY(ncclGroupStart());
+    RCCL_API(R);
+    NCCL_TRY(R->GroupStart());
     for (size_t i = 0; i < g.sh.size(); ++i) {
       pdhg_handle *s = g.sh[i];
       HIP_TRY(hipSetDevice(s->device));
@@ -280,10 +482,10 @@ int dist_all_gather_rows(DistGroup &g, Sel sel) {
       for (int q = 0; q < g.world; ++q) {
         const int64_t cnt = g.row_lo[q + 1] - g.row_lo[q];
         if (cnt > 0)
-          NCCL_TRY(ncclBroadcast(b + g.row_lo[q], b + g.row_lo[q], (size_t)cnt, ncclDouble, q, g.comm[i], s->stream));
+          NCCL_TRY(R->Broadcast(b + g.row_lo[q], b + g.row_lo[q], (size_t)cnt, ncclDouble, q, g.comm[i], s->stream));
       }
     }
-    NCCL_TRY(ncclGroupEnd());
+    NCCL_TRY(R->GroupEnd());
     return 0;
   }
   int rc;
@@ -330,7 +532,8 @@ int combine_scalars(const Shards &L, int k, int nsum, double *out) {
   // one local shard per process: gather everybody's scalars through RCCL
   pdhg_handle *s = L.p[0];
   HIP_TRY(hipSetDevice(s->device));
-  NCCL_TRY(ncclAllGather(s->scal_dev, s->scal_all, (size_t)SCAL_MAX, ncclDouble, g->comm[0], s->stream));
+  RCCL_API(R);
+  NCCL_TRY(R->AllGather(s->scal_dev, s->scal_all, (size_t)SCAL_MAX, ncclDouble, g->comm[0], s->stream));
   HIP_TRY(hipMemcpyAsync(s->scal_host, s->scal_all, sizeof(double) * SCAL_MAX * g->world, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   for (int q = 0; q < k; ++q) {
@@ -348,15 +551,20 @@ int combine_scalars(const Shards &L, int k, int nsum, double *out) {
 
 // Contiguous row ranges balanced by nonzeros; equalities-first order is kept
 // because the ranges are contiguous.  bounds[world+1].
-void partition_rows_by_nnz(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int base, int world,
-                           std::vector<int64_t> &bounds) {
+// prefix[r] = nonzeros in rows [0, r)
+void row_nnz_prefix(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int base,
+                    std::vector<int64_t> &prefix) {
   const int64_t nnz = colptr[n] - base;
-  std::vector<int64_t> prefix((size_t)m + 1, 0);
+  prefix.assign((size_t)m + 1, 0);
   for (int64_t k = 0; k < nnz; ++k) {
     const int64_t r = rowval[k] - base;
     if (r >= 0 && r < m) prefix[(size_t)r + 1] += 1;
   }
   for (int64_t i = 0; i < m; ++i) prefix[(size_t)i + 1] += prefix[(size_t)i];
+}
+
+void partition_rows_from_prefix(const std::vector<int64_t> &prefix, int world, std::vector<int64_t> &bounds) {
+  const int64_t m = (int64_t)prefix.size() - 1, nnz = prefix[(size_t)m];
   bounds.assign((size_t)world + 1, 0);
   for (int p = 1; p < world; ++p) {
     // first row index r with prefix[r] >= nnz*p/world (exact rational compare)
@@ -369,6 +577,13 @@ void partition_rows_by_nnz(int64_t m, int64_t n, const int64_t *colptr, const in
     bounds[(size_t)p] = std::min<int64_t>(std::max<int64_t>(lo, bounds[(size_t)p - 1]), m);
   }
   bounds[(size_t)world] = m;
+}
+
+void partition_rows_by_nnz(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int base, int world,
+                           std::vector<int64_t> &bounds) {
+  std::vector<int64_t> prefix;
+  row_nnz_prefix(m, n, colptr, rowval, base, prefix);
+  partition_rows_from_prefix(prefix, world, bounds);
 }
 
 // CSC of rows [lo, hi) of a CSC matrix (row indices rebased to 0, 0-based output).

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -117,6 +119,7 @@ struct pdhg_handle {
   int64_t n_alloc = 0;             // length of the n-vectors that take part in collectives (world * S >= n)
   int64_t row_lo = 0;              // first GLOBAL row of this shard (m is the local row count)
   int64_t m_global = 0;
+  int mt_flip = 0;                     // event set of this shard's next threaded stream barrier
   hipStream_t comm_stream = nullptr;   // group: per-slice reductions run here, beside the product that feeds them
   std::vector<hipEvent_t> ev_part;     // [world] "slice k of A_p'y_p is complete" on `stream`
   hipEvent_t ev_comm = nullptr;        // "all of this shard's reductions are done" on `comm_stream`
@@ -181,6 +184,8 @@ struct ProfScope {
 // this one (hipFuncSetAttribute sets the limit, it does not raise it).
 int ensure_lds_limit(pdhg_handle *h, int mode, bool scratch, size_t lds, const void *func) {
   static size_t limit[64][3][2] = {};
+  static std::mutex mu;            // handles may be created / driven from several host threads (shard pool, Julia tasks)
+  std::lock_guard<std::mutex> lock(mu);
   size_t &cur = limit[h->device & 63][mode][scratch ? 1 : 0];
   if (cur < lds) {
     HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1044,11 +1049,17 @@ void destroy_shard(pdhg_handle *h) {
 
 void destroy_group(DistGroup *g) {
   if (!g) return;
+  if (g->n_trials > 0 && getenv("PDHG_VERBOSE"))
+    fprintf(stderr, "[pdhg_hip] %lld group trials over %zu local shards (%s): host us per trial: issuing %.1f, waiting for the scalars %.1f\n",
+            (long long)g->n_trials, g->sh.size(), g->pool ? "one issuing thread per shard" : "issued by the calling thread",
+            1e6 * g->t_issue / g->n_trials, 1e6 * g->t_wait / g->n_trials);
+  delete g->pool;
+  g->pool = nullptr;
   for (size_t i = 0; i < g->sh.size(); ++i) {
     (void)hipSetDevice(g->sh[i]->device);
     (void)hipStreamSynchronize(g->sh[i]->stream);
   }
-  for (ncclComm_t c : g->comm) if (c) (void)ncclCommDestroy(c);
+  for (ncclComm_t c : g->comm) if (c) (void)rccl_loader().api.CommDestroy(c);   // a communicator exists only if RCCL was bound
   for (int f = 0; f < 2; ++f)
     for (size_t i = 0; i < g->ev[f].size(); ++i) {
       (void)hipSetDevice(g->sh[i]->device);
@@ -1057,6 +1068,10 @@ void destroy_group(DistGroup *g) {
   for (pdhg_handle *s : g->sh) destroy_shard(s);
   delete g;
 }
+
+int create_rank_shard_local(DistGroup *g, int rank, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                            const double *nzval, int base, const double *c, const double *b_local, const double *lb,
+                            const double *ub, int device_id, void *stream, pdhg_handle **out);
 
 // Build rank `rank`'s shard of the GLOBAL problem: rows row_lo[rank]..row_lo[rank+1), all columns.
 int create_rank_shard(DistGroup *g, int rank, int64_t n, const int64_t *colptr, const int64_t *rowval,
@@ -1067,9 +1082,19 @@ int create_rank_shard(DistGroup *g, int rank, int64_t n, const int64_t *colptr, 
   uvec<int64_t> rv;
   dvec nv;
   slice_csc_rows(n, colptr, rowval, nzval, base, lo, hi, cp, rv, nv);
+  return create_rank_shard_local(g, rank, n, cp.data(), rv.data(), nv.data(), 0, c, b ? b + lo : nullptr, lb, ub,
+                                 device_id, stream, out);
+}
+
+// The same from the rank's OWN rows: (colptr, rowval, nzval) is the CSC of rows lo..hi of the
+// global matrix with row indices rebased to 0, b_local its hi - lo right-hand sides.
+int create_rank_shard_local(DistGroup *g, int rank, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                            const double *nzval, int base, const double *c, const double *b_local, const double *lb,
+                            const double *ub, int device_id, void *stream, pdhg_handle **out) {
+  const int64_t lo = g->row_lo[(size_t)rank], hi = g->row_lo[(size_t)rank + 1];
   const int64_t ne = std::min<int64_t>(std::max<int64_t>(g->num_eq_global - lo, 0), hi - lo);
   pdhg_handle *s = nullptr;
-  int rc = create_shard(&s, hi - lo, n, cp[(size_t)n], cp.data(), rv.data(), nv.data(), 0, c, b ? b + lo : nullptr,
+  int rc = create_shard(&s, hi - lo, n, colptr[n] - base, colptr, rowval, nzval, base, c, b_local,
                         lb, ub, ne, device_id, stream, g->world * g->S);
   if (rc) return rc;
   if (hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1108,17 +1133,26 @@ void choose_exchange_pattern(DistGroup *g) {
   g->overlap = ov ? (ov[0] != '0') : (g->backend == COMM_P2P && g->world > 1 && g->n * 8 > (4LL << 20));
 }
 
+// row_bounds != nullptr: the caller's partition ([world + 1], ascending, 0 .. m) instead of the
+// library's nnz-balanced one (colptr / rowval may then be null)
 int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int base,
-                        int64_t num_equalities, int world) {
+                        int64_t num_equalities, int world, const int64_t *row_bounds = nullptr) {
   if (world < 1 || world > DIST_MAX_WORLD) return fail(-1, "world size out of range (1..64)");
-  if (!colptr) return fail(-1, "null input array");
+  if (!colptr && !row_bounds) return fail(-1, "null input array");
   g->world = world;
   g->n = n;
   g->m_global = m;
   g->num_eq_global = num_equalities;
   const int64_t per = (n + world - 1) / world;
   g->S = std::max<int64_t>(16, (per + 15) / 16 * 16);      // slice stride: whole 128-byte lines
-  partition_rows_by_nnz(m, n, colptr, rowval, base, world, g->row_lo);
+  if (row_bounds) {
+    if (row_bounds[0] != 0 || row_bounds[world] != m) return fail(-1, "row_bounds must run from 0 to m");
+    for (int p = 0; p < world; ++p)
+      if (row_bounds[p + 1] < row_bounds[p]) return fail(-1, "row_bounds not ascending");
+    g->row_lo.assign(row_bounds, row_bounds + world + 1);
+  } else {
+    partition_rows_by_nnz(m, n, colptr, rowval, base, world, g->row_lo);
+  }
   const char *fr = getenv("PDHG_DIST_FORCE_REMOTE");
   g->force_remote = fr && fr[0] == '1';
   return 0;
@@ -1131,7 +1165,7 @@ int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colpt
 extern "C" {
 
 const char *pdhg_last_error(void) { return g_last_error.c_str(); }
-int pdhg_abi_version(void) { return 5; }
+int pdhg_abi_version(void) { return 6; }
 
 const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id) {
   const bool fused = !(h && h->grp);
@@ -1150,6 +1184,12 @@ const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id) {
   }
 }
 
+static int create_multi_impl(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
+                             const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                             int index_base, const double *c, const double *b, const double *lb,
+                             const double *ub, int64_t num_equalities, int n_devices, const int *device_ids,
+                             const int64_t *row_bounds);
+
 int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
                 const int64_t *colptr, const int64_t *rowval, const double *nzval,
                 int index_base, const double *c, const double *b, const double *lb,
@@ -1164,14 +1204,36 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   if (const char *ev = getenv("PDHG_MAX_SHARD_NNZ")) cap = std::max<int64_t>(1, atoll(ev));
   if (nnz > cap && m > 1) {
     *out = nullptr;
+    // The shards run on private streams and synchronise among themselves: work the caller
+    // orders against ITS stream would silently lose that ordering.
+    if (stream) return fail(-1, "a matrix beyond the 32-bit nonzero limit is sharded on the device and cannot run on a "
+                                "caller-supplied stream: pass stream = NULL");
+    if (index_base != 0 && index_base != 1) return fail(-1, "index_base must be 0 or 1");
+    if (!colptr || !rowval) return fail(-1, "null input array");
+    if (colptr[0] != index_base || colptr[n] - index_base != nnz) return fail(-1, "colptr does not match nnz / index_base");
     int dev = device_id;
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
-    const int64_t target = std::max<int64_t>(1, (cap / 10) * 8);          // shards balanced by nnz: aim at 80 %
-    const int64_t shards = std::min<int64_t>(m, (nnz + target - 1) / target);
-    if (shards > P2P_MAX_WORLD) return fail(-2, "more than 16 x 2^31 nonzeros on one device are not supported");
+    // shards balanced by nonzeros, aiming at 80 % of the limit; the partition works on whole
+    // rows, so every shard is checked against the limit and the count raised until all fit
+    const int64_t target = std::max<int64_t>(1, (cap / 10) * 8);
+    int64_t shards = std::min<int64_t>(m, (nnz + target - 1) / target);
+    std::vector<int64_t> prefix, bounds;
+    row_nnz_prefix(m, n, colptr, rowval, index_base, prefix);
+    for (int64_t r = 0; r < m; ++r)
+      if (prefix[(size_t)r + 1] - prefix[(size_t)r] > cap)
+        return fail(-2, "row " + std::to_string(r) + " alone holds " + std::to_string(prefix[(size_t)r + 1] - prefix[(size_t)r]) +
+                            " nonzeros, more than a shard can index (" + std::to_string(cap) + ")");
+    for (;; ++shards) {
+      if (shards > P2P_MAX_WORLD) return fail(-2, "more than 16 x 2^31 nonzeros on one device are not supported");
+      partition_rows_from_prefix(prefix, (int)shards, bounds);
+      int64_t worst = 0;
+      for (int64_t p = 0; p < shards; ++p)
+        worst = std::max(worst, prefix[(size_t)bounds[(size_t)p + 1]] - prefix[(size_t)bounds[(size_t)p]]);
+      if (worst <= cap) break;
+    }
     std::vector<int> ids((size_t)shards, dev);
-    return pdhg_create_multi(out, m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities,
-                             (int)shards, ids.data());
+    return create_multi_impl(out, m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities,
+                             (int)shards, ids.data(), bounds.data());
   }
   return create_shard(out, m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities,
                       device_id, stream, n);
@@ -1182,8 +1244,9 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
 int pdhg_dist_get_unique_id(void *id) {
   if (!id) return fail(-1, "id == NULL");
   static_assert(sizeof(ncclUniqueId) <= PDHG_UNIQUE_ID_BYTES, "unique id does not fit the ABI's buffer");
+  RCCL_API(R);
   ncclUniqueId u;
-  NCCL_TRY(ncclGetUniqueId(&u));
+  NCCL_TRY(R->GetUniqueId(&u));
   memset(id, 0, PDHG_UNIQUE_ID_BYTES);
   memcpy(id, &u, sizeof(u));
   return 0;
@@ -1214,9 +1277,11 @@ int pdhg_create_dist(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   g->comm.assign(1, nullptr);
   ncclUniqueId u;
   memcpy(&u, unique_id, sizeof(u));
-  ncclResult_t nr = ncclCommInitRank(&g->comm[0], world, u, rank);
+  const RcclApi *R = rccl();
+  if (!R) { destroy_group(g); return 2999; }
+  ncclResult_t nr = R->CommInitRank(&g->comm[0], world, u, rank);
   if (nr != ncclSuccess) {
-    g_last_error = std::string("ncclCommInitRank: ") + ncclGetErrorString(nr);
+    g_last_error = std::string("ncclCommInitRank: ") + R->GetErrorString(nr);
     destroy_group(g);
     return 2000 + (int)nr;
   }
@@ -1224,10 +1289,87 @@ int pdhg_create_dist(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   return 0;
 }
 
+int pdhg_partition_rows(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int index_base,
+                        int world, int64_t *row_bounds) {
+  if (!colptr || !row_bounds || m < 0 || n < 0) return fail(-1, "null / negative argument");
+  if (world < 1 || world > DIST_MAX_WORLD) return fail(-1, "world size out of range (1..64)");
+  if (index_base != 0 && index_base != 1) return fail(-1, "index_base must be 0 or 1");
+  if (colptr[0] != index_base) return fail(-1, "colptr[0] != index_base");
+  if (colptr[n] - index_base > 0 && !rowval) return fail(-1, "null input array");
+  std::vector<int64_t> b;
+  partition_rows_by_nnz(m, n, colptr, rowval, index_base, world, b);
+  for (int p = 0; p <= world; ++p) row_bounds[p] = b[(size_t)p];
+  return 0;
+}
+
+int pdhg_create_dist_rows(pdhg_handle **out, int64_t m_global, int64_t n, const int64_t *row_bounds,
+                          int64_t local_nnz, const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                          int index_base, const double *c, const double *b_local, const double *lb,
+                          const double *ub, int64_t num_equalities, int device_id, void *stream,
+                          const void *unique_id, int rank, int world) {
+  if (!out) return fail(-1, "out == NULL");
+  *out = nullptr;
+  if (!unique_id) return fail(-1, "unique_id == NULL");
+  if (rank < 0 || rank >= world) return fail(-1, "rank out of range");
+  if (index_base != 0 && index_base != 1) return fail(-1, "index_base must be 0 or 1");
+  if (num_equalities < 0 || num_equalities > m_global) return fail(-1, "num_equalities out of range");
+  if (!row_bounds || !colptr || (local_nnz > 0 && (!rowval || !nzval))) return fail(-1, "null input array");
+  if (colptr[0] != index_base || colptr[n] - index_base != local_nnz) return fail(-1, "colptr does not match local_nnz / index_base");
+  DistGroup *g = new DistGroup();
+  int rc = init_group_geometry(g, m_global, n, nullptr, nullptr, index_base, num_equalities, world, row_bounds);
+  if (rc) { delete g; return rc; }
+  g->backend = COMM_RCCL;
+  choose_exchange_pattern(g);
+  pdhg_handle *s = nullptr;
+  rc = create_rank_shard_local(g, rank, n, colptr, rowval, nzval, index_base, c, b_local, lb, ub, device_id, stream, &s);
+  if (rc) { delete g; return rc; }
+  g->sh.push_back(s);
+  g->comm.assign(1, nullptr);
+  ncclUniqueId u;
+  memcpy(&u, unique_id, sizeof(u));
+  const RcclApi *R = rccl();
+  if (!R) { destroy_group(g); return 2999; }
+  ncclResult_t nr = R->CommInitRank(&g->comm[0], world, u, rank);
+  if (nr != ncclSuccess) {
+    g_last_error = std::string("ncclCommInitRank: ") + R->GetErrorString(nr);
+    destroy_group(g);
+    return 2000 + (int)nr;
+  }
+  *out = s;
+  return 0;
+}
+
+int pdhg_rccl_info(int *compiled_version, int *runtime_version, char *path, int path_len) {
+  if (compiled_version) *compiled_version = NCCL_VERSION_CODE;
+  if (runtime_version) *runtime_version = 0;
+  if (path && path_len > 0) path[0] = 0;
+  RcclLoader &L = rccl_loader();
+  if (runtime_version) *runtime_version = L.api.runtime_version;
+  if (path && path_len > 0) snprintf(path, (size_t)path_len, "%s", L.api.path.c_str());
+  if (!L.ok) { g_last_error = L.api.error; return 2999; }
+  return 0;
+}
+
+int pdhg_host_issue_stats(pdhg_handle *h, int64_t *trials, double *issue_seconds, double *wait_seconds) {
+  if (!h || !trials || !issue_seconds || !wait_seconds) return fail(-1, "null argument");
+  if (h->grp) { *trials = h->grp->n_trials; *issue_seconds = h->grp->t_issue; *wait_seconds = h->grp->t_wait; }
+  else { *trials = h->n_graph_trials; *issue_seconds = h->t_set + h->t_launch; *wait_seconds = h->t_wait; }
+  return 0;
+}
+
 int pdhg_create_multi(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
                       const int64_t *colptr, const int64_t *rowval, const double *nzval,
                       int index_base, const double *c, const double *b, const double *lb,
                       const double *ub, int64_t num_equalities, int n_devices, const int *device_ids) {
+  return create_multi_impl(out, m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities,
+                           n_devices, device_ids, nullptr);
+}
+
+static int create_multi_impl(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
+                             const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                             int index_base, const double *c, const double *b, const double *lb,
+                             const double *ub, int64_t num_equalities, int n_devices, const int *device_ids,
+                             const int64_t *row_bounds) {
   if (!out) return fail(-1, "out == NULL");
   *out = nullptr;
   if (n_devices < 1 || !device_ids) return fail(-1, "n_devices < 1 or device_ids == NULL");
@@ -1236,7 +1378,7 @@ int pdhg_create_multi(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   if (!colptr || (nnz > 0 && (!rowval || !nzval))) return fail(-1, "null input array");
   if (colptr[0] != index_base || colptr[n] - index_base != nnz) return fail(-1, "colptr does not match nnz / index_base");
   DistGroup *g = new DistGroup();
-  int rc = init_group_geometry(g, m, n, colptr, rowval, index_base, num_equalities, n_devices);
+  int rc = init_group_geometry(g, m, n, colptr, rowval, index_base, num_equalities, n_devices, row_bounds);
   if (rc) { delete g; return rc; }
   // Back end: RCCL (ncclCommInitAll) when every shard has its own device; direct peer
   // kernels when devices repeat (several shards on one GPU: tests, oversubscription)
@@ -1256,9 +1398,11 @@ int pdhg_create_multi(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   }
   if (g->backend == COMM_RCCL) {
     g->comm.assign((size_t)n_devices, nullptr);
-    ncclResult_t nr = ncclCommInitAll(g->comm.data(), n_devices, device_ids);
+    const RcclApi *R = rccl();
+    if (!R) { destroy_group(g); return 2999; }
+    ncclResult_t nr = R->CommInitAll(g->comm.data(), n_devices, device_ids);
     if (nr != ncclSuccess) {
-      g_last_error = std::string("ncclCommInitAll: ") + ncclGetErrorString(nr);
+      g_last_error = std::string("ncclCommInitAll: ") + R->GetErrorString(nr);
       destroy_group(g);
       return 2000 + (int)nr;
     }
@@ -1281,6 +1425,11 @@ int pdhg_create_multi(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
           return fail(999, "hipEventCreate failed");
         }
     }
+  }
+  // one issuing host thread per shard for the trial steps (dist.hpp, ShardPool)
+  {
+    const char *ev = getenv("PDHG_SHARD_THREADS");
+    if (n_devices > 1 && !(ev && ev[0] == '0')) g->pool = new ShardPool(n_devices);
   }
   *out = g->sh[0];
   return 0;
@@ -1350,11 +1499,95 @@ static int trial_dual_single(pdhg_handle *h, double step_size, double primal_wei
   return 0;
 }
 
+// One shard's whole trial, issued by that shard's own host thread (ShardPool): the same
+// launches, in the same order, as trial_dual_group issues for it from the calling thread.
+struct TrialArgs {
+  double step_size, primal_weight, theta;
+  bool primal;      // K1+K2 first (pdhg_trial_step); false: xbar only (pdhg_trial_dual)
+};
+static int trial_shard_mt(DistGroup &g, pdhg_handle *s, int i, const TrialArgs &a, double *t_issued) {
+  HIP_TRY(hipSetDevice(s->device));
+  int rc;
+  if (a.primal) { if ((rc = launch_primal(s, a.step_size / a.primal_weight, a.theta, true))) return rc; }
+  else if ((rc = launch_xbar(s, a.theta))) return rc;
+  if ((rc = mt_all_gather(g, s, i, [](pdhg_handle *q) { return q->xbar; }, g.S))) return rc;
+  if (s->has_q && (rc = mt_all_gather(g, s, i, [](pdhg_handle *q) { return q->x_next; }, g.S))) return rc;
+  const double sigma = a.primal_weight * a.step_size;
+  if ((rc = launch_dual(s, sigma))) return rc;
+  if (!g.overlap) {
+    if ((rc = launch_aty_plain(s, s->y_next, s->aty_next))) return rc;
+    if ((rc = mt_reduce_scatter(g, s, i, [](pdhg_handle *q) { return q->aty_next; }, g.S))) return rc;
+  } else {
+    // see trial_dual_group: the product in residency rounds, slice k reduced as soon as its rows are complete
+    const char *rw_env = getenv("PDHG_DIST_ROUND_WGS");
+    const int round_wgs = rw_env ? std::max(1, atoi(rw_env)) : 256 * 2;
+    const CsrDev &T = s->At;
+    int issued = 0, next_wg = 0;
+    for (int k = 0; k < g.world; ++k) {
+      const int64_t need = std::min<int64_t>(s->n, (int64_t)(k + 1) * g.S);
+      if (!T.tiled) {
+        if (!issued) { if ((rc = launch_aty_plain(s, s->y_next, s->aty_next))) return rc; issued = 1; }
+      } else {
+        while (next_wg < T.grid || !issued) {
+          const int g0 = next_wg;
+          const bool covered = g0 >= T.grid || (int64_t)T.wg_first_row[(size_t)g0] >= need;
+          if (covered && issued) break;
+          int g1 = std::min(T.grid, g0 + round_wgs);
+          if (T.grid - g1 < round_wgs / 2) g1 = T.grid;
+          if ((rc = launch_spmv_plain_part(s, T, s->y_next, s->aty_next, g0, g1, !issued))) return rc;
+          issued = 1;
+          next_wg = g1;
+        }
+      }
+      HIP_TRY(hipEventRecord(s->ev_part[(size_t)k], s->stream));
+      if ((rc = mt_reduce_slice_async(g, s, i, [](pdhg_handle *q) { return q->aty_next; }, g.S, k))) return rc;
+    }
+    if ((rc = mt_join_comm(g, s, i))) return rc;
+  }
+  {
+    const int64_t o = s->clo;
+    hipLaunchKernelGGL(interaction_kernel, dim3(ew_grid(s->cn)), dim3(TPB), 0, s->stream, (int)s->cn, s->x + o,
+                       s->x_next + o, s->aty + o, s->aty_next + o, s->pAt, s->pAt_stride);
+    HIP_TRY(hipGetLastError());
+  }
+  int qcount = 0;
+  if ((rc = launch_q_interaction(s, &qcount))) return rc;
+  if ((rc = launch_final(s, s->pAt, ew_grid(s->cn), s->pAt_stride, s->pA, s->A.slots(), qcount))) return rc;
+  HIP_TRY(hipMemcpyAsync(s->scal_host, s->scal_dev, sizeof(double) * 5, hipMemcpyDeviceToHost, s->stream));
+  *t_issued = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+static int trial_group_mt(const Shards &L, const TrialArgs &a, double out[5]) {
+  DistGroup &g = *L.g;
+  const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  std::vector<double> issued((size_t)L.count, t0);
+  int rc = g.pool->run([&](int i) { return trial_shard_mt(g, L.p[i], i, a, &issued[(size_t)i]); });
+  if (rc) return rc;
+  const double t2 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  double t1 = t0;
+  for (double v : issued) t1 = std::max(t1, v);
+  g.t_issue += t1 - t0; g.t_wait += t2 - t1; g.n_trials += 1;
+  // the shards' scalars, added in rank order ([4], dx'Q dx, is replicated: maxed) -- as combine_scalars does
+  for (int q = 0; q < 5; ++q) {
+    double v = L.p[0]->scal_host[q];
+    for (int i = 1; i < L.count; ++i) {
+      const double t = L.p[i]->scal_host[q];
+      v = (q < 4) ? v + t : std::fmax(v, t);
+    }
+    out[q] = v;
+  }
+  out[4] *= 0.5;
+  return 0;
+}
+
 // Row-partitioned group: the dual half of a trial.  xbar's owned slices are ready.
 static int trial_dual_group(const Shards &L, double step_size, double primal_weight, double out[5]) {
   DistGroup &g = *L.g;
   pdhg_handle *lead = L.p[0];
   int rc;
+  const auto t_begin = std::chrono::steady_clock::now();
   {
     ProfScope ps(lead, PDHG_K_ALLGATHER);
     if ((rc = dist_all_gather(g, [](pdhg_handle *s) { return s->xbar; }, g.S))) return rc;
@@ -1425,8 +1658,12 @@ static int trial_dual_group(const Shards &L, double step_size, double primal_wei
     if ((rc = launch_final(s, s->pAt, ew_grid(s->cn), s->pAt_stride, s->pA, s->A.slots(), qcount))) return rc;
   }
   double r[5];
+  const auto t_issued = std::chrono::steady_clock::now();
   // [0..4) are added in rank order; [4] (dx'Q dx, replicated: the same value on every rank) is "maxed"
   if ((rc = combine_scalars(L, 5, 4, r))) return rc;
+  g.t_issue += std::chrono::duration<double>(t_issued - t_begin).count();
+  g.t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_issued).count();
+  g.n_trials += 1;
   for (int q = 0; q < 4; ++q) out[q] = r[q];
   out[4] = 0.5 * r[4];
   return 0;
@@ -1445,6 +1682,7 @@ int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight, doub
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
+  if (L.g && L.g->pool && !L.p[0]->profile) return trial_group_mt(L, TrialArgs{step_size, primal_weight, theta, false}, out);
   FOR_SHARDS(L, s) { if ((rc = launch_xbar(s, theta))) return rc; }
   if (L.g) return trial_dual_group(L, step_size, primal_weight, out);
   return trial_dual_single(h, step_size, primal_weight, out);
@@ -1456,6 +1694,7 @@ int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, doub
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
   if (!L.g && graph_eligible(h)) return graph_trial(h, step_size, primal_weight, theta, out);
+  if (L.g && L.g->pool && !L.p[0]->profile) return trial_group_mt(L, TrialArgs{step_size, primal_weight, theta, true}, out);
   FOR_SHARDS(L, s) { if ((rc = launch_primal(s, step_size / primal_weight, theta, true))) return rc; }
   if (L.g) return trial_dual_group(L, step_size, primal_weight, out);
   return trial_dual_single(h, step_size, primal_weight, out);
@@ -1523,7 +1762,10 @@ int pdhg_take_step_adaptive(pdhg_handle *h, double reduction_exponent, double gr
     const double k1 = (double)(*total_number_iterations_io + 1);
     const double first_term = (1 - pow(k1, -reduction_exponent)) * step_size_limit;
     const double second_term = (1 + pow(k1, -growth_exponent)) * step_size;
-    step_size = (second_term < first_term) ? second_term : first_term;
+    // Julia's min (pdhg.jl:729): a NaN operand gives NaN, so the step size the reference would
+    // carry after a NaN trial is NaN, not the finite operand (`a < b ? a : b` drops the NaN)
+    step_size = (first_term != first_term || second_term != second_term)
+                    ? NAN : ((first_term < second_term) ? first_term : second_term);
   }
   *step_size_io = step_size;
   return 0;
@@ -2099,7 +2341,9 @@ int pdhg_rescale(pdhg_handle *h0, int l_inf_ruiz_iterations, int l2_norm_rescali
     }
   };
 #define RS(expr) do { int _r = (expr); if (_r) { cleanup(); return _r; } } while (0)
-#define EACH(h, t) for (int _i = 0; _i < L.count; ++_i) if (pdhg_handle *h = L.p[_i]) if (hipSetDevice(h->device) == hipSuccess) if (RescaleTmp *_tp = &T[(size_t)_i]) if (RescaleTmp &t = *_tp; true)
+#define EACH(h, t) for (int _i = 0; _i < L.count; ++_i) if (pdhg_handle *h = L.p[_i]) \
+    if (hipError_t _sde = hipSetDevice(h->device); _sde != hipSuccess) { cleanup(); return fail_hip(_sde, "hipSetDevice (rescale)"); } \
+    else if (RescaleTmp *_tp = &T[(size_t)_i]) if (RescaleTmp &t = *_tp; true)
   EACH(h, t) {
     RS(alloc_zero(&t.ev, h->m)); RS(alloc_zero(&t.dv, h->n_alloc)); RS(alloc_zero(&t.inv_e, h->m)); RS(alloc_zero(&t.inv_d, h->n));
     RS(alloc_zero(&t.cum_e, h->m)); RS(alloc_zero(&t.cum_d, h->n)); RS(alloc_zero(&t.tmp_e, h->m)); RS(alloc_zero(&t.tmp_d, h->n_alloc));

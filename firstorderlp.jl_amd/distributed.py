@@ -100,6 +100,40 @@ def make_row_partitioned_hip_engine(problem, device_id=None, group=None):
                                       rank=rank, world=world)
 
 
+def make_row_shard_hip_engine(shard, device_id=None, group=None):
+    """One process per GPU with rank-local ingest (pdhg_create_dist_rows): ``shard`` is what
+    ``row_shard_of`` produced for THIS rank -- only its rows of the matrix and of b plus the
+    global n-vectors -- so no rank ever holds the whole matrix."""
+    import torch.distributed as dist
+    from .engine import HipPdhgEngine
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if device_id is None:
+        device_id = int(os.environ.get("LOCAL_RANK", rank))
+    uid = broadcast_unique_id(rank, group)
+    return HipPdhgEngine.from_row_shard(
+        shard["m_global"], shard["row_bounds"], shard["constraint_rows"], shard["objective_vector"],
+        shard["right_hand_side_rows"], shard["variable_lower_bound"], shard["variable_upper_bound"],
+        shard["num_equalities"], uid, rank, world, device_id=device_id,
+        objective_matrix=shard.get("objective_matrix"))
+
+
+def row_shard_of(problem, row_bounds, rank):
+    """Rank ``rank``'s slice of ``problem`` for ``make_row_shard_hip_engine`` (rows
+    row_bounds[rank]..row_bounds[rank+1] in CSR order -- slicing is a view-cheap operation
+    there -- and the global vectors)."""
+    lo, hi = int(row_bounds[rank]), int(row_bounds[rank + 1])
+    A = problem.constraint_matrix
+    rows = (A if A.format == "csr" else A.tocsr())[lo:hi, :]
+    Q = getattr(problem, "objective_matrix", None)
+    return dict(m_global=int(A.shape[0]), row_bounds=np.asarray(row_bounds, dtype=np.int64),
+                constraint_rows=rows, objective_vector=problem.objective_vector,
+                right_hand_side_rows=np.ascontiguousarray(problem.right_hand_side[lo:hi]),
+                variable_lower_bound=problem.variable_lower_bound,
+                variable_upper_bound=problem.variable_upper_bound,
+                num_equalities=int(problem.num_equalities),
+                objective_matrix=Q if (Q is not None and Q.nnz > 0) else None)
+
+
 def make_multi_device_hip_engine(problem, device_ids):
     """One process driving several GPUs (pdhg_create_multi)."""
     from .engine import HipPdhgEngine

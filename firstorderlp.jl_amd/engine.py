@@ -81,6 +81,70 @@ class HipPdhgEngine:
             _lib.check(self._L.pdhg_set_objective_matrix(
                 self._h, len(qv), _pi(qc), _pi(qr), _pd(qv), 0))
 
+    @classmethod
+    def from_row_shard(cls, m_global, row_bounds, constraint_rows, objective_vector, right_hand_side_rows,
+                       variable_lower_bound, variable_upper_bound, num_equalities, unique_id, rank, world,
+                       device_id=-1, stream=None, objective_matrix=None):
+        """One process per GPU with RANK-LOCAL ingest (``pdhg_create_dist_rows``): this rank
+        passes only ITS rows -- ``constraint_rows`` = rows row_bounds[rank]..row_bounds[rank+1] of
+        the global matrix as an (hi - lo) x n sparse matrix, ``right_hand_side_rows`` their
+        right-hand sides -- plus the global n-vectors; ``num_equalities`` is global.  The handle
+        behaves exactly like one from ``unique_id=, rank=, world=`` (global vector lengths)."""
+        self = cls.__new__(cls)
+        self._L = _lib.lib()
+        A = constraint_rows.tocsc()
+        bounds = _i(row_bounds)
+        if bounds.shape != (world + 1,):
+            raise ValueError("row_bounds must hold world + 1 entries")
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        self.m, self.n = int(m_global), int(A.shape[1])
+        if A.shape[0] != hi - lo:
+            raise ValueError("constraint_rows does not match row_bounds[rank]..row_bounds[rank+1]")
+        colptr, rowval, nzval = _i(A.indptr), _i(A.indices), _d(A.data)
+        c, b = _d(objective_vector), _d(right_hand_side_rows)
+        lb, ub = _d(variable_lower_bound), _d(variable_upper_bound)
+        if c.shape != (self.n,) or lb.shape != (self.n,) or ub.shape != (self.n,) or b.shape != (hi - lo,):
+            raise ValueError("vector lengths do not match the row shard")
+        h = ctypes.c_void_p()
+        uid = ctypes.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES)
+        _lib.check(self._L.pdhg_create_dist_rows(
+            ctypes.byref(h), self.m, self.n, _pi(bounds), len(nzval), _pi(colptr), _pi(rowval), _pd(nzval), 0,
+            _pd(c), _pd(b), _pd(lb), _pd(ub), int(num_equalities), int(device_id),
+            ctypes.c_void_p(stream) if stream else None, uid, int(rank), int(world)))
+        self._h = h
+        if objective_matrix is not None and objective_matrix.nnz > 0:
+            Q = objective_matrix
+            qc, qr, qv = _i(Q.indptr), _i(Q.indices), _d(Q.data)
+            _lib.check(self._L.pdhg_set_objective_matrix(self._h, len(qv), _pi(qc), _pi(qr), _pd(qv), 0))
+        return self
+
+    @staticmethod
+    def partition_rows(constraint_matrix, world):
+        """The library's nnz-balanced contiguous row partition (``pdhg_partition_rows``; host-only,
+        needs no GPU): ``world + 1`` ascending bounds."""
+        A = constraint_matrix.tocsc()
+        colptr, rowval = _i(A.indptr), _i(A.indices)
+        out = np.zeros(world + 1, dtype=np.int64)
+        _lib.check(_lib.lib().pdhg_partition_rows(int(A.shape[0]), int(A.shape[1]), _pi(colptr), _pi(rowval), 0,
+                                                  int(world), _pi(out)))
+        return out
+
+    @staticmethod
+    def rccl_info():
+        """Which RCCL the library bound at run time: dict(compiled_version, runtime_version, path).
+        Raises if RCCL is unavailable or its major version differs from the compiled header's."""
+        cv, rv = ctypes.c_int(0), ctypes.c_int(0)
+        buf = ctypes.create_string_buffer(1024)
+        _lib.check(_lib.lib().pdhg_rccl_info(ctypes.byref(cv), ctypes.byref(rv), buf, 1024))
+        return {"compiled_version": cv.value, "runtime_version": rv.value, "path": buf.value.decode()}
+
+    def host_issue_stats(self):
+        """(trials, seconds issuing, seconds waiting) of the trial steps so far (``pdhg_host_issue_stats``)."""
+        n = ctypes.c_int64(0)
+        a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _lib.check(self._L.pdhg_host_issue_stats(self._h, ctypes.byref(n), ctypes.byref(a), ctypes.byref(b)))
+        return n.value, a.value, b.value
+
     @staticmethod
     def dist_unique_id():
         """128 opaque bytes identifying a new RCCL communicator (rank 0 calls this

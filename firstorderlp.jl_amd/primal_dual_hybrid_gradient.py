@@ -76,6 +76,17 @@ def interaction_and_movement(raw, primal_weight):
     return interaction, movement
 
 
+def julia_min(a, b):
+    """Julia's ``min`` on Float64: a NaN operand gives NaN (Python's ``min`` returns
+    whichever operand the comparison happens to favour).  pdhg.jl:729 uses Julia's: once a
+    NaN reaches the step-size rule the reference's step size IS NaN from then on (and, since
+    `step_size <= limit` is false for a NaN on either side, its retry loop never accepts
+    again -- the reference relies on NaN-free data); the twins here keep the same scalars."""
+    if a != a or b != b:
+        return math.nan
+    return a if a < b else b
+
+
 def take_step_adaptive(step_params, solver_state):
     """take_step(::AdaptiveStepsizeParams, ...)  pdhg.jl:653-731.
 
@@ -117,7 +128,7 @@ def take_step_adaptive(step_params, solver_state):
         k1 = float(solver_state.total_number_iterations + 1)
         first_term = (1 - k1 ** (-step_params.reduction_exponent)) * step_size_limit
         second_term = (1 + k1 ** (-step_params.growth_exponent)) * step_size
-        step_size = min(first_term, second_term)
+        step_size = julia_min(first_term, second_term)
     solver_state.step_size = step_size
 
 

@@ -53,7 +53,9 @@ int pdhg_abi_version(void);
  * Sizes: m, n and m + n below 2^31.  nnz may exceed 2^31 - 1 (the reference's
  * index type is Int64): the matrix is then cut into row shards of fewer nonzeros
  * on the same device (the row-partitioned form below with its peer-kernel
- * exchange; up to 16 shards), behind the same handle; `stream` is ignored then.
+ * exchange; up to 16 shards, every shard checked against the limit), behind the same
+ * handle; `stream` must be NULL then (the shards run on private streams: -1 otherwise),
+ * and a single row beyond the limit is refused with -2, naming the row.
  */
 int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
                 const int64_t *colptr, const int64_t *rowval,
@@ -180,6 +182,27 @@ int pdhg_create_dist(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
                      const double *b, const double *lb, const double *ub,
                      int64_t num_equalities, int device_id, void *stream,
                      const void *unique_id, int rank, int world);
+/*
+ * The same with RANK-LOCAL ingest: every rank hands over only ITS rows.  row_bounds[world+1]
+ * is the global row partition (ascending, row_bounds[0] = 0, row_bounds[world] = m_global;
+ * rank r owns rows row_bounds[r] .. row_bounds[r+1]); (colptr, rowval, nzval) is the CSC of
+ * those rows -- all n columns, row indices REBASED to 0 (+ index_base) -- and b_local their
+ * right-hand sides.  c, lb, ub are the global n-vectors; num_equalities is global
+ * (equalities-first order: rank r's equalities are the rows below num_equalities).  Nothing
+ * of the other ranks' rows is read, so a host can generate or load the matrix once and hand
+ * each rank its slice.  pdhg_partition_rows gives the library's own nnz-balanced partition of
+ * a global matrix (what pdhg_create_dist / pdhg_create_multi use); any contiguous partition
+ * is accepted.  Host-only helper: needs no GPU.
+ */
+int pdhg_partition_rows(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                        int index_base, int world, int64_t *row_bounds /* world + 1 */);
+int pdhg_create_dist_rows(pdhg_handle **out, int64_t m_global, int64_t n,
+                          const int64_t *row_bounds, int64_t local_nnz,
+                          const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                          int index_base, const double *c, const double *b_local,
+                          const double *lb, const double *ub, int64_t num_equalities,
+                          int device_id, void *stream, const void *unique_id, int rank,
+                          int world);
 /* One process driving n_devices GPUs (what a single Julia process would use):
  * all ranks live inside the returned handle; every call fans out over the
  * devices (one stream and one RCCL communicator per device, ncclCommInitAll).
@@ -195,6 +218,25 @@ int pdhg_create_multi(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
  * shard, [3] exchange back end (0 RCCL, 1 peer kernels, -1 none), [4],[5] its row
  * range, [6],[7] its owned column range. */
 int pdhg_dist_info(pdhg_handle *h, int64_t info[8]);
+/*
+ * RCCL is bound at RUN time, on the first multi-GPU entry point (csrc/rccl_loader.hpp):
+ * PDHG_RCCL_LIB if set, else the librccl the process has already loaded (e.g. torch's), else
+ * $ROCM_PATH/lib/librccl.so.1, else the loader's search path.  Its ncclGetVersion() must have
+ * the MAJOR version of the rccl.h this library was compiled against, or every multi-GPU
+ * creator fails with 2999 and a message.  This call forces the binding and reports it:
+ * compiled_version = NCCL_VERSION_CODE of the header, runtime_version = ncclGetVersion(),
+ * path = file the symbols came from.  Returns 2999 if RCCL is unavailable or refused.
+ */
+int pdhg_rccl_info(int *compiled_version, int *runtime_version, char *path, int path_len);
+/*
+ * Host-side cost of the trial steps so far.  Group handles: seconds until the last launch /
+ * collective call of a trial returned (max over the issuing threads: pdhg_create_multi
+ * issues every shard's sequence from its own host thread, PDHG_SHARD_THREADS=0 from the
+ * calling thread alone) and seconds from then until the scalars were on the host.  Plain
+ * handles on the one-launch path: node updates + launch call, and the wait for the result.
+ */
+int pdhg_host_issue_stats(pdhg_handle *h, int64_t *trials, double *issue_seconds,
+                          double *wait_seconds);
 
 /*
  * ---- evaluation branch on the device ("next" row N1) -----------------------

@@ -1,4 +1,4 @@
-# FirstOrderLpHIP.jl -- `ccall` shim over libpdhg_hip.so (include/pdhg_hip.h, abi 5).
+# FirstOrderLpHIP.jl -- `ccall` shim over libpdhg_hip.so (include/pdhg_hip.h, abi 6).
 #
 # Drop-in for FirstOrderLp.jl's PDHG path on MI355X:
 #
@@ -26,7 +26,7 @@ using SparseArrays
 import Random
 
 const LIB = get(ENV, "PDHG_HIP_LIB", "libpdhg_hip.so")
-const ABI_VERSION = 5
+const ABI_VERSION = 6
 const POINT_CURRENT = Cint(0)
 const POINT_AVERAGE = Cint(1)
 const POINT_RESTART = Cint(2)
@@ -120,6 +120,61 @@ function unique_id()
   id = zeros(UInt8, UNIQUE_ID_BYTES)
   check(ccall((:pdhg_dist_get_unique_id, LIB), Cint, (Ptr{UInt8},), id))
   return id
+end
+
+"""
+The library's nnz-balanced contiguous row partition of a global matrix (`pdhg_partition_rows`,
+host-only): `world + 1` ascending 0-based bounds; rank r owns rows bounds[r+1]+1 : bounds[r+2]
+in Julia's 1-based terms.
+"""
+function partition_rows(A::SparseMatrixCSC{Float64,Int64}, world::Integer)
+  bounds = zeros(Int64, world + 1)
+  GC.@preserve A check(ccall((:pdhg_partition_rows, LIB), Cint,
+    (Int64, Int64, Ptr{Int64}, Ptr{Int64}, Cint, Cint, Ptr{Int64}),
+    size(A, 1), size(A, 2), A.colptr, A.rowval, 1, world, bounds))
+  return bounds
+end
+
+"""
+One process per GPU with RANK-LOCAL ingest (`pdhg_create_dist_rows`): `rows` is this rank's
+row block `A[bounds[rank+1]+1 : bounds[rank+2], :]` of the global constraint matrix (so its row
+indices are already rebased), `b_rows` the matching right-hand sides; `c, lb, ub` are the
+global vectors and `num_equalities` is global.  `dist = (id, rank, world)` as for
+`HipSolverState(problem; dist = ...)`.  No rank needs the whole matrix.
+"""
+function HipSolverStateFromRows(m_global::Integer, bounds::Vector{Int64},
+                                rows::SparseMatrixCSC{Float64,Int64}, c::Vector{Float64},
+                                b_rows::Vector{Float64}, lb::Vector{Float64}, ub::Vector{Float64},
+                                num_equalities::Integer, dist; device_id::Integer = -1)
+  id, rank, world = dist
+  n = size(rows, 2)
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  GC.@preserve rows c b_rows lb ub bounds id check(ccall((:pdhg_create_dist_rows, LIB), Cint,
+    (Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint,
+     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint),
+    h, m_global, n, bounds, length(rows.nzval), rows.colptr, rows.rowval, rows.nzval, 1,
+    c, b_rows, lb, ub, num_equalities, device_id, C_NULL, id, rank, world))
+  state = HipSolverState(h[], n, m_global, 0.0, 1.0, false, 0.0, 0, nothing, nothing)
+  finalizer(s -> ccall((:pdhg_destroy, LIB), Cvoid, (Ptr{Cvoid},), s.handle), state)
+  return state
+end
+
+"Which RCCL the library bound at run time (`pdhg_rccl_info`); errors if it is unavailable or of another major version."
+function rccl_info()
+  compiled = Ref{Cint}(0); runtime = Ref{Cint}(0)
+  path = zeros(UInt8, 1024)
+  check(ccall((:pdhg_rccl_info, LIB), Cint, (Ref{Cint}, Ref{Cint}, Ptr{UInt8}, Cint),
+    compiled, runtime, path, length(path)))
+  return (compiled_version = compiled[], runtime_version = runtime[],
+          path = unsafe_string(pointer(path)))
+end
+
+"Host-side cost of the trial steps so far: (trials, seconds issuing, seconds waiting) (`pdhg_host_issue_stats`)."
+function host_issue_stats(s::HipSolverState)
+  trials = Ref{Int64}(0); issue = Ref{Float64}(0.0); wait = Ref{Float64}(0.0)
+  check(ccall((:pdhg_host_issue_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Float64}, Ref{Float64}),
+    s.handle, trials, issue, wait))
+  return trials[], issue[], wait[]
 end
 
 function dist_info(s::HipSolverState)

@@ -432,7 +432,9 @@ int oracle_take_step_adaptive(oracle_state *s, double reduction_exponent,
     const double first_term =
         (1 - pow(k1, -reduction_exponent)) * step_size_limit;
     const double second_term = (1 + pow(k1, -growth_exponent)) * step_size;
-    step_size = first_term < second_term ? first_term : second_term;
+    /* Julia's min: NaN if either operand is NaN */
+    step_size = (first_term != first_term || second_term != second_term)
+                    ? NAN : (first_term < second_term ? first_term : second_term);
   }
   s->step_size = step_size;
   return iter;

@@ -27,7 +27,7 @@ def test_header_symbols_all_exported():
     L = ctypes.CDLL(_lib.LIB_PATH)       # loads without a GPU
     for name in declared:
         assert hasattr(L, name), f"{name} not exported by libpdhg_hip.so"
-    assert _lib.lib().pdhg_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib().pdhg_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_create_fails_loudly_without_gpu():
@@ -80,3 +80,48 @@ def test_residual_and_objective_helpers():
     ds = compute_dual_stats(lp, x_opt, np.array([0.5, 4.0, 0.0]))
     assert abs(ds.dual_objective - (-1.0)) < 1e-14
     assert np.max(np.abs(ds.dual_residual)) == 0.0
+
+
+def test_partition_rows_helper_needs_no_gpu_and_matches_the_host_mirror():
+    """pdhg_partition_rows (host-only export): the nnz-balanced contiguous row partition
+    pdhg_create_dist / pdhg_create_multi use, which a host needs to slice a matrix for
+    pdhg_create_dist_rows."""
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd import HipPdhgEngine
+    from firstorderlp_jl_amd.distributed import partition_rows, row_shard_of
+    from firstorderlp_jl_amd.generators import random_lp
+    A = sp.random(1000, 700, density=0.01, format="csc", random_state=1)
+    for world in (1, 2, 3, 8):
+        got = HipPdhgEngine.partition_rows(A, world)
+        ref = partition_rows(A, world)
+        assert list(got) == [ref[0][0]] + [hi for _, hi in ref]
+    p = random_lp(300, 200, 5, seed=1)
+    bounds = HipPdhgEngine.partition_rows(p.constraint_matrix, 3)
+    total = 0
+    for r in range(3):
+        sh = row_shard_of(p, bounds, r)
+        assert sh["constraint_rows"].shape == (bounds[r + 1] - bounds[r], 200)
+        assert sh["right_hand_side_rows"].shape == (bounds[r + 1] - bounds[r],)
+        total += sh["constraint_rows"].nnz
+    assert total == p.constraint_matrix.nnz
+
+
+def test_library_has_no_link_time_rccl_dependency():
+    """RCCL is bound at run time (csrc/rccl_loader.hpp): the shared object must load where no
+    librccl exists, so it may not carry a DT_NEEDED on it."""
+    import subprocess
+    from firstorderlp_jl_amd import _lib
+    out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    if not out:
+        import pytest
+        pytest.skip("readelf not available")
+    needed = [ln for ln in out.splitlines() if "NEEDED" in ln]
+    assert needed and not any("rccl" in ln for ln in needed), needed
+
+
+def test_julia_min_propagates_nan():
+    import math
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import julia_min
+    assert julia_min(1.0, 2.0) == 1.0 and julia_min(2.0, 1.0) == 1.0
+    assert math.isnan(julia_min(math.nan, 1.0)) and math.isnan(julia_min(1.0, math.nan))
+    assert julia_min(math.inf, 3.0) == 3.0

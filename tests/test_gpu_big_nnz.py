@@ -82,3 +82,38 @@ def test_2p2_billion_nonzeros(gpu_required):
     raw = eng.trial_step(0.1, 1.0, 1.0)
     assert np.all(np.isfinite(raw))
     eng.close()
+
+
+def test_sharded_create_checks_every_shard_and_refuses_a_caller_stream(gpu_required, monkeypatch):
+    """The partition works on whole rows: a heavy row block can exceed the limit although the
+    average shard does not -- the shard count is raised until every shard fits; a single row
+    beyond the limit is refused naming the row; a caller stream cannot be honoured."""
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd.quadratic_programming import QuadraticProgrammingProblem
+    rng = np.random.default_rng(5)
+    m, n = 4000, 3000
+    A = sp.random(m, n, density=0.004, format="lil", random_state=7)
+    for r in range(40):                              # 40 rows of 1500 entries at the top: 60k of ~108k nonzeros
+        cols = np.sort(rng.choice(n, 1500, replace=False))
+        A.rows[r] = cols.tolist()
+        A.data[r] = rng.standard_normal(1500).tolist()
+    A = A.tocsc()
+    p = QuadraticProgrammingProblem(
+        variable_lower_bound=np.zeros(n), variable_upper_bound=np.full(n, np.inf),
+        objective_matrix=sp.csc_matrix((n, n)), objective_vector=rng.standard_normal(n), objective_constant=0.0,
+        constraint_matrix=A, right_hand_side=rng.standard_normal(m), num_equalities=100)
+    monkeypatch.setenv("PDHG_MAX_SHARD_NNZ", "30000")
+    eng = HipPdhgEngine.from_problem(p)
+    info = eng.dist_info()
+    assert info["world"] >= 4 and info["backend"] == 1
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    np.testing.assert_allclose(eng.spmv(x), A @ x, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(eng.spmv_t(y), A.T @ y, rtol=1e-11, atol=1e-11)
+    eng.close()
+    monkeypatch.setenv("PDHG_MAX_SHARD_NNZ", "1000")            # a 1500-entry row cannot be indexed
+    with pytest.raises(Exception, match="row 0 alone holds 1500"):
+        HipPdhgEngine.from_problem(p)
+    monkeypatch.setenv("PDHG_MAX_SHARD_NNZ", "30000")
+    import torch
+    with pytest.raises(Exception, match="caller-supplied stream"):
+        HipPdhgEngine.from_problem(p, stream=torch.cuda.Stream().cuda_stream)

@@ -298,3 +298,72 @@ def test_group_solve_matches_single_engine_solve(gpu_required):
     assert abs(c3.primal_objective - c1.primal_objective) <= 50 * tol * scale
     assert abs(c3.dual_objective - c1.dual_objective) <= 50 * tol * scale
     assert 0.5 <= grp.iteration_count / one.iteration_count <= 2.0
+
+
+# ---- round 3: one issuing host thread per shard, rank-local ingest, RCCL binding --------------
+
+@pytest.mark.parametrize("overlap", ["0", "1"], ids=["reduce_scatter", "per_slice_reduce"])
+@pytest.mark.parametrize("device_ids", [[0, 0], [0] * 8], ids=["2", "8"])
+def test_thread_per_shard_issue_is_bitwise_the_single_thread_issue(gpu_required, monkeypatch, device_ids, overlap):
+    """pdhg_create_multi issues every shard's trial from its own host thread (ShardPool);
+    PDHG_SHARD_THREADS=0 issues all of them from the caller.  Same launches, same order per
+    stream, rank-ordered sums: not a bit may differ.  (Peer-kernel back end here; the RCCL
+    back end takes the same route on >= 2 GPUs, tests/test_gpu_multi_device.py.)"""
+    monkeypatch.setenv("PDHG_DIST_OVERLAP", overlap)
+    p = random_lp(30000, 20000, 6, seed=21)
+    runs = {}
+    for threads in ("1", "0"):
+        monkeypatch.setenv("PDHG_SHARD_THREADS", threads)
+        eng = HipPdhgEngine.from_problem(p, device_ids=device_ids)
+        runs[threads] = _run(eng, p, 60, 25)
+        trials, issue, wait = eng.host_issue_stats()
+        assert trials >= 60 and issue > 0.0
+        eng.close()
+    for key, val in runs["1"].items():
+        assert np.array_equal(np.asarray(val), np.asarray(runs["0"][key])), key
+
+
+def test_thread_per_shard_qp_group(gpu_required):
+    from tests.test_gpu_kat import hip_factory  # noqa: F401  (imported for its side effect-free helpers)
+    kat_common.quadratic_programming_1(_group_factory([0, 0, 0]))
+    kat_common.malitsky_pock_smoothing(_group_factory([0, 0, 0]))
+
+
+@pytest.mark.parametrize("ingest", ["global", "rows"])
+def test_one_process_per_gpu_route_with_one_rank(gpu_required, ingest):
+    """tests/workers/dist_rank_worker.py under torch.distributed.run with ONE rank: gloo group,
+    id broadcast, pdhg_create_dist (global ingest) / pdhg_create_dist_rows (rank-local
+    ingest), 1-rank RCCL communicator, compared with the single handle inside the worker."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29611",
+           os.path.join(root, "tests", "workers", "dist_rank_worker.py"), ingest, "0"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0 and "dist worker ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_rank_local_ingest_equals_global_ingest_bitwise(gpu_required):
+    """pdhg_create_dist_rows on the rank's own rows == pdhg_create_dist on the global matrix
+    (1-rank communicator: the slice is the whole matrix, the code path is the rank-local one)."""
+    from firstorderlp_jl_amd.distributed import row_shard_of
+    p = random_lp(9000, 7000, 7, seed=3)
+    uid = HipPdhgEngine.dist_unique_id()
+    a = HipPdhgEngine.from_problem(p, unique_id=uid, rank=0, world=1, device_id=0)
+    ra = _run(a, p, 40, 10)
+    a.close()
+    sh = row_shard_of(p, HipPdhgEngine.partition_rows(p.constraint_matrix, 1), 0)
+    b = HipPdhgEngine.from_row_shard(sh["m_global"], sh["row_bounds"], sh["constraint_rows"], sh["objective_vector"],
+                                     sh["right_hand_side_rows"], sh["variable_lower_bound"], sh["variable_upper_bound"],
+                                     sh["num_equalities"], HipPdhgEngine.dist_unique_id(), 0, 1, device_id=0)
+    rb = _run(b, p, 40, 10)
+    for key, val in ra.items():
+        assert np.array_equal(np.asarray(val), np.asarray(rb[key])), key
+
+
+def test_rccl_binding_is_reported_and_version_checked(gpu_required):
+    info = HipPdhgEngine.rccl_info()
+    assert info["path"].endswith(".so") or ".so." in info["path"], info
+    assert info["runtime_version"] // 10000 == info["compiled_version"] // 10000 == 2, info
+    print("RCCL bound at run time:", info)

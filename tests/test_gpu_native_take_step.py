@@ -68,3 +68,4 @@ def test_native_take_step_reports_zero_movement(gpu_required):
         if st.numerical_error:
             break
     assert st.numerical_error
+

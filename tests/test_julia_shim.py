@@ -46,7 +46,7 @@ _C2JL = {
     "pdhg_handle*": {"Ptr{Cvoid}"},
     "pdhg_handle**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
     "void*": {"Ptr{Cvoid}", "Ptr{UInt8}"},
-    "char*": {"Cstring", "Ptr{UInt8}"},
+    "char*": {"Cstring", "Ptr{UInt8}", "Ptr{Cchar}"},
     "void": {"Cvoid"},
 }
 
