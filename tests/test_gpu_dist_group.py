@@ -324,7 +324,6 @@ def test_thread_per_shard_issue_is_bitwise_the_single_thread_issue(gpu_required,
 
 
 def test_thread_per_shard_qp_group(gpu_required):
-    from tests.test_gpu_kat import hip_factory  # noqa: F401  (imported for its side effect-free helpers)
     kat_common.quadratic_programming_1(_group_factory([0, 0, 0]))
     kat_common.malitsky_pock_smoothing(_group_factory([0, 0, 0]))
 
