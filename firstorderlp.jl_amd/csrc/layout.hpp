@@ -39,7 +39,7 @@ struct CsrDev {
   int *step_tile = nullptr;       // first column of the tile of every step, workgroup after workgroup
   int *wg_step_off = nullptr;     // [grid+1] start of a workgroup's steps inside step_tile
   int64_t total_steps = 0;
-  bool tw_scratch = false;        // long same-row runs: use the LDS-scratch chunk variant
+  int tw_mode = 0;                // chunk accumulation: 0 lane shuffles, 1 LDS scratch (long runs, strict order), 2 relaxed order
   unsigned *pk = nullptr;
   double *tv = nullptr;
   std::vector<int> wg_first_row;  // host copy: first row of every tiled workgroup (+ rows), for partial launches
@@ -118,7 +118,7 @@ inline int tile_width_cap(int64_t rows) {
 // <= TW_ROWS consecutive non-long rows) and their entries counting-sorted by
 // column tile (stable, so (row, col) order is kept inside a tile).
 int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec &col,
-                const dvec &val, int tile_cols) {
+                const dvec &val, int tile_cols, bool relaxed) {
   // Tile boundaries.  Uniform width tile_cols by default.  When the columns are skewed
   // (hub columns: the fullest uniform tile holds more than 1.5x the average), the
   // boundaries are moved so that every tile holds about the same number of entries
@@ -354,7 +354,9 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   {
     const char *mode_env = getenv("PDHG_SPMV");
     const bool forced = mode_env && !strcmp(mode_env, "tiled");
-    if (!forced && max_run > 32) return 0;
+    // In relaxed-order mode long runs are reduced by a shuffle tree (tiled_chunk_relaxed) and
+    // are no reason to decline.
+    if (!forced && !relaxed && max_run > 32) return 0;
   }
   D.wg_first_row.resize((size_t)grid + 1);
   for (int g = 0; g < grid; ++g) D.wg_first_row[g] = wave_rows[(size_t)g * TW_WPB].x;
@@ -379,7 +381,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
             rows, D.cols, ntiles, widest, uniform ? "" : ", equal-nonzero widths", nwaves, TW_ROWS, grid,
             grid ? (double)D.total_steps / grid : 0.0, mx, max_run);
   }
-  D.tw_scratch = max_run > 8;
+  D.tw_mode = max_run > 8 ? (relaxed ? 2 : 1) : 0;
   int rc;
   if ((rc = upload(&D.wave_rows, wave_rows))) return rc;
   if ((rc = upload(&D.wave_ent, step_ptr))) return rc;
@@ -465,7 +467,7 @@ int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, c
 
 int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
                   const ivec &col, const dvec &val,
-                  bool remap, int tile_cols = 0) {
+                  bool remap, int tile_cols = 0, bool relaxed = false) {
   D.rows = rows;
   D.cols = cols;
   D.nnz = rowptr[rows];
@@ -515,7 +517,7 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
   if ((rc = upload(&D.chunk_off, chunk_off))) return rc;
   if ((rc = alloc_zero(&D.chunk_partial, D.nchunks))) return rc;
   if (tile_cols > 0) {
-    if ((rc = build_tiled(D, rows, rowptr, col, val, tile_cols))) return rc;
+    if ((rc = build_tiled(D, rows, rowptr, col, val, tile_cols, relaxed))) return rc;
   }
   if (!D.tiled) {
     if ((rc = build_slabs(D, rows, cols, rowptr, col, val, remap))) return rc;

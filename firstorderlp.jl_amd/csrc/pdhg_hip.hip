@@ -43,6 +43,7 @@
 #include "eval_kernels.hpp"
 #include "rescale_kernels.hpp"
 #include "layout.hpp"
+#include "trial_kernel.hpp"
 
 namespace { struct DistGroup; }
 
@@ -52,6 +53,10 @@ struct pdhg_handle {
   bool own_stream = false;
   int64_t m = 0, n = 0, nnz = 0, num_eq = 0;
   bool remap = true;
+  // PDHG_ROW_ORDER=strict: every row sum strictly left to right (bit-exact with the CPU loops for rows
+  // <= BLOCK_NNZ entries); default "relaxed": rows of more than 64 entries are summed wave-parallel in a
+  // fixed order, within 1e-13 * sum |a x| of the sequential sum (spmv_kernels.hpp)
+  bool relaxed = true;
 
   CsrDev A;    // m x n, rows = constraints   (K3)
   CsrDev At;   // n x m, rows = variables     (K5) == Julia's CSC arrays
@@ -140,6 +145,12 @@ struct pdhg_handle {
     bool add_x = false, add_y = false;                         // deferred K7 baked into the primal / dual nodes
     double add_wx = 0.0, add_wy = 0.0;
   } tgraph[2];
+  // ---- one trial as ONE kernel launch (trial_kernel.hpp): stream layouts without column slabs, LP
+  int coop_mode = -1;                   // -1 undecided, 0 off, 1 on
+  int coop_grid = 0;                    // workgroups of the persistent launch (multiple of 8, all co-resident)
+  unsigned coop_nxcd = 0;               // XCDs that hold workgroups of such a launch
+  unsigned long long coop_launches = 0;
+  GridSync *gsync = nullptr;
   int graph_mode = -1;                  // -1 undecided, 0 off, 1 on
   hipStream_t graph_stream = nullptr;   // graphs launch here (== stream)
   unsigned long long *seq_dev = nullptr;   // launch counter, incremented by the final kernel
@@ -182,11 +193,11 @@ struct ProfScope {
 // The opt-in for > 64 KiB of dynamic LDS is per device and per kernel instance,
 // and must only ever grow: another handle on the same device may need more than
 // this one (hipFuncSetAttribute sets the limit, it does not raise it).
-int ensure_lds_limit(pdhg_handle *h, int mode, bool scratch, size_t lds, const void *func) {
-  static size_t limit[64][3][2] = {};
+int ensure_lds_limit(pdhg_handle *h, int mode, int chunk_mode, size_t lds, const void *func) {
+  static size_t limit[64][3][3] = {};
   static std::mutex mu;            // handles may be created / driven from several host threads (shard pool, Julia tasks)
   std::lock_guard<std::mutex> lock(mu);
-  size_t &cur = limit[h->device & 63][mode][scratch ? 1 : 0];
+  size_t &cur = limit[h->device & 63][mode][chunk_mode];
   if (cur < lds) {
     HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     cur = lds;
@@ -201,27 +212,38 @@ int ensure_lds_limit(pdhg_handle *h, int mode, bool scratch, size_t lds, const v
 // per CU gather from more tiles at once -- 10M-nnz-per-million-rows LPs of 5.3M-6.5M rows ran
 // at 10 ps per nonzero, against 7.0 at 5M and 7.7 at 7M (profiles/r02_locality.txt).
 size_t tiled_lds_bytes(const CsrDev &D) {
-  const size_t need = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_scratch ? TW_WPB * WAVE : 0));
+  const size_t need = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_mode == 1 ? TW_WPB * WAVE : 0));
   return std::max(need, D.tw_lds_floor);
 }
 
+// the tiled kernel's three chunk variants behind one call
 template <int MODE>
+int launch_tiled(pdhg_handle *h, const CsrDev &D, const double *xin, const EpiArgs &e, int g0, int g1) {
+  const size_t lds = tiled_lds_bytes(D);
+  const int w0 = g0 * TW_WPB;
+  int rc;
+#define PDHG_TILED(CH)                                                                                              \
+  do {                                                                                                             \
+    if ((rc = ensure_lds_limit(h, MODE, CH, lds, (const void *)spmv_tiled_kernel<MODE, CH>))) return rc;           \
+    hipLaunchKernelGGL((spmv_tiled_kernel<MODE, CH>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,          \
+                       D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,        \
+                       D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);                                \
+  } while (0)
+  if (D.tw_mode == 1) PDHG_TILED(1);
+  else if (D.tw_mode == 2) PDHG_TILED(2);
+  else PDHG_TILED(0);
+#undef PDHG_TILED
+  return 0;
+}
+
+// TAG: 0 the constraint matrix, 1 its transpose, 2 the objective matrix (profiler names)
+template <int MODE, int TAG>
 int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
+  const int rx = h->relaxed ? 1 : 0;
   if (D.tiled) {
     if (D.grid > 0) {
-      const size_t lds = tiled_lds_bytes(D);
-      int rc;
-      if (D.tw_scratch) {
-        if ((rc = ensure_lds_limit(h, MODE, true, lds, (const void *)spmv_tiled_kernel<MODE, true>))) return rc;
-        hipLaunchKernelGGL((spmv_tiled_kernel<MODE, true>), dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
-                           D.wave_rows, D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves,
-                           D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
-      } else {
-        if ((rc = ensure_lds_limit(h, MODE, false, lds, (const void *)spmv_tiled_kernel<MODE, false>))) return rc;
-        hipLaunchKernelGGL((spmv_tiled_kernel<MODE, false>), dim3(D.grid), dim3(TW_WPB * WAVE), lds, h->stream,
-                           D.wave_rows, D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves,
-                           D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
-      }
+      int rc = launch_tiled<MODE>(h, D, xin, e, 0, D.grid);
+      if (rc) return rc;
     }
   } else if (!D.slabs.empty()) {
     // column-slab passes, ascending: partial row sums travel through slab_partial
@@ -233,24 +255,24 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
         pe.out = D.slab_partial;
         pe.init = D.slab_partial;
         if (p == 0)
-          hipLaunchKernelGGL((spmv_stream_kernel<MODE_PLAIN, false>), dim3(S.grid), dim3(TPB), 0, h->stream,
-                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, pe);
+          hipLaunchKernelGGL((spmv_stream_kernel<MODE_PLAIN, false, TAG>), dim3(S.grid), dim3(TPB), 0, h->stream,
+                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx, pe);
         else
-          hipLaunchKernelGGL((spmv_stream_kernel<MODE_PLAIN, true>), dim3(S.grid), dim3(TPB), 0, h->stream,
-                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, pe);
+          hipLaunchKernelGGL((spmv_stream_kernel<MODE_PLAIN, true, TAG>), dim3(S.grid), dim3(TPB), 0, h->stream,
+                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx, pe);
       } else {
         EpiArgs le = e;
         le.init = D.slab_partial;
-        hipLaunchKernelGGL((spmv_stream_kernel<MODE, true>), dim3(S.grid), dim3(TPB), 0, h->stream,
-                           S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, le);
+        hipLaunchKernelGGL((spmv_stream_kernel<MODE, true, TAG>), dim3(S.grid), dim3(TPB), 0, h->stream,
+                           S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx, le);
       }
     }
   } else if (D.grid > 0) {
-    hipLaunchKernelGGL((spmv_stream_kernel<MODE, false>), dim3(D.grid), dim3(TPB), 0, h->stream,
-                       D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, e);
+    hipLaunchKernelGGL((spmv_stream_kernel<MODE, false, TAG>), dim3(D.grid), dim3(TPB), 0, h->stream,
+                       D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, e);
   }
   if (D.nlong > 0) {
-    hipLaunchKernelGGL(spmv_long_partial_kernel, dim3(D.nchunks), dim3(TPB), 0, h->stream,
+    hipLaunchKernelGGL(spmv_long_partial_kernel<TAG>, dim3(D.nchunks), dim3(TPB), 0, h->stream,
                        D.view(), xin, D.chunk_row, D.chunk_off, D.chunk_partial);
     hipLaunchKernelGGL(spmv_long_final_kernel<MODE>, dim3(D.long_grid), dim3(TPB), 0, h->stream,
                        D.long_row, D.long_chunk_ptr, D.nlong, D.chunk_partial, e, D.grid);
@@ -269,27 +291,14 @@ int launch_spmv_plain_part(pdhg_handle *h, const CsrDev &D, const double *xin, d
   EpiArgs e{};
   e.out = out;
   if (with_long && D.nlong > 0) {
-    hipLaunchKernelGGL(spmv_long_partial_kernel, dim3(D.nchunks), dim3(TPB), 0, h->stream,
+    hipLaunchKernelGGL(spmv_long_partial_kernel<1>, dim3(D.nchunks), dim3(TPB), 0, h->stream,
                        D.view(), xin, D.chunk_row, D.chunk_off, D.chunk_partial);
     hipLaunchKernelGGL(spmv_long_final_kernel<MODE_PLAIN>, dim3(D.long_grid), dim3(TPB), 0, h->stream,
                        D.long_row, D.long_chunk_ptr, D.nlong, D.chunk_partial, e, D.grid);
   }
   if (g1 > g0) {
-    const size_t lds = tiled_lds_bytes(D);
-    const int w0 = g0 * TW_WPB;
-    if (D.tw_scratch) {
-      int rc = ensure_lds_limit(h, MODE_PLAIN, true, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, true>);
-      if (rc) return rc;
-      hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, true>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
-                         D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
-                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
-    } else {
-      int rc = ensure_lds_limit(h, MODE_PLAIN, false, lds, (const void *)spmv_tiled_kernel<MODE_PLAIN, false>);
-      if (rc) return rc;
-      hipLaunchKernelGGL((spmv_tiled_kernel<MODE_PLAIN, false>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,
-                         D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,
-                         D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);
-    }
+    int rc = launch_tiled<MODE_PLAIN>(h, D, xin, e, g0, g1);
+    if (rc) return rc;
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -302,7 +311,7 @@ int launch_primal(pdhg_handle *h, double tau, double theta, bool write_xbar) {
   if (h->has_q) {
     EpiArgs e{};
     e.out = h->qx;
-    int rc = launch_spmv<MODE_PLAIN>(h, h->Q, h->x, e);
+    int rc = launch_spmv<MODE_PLAIN, 2>(h, h->Q, h->x, e);
     if (rc) return rc;
   }
   const int n = (int)h->cn;
@@ -334,7 +343,7 @@ int launch_dual(pdhg_handle *h, double sigma) {
   e.y = h->y; e.b = h->b; e.y_next = h->y_next; e.sigma = sigma; e.num_eq = (int)h->num_eq;
   e.partials = h->pA; e.stride = h->A.slots();
   if (h->pend_y) { e.sum_y = h->sum_y; e.avg_w = h->pend_w; }
-  const int rc = launch_spmv<MODE_DUAL>(h, h->A, h->xbar, e);
+  const int rc = launch_spmv<MODE_DUAL, 0>(h, h->A, h->xbar, e);
   if (!rc) h->pend_y = false;
   return rc;
 }
@@ -344,14 +353,14 @@ int launch_aty_fused(pdhg_handle *h) {
   EpiArgs e{};
   e.x = h->x; e.x_next = h->x_next; e.aty = h->aty; e.aty_next = h->aty_next;
   e.partials = h->pAt; e.stride = h->pAt_stride;
-  return launch_spmv<MODE_ATY>(h, h->At, h->y_next, e);
+  return launch_spmv<MODE_ATY, 1>(h, h->At, h->y_next, e);
 }
 
 int launch_aty_plain(pdhg_handle *h, const double *yin, double *out) {
   ProfScope ps(h, PDHG_K_SPMV_ATY);
   EpiArgs e{};
   e.out = out;
-  return launch_spmv<MODE_PLAIN>(h, h->At, yin, e);
+  return launch_spmv<MODE_PLAIN, 1>(h, h->At, yin, e);
 }
 
 // 0.5 * dx' Q dx partials into pQ (QP only; full vectors -- replicated in a group)
@@ -362,7 +371,7 @@ int launch_q_interaction(pdhg_handle *h, int *count) {
   hipLaunchKernelGGL(diff_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, h->x_next, h->x, h->tmp_n);
   EpiArgs e{};
   e.out = h->tmp_n2;
-  int rc = launch_spmv<MODE_PLAIN>(h, h->Qt, h->tmp_n, e);  // (dx' Q)' = Q' dx
+  int rc = launch_spmv<MODE_PLAIN, 2>(h, h->Qt, h->tmp_n, e);  // (dx' Q)' = Q' dx
   if (rc) return rc;
   hipLaunchKernelGGL(dot_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, h->tmp_n2, h->tmp_n, h->pQ);
   HIP_TRY(hipGetLastError());
@@ -394,7 +403,7 @@ int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int,
 __global__ __launch_bounds__(FINAL_TPB) void final_reduce_host_kernel(FinalSpec sp, unsigned long long *seq_dev,
                                                                       volatile double *res_host) {
   double res[5];
-  final_reduce_body(sp, res);
+  final_reduce_body<FINAL_TPB / WAVE>(sp, res);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) res_host[k] = res[k];
@@ -424,6 +433,145 @@ hipError_t graph_set_kernel(hipGraphExec_t exec, hipGraphNode_t node, const void
   p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0;
   p.kernelParams = params; p.extra = nullptr;
   return hipGraphExecKernelNodeSetParams(exec, node, &p);
+}
+
+// pinned, host-coherent result word of the one-launch paths: [0..5) sums, [6] error, [7] sequence number
+int ensure_result_word(pdhg_handle *h) {
+  if (h->seq_dev) return 0;
+  HIP_TRY(hipMalloc((void **)&h->seq_dev, sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(h->seq_dev, 0, sizeof(unsigned long long), nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));   // the null stream does not order against h->stream
+  HIP_TRY(hipHostMalloc((void **)&h->res_host, 8 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+  for (int q = 0; q < 8; ++q) h->res_host[q] = 0.0;
+  return 0;
+}
+
+// wait for launch number seq_expected's results in pinned memory (bounded spin, then the stream)
+int wait_result_word(pdhg_handle *h, double out[5]) {
+  const double want = (double)h->seq_expected;
+  bool seen = false;
+  for (long spin = 0; spin < 40000000L; ++spin) {
+    if (h->res_host[7] == want) { seen = true; break; }
+    if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+  }
+  if (!seen) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->res_host[7] != want) {
+      h->seq_expected = (unsigned long long)h->res_host[7];   // resynchronise: the next launch can succeed
+      return fail(998, "one-launch trial finished without publishing its results");
+    }
+  }
+  for (int q = 0; q < 5; ++q) out[q] = h->res_host[q];
+  out[4] *= 0.5;
+  return 0;
+}
+
+// ---- the trial step as ONE persistent kernel (trial_kernel.hpp) -----------------------------
+
+bool coop_eligible(pdhg_handle *h) {
+  if (h->coop_mode < 0) {
+    const char *ev = getenv("PDHG_COOP");
+    bool on = !h->grp && !h->has_q && !h->A.tiled && !h->At.tiled && h->A.slabs.empty() && h->At.slabs.empty() &&
+              h->n > 0 && h->m > 0;
+    if (ev) on = on && ev[0] != '0';
+    const char *gv = getenv("PDHG_GRAPH");             // PDHG_GRAPH=0: separate launches, no one-launch path of either kind
+    if (gv) on = on && gv[0] != '0';
+    h->coop_mode = on ? 1 : 0;
+  }
+  return h->coop_mode == 1 && !h->has_q && !h->profile;
+}
+
+// grid of the persistent launch + the census of workgroups per XCD (once per handle)
+int coop_prepare(pdhg_handle *h) {
+  if (h->gsync) return 0;
+  int rc = ensure_result_word(h);
+  if (rc) return rc;
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trial_kernel, TPB, 0));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+  int cap = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
+  if (const char *ev = getenv("PDHG_COOP_WGS")) cap = std::max(8, std::min(cap, atoi(ev) / 8 * 8));
+  const int items = std::max(std::max(h->A.grid + h->A.nchunks, h->At.grid + h->At.nchunks), ew_grid((h->n + 1) / 2));
+  h->coop_grid = std::min(cap, std::max(8, (items + 7) / 8 * 8));
+  HIP_TRY(hipMalloc((void **)&h->gsync, sizeof(GridSync)));
+  HIP_TRY(hipMemsetAsync(h->gsync, 0, sizeof(GridSync), h->stream));
+  hipLaunchKernelGGL(xcd_register_kernel, dim3(h->coop_grid), dim3(TPB), 0, h->stream, h->gsync);
+  HIP_TRY(hipGetLastError());
+  GridSync host;
+  HIP_TRY(hipMemcpyAsync(&host, h->gsync, sizeof(GridSync), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  unsigned long long total = 0;
+  h->coop_nxcd = 0;
+  for (int x = 0; x < 8; ++x) { total += host.xcd_count[x][0]; h->coop_nxcd += host.xcd_count[x][0] > 0; }
+  if (total != (unsigned long long)h->coop_grid || h->coop_nxcd == 0) {
+    h->coop_mode = 0;
+    return fail(996, "one-launch trial: workgroup census does not add up");
+  }
+  if (getenv("PDHG_VERBOSE"))
+    fprintf(stderr, "[pdhg_hip] one-launch trial: %d workgroups (%d per CU possible) on %u XCDs, %d + %d / %d + %d row blocks + long chunks\n",
+            h->coop_grid, per_cu, h->coop_nxcd, h->A.grid, h->A.nchunks, h->At.grid, h->At.nchunks);
+  return 0;
+}
+
+TrialProduct trial_product(pdhg_handle *h, const CsrDev &D, const double *xin, const EpiArgs &e) {
+  TrialProduct P{};
+  P.M = D.view();
+  P.blks = D.blks; P.nblk = D.nblk; P.per_xcd = D.per_xcd; P.grid = D.grid; P.remap = h->remap ? 1 : 0;
+  P.nchunks = D.nchunks; P.nlong = D.nlong; P.long_grid = D.long_grid;
+  P.chunk_row = D.chunk_row; P.chunk_off = D.chunk_off; P.chunk_partial = D.chunk_partial;
+  P.long_row = D.long_row; P.long_chunk_ptr = D.long_chunk_ptr;
+  P.xin = xin; P.e = e;
+  return P;
+}
+
+int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double theta, bool xbar_only, double out[5]) {
+  int rc = coop_prepare(h);
+  if (rc) return rc;
+  const auto c0 = std::chrono::steady_clock::now();
+  TrialKernelArgs a{};
+  a.n = (int)h->n; a.xbar_only = xbar_only ? 1 : 0;
+  a.x = h->x; a.c = h->c; a.aty = h->aty; a.lb = h->lb; a.ub = h->ub;
+  a.tau = step_size / primal_weight; a.theta = theta;
+  a.x_next = h->x_next; a.xbar = h->xbar;
+  a.avg_w = h->pend_w; a.sum_x = (h->pend_x && !xbar_only) ? h->sum_x : nullptr;
+  EpiArgs de{};
+  de.y = h->y; de.b = h->b; de.y_next = h->y_next; de.sigma = primal_weight * step_size; de.num_eq = (int)h->num_eq;
+  de.partials = h->pA; de.stride = h->A.slots();
+  if (h->pend_y) { de.sum_y = h->sum_y; de.avg_w = h->pend_w; }
+  a.A = trial_product(h, h->A, h->xbar, de);
+  EpiArgs te{};
+  te.x = h->x; te.x_next = h->x_next; te.aty = h->aty; te.aty_next = h->aty_next;
+  te.partials = h->pAt; te.stride = h->pAt_stride;
+  a.T = trial_product(h, h->At, h->y_next, te);
+  a.sp.ptr[0] = h->pAt;                       a.sp.count[0] = h->At.slots();
+  a.sp.ptr[1] = h->pAt + h->pAt_stride;       a.sp.count[1] = h->At.slots();
+  a.sp.ptr[2] = h->pA;                        a.sp.count[2] = h->A.slots();
+  a.sp.ptr[3] = h->pAt + 2 * h->pAt_stride;   a.sp.count[3] = h->At.slots();
+  a.sp.ptr[4] = h->pQ;                        a.sp.count[4] = 0;
+  a.sp.out = nullptr;
+  a.seq_dev = h->seq_dev; a.res_host = h->res_host; a.sync = h->gsync;
+  a.launch = h->coop_launches; a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
+  h->coop_launches += 1;
+  h->seq_expected += 1;
+  const auto c1 = std::chrono::steady_clock::now();
+  hipLaunchKernelGGL(trial_kernel, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  const auto c2 = std::chrono::steady_clock::now();
+  h->t_set += std::chrono::duration<double>(c1 - c0).count();
+  h->t_launch += std::chrono::duration<double>(c2 - c1).count();
+  h->n_graph_trials += 1;
+  if (!xbar_only) h->pend_x = false;
+  h->pend_y = false;                  // the launch carries the deferred average update
+  rc = wait_result_word(h, out);
+  h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
+  if (rc) return rc;
+  if (h->res_host[6] != 0.0) {
+    h->coop_mode = 0;                 // the barrier counters are out of step now: never again on this handle
+    return fail(996, "one-launch trial: a grid barrier timed out (are all workgroups co-resident? is the device shared?); "
+                     "set PDHG_COOP=0 to use the graph path");
+  }
+  return 0;
 }
 
 bool graph_eligible(pdhg_handle *h) {
@@ -460,11 +608,11 @@ struct GraphArgs {
 // nodes of one fused SpMV: stream kernel (one node) or its column-slab passes (a chain),
 // beside the long-row pair.  `done` receives the nodes the next stage must wait for;
 // main_node / long_node (optional) receive the nodes that carry the epilogue's scalars.
-template <int MODE>
+template <int MODE, int TAG>
 int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const double *xin, const EpiArgs &e,
                    const std::vector<hipGraphNode_t> &deps, std::vector<hipGraphNode_t> &done,
                    hipGraphNode_t *main_node, hipGraphNode_t *long_node) {
-  const int rm = h->remap ? 1 : 0;
+  const int rm = h->remap ? 1 : 0, rx = h->relaxed ? 1 : 0;
   if (!D.slabs.empty()) {
     const int P = (int)D.slabs.size();
     std::vector<hipGraphNode_t> prev = deps;
@@ -475,14 +623,14 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
         EpiArgs pe{};
         pe.out = D.slab_partial;
         pe.init = D.slab_partial;
-        const void *fn = p == 0 ? (const void *)spmv_stream_kernel<MODE_PLAIN, false> : (const void *)spmv_stream_kernel<MODE_PLAIN, true>;
+        const void *fn = p == 0 ? (const void *)spmv_stream_kernel<MODE_PLAIN, false, TAG> : (const void *)spmv_stream_kernel<MODE_PLAIN, true, TAG>;
         HIP_TRY(graph_add_kernel(graph, &nd, prev, fn, dim3(S.grid), dim3(TPB), S.view(D.rows), xin, (const int2 *)S.blks,
-                                 S.nblk, S.per_xcd, rm, pe));
+                                 S.nblk, S.per_xcd, rm, rx, pe));
       } else {
         EpiArgs le = e;
         le.init = D.slab_partial;
-        HIP_TRY(graph_add_kernel(graph, &nd, prev, (const void *)spmv_stream_kernel<MODE, true>, dim3(S.grid), dim3(TPB),
-                                 S.view(D.rows), xin, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, le));
+        HIP_TRY(graph_add_kernel(graph, &nd, prev, (const void *)spmv_stream_kernel<MODE, true, TAG>, dim3(S.grid), dim3(TPB),
+                                 S.view(D.rows), xin, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, rx, le));
         if (main_node) *main_node = nd;
       }
       prev.assign(1, nd);
@@ -490,14 +638,14 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
     done.push_back(prev[0]);
   } else if (D.grid > 0) {
     hipGraphNode_t nd = nullptr;
-    HIP_TRY(graph_add_kernel(graph, &nd, deps, (const void *)spmv_stream_kernel<MODE, false>, dim3(D.grid), dim3(TPB),
-                             D.view(), xin, (const int2 *)D.blks, D.nblk, D.per_xcd, rm, e));
+    HIP_TRY(graph_add_kernel(graph, &nd, deps, (const void *)spmv_stream_kernel<MODE, false, TAG>, dim3(D.grid), dim3(TPB),
+                             D.view(), xin, (const int2 *)D.blks, D.nblk, D.per_xcd, rm, rx, e));
     if (main_node) *main_node = nd;
     done.push_back(nd);
   }
   if (D.nlong > 0) {
     hipGraphNode_t part = nullptr, fin = nullptr;
-    HIP_TRY(graph_add_kernel(graph, &part, deps, (const void *)spmv_long_partial_kernel, dim3(D.nchunks), dim3(TPB),
+    HIP_TRY(graph_add_kernel(graph, &part, deps, (const void *)spmv_long_partial_kernel<TAG>, dim3(D.nchunks), dim3(TPB),
                              D.view(), xin, (const int *)D.chunk_row, (const int *)D.chunk_off, D.chunk_partial));
     HIP_TRY(graph_add_kernel(graph, &fin, {part}, (const void *)spmv_long_final_kernel<MODE>, dim3(D.long_grid), dim3(TPB),
                              (const int *)D.long_row, (const int *)D.long_chunk_ptr, D.nlong,
@@ -511,17 +659,17 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
 // the dual stream node's parameters again, with a new sigma
 int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &dual_epi) {
   const CsrDev &A = h->A;
-  const int rm = h->remap ? 1 : 0;
+  const int rm = h->remap ? 1 : 0, rx = h->relaxed ? 1 : 0;
   if (G.n_dual) {
     if (!A.slabs.empty()) {
       const SlabDev &S = A.slabs.back();
       EpiArgs le = dual_epi;
       le.init = A.slab_partial;
-      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, true>, dim3(S.grid), dim3(TPB),
-                               S.view(A.rows), (const double *)h->xbar, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, le));
+      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, true, 0>, dim3(S.grid), dim3(TPB),
+                               S.view(A.rows), (const double *)h->xbar, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, rx, le));
     } else {
-      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, false>, dim3(A.grid), dim3(TPB),
-                               A.view(), (const double *)h->xbar, (const int2 *)A.blks, A.nblk, A.per_xcd, rm, dual_epi));
+      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, false, 0>, dim3(A.grid), dim3(TPB),
+                               A.view(), (const double *)h->xbar, (const int2 *)A.blks, A.nblk, A.per_xcd, rm, rx, dual_epi));
     }
   }
   if (G.n_dual_long)
@@ -533,13 +681,8 @@ int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &du
 
 int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double theta, double sigma) {
   graph_destroy(G);
-  if (!h->seq_dev) {
-    HIP_TRY(hipMalloc((void **)&h->seq_dev, sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(h->seq_dev, 0, sizeof(unsigned long long), nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));   // the null stream does not order against h->stream
-    HIP_TRY(hipHostMalloc((void **)&h->res_host, 8 * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
-    for (int q = 0; q < 8; ++q) h->res_host[q] = 0.0;
-  }
+  int rcw = ensure_result_word(h);
+  if (rcw) return rcw;
   HIP_TRY(hipGraphCreate(&G.graph, 0));
   GraphArgs a(h, sigma);
   const double *nullq = nullptr;
@@ -552,7 +695,7 @@ int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double t
   // chain) and the long-row pair are independent branches
   std::vector<hipGraphNode_t> dual_done, aty_done;
   {
-    int rc = graph_add_spmv<MODE_DUAL>(h, G.graph, h->A, h->xbar, a.dual_epi, {G.n_primal}, dual_done, &G.n_dual, &G.n_dual_long);
+    int rc = graph_add_spmv<MODE_DUAL, 0>(h, G.graph, h->A, h->xbar, a.dual_epi, {G.n_primal}, dual_done, &G.n_dual, &G.n_dual_long);
     if (rc) return rc;
   }
   if (dual_done.empty()) dual_done.push_back(G.n_primal);
@@ -562,7 +705,7 @@ int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double t
   te.x = h->x; te.x_next = h->x_next; te.aty = h->aty; te.aty_next = h->aty_next;
   te.partials = h->pAt; te.stride = h->pAt_stride;
   {
-    int rc = graph_add_spmv<MODE_ATY>(h, G.graph, T, h->y_next, te, dual_done, aty_done, nullptr, nullptr);
+    int rc = graph_add_spmv<MODE_ATY, 1>(h, G.graph, T, h->y_next, te, dual_done, aty_done, nullptr, nullptr);
     if (rc) return rc;
   }
   if (aty_done.empty()) aty_done = dual_done;
@@ -622,24 +765,9 @@ int graph_trial(pdhg_handle *h, double step_size, double primal_weight, double t
   h->t_launch += std::chrono::duration<double>(c2 - c1).count();
   h->n_graph_trials += 1;
   h->pend_x = h->pend_y = false;     // the launch carries the deferred average update
-  // wait for this launch's sequence number in pinned memory (bounded spin, then the stream)
-  const double want = (double)h->seq_expected;
-  bool seen = false;
-  for (long spin = 0; spin < 40000000L; ++spin) {
-    if (h->res_host[7] == want) { seen = true; break; }
-    if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
-  }
-  if (!seen) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->res_host[7] != want) {
-      h->seq_expected = (unsigned long long)h->res_host[7];   // resynchronise: the next launch can succeed
-      return fail(998, "trial graph finished without publishing its results");
-    }
-  }
+  int rcw = wait_result_word(h, out);
   h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
-  for (int q = 0; q < 5; ++q) out[q] = h->res_host[q];
-  out[4] *= 0.5;
-  return 0;
+  return rcw;
 }
 
 int check_handle(pdhg_handle *h) {
@@ -970,6 +1098,8 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   h->cn = n; h->n_alloc = n_alloc; h->m_global = m;
   const char *env = getenv("PDHG_XCD_REMAP");
   h->remap = !(env && env[0] == '0');
+  env = getenv("PDHG_ROW_ORDER");         // strict: every row sum strictly left to right; relaxed (default): long rows wave-parallel
+  h->relaxed = !(env && !strcmp(env, "strict"));
   env = getenv("PDHG_LAZY_ACCEPT");       // 0: pdhg_accept runs K7 itself (one more launch and n + m more words per iteration)
   h->lazy_accept = !(env && env[0] == '0');
   if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
@@ -979,9 +1109,9 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     h->own_stream = true;
   }
 #define CK(expr) do { int _rc = (expr); if (_rc) { destroy_shard(h); return _rc; } } while (0)
-  CK(build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, choose_tile_cols(n, nnz, m)));
+  CK(build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, choose_tile_cols(n, nnz, m), h->relaxed));
   const auto t_a = now();
-  CK(build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, choose_tile_cols(m, nnz, n)));
+  CK(build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, choose_tile_cols(m, nnz, n), h->relaxed));
   const auto t_at = now();
   if (verbose)
     fprintf(stderr, "pdhg_create: CSC -> CSR(A), CSR(A') %.2fs; layouts + upload A %.2fs, A' %.2fs\n",
@@ -1039,6 +1169,7 @@ void destroy_shard(pdhg_handle *h) {
   for (hipEvent_t ev : h->ev_part) if (ev) (void)hipEventDestroy(ev);
   if (h->ev_comm) (void)hipEventDestroy(h->ev_comm);
   if (h->seq_dev) (void)hipFree(h->seq_dev);
+  if (h->gsync) (void)hipFree(h->gsync);
   if (h->res_host) (void)hipHostFree((void *)h->res_host);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1682,6 +1813,7 @@ int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight, doub
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
+  if (!L.g && coop_eligible(h)) return coop_trial(h, step_size, primal_weight, theta, true, out);   // Malitsky-Pock retries: xbar + the dual half
   if (L.g && L.g->pool && !L.p[0]->profile) return trial_group_mt(L, TrialArgs{step_size, primal_weight, theta, false}, out);
   FOR_SHARDS(L, s) { if ((rc = launch_xbar(s, theta))) return rc; }
   if (L.g) return trial_dual_group(L, step_size, primal_weight, out);
@@ -1693,6 +1825,7 @@ int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, doub
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
+  if (!L.g && coop_eligible(h)) return coop_trial(h, step_size, primal_weight, theta, false, out);
   if (!L.g && graph_eligible(h)) return graph_trial(h, step_size, primal_weight, theta, out);
   if (L.g && L.g->pool && !L.p[0]->profile) return trial_group_mt(L, TrialArgs{step_size, primal_weight, theta, true}, out);
   FOR_SHARDS(L, s) { if ((rc = launch_primal(s, step_size / primal_weight, theta, true))) return rc; }
@@ -1898,7 +2031,7 @@ int pdhg_spmv(pdhg_handle *h0, const double *x, double *out) {
   FOR_SHARDS(L, h) {
     EpiArgs e{};
     e.out = h->tmp_m;
-    if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, h->tmp_n, e))) return rc;
+    if ((rc = launch_spmv<MODE_PLAIN, 0>(h, h->A, h->tmp_n, e))) return rc;
   }
   if ((rc = rows_to_host(L, [](pdhg_handle *s) { return s->tmp_m; }, out))) return rc;
   return sync_all(L);
@@ -2011,10 +2144,10 @@ static int point_products(const Shards &L, int point) {
     const double *xfull = L.g ? h->ev_xg : h->pt_x;
     EpiArgs e{};
     e.out = h->pt_ax;
-    if ((rc = launch_spmv<MODE_PLAIN>(h, h->A, xfull, e))) return rc;
+    if ((rc = launch_spmv<MODE_PLAIN, 0>(h, h->A, xfull, e))) return rc;
     if (h->has_q) {
       e.out = h->pt_qx;
-      if ((rc = launch_spmv<MODE_PLAIN>(h, h->Q, xfull, e))) return rc;
+      if ((rc = launch_spmv<MODE_PLAIN, 2>(h, h->Q, xfull, e))) return rc;
     }
   }
   return dual_product(L, [](pdhg_handle *s) { return s->pt_y; }, [](pdhg_handle *s) { return s->pt_aty; });
@@ -2559,7 +2692,8 @@ int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps) {
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   if (!h) return fail(-1, "null handle");
   info[12] = (int64_t)h->A.slabs.size(); info[13] = (int64_t)h->At.slabs.size();
-  info[14] = graph_eligible(h) || (h->graph_mode == 1 && !h->has_q) ? 1 : 0;
+  // 2: one persistent kernel per trial (trial_kernel.hpp), 1: one graph launch, 0: separate launches
+  info[14] = (coop_eligible(h) || (h->coop_mode == 1 && !h->has_q)) ? 2 : ((graph_eligible(h) || (h->graph_mode == 1 && !h->has_q)) ? 1 : 0);
   info[15] = (h->A.tiled && h->A.var_tiles ? 1 : 0) + (h->At.tiled && h->At.var_tiles ? 2 : 0);
   info[0] = h->A.nblk; info[1] = h->A.nlong; info[2] = h->A.nchunks; info[3] = h->A.max_row_nnz;
   info[4] = h->At.nblk; info[5] = h->At.nlong; info[6] = h->At.nchunks; info[7] = h->At.max_row_nnz;

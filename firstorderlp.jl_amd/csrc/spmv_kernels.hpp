@@ -93,53 +93,74 @@ struct ModeNQ { static constexpr int value = (MODE == MODE_PLAIN) ? 0 : (MODE ==
 // stays L2-resident on every XCD (the kernel boundary is the chip-wide synchronisation
 // the tiled sweep cannot afford), and the rows still receive their products strictly
 // left to right, so the result is bit-identical to the single pass.
-template <int MODE, bool INIT = false>
-__global__ __launch_bounds__(TPB) void spmv_stream_kernel(
-    CsrView A, const double *__restrict__ xin, const int2 *__restrict__ blks,
-    int nblk, int per_xcd, int remap, EpiArgs e) {
-  __shared__ double prod[BLOCK_NNZ];
-  __shared__ double red[3][TPB / WAVE];
-  const int b = blockIdx.x;
-  const int blk = remap ? ((b & (NUM_XCD - 1)) * per_xcd + (b >> 3)) : b;
-  double acc[3] = {0.0, 0.0, 0.0};
-  const bool active = remap ? ((b >> 3) < per_xcd && blk < nblk) : (blk < nblk);
-  if (active) {
-    const int2 rr = blks[blk];
-    const int r0 = rr.x, r1 = rr.y;
-    const int k0 = A.rowptr[r0];
-    const int k1 = A.rowptr[r1];
-    const int tid = threadIdx.x;
-    int cidx[UNROLL];
-    double v[UNROLL];
-    double xv[UNROLL];
+// One row block of the stream layout, in two halves so that the one-launch trial kernel
+// (trial_kernel.hpp) can issue the first half -- which reads only the static matrix -- BEFORE
+// the grid barrier that delivers the gathered vector.
+struct StreamRegs {
+  int r0, r1, k0, k1;
+  int cidx[UNROLL];
+  double v[UNROLL];
+};
+
+// first half: the block's extent and its (col, val) entries, UNROLL independent coalesced
+// non-temporal loads per lane
+__device__ __forceinline__ void stream_block_load(const CsrView &A, int2 rr, StreamRegs &g) {
+  g.r0 = rr.x; g.r1 = rr.y;
+  g.k0 = A.rowptr[g.r0];
+  g.k1 = A.rowptr[g.r1];
+  const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) {
-      const int k = k0 + tid + i * TPB;
-      const bool ok = k < k1;
-      cidx[i] = ok ? __builtin_nontemporal_load(A.col + k) : 0;
-      v[i] = ok ? __builtin_nontemporal_load(A.val + k) : 0.0;
-    }
+  for (int i = 0; i < UNROLL; ++i) {
+    const int k = g.k0 + tid + i * TPB;
+    const bool ok = k < g.k1;
+    g.cidx[i] = ok ? __builtin_nontemporal_load(A.col + k) : 0;
+    g.v[i] = ok ? __builtin_nontemporal_load(A.val + k) : 0.0;
+  }
+}
+
+// Rows of more than this many entries are summed by a whole wave in relaxed-order mode
+constexpr int RELAXED_MIN_ROW = 64;
+
+// second half: gathers, products into LDS, per-row sums, fused epilogue.  acc[] receives this
+// thread's contributions to the block partials.
+// relaxed == 0 (PDHG_ROW_ORDER=strict): every row is added strictly left to right by one lane.
+// relaxed != 0 (default): rows of more than RELAXED_MIN_ROW entries are summed by their whole wave --
+// lane l adds products l, l + 64, ... in ascending order, then a shuffle tree -- a fixed order
+// (bitwise reproducible), but not the sequential one: |result - sequential| <= 1e-13 * sum |a x|,
+// the bar the rows beyond BLOCK_NNZ have always had.  The row stays OWNED by the lane that
+// would have added it (epilogue, partial sums): nothing else changes.
+template <int MODE, bool INIT>
+__device__ __forceinline__ void stream_block_finish(const CsrView &A, const double *xin, const StreamRegs &g,
+                                                    const EpiArgs &e, int relaxed, double (&acc)[3], double *prod) {
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1);
+  const int k0 = g.k0, k1 = g.k1;
+  double xv[UNROLL];
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) {
-      const int k = k0 + tid + i * TPB;
-      xv[i] = (k < k1) ? xin[cidx[i]] : 0.0;
-    }
+  for (int i = 0; i < UNROLL; ++i) {
+    const int k = k0 + tid + i * TPB;
+    xv[i] = (k < k1) ? xin[g.cidx[i]] : 0.0;
+  }
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) {
-      const int k = tid + i * TPB;
-      if (k0 + k < k1) prod[k] = v[i] * xv[i];
-    }
-    __syncthreads();
-    for (int r = r0 + tid; r < r1; r += TPB) {
-      const int ks = A.rowptr[r] - k0;
-      const int ke = A.rowptr[r + 1] - k0;
-      double s = INIT ? e.init[r] : 0.0;
+  for (int i = 0; i < UNROLL; ++i) {
+    const int k = tid + i * TPB;
+    if (k0 + k < k1) prod[k] = g.v[i] * xv[i];
+  }
+  __syncthreads();
+  for (int base = g.r0; base < g.r1; base += TPB) {     // workgroup-uniform trip count (the wave sums below need all lanes)
+    const int r = base + tid;
+    const bool have = r < g.r1;
+    const int ks = have ? A.rowptr[r] - k0 : 0;
+    const int ke = have ? A.rowptr[r + 1] - k0 : 0;
+    double s = (INIT && have) ? e.init[r] : 0.0;
+    const bool wide = relaxed && (ke - ks > RELAXED_MIN_ROW);
+    if (have && !wide) {
       int k = ks;
       // Adds strictly left to right (bit-exact order).  A row of hundreds of
       // products (hub rows, dense feature columns) is one dependent chain on one
       // lane, so its LDS reads are software-pipelined: the next 8 products are
       // requested before the current 8 are added, which leaves the chain at the
-      // latency of the adds alone (L1-SVM A': 29.8 -> see profiles/r02).
+      // latency of the adds alone.
       if (k + 8 <= ke) {
 #define LD8(p, q) const double p##0 = prod[q], p##1 = prod[(q) + 1], p##2 = prod[(q) + 2], p##3 = prod[(q) + 3], \
                                p##4 = prod[(q) + 4], p##5 = prod[(q) + 5], p##6 = prod[(q) + 6], p##7 = prod[(q) + 7]
@@ -170,8 +191,41 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
 #undef ADD8
       }
       for (; k < ke; ++k) s = s + prod[k];
-      row_epilogue<MODE>(e, r, s, acc);
     }
+    if (relaxed) {
+      unsigned long long todo = __ballot(wide);
+      while (todo) {                                   // wave-uniform
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int lks = __shfl(ks, l, WAVE), lke = __shfl(ke, l, WAVE);
+        double part = 0.0;
+        for (int k = lks + lane; k < lke; k += WAVE) part = part + prod[k];
+        part = wave_sum(part);                          // fixed shuffle tree; lane 0 holds the total
+        const double total = __shfl(part, 0, WAVE);
+        if (lane == l) s = s + total;
+      }
+    }
+    if (have) row_epilogue<MODE>(e, r, s, acc);
+  }
+}
+
+// TAG names the product in profiler output (0: the constraint matrix A, 1: its transpose,
+// 2: the objective matrix): the MODE_PLAIN passes of a slab layout and the evaluation
+// products would otherwise share one kernel name for both products.
+template <int MODE, bool INIT = false, int TAG = 0>
+__global__ __launch_bounds__(TPB) void spmv_stream_kernel(
+    CsrView A, const double *__restrict__ xin, const int2 *__restrict__ blks,
+    int nblk, int per_xcd, int remap, int relaxed, EpiArgs e) {
+  __shared__ double prod[BLOCK_NNZ];
+  __shared__ double red[3][TPB / WAVE];
+  const int b = blockIdx.x;
+  const int blk = remap ? ((b & (NUM_XCD - 1)) * per_xcd + (b >> 3)) : b;
+  double acc[3] = {0.0, 0.0, 0.0};
+  const bool active = remap ? ((b >> 3) < per_xcd && blk < nblk) : (blk < nblk);
+  if (active) {
+    StreamRegs g;
+    stream_block_load(A, blks[blk], g);
+    stream_block_finish<MODE, INIT>(A, xin, g, e, relaxed, acc, prod);
   }
   constexpr int NQ = ModeNQ<MODE>::value;
   if (NQ > 0) {
@@ -279,7 +333,55 @@ __device__ __forceinline__ void tiled_chunk_scratch(double *acc, double *scratch
   }
 }
 
-template <int MODE, bool SCR>
+// Relaxed-order variant (PDHG_ROW_ORDER=relaxed, the default): same-row runs of up to
+// TW_STRICT_RUN entries inside a chunk are still added strictly left to right by the run
+// head (so rows whose entries scatter over the tiles -- every row of a random LP -- stay
+// bit-identical to the CPU loops); when a chunk holds a longer run (hub rows, dense blocks)
+// the whole chunk is reduced by a segmented shuffle tree instead: log2(64) steps whatever
+// the run lengths, a fixed order (reproducible), |result - sequential| <= 1e-13 * sum |a x|.
+// This is what lets matrices with hub rows use the sweep at all: in strict order one lane adds
+// a 1 500-entry row's ~90 products per tile one after the other.
+constexpr int TW_STRICT_RUN = 8;
+__device__ __forceinline__ void tiled_chunk_relaxed(double *acc, unsigned p, double v, double xv,
+                                                    int tile_shift, int lane) {
+  const bool valid = p != TW_PAD;
+  // padding lanes get pairwise different pseudo-rows (no real row_local reaches 0xFFFFFF00: it is < 2^31)
+  const unsigned row = valid ? (p >> tile_shift) : (0xFFFFFF00u | (unsigned)lane);
+  const double prod = v * xv;
+  const unsigned rowp = __shfl_up(row, 1, WAVE);
+  const bool head = valid && (lane == 0 || rowp != row);
+  const unsigned long long hmask = __ballot(head);
+  const unsigned long long vmask = __ballot(valid);
+  const unsigned long long above = (lane == WAVE - 1) ? 0ull : (hmask >> (lane + 1));
+  const int nvalid = __popcll(vmask);                                   // valid lanes are a prefix
+  const int len = head ? (above ? __ffsll((long long)above) : (nvalid - lane)) : 0;
+  if (!__any(len > TW_STRICT_RUN)) {
+    double s = head ? acc[row] : 0.0;
+    for (int j = 0; j <= TW_STRICT_RUN; ++j) {
+      const double pj = __shfl_down(prod, j, WAVE);
+      const unsigned rj = __shfl_down(row, j, WAVE);
+      const bool take = head && (lane + j < WAVE) && (rj == row);
+      if (!__any(take)) break;
+      if (take) s = s + pj;
+    }
+    if (head) acc[row] = s;
+    return;
+  }
+  double val = valid ? prod : 0.0;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const unsigned rd = __shfl_down(row, d, WAVE);
+    const double vd = __shfl_down(val, d, WAVE);
+    const bool same = (lane + d < WAVE) && (rd == row);
+    if (!__any(same)) break;             // runs are contiguous: none at distance d, none beyond
+    if (same) val = val + vd;
+  }
+  if (head) acc[row] = acc[row] + val;
+}
+
+// CH: how a 64-entry chunk is accumulated -- 0 lane shuffles (strict order), 1 LDS scratch
+// (strict order, long runs), 2 relaxed (see tiled_chunk_relaxed)
+template <int MODE, int CH>
 __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
     const int2 *__restrict__ wave_rows, const int *__restrict__ step_ptr,
     const int *__restrict__ wave_step_off, const int *__restrict__ step_tile,
@@ -294,7 +396,7 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   double(*red)[TW_WPB] = reinterpret_cast<double(*)[TW_WPB]>(tw_lds + TW_WPB * TW_ROWS);
   const int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x / WAVE;
-  double *scratch = tw_lds + TW_WPB * TW_ROWS + 3 * TW_WPB + wid * WAVE;   // SCR only: 64 doubles per wave
+  double *scratch = tw_lds + TW_WPB * TW_ROWS + 3 * TW_WPB + wid * WAVE;   // CH == 1 only: 64 doubles per wave
   const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * TW_WPB + wid);
   const bool live = w < nwaves;
   double acc3[3] = {0.0, 0.0, 0.0};
@@ -374,7 +476,8 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
 #pragma unroll
         for (int i = 0; i < U; ++i) {
           if (ks[s] + i * WAVE < ke[s]) {  // wave-uniform
-            if (SCR) tiled_chunk_scratch(acc, scratch, p[s][i], v[s][i], xv[i], tile_shift, lane);
+            if (CH == 1) tiled_chunk_scratch(acc, scratch, p[s][i], v[s][i], xv[i], tile_shift, lane);
+            else if (CH == 2) tiled_chunk_relaxed(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
             else tiled_chunk(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
           }
         }
@@ -384,7 +487,8 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
           const unsigned pp = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
           const double vv = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
           const double xx = ok ? xt[pp & cmask] : 0.0;
-          if (SCR) tiled_chunk_scratch(acc, scratch, pp, vv, xx, tile_shift, lane);
+          if (CH == 1) tiled_chunk_scratch(acc, scratch, pp, vv, xx, tile_shift, lane);
+          else if (CH == 2) tiled_chunk_relaxed(acc, pp, vv, xx, tile_shift, lane);
           else tiled_chunk(acc, pp, vv, xx, tile_shift, lane);
         }
         // 4. pacing barrier: keep the workgroup inside one column tile
@@ -407,14 +511,10 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
 }
 
 // Rows longer than BLOCK_NNZ: split into LONG_CHUNK pieces, one workgroup
-// each (tree sum inside the chunk), partial per chunk.
-__global__ __launch_bounds__(TPB) void spmv_long_partial_kernel(
-    CsrView A, const double *__restrict__ xin, const int *__restrict__ chunk_row,
-    const int *__restrict__ chunk_off, double *__restrict__ chunk_partial) {
-  __shared__ double red[3][TPB / WAVE];
-  const int c = blockIdx.x;
-  const int r = chunk_row[c];
-  const int kbeg = A.rowptr[r] + chunk_off[c];
+// each (tree sum inside the chunk), partial per chunk.  Thread 0 returns the chunk's sum.
+__device__ __forceinline__ double long_chunk_body(const CsrView &A, const double *xin, int r, int off,
+                                                  double (*red)[TPB / WAVE]) {
+  const int kbeg = A.rowptr[r] + off;
   const int kend = min(kbeg + LONG_CHUNK, A.rowptr[r + 1]);
   double acc[3] = {0.0, 0.0, 0.0};
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -436,18 +536,27 @@ __global__ __launch_bounds__(TPB) void spmv_long_partial_kernel(
   for (; k < kend; k += TPB) s0 += A.val[k] * xin[A.col[k]];
   acc[0] = (s0 + s1) + (s2 + s3);
   block_sum<1, TPB>(acc, red);
-  if (threadIdx.x == 0) chunk_partial[c] = acc[0];
+  return acc[0];
 }
 
-// One lane per long row: add the chunk partials in order, run the epilogue.
-template <int MODE>
-__global__ __launch_bounds__(TPB) void spmv_long_final_kernel(
-    const int *__restrict__ long_row, const int *__restrict__ long_chunk_ptr,
-    int nlong, const double *__restrict__ chunk_partial, EpiArgs e,
-    int slot_base) {
+template <int TAG = 0>
+__global__ __launch_bounds__(TPB) void spmv_long_partial_kernel(
+    CsrView A, const double *__restrict__ xin, const int *__restrict__ chunk_row,
+    const int *__restrict__ chunk_off, double *__restrict__ chunk_partial) {
   __shared__ double red[3][TPB / WAVE];
+  const int c = blockIdx.x;
+  const double s = long_chunk_body(A, xin, chunk_row[c], chunk_off[c], red);
+  if (threadIdx.x == 0) chunk_partial[c] = s;
+}
+
+// One lane per long row: add the chunk partials in order, run the epilogue.  `lb` is the
+// block of TPB long rows this workgroup handles; its block partials go to slot_base + lb.
+template <int MODE>
+__device__ __forceinline__ void long_final_body(int lb, const int *long_row, const int *long_chunk_ptr, int nlong,
+                                                const double *chunk_partial, const EpiArgs &e, int slot_base,
+                                                double (*red)[TPB / WAVE]) {
   double acc[3] = {0.0, 0.0, 0.0};
-  const int l = blockIdx.x * TPB + threadIdx.x;
+  const int l = lb * TPB + threadIdx.x;
   if (l < nlong) {
     double s = 0.0;
     int c = long_chunk_ptr[l];
@@ -468,9 +577,18 @@ __global__ __launch_bounds__(TPB) void spmv_long_final_kernel(
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        e.partials[q * e.stride + slot_base + blockIdx.x] = acc[q];
+        e.partials[q * e.stride + slot_base + lb] = acc[q];
     }
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TPB) void spmv_long_final_kernel(
+    const int *__restrict__ long_row, const int *__restrict__ long_chunk_ptr,
+    int nlong, const double *__restrict__ chunk_partial, EpiArgs e,
+    int slot_base) {
+  __shared__ double red[3][TPB / WAVE];
+  long_final_body<MODE>(blockIdx.x, long_row, long_chunk_ptr, nlong, chunk_partial, e, slot_base, red);
 }
 
 }  // namespace

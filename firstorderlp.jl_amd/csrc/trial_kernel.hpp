@@ -1,0 +1,230 @@
+// trial_kernel.hpp -- part of the single translation unit pdhg_hip.hip (included there, in order).
+// One PDHG trial step (pdhg.jl:442-549: K1+K2, K3+K4, K5+K6, second-stage reduction) as ONE
+// kernel launch for stream-layout LPs: persistent workgroups, two grid-wide barriers.
+//
+// Why: on small / medium LPs a trial is latency, not bandwidth.  As a HIP graph (round 2) the
+// L1-SVM LP's iteration was 47 us of kernels + ~15 us of launch / dependency latency between
+// the 6-10 nodes + 28 us of host time inside hipGraphLaunch.  Here the chain is one launch,
+// the barriers cost 4-5 us each, and -- what only a fused kernel can do -- every workgroup
+// requests its first row block's (col, val) entries BEFORE the barrier that delivers the
+// vector they will be multiplied with: the static half of the SpMV's dependent memory chain
+// (block descriptor -> row pointers -> entries) overlaps the previous phase's tail.
+// The boundary of SURVEY 8b does not move: pdhg_trial_step still returns the five sums and the
+// step-size rule stays on the host.
+//
+// The phase bodies are the SAME device functions the separate kernels run (spmv_kernels.hpp,
+// vector_kernels.hpp), every block writes the same partial slot and the second stage adds
+// them in the same order, so the results are bitwise those of the separate launches
+// (tests/test_gpu_native_take_step.py).
+//
+// Grid barrier (measured: tools/grid_barrier_probe.hip, profiles/r03_grid_barrier_probe.txt).
+// An agent-scope release / acquire on this chip writes back / invalidates the XCD's L2
+// (buffer_wbl2 sc1 / buffer_inv sc1), and when every workgroup issues its own they serialise
+// in the L2: 9.4 us per barrier for 256 workgroups, 19 us for 512, 65 us for 2048, whatever
+// the counter structure (flat, tree, per-XCD).  So the fences are scoped by hand: a
+// workgroup's stores are in its XCD's L2 once `s_waitcnt vmcnt(0)` returns (the L1 is
+// write-through); it then arrives on its XCD's counter; only the LAST arriver of the XCD writes
+// the L2 back, arrives on the global counter, waits for all 8 XCDs, invalidates the L2 and
+// releases its XCD.  3.2 / 3.8 / 5.0 / 7.4 us for 256 / 512 / 1024 / 2048 workgroups.
+// The other workgroups do NOT invalidate their CU's L1 (`buffer_inv sc0` is a no-op on this
+// chip, `sc1` would serialise in the L2 again): not needed for THIS kernel's data flow -- the
+// L1 is clean at kernel start and no address is read before the phase that produces it has
+// completed (x', xbar: written in phase 0, read from phase 1 on; y': written in phase 1, read
+// in phase 2; partial sums: read at the end only), so no CU can hold a stale line.
+// The XCD of a workgroup comes from the hardware register (XCC_ID); how many workgroups of a
+// launch land on each XCD is counted once per handle by a registration launch of the same
+// shape (the dispatcher deals workgroups round-robin; the probe saw exact, repeatable counts).
+// Every spin is bounded: a barrier that cannot complete (workgroups not co-resident because
+// the device is shared) raises the error word instead of hanging, and the host reports it.
+#pragma once
+
+namespace {
+
+struct GridSync {                           // device memory, one per handle; one 128-byte line per word
+  unsigned long long global[16];            // XCD leaders arrived (monotonic over launches)
+  unsigned long long xcd_arrive[8][16];
+  unsigned long long xcd_release[8][16];    // last completed barrier epoch of the XCD
+  unsigned long long xcd_count[8][16];      // workgroups of one launch on each XCD
+  unsigned long long ticket[3][16];         // long chunks of A done, of A' done, workgroups done
+  unsigned long long error[16];
+};
+
+__device__ __forceinline__ unsigned xcc_id() {
+  return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7;   // hwreg(HW_REG_XCC_ID, 0, 4)
+}
+
+__global__ __launch_bounds__(TPB) void xcd_register_kernel(GridSync *s) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(&s->xcd_count[xcc_id()][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr long GRID_SPIN_LIMIT = 4000000L;   // x s_sleep(1): ~0.1 s
+
+// epoch = 1, 2, ... over the life of the handle; nxcd = XCDs that hold workgroups
+__device__ __forceinline__ void grid_barrier(GridSync *s, unsigned long long epoch, unsigned nxcd) {
+  __syncthreads();       // every wave's workgroup-scope release: its stores have reached the XCD's L2
+  if (threadIdx.x == 0 && __hip_atomic_load(&s->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    const unsigned x = xcc_id();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long cnt = __hip_atomic_load(&s->xcd_count[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long prev = __hip_atomic_fetch_add(&s->xcd_arrive[x][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long spins = 0;
+    if (prev + 1 == cnt * epoch) {
+      asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&s->global[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(&s->global[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)nxcd * epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > GRID_SPIN_LIMIT) { __hip_atomic_store(&s->error[0], 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      asm volatile("buffer_inv sc1" ::: "memory");
+      __hip_atomic_store(&s->xcd_release[x][0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(&s->xcd_release[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > GRID_SPIN_LIMIT) { __hip_atomic_store(&s->error[0], 3ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    asm volatile("s_dcache_inv" ::: "memory");
+  }
+  __syncthreads();
+}
+
+// store that is visible device-wide once `s_waitcnt vmcnt(0)` has returned (write-through,
+// no L2 write-back needed): the few words a workgroup hands to a "last one finishes" ticket
+__device__ __forceinline__ void store_agent(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One fused SpMV of the trial: a stream layout (row blocks + long-row chunks) with its epilogue
+struct TrialProduct {
+  CsrView M;
+  const int2 *blks;
+  int nblk, per_xcd, grid, remap;
+  int nchunks, nlong, long_grid;
+  const int *chunk_row, *chunk_off;
+  double *chunk_partial;
+  const int *long_row, *long_chunk_ptr;
+  const double *xin;
+  EpiArgs e;
+};
+
+struct TrialKernelArgs {
+  // phase 0: K1+K2 (or xbar alone for the Malitsky-Pock retries)
+  int n, xbar_only;
+  const double *x, *c, *aty, *lb, *ub;
+  double tau, theta;
+  double *x_next, *xbar;
+  double avg_w;
+  double *sum_x;
+  TrialProduct A, T;
+  FinalSpec sp;
+  unsigned long long *seq_dev;
+  volatile double *res_host;
+  GridSync *sync;
+  unsigned long long launch;     // 0, 1, 2, ...: this handle's launches of this kernel so far
+  unsigned nxcd;
+  int relaxed;
+};
+
+__device__ __forceinline__ bool product_block_of(const TrialProduct &P, int b, int *blk) {
+  const int k = P.remap ? ((b & (NUM_XCD - 1)) * P.per_xcd + (b >> 3)) : b;
+  *blk = k;
+  return P.remap ? ((b >> 3) < P.per_xcd && k < P.nblk) : (k < P.nblk);
+}
+
+// this workgroup's share of one product: long-row chunks w, w + nwg, ... then row blocks
+// b = w, w + nwg, ... (b mod 8 == w mod 8: every XCD walks the same contiguous eighth of the row
+// blocks as in the separate launch).  `pre`: block w's entries are already in `g`.
+template <int MODE>
+__device__ __forceinline__ void product_phase(const TrialProduct &P, GridSync *s, int ticket_id, unsigned long long launch,
+                                              int relaxed, bool pre, StreamRegs &g, double *prod, double (*red)[TPB / WAVE],
+                                              bool *ran_long_final) {
+  const int w = blockIdx.x, nwg = gridDim.x;
+  __shared__ int last_flag;
+  for (int c = w; c < P.nchunks; c += nwg) {
+    __syncthreads();
+    const double part = long_chunk_body(P.M, P.xin, P.chunk_row[c], P.chunk_off[c], red);
+    if (threadIdx.x == 0) {
+      store_agent(P.chunk_partial + c, part);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long t = __hip_atomic_fetch_add(&s->ticket[ticket_id][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_flag = (t + 1 == (launch + 1) * (unsigned long long)P.nchunks);
+      if (last_flag) asm volatile("buffer_inv sc1" ::: "memory");      // every chunk's partial is in memory: read them fresh
+    }
+    __syncthreads();
+    if (last_flag) {                                                    // workgroup-uniform
+      for (int lb = 0; lb < P.long_grid; ++lb) {
+        __syncthreads();
+        long_final_body<MODE>(lb, P.long_row, P.long_chunk_ptr, P.nlong, P.chunk_partial, P.e, P.grid, red);
+      }
+      *ran_long_final = true;
+    }
+  }
+  constexpr int NQ = ModeNQ<MODE>::value;
+  for (int b = w; b < P.grid; b += nwg) {
+    __syncthreads();                   // `prod` and `red` are free again
+    int blk;
+    const bool active = product_block_of(P, b, &blk);
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (active) {
+      if (!(pre && b == w)) stream_block_load(P.M, P.blks[blk], g);
+      stream_block_finish<MODE, false>(P.M, P.xin, g, P.e, relaxed, acc, prod);
+    }
+    if (NQ > 0) {
+      block_sum<NQ, TPB>(acc, red);
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) store_agent(P.e.partials + q * P.e.stride + b, acc[q]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void trial_kernel(TrialKernelArgs a) {
+  __shared__ double prod[BLOCK_NNZ];
+  __shared__ double red[3][TPB / WAVE];
+  __shared__ int done_flag;
+  const int w = blockIdx.x, nwg = gridDim.x;
+  // ---- phase 0: x' and xbar (elementwise; any distribution over the workgroups gives the same bits)
+  if (a.xbar_only) xbar_body(a.n, a.x, a.x_next, a.theta, a.xbar, w, nwg);
+  else primal_body<false, true>(a.n, a.x, a.c, a.aty, nullptr, a.lb, a.ub, a.tau, a.theta, a.x_next, a.xbar, a.avg_w, a.sum_x, w, nwg);
+  StreamRegs g;
+  int blk;
+  bool pre = w < a.A.grid && product_block_of(a.A, w, &blk);
+  if (pre) stream_block_load(a.A.M, a.A.blks[blk], g);          // static data: requested before the barrier
+  grid_barrier(a.sync, 2 * a.launch + 1, a.nxcd);
+  // ---- phase 1: y' = proj(y + sigma (b - A xbar)), sum dy^2   (K3+K4)
+  bool long_final_A = false, long_final_T = false;
+  product_phase<MODE_DUAL>(a.A, a.sync, 0, a.launch, a.relaxed, pre, g, prod, red, &long_final_A);
+  pre = w < a.T.grid && product_block_of(a.T, w, &blk);
+  if (pre) stream_block_load(a.T.M, a.T.blks[blk], g);
+  grid_barrier(a.sync, 2 * a.launch + 2, a.nxcd);
+  // ---- phase 2: A'y' and the interaction sums   (K5+K6)
+  product_phase<MODE_ATY>(a.T, a.sync, 1, a.launch, a.relaxed, pre, g, prod, red, &long_final_T);
+  // ---- second stage: the workgroup that finishes last adds the block partials (K6b)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // this workgroup's block partials went out as write-through stores; the long-row epilogue
+    // (if it ran here) stored its own plainly: write those back before taking the ticket
+    if (long_final_T) __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t = __hip_atomic_fetch_add(&a.sync->ticket[2][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    done_flag = (t + 1 == (a.launch + 1) * (unsigned long long)nwg);
+    if (done_flag) asm volatile("buffer_inv sc1" ::: "memory");
+  }
+  __syncthreads();
+  if (done_flag) {
+    double res[5];
+    final_reduce_body<TPB / WAVE>(a.sp, res);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) a.res_host[k] = res[k];
+      a.res_host[6] = (double)__hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long sq = *a.seq_dev + 1ull;
+      *a.seq_dev = sq;
+      __threadfence_system();
+      a.res_host[7] = (double)sq;      // exact up to 2^53 launches
+    }
+  }
+}
+
+}  // namespace

@@ -30,18 +30,17 @@ __device__ __forceinline__ void primal_one(double x, double c, double aty,
   }
 }
 
+// Workgroup `bid` of `nb` (grid-stride; elementwise, so the distribution does not matter for the bits).
 template <bool HAS_Q, bool WRITE_XBAR>
-__global__ __launch_bounds__(TPB) void primal_kernel(
-    int n, const double *__restrict__ x, const double *__restrict__ c,
-    const double *__restrict__ aty, const double *__restrict__ qx,
-    const double *__restrict__ lb, const double *__restrict__ ub, double tau,
-    double theta, double *__restrict__ x_next, double *__restrict__ xbar,
-    double avg_w, double *__restrict__ sum_x) {
+__device__ __forceinline__ void primal_body(
+    int n, const double *x, const double *c, const double *aty, const double *qx,
+    const double *lb, const double *ub, double tau, double theta, double *x_next, double *xbar,
+    double avg_w, double *sum_x, int bid, int nb) {
   // sum_x != nullptr: the accept of the previous iteration left its K7 to this kernel
   // (sum_x += avg_w * x, x being the iterate accepted then; same two roundings)
   const int npair = n >> 1;
-  const int stride = gridDim.x * TPB;
-  for (int p = blockIdx.x * TPB + threadIdx.x; p < npair; p += stride) {
+  const int stride = nb * TPB;
+  for (int p = bid * TPB + threadIdx.x; p < npair; p += stride) {
     const double2 xv = reinterpret_cast<const double2 *>(x)[p];
     if (sum_x) {
       double2 sv = reinterpret_cast<double2 *>(sum_x)[p];
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(TPB) void primal_kernel(
     reinterpret_cast<double2 *>(x_next)[p] = xn;
     if (WRITE_XBAR) reinterpret_cast<double2 *>(xbar)[p] = xb;
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+  if ((n & 1) && bid == 0 && threadIdx.x == 0) {
     const int j = n - 1;
     double xn, xb;
     if (sum_x) {
@@ -75,17 +74,31 @@ __global__ __launch_bounds__(TPB) void primal_kernel(
   }
 }
 
+template <bool HAS_Q, bool WRITE_XBAR>
+__global__ __launch_bounds__(TPB) void primal_kernel(
+    int n, const double *__restrict__ x, const double *__restrict__ c,
+    const double *__restrict__ aty, const double *__restrict__ qx,
+    const double *__restrict__ lb, const double *__restrict__ ub, double tau,
+    double theta, double *__restrict__ x_next, double *__restrict__ xbar,
+    double avg_w, double *__restrict__ sum_x) {
+  primal_body<HAS_Q, WRITE_XBAR>(n, x, c, aty, qx, lb, ub, tau, theta, x_next, xbar, avg_w, sum_x, blockIdx.x, gridDim.x);
+}
+
 // xbar = x' + theta*(x' - x) on its own (Malitsky-Pock retries, pdhg.jl:590-601)
-__global__ __launch_bounds__(TPB) void xbar_kernel(int n, const double *__restrict__ x,
-                                                   const double *__restrict__ x_next,
-                                                   double theta, double *__restrict__ xbar) {
-  const int stride = gridDim.x * TPB;
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) {
+__device__ __forceinline__ void xbar_body(int n, const double *x, const double *x_next, double theta, double *xbar,
+                                          int bid, int nb) {
+  const int stride = nb * TPB;
+  for (int j = bid * TPB + threadIdx.x; j < n; j += stride) {
     const double v = x_next[j];
     const double d = v - x[j];
     const double t = theta * d;
     xbar[j] = v + t;
   }
+}
+__global__ __launch_bounds__(TPB) void xbar_kernel(int n, const double *__restrict__ x,
+                                                   const double *__restrict__ x_next,
+                                                   double theta, double *__restrict__ xbar) {
+  xbar_body(n, x, x_next, theta, xbar, blockIdx.x, gridDim.x);
 }
 
 // dx = x' - x  (for the QP interaction term 0.5*dx'Q dx, pdhg.jl:536-541)
@@ -164,33 +177,35 @@ struct FinalSpec {
   int count[5];
   double *out;     // 5 doubles (host-mapped or device)
 };
-// The five sums in parallel: quantity q is summed by waves 3q..3q+2 (192 threads; fixed
-// order: strided per-thread sums, wave shuffle tree, then the three wave totals left to
-// right).  Thread 0 ends with all five in res[]; both final kernels (device result,
-// host-polled result of the trial graph) share it, so the two launch paths agree bitwise.
+// The five sums: quantity q is summed by three "virtual waves" 3q..3q+2 (fixed order:
+// strided per-lane sums, wave shuffle tree, then the three wave totals left to right).  A
+// workgroup of NW waves runs virtual wave v on wave v mod NW: the separate final kernels have
+// 16 waves (one virtual wave each), the one-launch trial kernel 4 -- the arithmetic, hence the
+// bits, are the same.  Thread 0 ends with all five in res[].
+template <int NW>
 __device__ __forceinline__ void final_reduce_body(const FinalSpec &sp, double (&res)[5]) {
   __shared__ double wsum[16];
   const int wid = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  const int q = wid / 3, sub = wid % 3;
-  double acc = 0.0;
-  if (q < 5) {
+  for (int v = wid; v < 15; v += NW) {
+    const int q = v / 3, sub = v % 3;
+    double acc = 0.0;
     const double *p = sp.ptr[q];
     const int cnt = sp.count[q];
     // eight loads in flight per lane (the partials come from other CUs' stores: every one is a
     // trip to memory), added in the same ascending order as a plain loop would
     for (int i0 = sub * WAVE + lane; i0 < cnt; i0 += 8 * 3 * WAVE) {
-      double v[8];
+      double t[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * 3 * WAVE;
-        v[u] = i < cnt ? p[i] : 0.0;
+        t[u] = i < cnt ? p[i] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (i0 + u * 3 * WAVE < cnt) acc += v[u];
+        if (i0 + u * 3 * WAVE < cnt) acc += t[u];
     }
     acc = wave_sum(acc);
-    if (lane == 0) wsum[wid] = acc;
+    if (lane == 0) wsum[v] = acc;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -201,7 +216,7 @@ __device__ __forceinline__ void final_reduce_body(const FinalSpec &sp, double (&
 
 __global__ __launch_bounds__(FINAL_TPB) void final_reduce_kernel(FinalSpec sp) {
   double res[5];
-  final_reduce_body(sp, res);
+  final_reduce_body<FINAL_TPB / WAVE>(sp, res);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) sp.out[k] = res[k];

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 LAYOUTS = {
     "plain": {"PDHG_GRAPH": "0"},
-    "graph": {"PDHG_GRAPH": "1"},
+    "graph": {"PDHG_GRAPH": "1", "PDHG_COOP": "0"},          # one HIP-graph launch per trial
+    "one_kernel": {"PDHG_GRAPH": "1", "PDHG_COOP": "1"},     # one persistent kernel per trial (trial_kernel.hpp)
     "tiled": {"PDHG_SPMV": "tiled", "PDHG_TILE_COLS": "700"},
     "python_take_step": {"PDHG_PY_TAKE_STEP": "1", "PDHG_GRAPH": "0"},
 }
@@ -27,7 +28,7 @@ MAKERS = {"random": lambda: random_lp(5000, 4001, 8, seed=7),          # odd n: 
 
 
 def _run(p, env, monkeypatch, lazy, steps=60, **kw):
-    for k in ("PDHG_GRAPH", "PDHG_SPMV", "PDHG_TILE_COLS", "PDHG_SLAB_MB", "PDHG_PY_TAKE_STEP"):
+    for k in ("PDHG_GRAPH", "PDHG_COOP", "PDHG_SPMV", "PDHG_TILE_COLS", "PDHG_SLAB_MB", "PDHG_PY_TAKE_STEP"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -128,11 +129,12 @@ SCRIPTS = {
 }
 
 
-@pytest.mark.parametrize("graph", ["0", "1"])
+@pytest.mark.parametrize("graph", ["0", "1", "one_kernel"])
 @pytest.mark.parametrize("name", sorted(SCRIPTS))
 def test_lazy_accept_interleavings(gpu_required, monkeypatch, name, graph):
     p = random_lp(700, 901, 6, seed=3)
-    monkeypatch.setenv("PDHG_GRAPH", graph)
+    monkeypatch.setenv("PDHG_GRAPH", "1" if graph == "one_kernel" else graph)
+    monkeypatch.setenv("PDHG_COOP", "1" if graph == "one_kernel" else "0")
     results = []
     for lazy in ("0", "1"):
         monkeypatch.setenv("PDHG_LAZY_ACCEPT", lazy)

@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _trajectory(p, steps, monkeypatch, graph, native):
+    # graph: False = separate launches, True = one HIP-graph launch per trial, "one_kernel" = one persistent kernel
     monkeypatch.setenv("PDHG_GRAPH", "1" if graph else "0")
+    monkeypatch.setenv("PDHG_COOP", "1" if graph == "one_kernel" else "0")
     monkeypatch.setenv("PDHG_PY_TAKE_STEP", "0" if native else "1")
     eng = HipPdhgEngine.from_problem(p)
     step, pw = H.initial_step_and_weight(p)
@@ -40,13 +42,19 @@ def _trajectory(p, steps, monkeypatch, graph, native):
 def test_graph_and_native_take_step_are_bitwise_the_plain_path(gpu_required, monkeypatch, maker):
     p = maker()
     ref = _trajectory(p, 80, monkeypatch, graph=False, native=False)
-    for graph, native in ((True, False), (False, True), (True, True)):
+    for graph, native in ((True, False), (False, True), (True, True), ("one_kernel", False), ("one_kernel", True)):
         got = _trajectory(p, 80, monkeypatch, graph=graph, native=native)
+        if graph == "one_kernel":
+            monkeypatch.setenv("PDHG_GRAPH", "1")
+            monkeypatch.setenv("PDHG_COOP", "1")
+            probe = HipPdhgEngine.from_problem(p)
+            assert probe.layout_info()["trial_graph"] == 2        # the persistent-kernel path really ran
+            probe.close()
         for a, b in zip(ref, got):
             assert np.array_equal(a, b), (graph, native)
     # and the oracle, over a short free-running stretch (reduction scalars agree to 1e-12
     # per step and long rows to 1e-13, so trajectories drift apart slowly: DESIGN.md section 2)
-    short = _trajectory(p, 30, monkeypatch, graph=True, native=True)
+    short = _trajectory(p, 30, monkeypatch, graph="one_kernel", native=True)
     st = H.oracle_from_problem(p)
     step, pw = H.initial_step_and_weight(p)
     st.step_size, st.primal_weight = step, pw
