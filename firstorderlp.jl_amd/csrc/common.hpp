@@ -9,10 +9,7 @@ constexpr int WAVE = 64;
 constexpr int BLOCK_NNZ = 2048;      // products staged in LDS per workgroup (16 KiB)
 constexpr int UNROLL = BLOCK_NNZ / TPB;
 constexpr int MAX_ROWS_PER_BLOCK = 4 * TPB;
-#ifndef TWD_LONG_CHUNK   // dev builds (tools/variants.sh) may override
-#define TWD_LONG_CHUNK 8192
-#endif
-constexpr int LONG_CHUNK = TWD_LONG_CHUNK;     // nnz per workgroup for rows longer than BLOCK_NNZ
+constexpr int LONG_CHUNK = BLOCK_NNZ;   // nnz per workgroup for rows longer than BLOCK_NNZ: read like a row block (spmv_kernels.hpp)
 constexpr int NUM_XCD = 8;
 constexpr int EW_MAX_BLOCKS = 256 * 8;  // elementwise kernels: grid-stride above this
 constexpr int FINAL_TPB = 1024;

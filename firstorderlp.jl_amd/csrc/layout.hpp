@@ -24,8 +24,10 @@ struct CsrDev {
   double *val = nullptr;
   int2 *blks = nullptr;
   int nblk = 0, per_xcd = 0, grid = 0;
-  int nlong = 0, nchunks = 0, long_grid = 0;
+  int nlong = 0, nchunks = 0, long_grid = 0;      // long_grid: workgroups of the long-row final kernel (4 rows each)
   int *long_row = nullptr, *long_chunk_ptr = nullptr, *chunk_row = nullptr, *chunk_off = nullptr;
+  int *chunk_lidx = nullptr;                 // [nchunks] index of the chunk's row in long_row
+  unsigned long long *long_ticket = nullptr; // [nlong] chunks of the row completed, over all one-launch trials
   double *chunk_partial = nullptr;
   int64_t max_row_nnz = 0;
   // tiled-sweep layout (optional)
@@ -47,7 +49,7 @@ struct CsrDev {
   // stream-kernel launch per slab and `grid` is the LAST slab's grid (its blocks write the partials)
   std::vector<SlabDev> slabs;
   double *slab_partial = nullptr;   // [rows] row sums between the passes
-  int slots() const { return grid + long_grid; }
+  int slots() const { return grid + nlong; }      // block partials: one per row block, one per long row
   CsrView view() const { return CsrView{rows, rowptr, col, val}; }
 };
 
@@ -354,9 +356,10 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   {
     const char *mode_env = getenv("PDHG_SPMV");
     const bool forced = mode_env && !strcmp(mode_env, "tiled");
-    // In relaxed-order mode long runs are reduced by a shuffle tree (tiled_chunk_relaxed) and
-    // are no reason to decline.
-    if (!forced && !relaxed && max_run > 32) return 0;
+    // (Relaxed order reduces long runs with a shuffle tree -- tiled_chunk_relaxed -- but that did
+    // not make the sweep competitive either: PageRank-1M 0.168 ms swept in relaxed order against
+    // 0.104 ms streamed, profiles/r03_row_order.txt.  The rule stands in both modes.)
+    if (!forced && max_run > 32) return 0;
   }
   D.wg_first_row.resize((size_t)grid + 1);
   for (int g = 0; g < grid; ++g) D.wg_first_row[g] = wave_rows[(size_t)g * TW_WPB].x;
@@ -381,7 +384,9 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
             rows, D.cols, ntiles, widest, uniform ? "" : ", equal-nonzero widths", nwaves, TW_ROWS, grid,
             grid ? (double)D.total_steps / grid : 0.0, mx, max_run);
   }
-  D.tw_mode = max_run > 8 ? (relaxed ? 2 : 1) : 0;
+  // relaxed order only where strict order is hopeless (a forced sweep over long runs); the automatically
+  // chosen sweeps (runs <= 32) keep the strict-order variants and stay bit-exact with the CPU loops
+  D.tw_mode = max_run > 8 ? ((relaxed && max_run > 32) ? 2 : 1) : 0;
   int rc;
   if ((rc = upload(&D.wave_rows, wave_rows))) return rc;
   if ((rc = upload(&D.wave_ent, step_ptr))) return rc;
@@ -472,7 +477,7 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
   D.cols = cols;
   D.nnz = rowptr[rows];
   std::vector<int2> blks;
-  std::vector<int> long_row, long_chunk_ptr(1, 0), chunk_row, chunk_off;
+  std::vector<int> long_row, long_chunk_ptr(1, 0), chunk_row, chunk_off, chunk_lidx;
   int r = 0;
   while (r < rows) {
     int len = rowptr[r + 1] - rowptr[r];
@@ -483,9 +488,9 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
       for (int off = 0; off < len; off += LONG_CHUNK) {
         chunk_row.push_back(r);
         chunk_off.push_back(off);
+        chunk_lidx.push_back(l);
       }
       long_chunk_ptr.push_back((int)chunk_row.size());
-      (void)l;
       ++r;
       continue;
     }
@@ -505,7 +510,7 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
   D.grid = remap ? D.per_xcd * NUM_XCD : D.nblk;
   D.nlong = (int)long_row.size();
   D.nchunks = (int)chunk_row.size();
-  D.long_grid = (D.nlong + TPB - 1) / TPB;
+  D.long_grid = (D.nlong + LONG_ROWS_PER_WG - 1) / LONG_ROWS_PER_WG;     // one wave per long row
   int rc;
   if ((rc = upload(&D.rowptr, rowptr))) return rc;
   if ((rc = upload(&D.col, col))) return rc;
@@ -515,6 +520,12 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
   if ((rc = upload(&D.long_chunk_ptr, long_chunk_ptr))) return rc;
   if ((rc = upload(&D.chunk_row, chunk_row))) return rc;
   if ((rc = upload(&D.chunk_off, chunk_off))) return rc;
+  if ((rc = upload(&D.chunk_lidx, chunk_lidx))) return rc;
+  {
+    double *z = nullptr;
+    if ((rc = alloc_zero(&z, D.nlong))) return rc;
+    D.long_ticket = reinterpret_cast<unsigned long long *>(z);
+  }
   if ((rc = alloc_zero(&D.chunk_partial, D.nchunks))) return rc;
   if (tile_cols > 0) {
     if ((rc = build_tiled(D, rows, rowptr, col, val, tile_cols, relaxed))) return rc;
@@ -527,7 +538,7 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
 
 void free_csr_dev(CsrDev &D) {
   void *ptrs[] = {D.rowptr, D.col, D.val, D.blks, D.long_row, D.long_chunk_ptr,
-                  D.chunk_row, D.chunk_off, D.chunk_partial, D.wave_rows, D.wave_ent, D.pk, D.tv,
+                  D.chunk_row, D.chunk_off, D.chunk_lidx, D.long_ticket, D.chunk_partial, D.wave_rows, D.wave_ent, D.pk, D.tv,
                   D.wave_step_off, D.step_tile, D.wg_step_off};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (SlabDev &S : D.slabs) {

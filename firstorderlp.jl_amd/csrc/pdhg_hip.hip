@@ -149,13 +149,16 @@ struct pdhg_handle {
   int coop_mode = -1;                   // -1 undecided, 0 off, 1 on
   int coop_grid = 0;                    // workgroups of the persistent launch (multiple of 8, all co-resident)
   unsigned coop_nxcd = 0;               // XCDs that hold workgroups of such a launch
+  unsigned coop_xcd_cnt[8] = {0};       // ... and how many each
   unsigned long long coop_launches = 0;
   GridSync *gsync = nullptr;
+  unsigned long long *coop_trace = nullptr;   // PDHG_COOP_TRACE=1: phase stamps of the last launch
   int graph_mode = -1;                  // -1 undecided, 0 off, 1 on
   hipStream_t graph_stream = nullptr;   // graphs launch here (== stream)
   unsigned long long *seq_dev = nullptr;   // launch counter, incremented by the final kernel
   volatile double *res_host = nullptr;     // pinned, coherent: 5 results + [7] = sequence number
   unsigned long long seq_expected = 0;
+  double res_error = 0.0;                   // error word of the last checked result read
   // host-side breakdown of graph trials (PDHG_VERBOSE): seconds in node updates, in hipGraphLaunch, waiting
   double t_set = 0.0, t_launch = 0.0, t_wait = 0.0;
   long n_graph_trials = 0;
@@ -446,27 +449,44 @@ int ensure_result_word(pdhg_handle *h) {
   return 0;
 }
 
-// wait for launch number seq_expected's results in pinned memory (bounded spin, then the stream)
-int wait_result_word(pdhg_handle *h, double out[5]) {
+// wait for launch number seq_expected's results in pinned memory (bounded spin, then the stream).
+// checked: the trial kernel publishes without a system-scope fence -- a read counts only when
+// the sequence number AND the checksum over the eight words match (trial_kernel.hpp).
+int wait_result_word(pdhg_handle *h, double out[5], bool checked = false) {
   const double want = (double)h->seq_expected;
+  const volatile unsigned long long *bits = reinterpret_cast<const volatile unsigned long long *>(h->res_host);
+  auto ready = [&]() -> bool {
+    if (h->res_host[7] != want) return false;
+    if (!checked) return true;
+    unsigned long long w[8];
+    for (int q = 0; q < 8; ++q) w[q] = bits[q];
+    unsigned long long ck = RESULT_CHECK_SALT ^ w[6] ^ w[7];
+    for (int q = 0; q < 5; ++q) ck ^= w[q];
+    if (ck != w[5]) return false;
+    for (int q = 0; q < 5; ++q) memcpy(&out[q], &w[q], 8);
+    memcpy(&h->res_error, &w[6], 8);
+    return true;
+  };
   bool seen = false;
   for (long spin = 0; spin < 40000000L; ++spin) {
-    if (h->res_host[7] == want) { seen = true; break; }
+    if (ready()) { seen = true; break; }
     if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
   }
   if (!seen) {
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->res_host[7] != want) {
+    if (!ready()) {
       h->seq_expected = (unsigned long long)h->res_host[7];   // resynchronise: the next launch can succeed
       return fail(998, "one-launch trial finished without publishing its results");
     }
   }
-  for (int q = 0; q < 5; ++q) out[q] = h->res_host[q];
+  if (!checked) for (int q = 0; q < 5; ++q) out[q] = h->res_host[q];
   out[4] *= 0.5;
   return 0;
 }
 
 // ---- the trial step as ONE persistent kernel (trial_kernel.hpp) -----------------------------
+
+int coop_prepare(pdhg_handle *h);
 
 bool coop_eligible(pdhg_handle *h) {
   if (h->coop_mode < 0) {
@@ -477,6 +497,7 @@ bool coop_eligible(pdhg_handle *h) {
     const char *gv = getenv("PDHG_GRAPH");             // PDHG_GRAPH=0: separate launches, no one-launch path of either kind
     if (gv) on = on && gv[0] != '0';
     h->coop_mode = on ? 1 : 0;
+    if (on && coop_prepare(h) != 0) h->coop_mode = 0;  // too many items for one co-resident grid, or no census: graph / plain path
   }
   return h->coop_mode == 1 && !h->has_q && !h->profile;
 }
@@ -484,6 +505,7 @@ bool coop_eligible(pdhg_handle *h) {
 // grid of the persistent launch + the census of workgroups per XCD (once per handle)
 int coop_prepare(pdhg_handle *h) {
   if (h->gsync) return 0;
+  HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_result_word(h);
   if (rc) return rc;
   int per_cu = 0;
@@ -492,10 +514,22 @@ int coop_prepare(pdhg_handle *h) {
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));
   int cap = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
   if (const char *ev = getenv("PDHG_COOP_WGS")) cap = std::max(8, std::min(cap, atoi(ev) / 8 * 8));
-  const int items = std::max(std::max(h->A.grid + h->A.nchunks, h->At.grid + h->At.nchunks), ew_grid((h->n + 1) / 2));
+  // one item per workgroup and phase where the device can hold that many: row blocks from the front, long-row chunks from the end
+  const int items = std::max(h->A.grid + h->A.nchunks, h->At.grid + h->At.nchunks);
   h->coop_grid = std::min(cap, std::max(8, (items + 7) / 8 * 8));
+  // More items than co-resident workgroups: the persistent kernel would walk several row blocks per workgroup at
+  // 5 workgroups per CU, where the separate stream kernels keep 8 per CU in flight -- measured slower (PageRank-1M,
+  // 4 552 items on 1 280 workgroups: 4 380 it/s against 4 620 as a graph of slab passes).  Leave those to the graph.
+  if (items > cap && !getenv("PDHG_COOP_FORCE")) {
+    h->coop_mode = 0;
+    return 1;       // not an error: the caller falls through to the graph / plain path
+  }
   HIP_TRY(hipMalloc((void **)&h->gsync, sizeof(GridSync)));
   HIP_TRY(hipMemsetAsync(h->gsync, 0, sizeof(GridSync), h->stream));
+  if (getenv("PDHG_COOP_TRACE")) {
+    HIP_TRY(hipMalloc((void **)&h->coop_trace, sizeof(unsigned long long) * 8 * (size_t)h->coop_grid));
+    HIP_TRY(hipMemsetAsync(h->coop_trace, 0, sizeof(unsigned long long) * 8 * (size_t)h->coop_grid, h->stream));
+  }
   hipLaunchKernelGGL(xcd_register_kernel, dim3(h->coop_grid), dim3(TPB), 0, h->stream, h->gsync);
   HIP_TRY(hipGetLastError());
   GridSync host;
@@ -503,7 +537,7 @@ int coop_prepare(pdhg_handle *h) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   unsigned long long total = 0;
   h->coop_nxcd = 0;
-  for (int x = 0; x < 8; ++x) { total += host.xcd_count[x][0]; h->coop_nxcd += host.xcd_count[x][0] > 0; }
+  for (int x = 0; x < 8; ++x) { total += host.xcd_count[x][0]; h->coop_nxcd += host.xcd_count[x][0] > 0; h->coop_xcd_cnt[x] = (unsigned)host.xcd_count[x][0]; }
   if (total != (unsigned long long)h->coop_grid || h->coop_nxcd == 0) {
     h->coop_mode = 0;
     return fail(996, "one-launch trial: workgroup census does not add up");
@@ -519,12 +553,14 @@ TrialProduct trial_product(pdhg_handle *h, const CsrDev &D, const double *xin, c
   P.M = D.view();
   P.blks = D.blks; P.nblk = D.nblk; P.per_xcd = D.per_xcd; P.grid = D.grid; P.remap = h->remap ? 1 : 0;
   P.nchunks = D.nchunks; P.nlong = D.nlong; P.long_grid = D.long_grid;
-  P.chunk_row = D.chunk_row; P.chunk_off = D.chunk_off; P.chunk_partial = D.chunk_partial;
+  P.chunk_row = D.chunk_row; P.chunk_off = D.chunk_off; P.chunk_lidx = D.chunk_lidx; P.chunk_partial = D.chunk_partial;
+  P.long_ticket = D.long_ticket;
   P.long_row = D.long_row; P.long_chunk_ptr = D.long_chunk_ptr;
   P.xin = xin; P.e = e;
   return P;
 }
 
+// returns 1 when the handle turned out not to suit the one-launch kernel (nothing was launched)
 int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double theta, bool xbar_only, double out[5]) {
   int rc = coop_prepare(h);
   if (rc) return rc;
@@ -551,9 +587,11 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
   a.sp.ptr[4] = h->pQ;                        a.sp.count[4] = 0;
   a.sp.out = nullptr;
   a.seq_dev = h->seq_dev; a.res_host = h->res_host; a.sync = h->gsync;
-  a.launch = h->coop_launches; a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
-  h->coop_launches += 1;
   h->seq_expected += 1;
+  a.launch = h->coop_launches; a.seq = h->seq_expected; a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
+  a.trace = h->coop_trace;
+  for (int x = 0; x < 8; ++x) a.xcd_cnt[x] = h->coop_xcd_cnt[x];
+  h->coop_launches += 1;
   const auto c1 = std::chrono::steady_clock::now();
   hipLaunchKernelGGL(trial_kernel, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
@@ -563,10 +601,10 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
   h->n_graph_trials += 1;
   if (!xbar_only) h->pend_x = false;
   h->pend_y = false;                  // the launch carries the deferred average update
-  rc = wait_result_word(h, out);
+  rc = wait_result_word(h, out, true);
   h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
   if (rc) return rc;
-  if (h->res_host[6] != 0.0) {
+  if (h->res_error != 0.0) {
     h->coop_mode = 0;                 // the barrier counters are out of step now: never again on this handle
     return fail(996, "one-launch trial: a grid barrier timed out (are all workgroups co-resident? is the device shared?); "
                      "set PDHG_COOP=0 to use the graph path");
@@ -1154,6 +1192,28 @@ void destroy_shard(pdhg_handle *h) {
     fprintf(stderr, "[pdhg_hip] %ld graph trials: host us per trial: node updates %.2f, hipGraphLaunch %.2f, wait for the result %.2f\n",
             h->n_graph_trials, 1e6 * h->t_set / h->n_graph_trials, 1e6 * h->t_launch / h->n_graph_trials,
             1e6 * h->t_wait / h->n_graph_trials);
+  if (h->coop_trace && h->coop_launches > 0) {
+    // phase timeline of the LAST one-launch trial: per phase, mean and max over the workgroups of its duration (us)
+    std::vector<unsigned long long> t((size_t)8 * h->coop_grid);
+    if (hipMemcpy(t.data(), h->coop_trace, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+      unsigned long long t0 = ~0ull, tend = 0;
+      for (int w = 0; w < h->coop_grid; ++w) { t0 = std::min(t0, t[(size_t)w * 8]); tend = std::max(tend, t[(size_t)w * 8 + 5]); }
+      const char *names[5] = {"phase 0 (x', xbar) + entry prefetch", "barrier 1", "phase 1 (A xbar, y')", "barrier 2", "phase 2 (A'y', sums)"};
+      fprintf(stderr, "[pdhg_hip] one-launch trial timeline (last launch, %d workgroups, 100 MHz clock):\n", h->coop_grid);
+      for (int k = 0; k < 5; ++k) {
+        double sum = 0, mx = 0, last_end = 0;
+        for (int w = 0; w < h->coop_grid; ++w) {
+          const double d = 0.01 * (double)(t[(size_t)w * 8 + k + 1] - t[(size_t)w * 8 + k]);
+          sum += d; mx = std::max(mx, d);
+          last_end = std::max(last_end, 0.01 * (double)(t[(size_t)w * 8 + k + 1] - t0));
+        }
+        fprintf(stderr, "    %-38s mean %6.2f us, max %6.2f us; last workgroup out at %6.2f us\n", names[k], sum / h->coop_grid, mx, last_end);
+      }
+      unsigned long long fin = 0;
+      for (int w = 0; w < h->coop_grid; ++w) fin = std::max(fin, t[(size_t)w * 8 + 6]);
+      fprintf(stderr, "    second-stage reduction published at %6.2f us\n", 0.01 * (double)(fin - t0));
+    }
+  }
   free_csr_dev(h->A); free_csr_dev(h->At); free_csr_dev(h->Q); free_csr_dev(h->Qt);
   double *bufs[] = {h->c, h->b, h->lb, h->ub, h->x, h->x_next, h->xbar, h->y, h->y_next,
                     h->aty, h->aty_next, h->sum_x, h->sum_y, h->qx, h->tmp_n, h->tmp_n2,
@@ -1170,6 +1230,7 @@ void destroy_shard(pdhg_handle *h) {
   if (h->ev_comm) (void)hipEventDestroy(h->ev_comm);
   if (h->seq_dev) (void)hipFree(h->seq_dev);
   if (h->gsync) (void)hipFree(h->gsync);
+  if (h->coop_trace) (void)hipFree(h->coop_trace);
   if (h->res_host) (void)hipHostFree((void *)h->res_host);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -118,13 +118,16 @@ __device__ __forceinline__ void stream_block_load(const CsrView &A, int2 rr, Str
   }
 }
 
-// Rows of more than this many entries are summed by a whole wave in relaxed-order mode
-constexpr int RELAXED_MIN_ROW = 64;
+// Rows of more than this many entries are summed by a whole wave in relaxed-order mode.  Measured on the
+// L1-SVM LP (feature columns of 65-2000 entries): with 64, a block of ~30 rows of ~70 entries costs its wave 30
+// wave-wide reductions one after the other and the iteration got SLOWER (14.8k it/s against 15.9k strict); a
+// lane adds 256 products in ~0.85 us, so only rows beyond that are worth a wave.
+constexpr int RELAXED_MIN_ROW = 256;
 
 // second half: gathers, products into LDS, per-row sums, fused epilogue.  acc[] receives this
 // thread's contributions to the block partials.
 // relaxed == 0 (PDHG_ROW_ORDER=strict): every row is added strictly left to right by one lane.
-// relaxed != 0 (default): rows of more than RELAXED_MIN_ROW entries are summed by their whole wave --
+// relaxed != 0 (default): rows of more than RELAXED_MIN_ROW (256) entries are summed by their whole wave --
 // lane l adds products l, l + 64, ... in ascending order, then a shuffle tree -- a fixed order
 // (bitwise reproducible), but not the sequential one: |result - sequential| <= 1e-13 * sum |a x|,
 // the bar the rows beyond BLOCK_NNZ have always had.  The row stays OWNED by the lane that
@@ -367,6 +370,16 @@ __device__ __forceinline__ void tiled_chunk_relaxed(double *acc, unsigned p, dou
     if (head) acc[row] = s;
     return;
   }
+  // a chunk with a long run: the short runs beside it are still added left to right ...
+  double s = head ? acc[row] : 0.0;
+  for (int j = 0; j <= TW_STRICT_RUN; ++j) {
+    const double pj = __shfl_down(prod, j, WAVE);
+    const unsigned rj = __shfl_down(row, j, WAVE);
+    const bool take = head && len <= TW_STRICT_RUN && (lane + j < WAVE) && (rj == row);
+    if (!__any(take)) break;
+    if (take) s = s + pj;
+  }
+  // ... the long ones by a segmented shuffle tree
   double val = valid ? prod : 0.0;
 #pragma unroll
   for (int d = 1; d < WAVE; d <<= 1) {
@@ -376,7 +389,7 @@ __device__ __forceinline__ void tiled_chunk_relaxed(double *acc, unsigned p, dou
     if (!__any(same)) break;             // runs are contiguous: none at distance d, none beyond
     if (same) val = val + vd;
   }
-  if (head) acc[row] = acc[row] + val;
+  if (head) acc[row] = (len <= TW_STRICT_RUN) ? s : acc[row] + val;
 }
 
 // CH: how a 64-entry chunk is accumulated -- 0 lane shuffles (strict order), 1 LDS scratch
@@ -510,33 +523,44 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   }
 }
 
-// Rows longer than BLOCK_NNZ: split into LONG_CHUNK pieces, one workgroup
-// each (tree sum inside the chunk), partial per chunk.  Thread 0 returns the chunk's sum.
-__device__ __forceinline__ double long_chunk_body(const CsrView &A, const double *xin, int r, int off,
-                                                  double (*red)[TPB / WAVE]) {
-  const int kbeg = A.rowptr[r] + off;
-  const int kend = min(kbeg + LONG_CHUNK, A.rowptr[r + 1]);
-  double acc[3] = {0.0, 0.0, 0.0};
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int k = kbeg + threadIdx.x;
-  for (; k + 3 * TPB < kend; k += 4 * TPB) {
-    const int c0 = __builtin_nontemporal_load(A.col + k);
-    const int c1 = __builtin_nontemporal_load(A.col + k + TPB);
-    const int c2 = __builtin_nontemporal_load(A.col + k + 2 * TPB);
-    const int c3 = __builtin_nontemporal_load(A.col + k + 3 * TPB);
-    const double v0 = __builtin_nontemporal_load(A.val + k);
-    const double v1 = __builtin_nontemporal_load(A.val + k + TPB);
-    const double v2 = __builtin_nontemporal_load(A.val + k + 2 * TPB);
-    const double v3 = __builtin_nontemporal_load(A.val + k + 3 * TPB);
-    s0 += v0 * xin[c0];
-    s1 += v1 * xin[c1];
-    s2 += v2 * xin[c2];
-    s3 += v3 * xin[c3];
+// Rows longer than BLOCK_NNZ: split into LONG_CHUNK (= BLOCK_NNZ) pieces, one workgroup each.
+// A chunk is read like a row block of the stream kernel -- UNROLL independent (col, val) load
+// pairs per lane, then UNROLL gathers -- and summed by a fixed tree: lane-local pairs, wave
+// shuffles, the waves left to right.  (Round 2 used 8192-entry chunks walked in 8 dependent
+// steps of 4 loads: ~11 us of latency per chunk on the critical path of a small LP's
+// iteration, and 123 workgroups for PageRank's 1M-entry row.)  Thread 0 returns the chunk's sum.
+// (two halves, like a row block: the one-launch trial kernel requests the entries before its grid
+// barrier.  A chunk uses the row block's register set: k0 / k1 are its extent, r0 / r1 unused.)
+__device__ __forceinline__ void long_chunk_load(const CsrView &A, int r, int off, StreamRegs &g) {
+  g.r0 = g.r1 = r;
+  g.k0 = A.rowptr[r] + off;
+  g.k1 = min(g.k0 + LONG_CHUNK, A.rowptr[r + 1]);
+#pragma unroll
+  for (int i = 0; i < UNROLL; ++i) {
+    const int k = g.k0 + threadIdx.x + i * TPB;
+    const bool ok = k < g.k1;
+    g.cidx[i] = ok ? __builtin_nontemporal_load(A.col + k) : 0;
+    g.v[i] = ok ? __builtin_nontemporal_load(A.val + k) : 0.0;
   }
-  for (; k < kend; k += TPB) s0 += A.val[k] * xin[A.col[k]];
-  acc[0] = (s0 + s1) + (s2 + s3);
+}
+__device__ __forceinline__ double long_chunk_finish(const double *xin, const StreamRegs &g, double (*red)[TPB / WAVE]) {
+  double acc[3] = {0.0, 0.0, 0.0};
+  double p[UNROLL];
+#pragma unroll
+  for (int i = 0; i < UNROLL; ++i) {
+    const int k = g.k0 + threadIdx.x + i * TPB;
+    p[i] = (k < g.k1) ? g.v[i] * xin[g.cidx[i]] : 0.0;
+  }
+  static_assert(UNROLL == 8 && LONG_CHUNK == UNROLL * TPB, "the chunk sum below is written for 8 products per lane");
+  acc[0] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   block_sum<1, TPB>(acc, red);
   return acc[0];
+}
+__device__ __forceinline__ double long_chunk_body(const CsrView &A, const double *xin, int r, int off,
+                                                  double (*red)[TPB / WAVE]) {
+  StreamRegs g;
+  long_chunk_load(A, r, off, g);
+  return long_chunk_finish(xin, g, red);
 }
 
 template <int TAG = 0>
@@ -549,46 +573,42 @@ __global__ __launch_bounds__(TPB) void spmv_long_partial_kernel(
   if (threadIdx.x == 0) chunk_partial[c] = s;
 }
 
-// One lane per long row: add the chunk partials in order, run the epilogue.  `lb` is the
-// block of TPB long rows this workgroup handles; its block partials go to slot_base + lb.
-template <int MODE>
-__device__ __forceinline__ void long_final_body(int lb, const int *long_row, const int *long_chunk_ptr, int nlong,
-                                                const double *chunk_partial, const EpiArgs &e, int slot_base,
-                                                double (*red)[TPB / WAVE]) {
-  double acc[3] = {0.0, 0.0, 0.0};
-  const int l = lb * TPB + threadIdx.x;
-  if (l < nlong) {
-    double s = 0.0;
-    int c = long_chunk_ptr[l];
-    const int c1 = long_chunk_ptr[l + 1];
-    // the chunk partials are added in chunk order (a fixed order: reproducible); 8 loads in
-    // flight at a time -- one lane owns the row, and a 1M-entry row has over a hundred chunks
-    for (; c + 8 <= c1; c += 8) {
-      const double t0 = chunk_partial[c], t1 = chunk_partial[c + 1], t2 = chunk_partial[c + 2], t3 = chunk_partial[c + 3];
-      const double t4 = chunk_partial[c + 4], t5 = chunk_partial[c + 5], t6 = chunk_partial[c + 6], t7 = chunk_partial[c + 7];
-      s = s + t0; s = s + t1; s = s + t2; s = s + t3; s = s + t4; s = s + t5; s = s + t6; s = s + t7;
-    }
-    for (; c < c1; ++c) s = s + chunk_partial[c];
+// One WAVE per long row: lane l adds chunk partials l, l + 64, ... in ascending order, then
+// the wave's shuffle tree (a fixed order: reproducible; a 1M-entry row has ~490 partials and
+// one lane adding them one after the other was 10 us), lane 0 runs the epilogue and writes the
+// row's contribution to the reductions into the row's OWN slot (slot_base + l): whichever
+// workgroup ends up finishing a long row -- a block of the separate kernel below, or, in the
+// one-launch trial, the workgroup that completed the row's last chunk -- the slots hold the
+// same bits.  Called by all 64 lanes of one wave.  AGENT: write-through stores (trial kernel).
+template <int MODE, bool AGENT>
+__device__ __forceinline__ void long_final_row(int l, const int *long_row, const int *long_chunk_ptr,
+                                               const double *chunk_partial, const EpiArgs &e, int slot_base) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int c0 = long_chunk_ptr[l], c1 = long_chunk_ptr[l + 1];
+  double s = 0.0;
+  for (int c = c0 + lane; c < c1; c += WAVE) s = s + chunk_partial[c];
+  s = wave_sum(s);
+  if (lane == 0) {
+    double acc[3] = {0.0, 0.0, 0.0};
     row_epilogue<MODE>(e, long_row[l], s, acc);
-  }
-  constexpr int NQ = ModeNQ<MODE>::value;
-  if (NQ > 0) {
-    block_sum<NQ, TPB>(acc, red);
-    if (threadIdx.x == 0) {
+    constexpr int NQ = ModeNQ<MODE>::value;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        e.partials[q * e.stride + slot_base + lb] = acc[q];
+    for (int q = 0; q < NQ; ++q) {
+      double *dst = e.partials + q * e.stride + slot_base + l;
+      if (AGENT) __hip_atomic_store(dst, acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *dst = acc[q];
     }
   }
 }
 
+constexpr int LONG_ROWS_PER_WG = TPB / WAVE;
 template <int MODE>
 __global__ __launch_bounds__(TPB) void spmv_long_final_kernel(
     const int *__restrict__ long_row, const int *__restrict__ long_chunk_ptr,
     int nlong, const double *__restrict__ chunk_partial, EpiArgs e,
     int slot_base) {
-  __shared__ double red[3][TPB / WAVE];
-  long_final_body<MODE>(blockIdx.x, long_row, long_chunk_ptr, nlong, chunk_partial, e, slot_base, red);
+  const int l = blockIdx.x * LONG_ROWS_PER_WG + threadIdx.x / WAVE;
+  if (l < nlong) long_final_row<MODE, false>(l, long_row, long_chunk_ptr, chunk_partial, e, slot_base);
 }
 
 }  // namespace

@@ -45,7 +45,8 @@ struct GridSync {                           // device memory, one per handle; on
   unsigned long long xcd_arrive[8][16];
   unsigned long long xcd_release[8][16];    // last completed barrier epoch of the XCD
   unsigned long long xcd_count[8][16];      // workgroups of one launch on each XCD
-  unsigned long long ticket[3][16];         // long chunks of A done, of A' done, workgroups done
+  unsigned long long xcd_done[8][16];       // workgroups of the XCD that have finished their last phase
+  unsigned long long ticket[3][16];         // [2]: XCDs done (the last workgroup of the last XCD runs the second-stage reduction)
   unsigned long long error[16];
 };
 
@@ -57,15 +58,21 @@ __global__ __launch_bounds__(TPB) void xcd_register_kernel(GridSync *s) {
   if (threadIdx.x == 0) __hip_atomic_fetch_add(&s->xcd_count[xcc_id()][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifndef PDHG_TRIAL_WAVES_PER_EU
+#define PDHG_TRIAL_WAVES_PER_EU 5
+#endif
+constexpr unsigned long long RESULT_CHECK_SALT = 0x9E3779B97F4A7C15ull;
 constexpr long GRID_SPIN_LIMIT = 4000000L;   // x s_sleep(1): ~0.1 s
 
 // epoch = 1, 2, ... over the life of the handle; nxcd = XCDs that hold workgroups
-__device__ __forceinline__ void grid_barrier(GridSync *s, unsigned long long epoch, unsigned nxcd) {
+// xcd_cnt: workgroups of this launch on each XCD (the census, passed in the kernel arguments: a load of it here
+// would put one more ~1.5 us trip to memory in front of every arrival)
+__device__ __forceinline__ void grid_barrier(GridSync *s, unsigned long long epoch, unsigned nxcd, const unsigned *xcd_cnt) {
   __syncthreads();       // every wave's workgroup-scope release: its stores have reached the XCD's L2
   if (threadIdx.x == 0 && __hip_atomic_load(&s->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
     const unsigned x = xcc_id();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    const unsigned long long cnt = __hip_atomic_load(&s->xcd_count[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long cnt = xcd_cnt[x];
     const unsigned long long prev = __hip_atomic_fetch_add(&s->xcd_arrive[x][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     long spins = 0;
     if (prev + 1 == cnt * epoch) {
@@ -100,9 +107,10 @@ struct TrialProduct {
   const int2 *blks;
   int nblk, per_xcd, grid, remap;
   int nchunks, nlong, long_grid;
-  const int *chunk_row, *chunk_off;
+  const int *chunk_row, *chunk_off, *chunk_lidx;
   double *chunk_partial;
   const int *long_row, *long_chunk_ptr;
+  unsigned long long *long_ticket;
   const double *xin;
   EpiArgs e;
 };
@@ -121,8 +129,11 @@ struct TrialKernelArgs {
   volatile double *res_host;
   GridSync *sync;
   unsigned long long launch;     // 0, 1, 2, ...: this handle's launches of this kernel so far
+  unsigned long long seq;        // sequence number to publish with the results
   unsigned nxcd;
+  unsigned xcd_cnt[8];           // workgroups of one launch on each XCD (census of coop_prepare)
   int relaxed;
+  unsigned long long *trace;     // PDHG_COOP_TRACE: [workgroup][8] wall-clock stamps (100 MHz) at the phase boundaries
 };
 
 __device__ __forceinline__ bool product_block_of(const TrialProduct &P, int b, int *blk) {
@@ -131,33 +142,56 @@ __device__ __forceinline__ bool product_block_of(const TrialProduct &P, int b, i
   return P.remap ? ((b >> 3) < P.per_xcd && k < P.nblk) : (k < P.nblk);
 }
 
-// this workgroup's share of one product: long-row chunks w, w + nwg, ... then row blocks
-// b = w, w + nwg, ... (b mod 8 == w mod 8: every XCD walks the same contiguous eighth of the row
-// blocks as in the separate launch).  `pre`: block w's entries are already in `g`.
-template <int MODE>
-__device__ __forceinline__ void product_phase(const TrialProduct &P, GridSync *s, int ticket_id, unsigned long long launch,
-                                              int relaxed, bool pre, StreamRegs &g, double *prod, double (*red)[TPB / WAVE],
-                                              bool *ran_long_final) {
+// this workgroup's share of one product: row blocks b = w, w + nwg, ... (b mod 8 == w mod 8:
+// every XCD walks the same contiguous eighth of the row blocks as in the separate launch) and
+// long-row chunks dealt from the END of the grid (chunk c to workgroup nwg - 1 - c mod nwg), so
+// that with a grid of blocks + chunks workgroups everybody has one item.  The workgroup that
+// completes a long row's last chunk (a ticket per row) finishes the row: ordered sum of its
+// chunk partials, epilogue, the row's slot of the block partials.  `pre`: block w's entries
+// are already in `g`.
+// the first item of a workgroup in a phase, requested before the grid barrier: a row block or
+// (workgroups at the end of the grid) a long-row chunk
+struct Prefetched {
+  int kind;            // 0 nothing, 1 row block, 2 long-row chunk
+  StreamRegs g;
+};
+__device__ __forceinline__ void product_prefetch(const TrialProduct &P, Prefetched &f) {
   const int w = blockIdx.x, nwg = gridDim.x;
-  __shared__ int last_flag;
-  for (int c = w; c < P.nchunks; c += nwg) {
+  int blk;
+  f.kind = 0;
+  const int c = nwg - 1 - w;
+  if (c < P.nchunks) {                                   // chunks are processed first
+    long_chunk_load(P.M, P.chunk_row[c], P.chunk_off[c], f.g);
+    f.kind = 2;
+  } else if (w < P.grid && product_block_of(P, w, &blk)) {
+    stream_block_load(P.M, P.blks[blk], f.g);
+    f.kind = 1;
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void product_phase(const TrialProduct &P, unsigned long long launch, int relaxed,
+                                              Prefetched &f, double *prod, double (*red)[TPB / WAVE]) {
+  const int w = blockIdx.x, nwg = gridDim.x;
+  __shared__ int finish_row;
+  StreamRegs &g = f.g;
+  const bool pre = f.kind == 1;
+  for (int c = nwg - 1 - w; c < P.nchunks; c += nwg) {
     __syncthreads();
-    const double part = long_chunk_body(P.M, P.xin, P.chunk_row[c], P.chunk_off[c], red);
+    if (!(f.kind == 2 && c == nwg - 1 - w)) long_chunk_load(P.M, P.chunk_row[c], P.chunk_off[c], f.g);
+    const double part = long_chunk_finish(P.xin, f.g, red);
     if (threadIdx.x == 0) {
       store_agent(P.chunk_partial + c, part);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned long long t = __hip_atomic_fetch_add(&s->ticket[ticket_id][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last_flag = (t + 1 == (launch + 1) * (unsigned long long)P.nchunks);
-      if (last_flag) asm volatile("buffer_inv sc1" ::: "memory");      // every chunk's partial is in memory: read them fresh
+      const int l = P.chunk_lidx[c];
+      const unsigned long long per_launch = (unsigned long long)(P.long_chunk_ptr[l + 1] - P.long_chunk_ptr[l]);
+      const unsigned long long t = __hip_atomic_fetch_add(P.long_ticket + l, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      finish_row = (t + 1 == (launch + 1) * per_launch) ? l : -1;
+      if (finish_row >= 0) asm volatile("buffer_inv sc1" ::: "memory");   // the row's partials are in memory: read them fresh
     }
     __syncthreads();
-    if (last_flag) {                                                    // workgroup-uniform
-      for (int lb = 0; lb < P.long_grid; ++lb) {
-        __syncthreads();
-        long_final_body<MODE>(lb, P.long_row, P.long_chunk_ptr, P.nlong, P.chunk_partial, P.e, P.grid, red);
-      }
-      *ran_long_final = true;
-    }
+    if (finish_row >= 0 && threadIdx.x < WAVE)                             // one wave finishes the row
+      long_final_row<MODE, true>(finish_row, P.long_row, P.long_chunk_ptr, P.chunk_partial, P.e, P.grid);
   }
   constexpr int NQ = ModeNQ<MODE>::value;
   for (int b = w; b < P.grid; b += nwg) {
@@ -179,52 +213,76 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, GridSync *s
   }
 }
 
-__global__ __launch_bounds__(TPB) void trial_kernel(TrialKernelArgs a) {
+// waves per SIMD: the kernel needs 96 VGPRs (5 waves per SIMD, 5 workgroups per CU).  Forcing the 8 of the separate
+// stream kernel (64 VGPRs) spills 132 bytes per lane and is 1.4-2x SLOWER (L1-SVM 8.9k against 12.3k it/s, PageRank-1M
+// 2.4k against 4.4k: profiles/r03_trial_kernel.txt).
+__global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(TrialKernelArgs a) {
   __shared__ double prod[BLOCK_NNZ];
   __shared__ double red[3][TPB / WAVE];
   __shared__ int done_flag;
   const int w = blockIdx.x, nwg = gridDim.x;
+#define PDHG_STAMP(k) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)w * 8 + (k)] = wall_clock64(); } while (0)
+  PDHG_STAMP(0);
   // ---- phase 0: x' and xbar (elementwise; any distribution over the workgroups gives the same bits)
   if (a.xbar_only) xbar_body(a.n, a.x, a.x_next, a.theta, a.xbar, w, nwg);
   else primal_body<false, true>(a.n, a.x, a.c, a.aty, nullptr, a.lb, a.ub, a.tau, a.theta, a.x_next, a.xbar, a.avg_w, a.sum_x, w, nwg);
-  StreamRegs g;
-  int blk;
-  bool pre = w < a.A.grid && product_block_of(a.A, w, &blk);
-  if (pre) stream_block_load(a.A.M, a.A.blks[blk], g);          // static data: requested before the barrier
-  grid_barrier(a.sync, 2 * a.launch + 1, a.nxcd);
+  Prefetched f;
+  product_prefetch(a.A, f);                                      // static data: requested before the barrier
+  PDHG_STAMP(1);
+  grid_barrier(a.sync, 2 * a.launch + 1, a.nxcd, a.xcd_cnt);
+  PDHG_STAMP(2);
   // ---- phase 1: y' = proj(y + sigma (b - A xbar)), sum dy^2   (K3+K4)
-  bool long_final_A = false, long_final_T = false;
-  product_phase<MODE_DUAL>(a.A, a.sync, 0, a.launch, a.relaxed, pre, g, prod, red, &long_final_A);
-  pre = w < a.T.grid && product_block_of(a.T, w, &blk);
-  if (pre) stream_block_load(a.T.M, a.T.blks[blk], g);
-  grid_barrier(a.sync, 2 * a.launch + 2, a.nxcd);
+  product_phase<MODE_DUAL>(a.A, a.launch, a.relaxed, f, prod, red);
+  product_prefetch(a.T, f);
+  PDHG_STAMP(3);
+  grid_barrier(a.sync, 2 * a.launch + 2, a.nxcd, a.xcd_cnt);
+  PDHG_STAMP(4);
   // ---- phase 2: A'y' and the interaction sums   (K5+K6)
-  product_phase<MODE_ATY>(a.T, a.sync, 1, a.launch, a.relaxed, pre, g, prod, red, &long_final_T);
+  product_phase<MODE_ATY>(a.T, a.launch, a.relaxed, f, prod, red);
+  PDHG_STAMP(5);
   // ---- second stage: the workgroup that finishes last adds the block partials (K6b)
   __syncthreads();
   if (threadIdx.x == 0) {
-    // this workgroup's block partials went out as write-through stores; the long-row epilogue
-    // (if it ran here) stored its own plainly: write those back before taking the ticket
-    if (long_final_T) __threadfence();
+    // every block partial of this workgroup went out as a write-through store: once they are
+    // acknowledged, take the ticket
+    // (two levels, like the barrier: atomics on ONE address are served at ~15-25 ns apiece, and a flat ticket over
+    // 500-1000 workgroups that finish together cost 8-12 us here)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long t = __hip_atomic_fetch_add(&a.sync->ticket[2][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    done_flag = (t + 1 == (a.launch + 1) * (unsigned long long)nwg);
+    const unsigned x = xcc_id();
+    const unsigned long long cnt = a.xcd_cnt[x];
+    const unsigned long long t = __hip_atomic_fetch_add(&a.sync->xcd_done[x][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    done_flag = 0;
+    if (t + 1 == (a.launch + 1) * cnt) {
+      const unsigned long long u = __hip_atomic_fetch_add(&a.sync->ticket[2][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      done_flag = (u + 1 == (a.launch + 1) * (unsigned long long)a.nxcd);
+    }
     if (done_flag) asm volatile("buffer_inv sc1" ::: "memory");
   }
   __syncthreads();
   if (done_flag) {
     double res[5];
+    // (requested before the partials so that its trip to memory overlaps theirs)
+    const unsigned long long errw = threadIdx.x == 0 ? __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     final_reduce_body<TPB / WAVE>(a.sp, res);
     if (threadIdx.x == 0) {
+      // Publish WITHOUT a system-scope fence (an L2 write-back, microseconds): the eight words
+      // may reach host memory in any order, so word 5 carries a checksum over the others and
+      // the host accepts a read only when the sequence number AND the checksum match.
+      const double err = (double)errw;
+      const double seq = (double)a.seq;                  // exact up to 2^53 launches
+      unsigned long long ck = RESULT_CHECK_SALT ^ (unsigned long long)__double_as_longlong(err) ^ (unsigned long long)__double_as_longlong(seq);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ck ^= (unsigned long long)__double_as_longlong(res[k]);
 #pragma unroll
       for (int k = 0; k < 5; ++k) a.res_host[k] = res[k];
-      a.res_host[6] = (double)__hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long sq = *a.seq_dev + 1ull;
-      *a.seq_dev = sq;
-      __threadfence_system();
-      a.res_host[7] = (double)sq;      // exact up to 2^53 launches
+      a.res_host[5] = __longlong_as_double((long long)ck);
+      a.res_host[6] = err;
+      a.res_host[7] = seq;
+      *a.seq_dev = a.seq;                                // the graph path's device-side counter stays in step
     }
+    PDHG_STAMP(6);
   }
+#undef PDHG_STAMP
 }
 
 }  // namespace

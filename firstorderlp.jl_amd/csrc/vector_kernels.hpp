@@ -186,26 +186,49 @@ template <int NW>
 __device__ __forceinline__ void final_reduce_body(const FinalSpec &sp, double (&res)[5]) {
   __shared__ double wsum[16];
   const int wid = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-  for (int v = wid; v < 15; v += NW) {
-    const int q = v / 3, sub = v % 3;
-    double acc = 0.0;
+  constexpr int VPW = (15 + NW - 1) / NW;        // virtual waves per physical wave
+  constexpr int B = 4;                           // loads in flight per lane and virtual wave
+  // The partials come from other CUs' stores: every load is a trip to memory.  All of a
+  // physical wave's first B loads per virtual wave are requested before anything is added
+  // (one round trip instead of VPW); the sums keep the ascending order of a plain loop.
+  double t[VPW][B];
+#pragma unroll
+  for (int j = 0; j < VPW; ++j) {
+    const int v = wid + j * NW;
+    const int q = v < 15 ? v / 3 : 0, sub = v % 3;
     const double *p = sp.ptr[q];
-    const int cnt = sp.count[q];
-    // eight loads in flight per lane (the partials come from other CUs' stores: every one is a
-    // trip to memory), added in the same ascending order as a plain loop would
-    for (int i0 = sub * WAVE + lane; i0 < cnt; i0 += 8 * 3 * WAVE) {
-      double t[8];
+    const int cnt = v < 15 ? sp.count[q] : 0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 3 * WAVE;
-        t[u] = i < cnt ? p[i] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (i0 + u * 3 * WAVE < cnt) acc += t[u];
+    for (int u = 0; u < B; ++u) {
+      const int i = sub * WAVE + lane + u * 3 * WAVE;
+      t[j][u] = i < cnt ? p[i] : 0.0;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) wsum[v] = acc;
+  }
+#pragma unroll
+  for (int j = 0; j < VPW; ++j) {
+    const int v = wid + j * NW;
+    if (v < 15) {                                 // wave-uniform
+      const int q = v / 3, sub = v % 3;
+      const double *p = sp.ptr[q];
+      const int cnt = sp.count[q];
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < B; ++u)
+        if (sub * WAVE + lane + u * 3 * WAVE < cnt) acc += t[j][u];
+      for (int i0 = sub * WAVE + lane + B * 3 * WAVE; i0 < cnt; i0 += B * 3 * WAVE) {
+        double r[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+          const int i = i0 + u * 3 * WAVE;
+          r[u] = i < cnt ? p[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+          if (i0 + u * 3 * WAVE < cnt) acc += r[u];
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) wsum[v] = acc;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -1,7 +1,7 @@
 """PDHG_ROW_ORDER: "strict" adds every row's products left to right on one lane (bit-exact with
 the CPU oracle's sequential loops for rows of <= 2048 entries); "relaxed" -- the library's
-default -- sums rows of more than 64 entries (stream layout) / same-row runs of more than 8
-entries inside a tile (sweep) wave-parallel in a FIXED order: reproducible, rows of <= 64
+default -- sums rows of more than 256 entries (stream layout) / same-row runs of more than 8
+entries inside a tile (sweep, only when forced onto a matrix with runs beyond 32) wave-parallel in a FIXED order: reproducible, rows of <= 256
 entries still bit-exact in the stream layout, everything within 1e-13 * sum |a_ij x_j| of the
 sequential sum -- the bar rows beyond 2048 entries have always had (saddle_point.jl:1102-1107,
 pdhg.jl:472-494 are the products)."""
@@ -57,32 +57,31 @@ def test_relaxed_products_are_within_the_stated_bound_and_short_rows_bit_exact(g
     assert np.array_equal(ax_s[len_rows <= 2048], ref[len_rows <= 2048])
     assert np.array_equal(aty_s[len_cols <= 2048], ref_t[len_cols <= 2048])
     if layout == "stream":
-        # relaxed, stream layout: rows of <= 64 entries are still added left to right by one lane
-        assert np.array_equal(ax_r[len_rows <= 64], ref[len_rows <= 64])
-        assert np.array_equal(aty_r[len_cols <= 64], ref_t[len_cols <= 64])
+        # relaxed, stream layout: rows of <= 256 entries are still added left to right by one lane
+        assert np.array_equal(ax_r[len_rows <= 256], ref[len_rows <= 256])
+        assert np.array_equal(aty_r[len_cols <= 256], ref_t[len_cols <= 256])
     else:
         # relaxed sweep: runs of <= 8 entries inside a tile are strict; rows of <= 8 entries always are
         assert np.array_equal(ax_r[len_rows <= 8], ref[len_rows <= 8])
         assert np.array_equal(aty_r[len_cols <= 8], ref_t[len_cols <= 8])
     if name != "random":
-        assert max(len_rows.max(), len_cols.max()) > 64          # the test matrices do have wide rows
+        assert max(len_rows.max(), len_cols.max()) > 256         # the test matrices do have wide rows
 
 
-def test_relaxed_mode_lets_hub_matrices_use_the_sweep(gpu_required, monkeypatch):
+def test_hub_matrices_keep_the_stream_layout_in_both_orders(gpu_required, monkeypatch):
     """A PageRank graph large enough for the automatic layout choice to try the sweep (gathered
-    vector beyond 3 MiB): in strict order its hub rows' long same-row runs make build_tiled
-    decline (one lane would add hundreds of products per tile, in order); in relaxed order the
-    runs are reduced by a shuffle tree and the sweep is kept."""
+    vector beyond 3 MiB): its hub rows' long same-row runs make build_tiled decline in strict
+    order (one lane would add hundreds of products per tile) and -- measured, 0.168 ms swept
+    against 0.104 ms streamed on PageRank-1M -- in relaxed order too; forcing the sweep in relaxed
+    order selects the shuffle-tree chunk variant and stays within the stated bound (test above)."""
     p = pagerank_lp(600_000, seed=3)
     monkeypatch.delenv("PDHG_SPMV", raising=False)
-    infos = {}
     for order in ("strict", "relaxed"):
         monkeypatch.setenv("PDHG_ROW_ORDER", order)
         eng = HipPdhgEngine.from_problem(p)
-        infos[order] = eng.layout_info()
+        info = eng.layout_info()
         eng.close()
-    assert infos["strict"]["A_tiled_waves"] == 0 and infos["strict"]["At_tiled_waves"] == 0
-    assert infos["relaxed"]["A_tiled_waves"] > 0 or infos["relaxed"]["At_tiled_waves"] > 0, infos["relaxed"]
+        assert info["A_tiled_waves"] == 0 and info["At_tiled_waves"] == 0, (order, info)
 
 
 @pytest.mark.parametrize("path", ["plain", "graph", "one_kernel"])
