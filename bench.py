@@ -73,6 +73,11 @@ def parse():
     ap.add_argument("--shards", type=int, default=0,
                     help="dev: run K row shards inside this one process on the one GPU (peer-kernel back end); "
                          "timings then show the sharded pipeline's total work, not a multi-GPU rate")
+    ap.add_argument("--plain-launches", action="store_true",
+                    help="measurement aid: every kernel as its own launch, in stream order (PDHG_GRAPH=0), also in the timed "
+                         "region -- the same kernels the one-launch paths run.  A rocprofv3 kernel trace of this command "
+                         "attributes time to each product's kernels without the graph's concurrent branches or the "
+                         "persistent trial kernel (profiles/r03_<workload>_rocprof_summary.json)")
     ap.add_argument("--profile-steps", type=int, default=30)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -250,19 +255,39 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
                 traffic_source = f"{PMC_TRAFFIC_FILE} ({table.get('_round', 'offline')} rocprofv3 --pmc passes of this command)"
         except OSError:
             pass
+    # What a HIP-event bracket holds besides kernel time (empty launches on the same stream): about 10 us for the first
+    # launch of a bracket and 3 us per further one -- noise for a 0.75 ms sweep, a third of a small LP's 15-30 us products.
+    # `achieved_net` / `frac_net` subtract it; a rocprofv3 kernel trace (which times kernels only) agrees with those.
+    net_ms = dk["avg_ms"]
+    overhead = None
+    try:
+        o1, o2 = eng.measure_launch_overhead(20)
+        n_launch = len(eng.kernel_name(dom).split(" + "))
+        overhead = {"first_launch_ms": round(o1, 5), "further_launch_ms": round(o2, 5), "launches_in_group": n_launch}
+        if dk["avg_ms"]:
+            net_ms = max(dk["avg_ms"] - o1 - o2 * (n_launch - 1), 1e-6)
+    except Exception:    # measurement extra
+        pass
     try:     # the box's own streaming ceiling next to the spec figure
         triad = round(eng.measure_triad(1 << 26, 5), 1)
     except Exception:   # measurement extra
         triad = None
     roofline = {"bound": "hbm", "kernel": eng.kernel_name(dom),
+                "kernel_is_group": " + " in eng.kernel_name(dom),
                 "achieved": dk["achieved_GBps"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(dk["achieved_GBps"] / HBM_PEAK_GBS, 4),
                 "peak_measured_triad": triad,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": dk["avg_ms"],
+                "event_bracket_overhead": overhead,
+                "avg_launch_ms_net": round(net_ms, 5) if net_ms else None,
+                "achieved_net": round(dk["algorithmic_bytes"] / (net_ms * 1e-3) / 1e9, 1) if net_ms else None,
+                "frac_net": round(dk["algorithmic_bytes"] / (net_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if net_ms else None,
                 "algorithmic_bytes_per_launch": dk["algorithmic_bytes"],
                 "note": "a random 8-byte gather per nonzero bounds this kernel (L2 request path), not HBM "
-                        "streaming: DESIGN.md section 4"}
+                        "streaming: DESIGN.md section 4.  `kernel` lists the launches of one fused product as rocprofv3 "
+                        "prints them (column-slab passes, long-row pair: joined by ' + '); avg_launch_ms brackets the whole "
+                        "group; profiles/r03_<workload>_rocprof_summary.json adds the same names up"}
 
     # ---- CPU baseline: the literal single-thread restatement, bounded sample
     cpu_baseline = cpu_socket = None
@@ -323,11 +348,19 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_socket": cpu_socket,
         "kernels": kernels,
         "layout": {k: v for k, v in eng.layout_info().items() if "tiled" in k or "tile_cols" in k or "slab" in k or "graph" in k},
+        "layout_products": [eng.kernel_name(_lib.K_SPMV_DUAL), eng.kernel_name(_lib.K_SPMV_ATY)],
+        "launch_path": {2: "one persistent kernel per trial (trial_kernel)", 1: "one HIP-graph launch per trial",
+                        0: "separate launches"}.get(eng.layout_info().get("trial_graph"), "?"),
         "setup_sec": {"generate": round(t_gen, 1), "create_upload": round(t_create, 1)},
     }
     if issue_stats is not None:
         out["host_us_per_trial"] = issue_stats
-    if out["layout"].get("trial_graph"):
+    if out["layout"].get("trial_graph") == 2:
+        out["kernels_note"] = ("the timed region runs one trial as ONE persistent kernel (trial_kernel: the same device "
+                               "functions as the separate kernels between two grid barriers); the per-kernel figures are "
+                               "HIP-event brackets around the separate launches of a profiling pass (launch latency included), "
+                               "so their sum exceeds ms_per_step")
+    elif out["layout"].get("trial_graph"):
         out["kernels_note"] = ("the timed region launches one trial as ONE HIP graph (long-row kernels on a parallel "
                                "branch, no result copy); the per-kernel figures are HIP-event brackets around the plain "
                                "launches of a separate profiling pass (launch latency included, branches serialised), so "
@@ -342,6 +375,8 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
 
 def main():
     args = parse()
+    if args.plain_launches:
+        os.environ["PDHG_GRAPH"] = "0"
     # Native libraries print to stdout too (RCCL's version banner on communicator
     # creation, for one).  The contract is ONE JSON line on rank 0's stdout: send
     # file descriptor 1 to stderr until that line is written.

@@ -1147,13 +1147,36 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     h->own_stream = true;
   }
 #define CK(expr) do { int _rc = (expr); if (_rc) { destroy_shard(h); return _rc; } } while (0)
-  CK(build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, choose_tile_cols(n, nnz, m), h->relaxed));
-  const auto t_a = now();
-  CK(build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, choose_tile_cols(m, nnz, n), h->relaxed));
-  const auto t_at = now();
-  if (verbose)
-    fprintf(stderr, "pdhg_create: CSC -> CSR(A), CSR(A') %.2fs; layouts + upload A %.2fs, A' %.2fs\n",
-            secs(t_start, t_conv), secs(t_conv, t_a), secs(t_a, t_at));
+  // the two layouts are independent: CSR(A) is built on a second host thread while this one builds CSR(A')
+  // (each fans out over host_threads() workers for the per-nonzero passes; uploads are synchronous copies)
+  {
+    int rc_a = 0;
+    std::string err_a;
+    double t_a = 0.0, t_at = 0.0;
+    const int tile_a = choose_tile_cols(n, nnz, m), tile_at = choose_tile_cols(m, nnz, n);
+    // Off by default: measured on the 2 x 64-core host of the GPU box at config S, the two builds side by side took
+    // 0.92 s against 0.83 s one after the other (0.78 ‖ 0.60 s against 0.47 + 0.36 s) -- the per-nonzero passes are bound
+    // by host memory bandwidth, not by threads (32 threads per pass instead of 16 changed nothing either).
+    const bool two = nnz >= (1 << 22) && getenv("PDHG_PARALLEL_LAYOUTS") != nullptr;
+    auto build_a = [&]() {
+      const auto t0 = now();
+      if (hipSetDevice(dev) != hipSuccess) { rc_a = 999; err_a = "hipSetDevice failed on the layout thread"; return; }
+      rc_a = build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, tile_a, h->relaxed);
+      if (rc_a) err_a = g_last_error;
+      t_a = secs(t0, now());
+    };
+    std::thread worker;
+    if (two) worker = std::thread(build_a); else build_a();
+    const auto t0 = now();
+    const int rc_t = build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, tile_at, h->relaxed);
+    t_at = secs(t0, now());
+    if (two) worker.join();
+    if (rc_a) { g_last_error = err_a; destroy_shard(h); return rc_a; }
+    CK(rc_t);
+    if (verbose)
+      fprintf(stderr, "pdhg_create: CSC -> CSR(A), CSR(A') %.2fs; layouts + upload A %.2fs %s A' %.2fs (%.2fs elapsed)\n",
+              secs(t_start, t_conv), t_a, two ? "beside" : "then", t_at, secs(t_conv, now()));
+  }
   auto up = [&](double **dst, const double *src, int64_t len) -> int {
     int r2 = alloc_zero(dst, len);
     if (r2) return r2;
@@ -1359,14 +1382,43 @@ extern "C" {
 const char *pdhg_last_error(void) { return g_last_error.c_str(); }
 int pdhg_abi_version(void) { return 6; }
 
+// The kernels behind one fused product, as rocprofv3 prints them (template arguments <MODE,
+// INIT, TAG> / <MODE, CH> / <TAG>; MODE 0 plain, 1 dual epilogue, 2 A'y epilogue; TAG 0 = A,
+// 1 = A'), joined by " + ": a profile of the separate launches adds up to the product by
+// summing these names (tools/rocprof_summary.py does).
+static std::string product_kernels(const CsrDev &D, int mode, int tag) {
+  std::string out;
+  auto add = [&](const std::string &k) { out += (out.empty() ? "" : " + ") + k; };
+  const std::string m = std::to_string(mode), t = std::to_string(tag);
+  if (D.tiled) {
+    if (D.grid > 0) add("spmv_tiled_kernel<" + m + ", " + std::to_string(D.tw_mode) + ">");
+  } else if (!D.slabs.empty()) {
+    add("spmv_stream_kernel<0, false, " + t + ">");
+    if (D.slabs.size() > 2) add("spmv_stream_kernel<0, true, " + t + ">");
+    add("spmv_stream_kernel<" + m + ", true, " + t + ">");
+  } else if (D.grid > 0) {
+    add("spmv_stream_kernel<" + m + ", false, " + t + ">");
+  }
+  if (D.nlong > 0) {
+    add("spmv_long_partial_kernel<" + t + ">");
+    add("spmv_long_final_kernel<" + m + ">");
+  }
+  return out.empty() ? "(no kernel: empty matrix)" : out;
+}
+
 const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id) {
+  static thread_local std::string buf;
   const bool fused = !(h && h->grp);
   switch (kernel_id) {
     case PDHG_K_PRIMAL: return "primal_kernel";
-    case PDHG_K_SPMV_DUAL: return (h && h->A.tiled) ? "spmv_tiled_kernel<MODE_DUAL>" : "spmv_stream_kernel<MODE_DUAL>";
+    case PDHG_K_SPMV_DUAL:
+      if (!h) return "spmv_stream_kernel<1, false, 0>";
+      buf = product_kernels(h->A, MODE_DUAL, 0);
+      return buf.c_str();
     case PDHG_K_SPMV_ATY:
-      if (h && h->At.tiled) return fused ? "spmv_tiled_kernel<MODE_ATY>" : "spmv_tiled_kernel<MODE_PLAIN>";
-      return fused ? "spmv_stream_kernel<MODE_ATY>" : "spmv_stream_kernel<MODE_PLAIN>";
+      if (!h) return "spmv_stream_kernel<2, false, 1>";
+      buf = product_kernels(h->At, fused ? MODE_ATY : MODE_PLAIN, 1);
+      return buf.c_str();
     case PDHG_K_FINAL: return "final_reduce_kernel";
     case PDHG_K_ACCEPT: return "accept_kernel";
     case PDHG_K_ALLGATHER: return "all_gather(xbar)";
@@ -2747,6 +2799,31 @@ int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps) {
   (void)hipFree(buf);
   HIP_TRY(err);
   *gbps = 24.0 * (double)(4 * len4) / ((double)best * 1e-3) / 1e9;
+  return 0;
+}
+
+namespace {
+__global__ void noop_kernel(int *sink) { if (sink && threadIdx.x == 1024) *sink = 0; }
+}  // namespace
+
+int pdhg_measure_launch_overhead(pdhg_handle *h, int reps, double out[2]) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (reps <= 0 || !out) return fail(-1, "bad arguments");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double best[2] = {1e30, 1e30};
+  for (int k = 1; k <= 2; ++k)
+    for (int r = 0; r <= reps; ++r) {          // pass 0 warms up
+      HIP_TRY(hipEventRecord(h->ev0, h->stream));
+      for (int q = 0; q < (k == 1 ? 1 : 5); ++q) hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, h->stream, (int *)nullptr);
+      HIP_TRY(hipEventRecord(h->ev1, h->stream));
+      HIP_TRY(hipEventSynchronize(h->ev1));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+      if (r > 0 && ms < best[k - 1]) best[k - 1] = ms;
+    }
+  out[0] = best[0];                              // one empty launch between two events
+  out[1] = (best[1] - best[0]) / 4.0;            // every further launch inside the same bracket
   return 0;
 }
 

@@ -334,6 +334,12 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_measure_triad(self._h, int(length), int(reps), ctypes.byref(out)))
         return out.value
 
+    def measure_launch_overhead(self, reps=20):
+        """(ms for one empty launch between two HIP events, ms per further launch in the same bracket)."""
+        out = np.zeros(2)
+        _lib.check(self._L.pdhg_measure_launch_overhead(self._h, int(reps), _pd(out)))
+        return float(out[0]), float(out[1])
+
     # ---- measurement -------------------------------------------------------------
     def profile_enable(self, enable=True):
         _lib.check(self._L.pdhg_profile_enable(self._h, int(bool(enable))))

@@ -335,8 +335,12 @@ int pdhg_profile_read(pdhg_handle *h, int kernel_id, int64_t *launches,
                       double *total_ms);
 /* Algorithmic HBM bytes one launch of `kernel_id` must move. */
 int64_t pdhg_kernel_algorithmic_bytes(pdhg_handle *h, int kernel_id);
-/* Name of the kernel `kernel_id` stands for ON THIS HANDLE (the SpMV layout is
- * chosen per matrix at create).  h == NULL gives the stream-layout names. */
+/* The kernel(s) `kernel_id` stands for ON THIS HANDLE (the SpMV layout is chosen per
+ * matrix at create), spelled as rocprofv3 prints them -- template arguments included --
+ * and joined by " + " when a product is a group of launches (column-slab passes, the
+ * long-row pair): summing those names in a kernel trace of the separate launches gives the
+ * time pdhg_profile_read brackets.  h == NULL gives the stream-layout names.  The string is
+ * valid until the calling thread's next call. */
 const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id);
 /* Layout statistics (diagnostics): [0..3] CSR(A) {row blocks, long rows, long
  * chunks, max row nnz}, [4..7] same for CSR(A'), [8],[9] tiled-sweep waves of
@@ -349,6 +353,13 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]);
  * doubles (len % 4 == 0) on this handle's device and stream (24*len bytes per pass), in GB/s --
  * the box's own streaming ceiling to put beside the 8 TB/s spec figure. */
 int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps);
+/* Measurement only: what a HIP-event bracket reports for EMPTY launches on this handle's
+ * stream -- out[0] ms for one empty kernel between the two events, out[1] ms for every further
+ * launch inside the same bracket (best of `reps`).  pdhg_profile_read's brackets contain this
+ * much that is not kernel time: about 10 us for the first launch and 3 us per further one,
+ * which matters for the 5-50 us kernels of a small LP (a rocprofv3 kernel trace, which times
+ * the kernels themselves, is shorter by that amount). */
+int pdhg_measure_launch_overhead(pdhg_handle *h, int reps, double out[2]);
 
 #ifdef __cplusplus
 }

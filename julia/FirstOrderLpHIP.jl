@@ -169,6 +169,13 @@ function rccl_info()
           path = unsafe_string(pointer(path)))
 end
 
+"HIP-event bracket of empty launches: (ms for one, ms per further launch in the same bracket) (`pdhg_measure_launch_overhead`)."
+function measure_launch_overhead(s::HipSolverState, reps::Integer = 20)
+  out = zeros(2)
+  check(ccall((:pdhg_measure_launch_overhead, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), s.handle, reps, out))
+  return out[1], out[2]
+end
+
 "Host-side cost of the trial steps so far: (trials, seconds issuing, seconds waiting) (`pdhg_host_issue_stats`)."
 function host_issue_stats(s::HipSolverState)
   trials = Ref{Int64}(0); issue = Ref{Float64}(0.0); wait = Ref{Float64}(0.0)

@@ -77,3 +77,31 @@ def test_native_take_step_reports_zero_movement(gpu_required):
             break
     assert st.numerical_error
 
+
+
+@pytest.mark.parametrize("maker", [lambda: random_lp(5000, 4000, 8, seed=7),
+                                   lambda: H.skewed_lp(3000, 9000, seed=7, dense_rows=2, dense_cols=2)],
+                         ids=["random", "skewed_long_rows"])
+def test_malitsky_pock_split_through_the_one_kernel_trial_is_bitwise_the_plain_path(gpu_required, monkeypatch, maker):
+    """take_step(::MalitskyPockStepsizeParameters) (pdhg.jl:555-647): x' once (pdhg_trial_primal), then
+    repeated dual trials (pdhg_trial_dual: xbar + K3..K6).  The dual trials run as ONE persistent
+    kernel too (its phase 0 is xbar alone); results must be the bits of the separate launches."""
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import MalitskyPockStepsizeParameters
+    p = maker()
+    runs = {}
+    for path in ("plain", "one_kernel"):
+        monkeypatch.setenv("PDHG_GRAPH", "0" if path == "plain" else "1")
+        monkeypatch.setenv("PDHG_COOP", "1" if path == "one_kernel" else "0")
+        eng = HipPdhgEngine.from_problem(p)
+        assert eng.layout_info()["trial_graph"] == (2 if path == "one_kernel" else 0)
+        step, pw = H.initial_step_and_weight(p)
+        st = PdhgSolverState(eng, step_size=step, primal_weight=pw, ratio_step_sizes=1.0)
+        mp = MalitskyPockStepsizeParameters(downscaling_factor=0.7, breaking_factor=0.99, interpolation_coefficient=1.0)
+        steps = []
+        for _ in range(60):
+            take_step(mp, st)
+            steps.append(st.step_size)
+        runs[path] = (np.array(steps), *eng.get_current(), *eng.get_average(), st.total_number_iterations)
+        eng.close()
+    for a, b in zip(runs["plain"], runs["one_kernel"]):
+        assert np.array_equal(a, b)
