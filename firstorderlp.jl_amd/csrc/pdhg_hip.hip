@@ -561,9 +561,17 @@ TrialProduct trial_product(pdhg_handle *h, const CsrDev &D, const double *xin, c
 }
 
 // returns 1 when the handle turned out not to suit the one-launch kernel (nothing was launched)
+// Two persistent launches that are both only PARTLY resident would wait for each other's workgroups for ever
+// (until the spin limit): one such kernel at a time per device, from launch until its results are back.
+std::mutex &coop_device_mutex(int device) {
+  static std::mutex mu[64];
+  return mu[device & 63];
+}
+
 int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double theta, bool xbar_only, double out[5]) {
   int rc = coop_prepare(h);
   if (rc) return rc;
+  std::lock_guard<std::mutex> one_at_a_time(coop_device_mutex(h->device));
   const auto c0 = std::chrono::steady_clock::now();
   TrialKernelArgs a{};
   a.n = (int)h->n; a.xbar_only = xbar_only ? 1 : 0;

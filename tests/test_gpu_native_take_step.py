@@ -105,3 +105,42 @@ def test_malitsky_pock_split_through_the_one_kernel_trial_is_bitwise_the_plain_p
         eng.close()
     for a, b in zip(runs["plain"], runs["one_kernel"]):
         assert np.array_equal(a, b)
+
+
+def test_two_handles_driving_one_kernel_trials_from_two_threads(gpu_required, monkeypatch):
+    """Two persistent trial kernels that are each only partly resident would wait for one another's
+    workgroups; the library runs one at a time per device (a mutex from launch to results).  Two host
+    threads, one handle each, must both finish with the bits of a handle run alone."""
+    import threading
+    monkeypatch.setenv("PDHG_GRAPH", "1")
+    monkeypatch.setenv("PDHG_COOP", "1")
+    p = random_lp(40000, 30000, 8, seed=9)
+
+    def solo():
+        eng = HipPdhgEngine.from_problem(p)
+        assert eng.layout_info()["trial_graph"] == 2
+        step, pw = H.initial_step_and_weight(p)
+        st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+        for _ in range(150):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+        out = (np.concatenate(eng.get_current()), st.total_number_iterations, st.step_size)
+        eng.close()
+        return out
+
+    ref = solo()
+    results, errors = [None, None], []
+
+    def work(k):
+        try:
+            results[k] = solo()
+        except Exception as exc:      # surfaced below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for r in results:
+        assert r is not None and np.array_equal(r[0], ref[0]) and r[1:] == ref[1:]
