@@ -41,6 +41,7 @@ struct CsrDev {
   int *step_tile = nullptr;       // first column of the tile of every step, workgroup after workgroup
   int *wg_step_off = nullptr;     // [grid+1] start of a workgroup's steps inside step_tile
   int64_t total_steps = 0;
+  int64_t tw_entries = 0, step_ptr_len = 0;   // lengths of pk / tv and of wave_ent (checksums, tests)
   int tw_mode = 0;                // chunk accumulation: 0 lane shuffles, 1 LDS scratch (long runs, strict order), 2 relaxed order
   unsigned *pk = nullptr;
   double *tv = nullptr;
@@ -119,8 +120,20 @@ inline int tile_width_cap(int64_t rows) {
 // Host-side construction of the tiled-sweep layout: wave row blocks (runs of
 // <= TW_ROWS consecutive non-long rows) and their entries counting-sorted by
 // column tile (stable, so (row, col) order is kept inside a tile).
-int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec &col,
-                const dvec &val, int tile_cols, bool relaxed) {
+// Device mode (col_p == nullptr; device_layout.hpp): D.rowptr / D.col / D.val are already in HBM.  The
+// three places that touch the entries -- the 16-column histogram of the skew test, the
+// per-(wave, tile) counts and the tile-major fill -- run as kernels there (tw_count_kernel,
+// cnt16_kernel, tw_fill_kernel) and everything else is the code below, unchanged: same plan, same
+// tables, bit-identical layout.  Returns 1 (nothing built, D untouched) when the device mode does
+// not cover the case -- equal-nonzero tiles of different widths, more than 1024 tiles, a count
+// matrix beyond 32M cells: the caller then fetches the entries and calls the host mode.
+int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec *col_p,
+                const dvec *val_p, int tile_cols, bool relaxed) {
+  const bool on_device = col_p == nullptr;
+  static const ivec no_col;
+  static const dvec no_val;
+  const ivec &col = on_device ? no_col : *col_p;
+  const dvec &val = on_device ? no_val : *val_p;
   // Tile boundaries.  Uniform width tile_cols by default.  When the columns are skewed
   // (hub columns: the fullest uniform tile holds more than 1.5x the average), the
   // boundaries are moved so that every tile holds about the same number of entries
@@ -134,7 +147,15 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     // entries per 16-column group, on host threads (integer counts: the result does not depend on the thread count)
     const int groups = (D.cols + 15) / 16;
     std::vector<int> cnt16((size_t)groups, 0);
-    {
+    if (on_device) {
+      int *d16 = nullptr;
+      HIP_TRY(hipMalloc((void **)&d16, sizeof(int) * (size_t)std::max(groups, 1)));
+      HIP_TRY(hipMemset(d16, 0, sizeof(int) * (size_t)std::max(groups, 1)));
+      hipLaunchKernelGGL(cnt16_kernel, dim3(2048), dim3(TPB), 0, nullptr, rows, (const int *)D.rowptr, (const int *)D.col, d16);
+      hipError_t e = hipMemcpy(cnt16.data(), d16, sizeof(int) * (size_t)groups, hipMemcpyDeviceToHost);
+      (void)hipFree(d16);
+      HIP_TRY(e);
+    } else {
       std::mutex merge;
       parallel_ranges(rows, 1 << 16, [&](int rb, int re) {
         std::vector<int> mine((size_t)groups, 0);
@@ -158,6 +179,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     const char *vt = getenv("PDHG_VAR_TILES");                   // 0 / 1 force
     bool variable = nt0 > 1 && (double)fullest > 1.5 * (double)total / (double)nt0;
     if (vt) variable = vt[0] != '0' && nt0 > 1;
+    if (on_device && (variable || nt0 > 1024)) return 1;      // host mode handles these
     if (!variable) {
       for (int t = 0; t <= nt0; ++t) tstart.push_back((int)std::min<int64_t>(D.cols, (int64_t)t * tile_cols));
     } else {
@@ -247,12 +269,43 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   // (A: sizes, serial prefix sums, B: fill).  The result does not depend on the
   // number of threads.
   std::vector<int> wg_nsteps((size_t)std::max(grid, 1), 0), wg_touched((size_t)std::max(grid, 1), 0);
+  // device mode: the per-(wave, tile) counts and the longest same-row run come from one kernel pass
+  std::vector<int> cell_cnt, dev_max_run;
+  int2 *d_wave_rows = nullptr;
+  int *d_cell_cnt = nullptr;
+  struct DevTmp {          // freed on every exit unless handed over
+    void **p;
+    ~DevTmp() { if (*p) (void)hipFree(*p); }
+  } tmp_wave_rows{(void **)&d_wave_rows}, tmp_cell_cnt{(void **)&d_cell_cnt};
+  if (on_device) {
+    if ((int64_t)nwaves * ntiles > (32LL << 20)) return 1;
+    cell_cnt.resize((size_t)std::max(nwaves, 1) * ntiles);
+    dev_max_run.assign((size_t)std::max(grid, 1), 0);
+    int rc2;
+    if ((rc2 = upload(&d_wave_rows, wave_rows))) return rc2;
+    int *d_mr = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_cell_cnt, sizeof(int) * std::max<size_t>(cell_cnt.size(), 1)));
+    HIP_TRY(hipMalloc((void **)&d_mr, sizeof(int) * dev_max_run.size()));
+    HIP_TRY(hipMemset(d_mr, 0, sizeof(int) * dev_max_run.size()));
+    if (nwaves > 0) {
+      const int wpb = TPB / WAVE;
+      hipLaunchKernelGGL(tw_count_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(TPB), sizeof(int) * wpb * ntiles, nullptr,
+                         (const int2 *)d_wave_rows, nwaves, (const int *)D.rowptr, (const int *)D.col, tile_cols, ntiles,
+                         d_cell_cnt, d_mr);
+      HIP_TRY(hipMemcpy(cell_cnt.data(), d_cell_cnt, sizeof(int) * cell_cnt.size(), hipMemcpyDeviceToHost));
+    }
+    hipError_t e = hipMemcpy(dev_max_run.data(), d_mr, sizeof(int) * dev_max_run.size(), hipMemcpyDeviceToHost);
+    (void)hipFree(d_mr);
+    HIP_TRY(e);
+  }
   auto count_cells = [&](int g, std::vector<std::vector<int>> &cnt, std::vector<int> &nsub) {
     const int w0 = g * TW_WPB, w1 = std::min(nwaves, w0 + TW_WPB);
     std::fill(nsub.begin(), nsub.end(), 0);
     for (int w = w0; w < w1; ++w) {
       std::vector<int> &c = cnt[w - w0];
       std::fill(c.begin(), c.end(), 0);
+      if (on_device) for (int t = 0; t < ntiles; ++t) c[t + 1] = cell_cnt[(size_t)w * ntiles + t];
+      else
       for (int k = rowptr[wave_rows[w].x]; k < rowptr[wave_rows[w].y]; ++k) c[tile_of(col[k]) + 1] += 1;
       for (int t = 0; t < ntiles; ++t) nsub[t] = std::max(nsub[t], (c[t + 1] + WIN - 1) / WIN);
       for (int t = 0; t < ntiles; ++t) c[t + 1] += c[t];   // prefix: cell start offsets
@@ -301,8 +354,8 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     }
   }
   if (step_ptr_len >= INT32_MAX) return fail(-2, "tiled layout: step table too large for 32-bit offsets");
-  uvec<unsigned> pk((size_t)wave_base[nwaves]);
-  dvec tv((size_t)wave_base[nwaves]);
+  uvec<unsigned> pk(on_device ? 0 : (size_t)wave_base[nwaves]);
+  dvec tv(on_device ? 0 : (size_t)wave_base[nwaves]);
   std::vector<int> step_ptr((size_t)step_ptr_len), step_tile((size_t)wg_step_off[grid]);
   std::vector<int> max_run_of((size_t)std::max(grid, 1), 0);   // longest same-row run inside one tile, per workgroup
   // pass B: step lists, per-wave step offsets and the entries, tile-major (stable in (row, col))
@@ -329,6 +382,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
         }
         *sp++ = (int)base + total;
         std::copy(c.begin(), c.end() - 1, next.begin());
+        if (!on_device)
         for (int rr = r0; rr < r1; ++rr) {
           const unsigned rl = (unsigned)(rr - r0) << tile_shift;
           int run = 0, run_tile = -1;
@@ -343,7 +397,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
           }
         }
       }
-      max_run_of[g] = max_run;
+      max_run_of[g] = on_device ? dev_max_run[(size_t)g] : max_run;
     }
   });
   int max_run = 0;
@@ -376,6 +430,8 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   D.nwaves = nwaves;
   D.grid = grid;
   D.total_steps = (int64_t)step_tile.size();
+  D.tw_entries = wave_base[nwaves];
+  D.step_ptr_len = step_ptr_len;
   if (getenv("PDHG_VERBOSE")) {
     int mx = 0;
     for (int g = 0; g < grid; ++g) mx = std::max(mx, wg_nsteps[(size_t)g]);
@@ -388,11 +444,33 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   // chosen sweeps (runs <= 32) keep the strict-order variants and stay bit-exact with the CPU loops
   D.tw_mode = max_run > 8 ? ((relaxed && max_run > 32) ? 2 : 1) : 0;
   int rc;
-  if ((rc = upload(&D.wave_rows, wave_rows))) return rc;
+  if (on_device) { D.wave_rows = d_wave_rows; d_wave_rows = nullptr; }
+  else if ((rc = upload(&D.wave_rows, wave_rows))) return rc;
   if ((rc = upload(&D.wave_ent, step_ptr))) return rc;
   if ((rc = upload(&D.wave_step_off, wave_step_off))) return rc;
   if ((rc = upload(&D.step_tile, step_tile))) return rc;
   if ((rc = upload(&D.wg_step_off, wg_step_off))) return rc;
+  if (on_device) {
+    // the tile-major copy: a stable counting sort per wave, in HBM (tw_fill_kernel)
+    const size_t total = (size_t)wave_base[nwaves];
+    HIP_TRY(hipMalloc((void **)&D.pk, sizeof(unsigned) * std::max<size_t>(total, 1)));
+    HIP_TRY(hipMalloc((void **)&D.tv, sizeof(double) * std::max<size_t>(total, 1)));
+    if (nwaves > 0) {
+      int64_t *d_base = nullptr;
+      if ((rc = upload(&d_base, wave_base))) return rc;
+      int tile_bits = 1;
+      while ((1 << tile_bits) < ntiles) ++tile_bits;
+      const int wpb = TPB / WAVE;
+      hipLaunchKernelGGL(tw_fill_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(TPB), sizeof(int) * wpb * ntiles, nullptr,
+                         (const int2 *)D.wave_rows, nwaves, (const int64_t *)d_base, (const int *)D.rowptr, (const int *)D.col,
+                         (const double *)D.val, tile_cols, ntiles, tile_bits, tile_shift, (const int *)d_cell_cnt, D.pk, D.tv);
+      hipError_t e = hipDeviceSynchronize();
+      (void)hipFree(d_base);
+      HIP_TRY(e);
+      HIP_TRY(hipGetLastError());
+    }
+    return 0;
+  }
   if ((rc = upload(&D.pk, pk))) return rc;
   if ((rc = upload(&D.tv, tv))) return rc;
   return 0;
@@ -470,9 +548,9 @@ int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, c
   return 0;
 }
 
-int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
-                  const ivec &col, const dvec &val,
-                  bool remap, int tile_cols = 0, bool relaxed = false) {
+// Everything of a CsrDev that follows from the row pointers alone: row blocks, the long-row
+// tables and their buffers.  (Host loops over the rows; the per-nonzero arrays are not touched.)
+int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, bool remap) {
   D.rows = rows;
   D.cols = cols;
   D.nnz = rowptr[rows];
@@ -512,9 +590,6 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
   D.nchunks = (int)chunk_row.size();
   D.long_grid = (D.nlong + LONG_ROWS_PER_WG - 1) / LONG_ROWS_PER_WG;     // one wave per long row
   int rc;
-  if ((rc = upload(&D.rowptr, rowptr))) return rc;
-  if ((rc = upload(&D.col, col))) return rc;
-  if ((rc = upload(&D.val, val))) return rc;
   if ((rc = upload(&D.blks, blks))) return rc;
   if ((rc = upload(&D.long_row, long_row))) return rc;
   if ((rc = upload(&D.long_chunk_ptr, long_chunk_ptr))) return rc;
@@ -527,11 +602,67 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
     D.long_ticket = reinterpret_cast<unsigned long long *>(z);
   }
   if ((rc = alloc_zero(&D.chunk_partial, D.nchunks))) return rc;
+  return 0;
+}
+
+int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
+                  const ivec &col, const dvec &val,
+                  bool remap, int tile_cols = 0, bool relaxed = false) {
+  int rc;
+  if ((rc = build_stream_tables(D, rows, cols, rowptr, remap))) return rc;
+  if ((rc = upload(&D.rowptr, rowptr))) return rc;
+  if ((rc = upload(&D.col, col))) return rc;
+  if ((rc = upload(&D.val, val))) return rc;
   if (tile_cols > 0) {
-    if ((rc = build_tiled(D, rows, rowptr, col, val, tile_cols, relaxed))) return rc;
+    if ((rc = build_tiled(D, rows, rowptr, &col, &val, tile_cols, relaxed))) return rc;
   }
   if (!D.tiled) {
     if ((rc = build_slabs(D, rows, cols, rowptr, col, val, remap))) return rc;
+  }
+  return 0;
+}
+
+// The same with D.rowptr / D.col / D.val ALREADY in HBM (device_layout.hpp): tables from the row
+// pointers, the sweep's layout by the device kernels.  Cases the device mode does not cover (tiles of
+// different widths, very many tiles; column slabs, which are built from host arrays) fetch the
+// entries back once and take the host builders.
+int build_csr_dev_resident(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, bool remap,
+                           int tile_cols, bool relaxed) {
+  int rc;
+  if ((rc = build_stream_tables(D, rows, cols, rowptr, remap))) return rc;
+  ivec col;
+  dvec val;
+  bool fetched = false;
+  auto fetch = [&]() -> int {
+    if (fetched) return 0;
+    col.resize((size_t)D.nnz);
+    val.resize((size_t)D.nnz);
+    if (D.nnz > 0) {
+      HIP_TRY(hipMemcpy(col.data(), D.col, sizeof(int) * (size_t)D.nnz, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(val.data(), D.val, sizeof(double) * (size_t)D.nnz, hipMemcpyDeviceToHost));
+    }
+    fetched = true;
+    return 0;
+  };
+  if (tile_cols > 0) {
+    rc = build_tiled(D, rows, rowptr, nullptr, nullptr, tile_cols, relaxed);
+    if (rc == 1) {                                   // not covered on the device
+      if ((rc = fetch())) return rc;
+      rc = build_tiled(D, rows, rowptr, &col, &val, tile_cols, relaxed);
+    }
+    if (rc) return rc;
+  }
+  if (!D.tiled) {
+    // column slabs apply to 1.25 .. 4 slab widths of gathered vector and >= 1M nonzeros (build_slabs)
+    const char *off = getenv("PDHG_SLABS");
+    const char *mb = getenv("PDHG_SLAB_MB");
+    const double slab_bytes = (mb ? std::max(0.25, atof(mb)) : 4.0) * 1048576.0, vec_bytes = 8.0 * (double)cols;
+    const int P = (int)std::ceil(vec_bytes / slab_bytes);
+    const bool slabs = !(off && off[0] == '0') && vec_bytes > 1.25 * slab_bytes && D.nnz >= (1 << 20) && P >= 2 && P <= 4;
+    if (slabs) {
+      if ((rc = fetch())) return rc;
+      if ((rc = build_slabs(D, rows, cols, rowptr, col, val, remap))) return rc;
+    }
   }
   return 0;
 }

@@ -42,6 +42,7 @@
 #include "vector_kernels.hpp"
 #include "eval_kernels.hpp"
 #include "rescale_kernels.hpp"
+#include "device_layout.hpp"
 #include "layout.hpp"
 #include "trial_kernel.hpp"
 
@@ -1104,6 +1105,70 @@ int csc_to_both(int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
   return 0;
 }
 
+// Large matrices: upload the caller's CSC arrays as they are and build CSR(A'), CSR(A) in HBM
+// (device_layout.hpp).  On return A / At hold rowptr, col, val on the device and the two host vectors the
+// row pointers (the only per-row data the host-side planning needs).  Validation as csc_to_both's.
+int ingest_on_device(CsrDev &A, CsrDev &At, int64_t rows, int64_t cols, int64_t nnz, const int64_t *colptr,
+                     const int64_t *rowval, const double *nzval, int base, std::vector<int> &rowptr,
+                     std::vector<int> &t_rowptr) {
+  if (rows >= INT32_MAX || cols >= INT32_MAX || nnz >= INT32_MAX || rows + cols >= INT32_MAX)
+    return fail(-2, "m, n, m + n or nnz >= 2^31 need the 64-bit index path (not built)");
+  if (colptr[0] != base) return fail(-1, "colptr[0] != index_base");
+  if (colptr[cols] - base != nnz) return fail(-1, "colptr[n] - base != nnz");
+  hipStream_t st = nullptr;
+  int64_t *d_colptr = nullptr, *d_rowval = nullptr;
+  int *key = nullptr, *key2 = nullptr, *col2 = nullptr, *row_cnt = nullptr, *flags = nullptr;
+  double *val2 = nullptr;
+  auto cleanup = [&]() {
+    for (void *p : {(void *)d_colptr, (void *)d_rowval, (void *)key, (void *)key2, (void *)col2, (void *)row_cnt, (void *)flags, (void *)val2})
+      if (p) (void)hipFree(p);
+  };
+#define DL(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail_hip(_e, #expr); } } while (0)
+  const size_t nz = (size_t)std::max<int64_t>(nnz, 1);
+  DL(hipMalloc((void **)&d_colptr, sizeof(int64_t) * (size_t)(cols + 1)));
+  DL(hipMalloc((void **)&d_rowval, sizeof(int64_t) * nz));
+  DL(hipMalloc((void **)&At.rowptr, sizeof(int) * (size_t)(cols + 1)));
+  DL(hipMalloc((void **)&At.col, sizeof(int) * nz));
+  DL(hipMalloc((void **)&At.val, sizeof(double) * nz));
+  DL(hipMalloc((void **)&A.rowptr, sizeof(int) * (size_t)(rows + 1)));
+  DL(hipMalloc((void **)&A.col, sizeof(int) * nz));
+  DL(hipMalloc((void **)&A.val, sizeof(double) * nz));
+  DL(hipMalloc((void **)&key, sizeof(int) * nz));
+  DL(hipMalloc((void **)&key2, sizeof(int) * nz));
+  DL(hipMalloc((void **)&col2, sizeof(int) * nz));
+  DL(hipMalloc((void **)&val2, sizeof(double) * nz));
+  DL(hipMalloc((void **)&row_cnt, sizeof(int) * (size_t)(rows + 1)));
+  DL(hipMalloc((void **)&flags, sizeof(int)));
+  DL(hipMemcpy(d_colptr, colptr, sizeof(int64_t) * (size_t)(cols + 1), hipMemcpyHostToDevice));
+  DL(hipMemcpy(d_rowval, rowval, sizeof(int64_t) * (size_t)nnz, hipMemcpyHostToDevice));
+  DL(hipMemcpy(At.val, nzval, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+  DL(hipMemsetAsync(row_cnt, 0, sizeof(int) * (size_t)(rows + 1), st));
+  DL(hipMemsetAsync(flags, 0, sizeof(int), st));
+  hipLaunchKernelGGL(ingest_colptr_kernel, dim3((unsigned)((cols + 1 + TPB - 1) / TPB)), dim3(TPB), 0, st,
+                     (const int64_t *)d_colptr, cols, nnz, base, At.rowptr, flags);
+  hipLaunchKernelGGL(ingest_entries_kernel, dim3(4096), dim3(TPB), 0, st, (const int64_t *)d_rowval, (const int *)At.rowptr, nnz,
+                     rows, cols, base, At.col, key, A.col, row_cnt, flags);
+  int hflags = 0;
+  DL(hipMemcpy(&hflags, flags, sizeof(int), hipMemcpyDeviceToHost));
+  if (hflags) { cleanup(); return fail(-1, (hflags & 2) ? "colptr not monotone" : "rowval out of range"); }
+  int rc = device_exclusive_scan(row_cnt, A.rowptr, rows + 1, nullptr, st);
+  if (rc) { cleanup(); return rc; }
+  DL(hipMemcpyAsync(A.val, At.val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, st));
+  int key_bits = 1;
+  while ((1LL << key_bits) < rows) ++key_bits;
+  bool in_scratch = false;
+  rc = device_radix_sort(key, A.col, A.val, key2, col2, val2, nnz, key_bits, &in_scratch, st);
+  if (rc) { cleanup(); return rc; }
+  if (in_scratch) { std::swap(A.col, col2); std::swap(A.val, val2); }
+  rowptr.resize((size_t)rows + 1);
+  t_rowptr.resize((size_t)cols + 1);
+  DL(hipMemcpy(rowptr.data(), A.rowptr, sizeof(int) * (size_t)(rows + 1), hipMemcpyDeviceToHost));
+  DL(hipMemcpy(t_rowptr.data(), At.rowptr, sizeof(int) * (size_t)(cols + 1), hipMemcpyDeviceToHost));
+#undef DL
+  cleanup();
+  return 0;
+}
+
 // One shard: device layouts + vectors for the rows it is given.  n_alloc >= n is the
 // allocation length of the n-vectors that take part in collectives.
 int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
@@ -1133,8 +1198,19 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   std::vector<int> t_rowptr, rowptr;
   ivec t_col, col;
   dvec t_val, val;
-  int rc = csc_to_both(m, n, nnz, colptr, rowval, nzval, index_base, t_rowptr, t_col, t_val, rowptr, col, val);
-  if (rc) return rc;
+  // Large matrices are laid out ON THE DEVICE (device_layout.hpp): bit-identical layouts, a fraction of
+  // the host builders' time.  PDHG_DEVICE_LAYOUT=0 keeps the host builders, =1 forces the device path.
+  bool device_layout = nnz >= (8 << 20) && m > 0 && n > 0;
+  if (const char *ev = getenv("PDHG_DEVICE_LAYOUT")) device_layout = ev[0] != '0' && nnz > 0 && m > 0 && n > 0;
+  int rc = 0;
+  CsrDev dev_A, dev_At;
+  if (device_layout) {
+    rc = ingest_on_device(dev_A, dev_At, m, n, nnz, colptr, rowval, nzval, index_base, rowptr, t_rowptr);
+    if (rc) { free_csr_dev(dev_A); free_csr_dev(dev_At); return rc; }
+  } else {
+    rc = csc_to_both(m, n, nnz, colptr, rowval, nzval, index_base, t_rowptr, t_col, t_val, rowptr, col, val);
+    if (rc) return rc;
+  }
   const auto t_conv = now();
 
   pdhg_handle *h = new pdhg_handle();
@@ -1166,24 +1242,28 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     // 0.92 s against 0.83 s one after the other (0.78 ‖ 0.60 s against 0.47 + 0.36 s) -- the per-nonzero passes are bound
     // by host memory bandwidth, not by threads (32 threads per pass instead of 16 changed nothing either).
     const bool two = nnz >= (1 << 22) && getenv("PDHG_PARALLEL_LAYOUTS") != nullptr;
+    if (device_layout) { h->A = dev_A; h->At = dev_At; dev_A = CsrDev(); dev_At = CsrDev(); }
     auto build_a = [&]() {
       const auto t0 = now();
       if (hipSetDevice(dev) != hipSuccess) { rc_a = 999; err_a = "hipSetDevice failed on the layout thread"; return; }
-      rc_a = build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, tile_a, h->relaxed);
+      rc_a = device_layout ? build_csr_dev_resident(h->A, (int)m, (int)n, rowptr, h->remap, tile_a, h->relaxed)
+                           : build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, tile_a, h->relaxed);
       if (rc_a) err_a = g_last_error;
       t_a = secs(t0, now());
     };
     std::thread worker;
     if (two) worker = std::thread(build_a); else build_a();
     const auto t0 = now();
-    const int rc_t = build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, tile_at, h->relaxed);
+    const int rc_t = device_layout ? build_csr_dev_resident(h->At, (int)n, (int)m, t_rowptr, h->remap, tile_at, h->relaxed)
+                                   : build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, tile_at, h->relaxed);
     t_at = secs(t0, now());
     if (two) worker.join();
     if (rc_a) { g_last_error = err_a; destroy_shard(h); return rc_a; }
     CK(rc_t);
     if (verbose)
-      fprintf(stderr, "pdhg_create: CSC -> CSR(A), CSR(A') %.2fs; layouts + upload A %.2fs %s A' %.2fs (%.2fs elapsed)\n",
-              secs(t_start, t_conv), t_a, two ? "beside" : "then", t_at, secs(t_conv, now()));
+      fprintf(stderr, "pdhg_create (%s): CSC -> CSR(A), CSR(A') %.2fs; layouts%s A %.2fs %s A' %.2fs (%.2fs elapsed)\n",
+              device_layout ? "device layout construction" : "host layout construction", secs(t_start, t_conv),
+              device_layout ? "" : " + upload", t_a, two ? "beside" : "then", t_at, secs(t_conv, now()));
   }
   auto up = [&](double **dst, const double *src, int64_t len) -> int {
     int r2 = alloc_zero(dst, len);
@@ -2832,6 +2912,33 @@ int pdhg_measure_launch_overhead(pdhg_handle *h, int reps, double out[2]) {
     }
   out[0] = best[0];                              // one empty launch between two events
   out[1] = (best[1] - best[0]) / 4.0;            // every further launch inside the same bracket
+  return 0;
+}
+
+int pdhg_layout_checksums(pdhg_handle *h, uint64_t out[32]) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!out) return fail(-1, "out == NULL");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const CsrDev *Ls[2] = {&h->A, &h->At};
+  for (int k = 0; k < 2; ++k) {
+    const CsrDev &D = *Ls[k];
+    const struct { const void *p; int64_t words; } parts[16] = {
+        {D.rowptr, (int64_t)D.rows + 1}, {D.col, D.nnz}, {D.val, 2 * D.nnz}, {D.blks, 2 * (int64_t)D.nblk},
+        {D.long_row, D.nlong}, {D.long_chunk_ptr, (int64_t)D.nlong + 1}, {D.chunk_row, D.nchunks}, {D.chunk_off, D.nchunks},
+        {D.tiled ? D.pk : nullptr, D.tw_entries}, {D.tiled ? D.tv : nullptr, 2 * D.tw_entries},
+        {D.tiled ? D.wave_rows : nullptr, 2 * (int64_t)D.nwaves}, {D.tiled ? D.wave_ent : nullptr, D.step_ptr_len},
+        {D.tiled ? D.wave_step_off : nullptr, D.nwaves}, {D.tiled ? D.step_tile : nullptr, D.total_steps},
+        {D.tiled ? D.wg_step_off : nullptr, D.tiled ? (int64_t)D.grid + 1 : 0}, {nullptr, 0}};
+    for (int q = 0; q < 16; ++q) {
+      unsigned long long v = 0;
+      if ((rc = device_checksum(parts[q].p, parts[q].words, &v, h->stream))) return rc;
+      out[16 * k + q] = v;
+    }
+    // the plan's scalars ride in the last slot
+    out[16 * k + 15] = (uint64_t)D.tiled + 2ull * (uint64_t)D.tw_mode + 8ull * (uint64_t)D.tile_shift + 1024ull * (uint64_t)D.tw_rows +
+                       (1ull << 32) * (uint64_t)D.grid;
+  }
   return 0;
 }
 

@@ -334,6 +334,12 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_measure_triad(self._h, int(length), int(reps), ctypes.byref(out)))
         return out.value
 
+    def layout_checksums(self):
+        """32 order-sensitive checksums of the device arrays of both layouts (pdhg_layout_checksums)."""
+        out = np.zeros(32, dtype=np.uint64)
+        _lib.check(self._L.pdhg_layout_checksums(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+        return out
+
     def measure_launch_overhead(self, reps=20):
         """(ms for one empty launch between two HIP events, ms per further launch in the same bracket)."""
         out = np.zeros(2)

@@ -349,6 +349,12 @@ const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id);
  * graph launch (small / medium LPs; not while profiling), [15] bit 0 / bit 1: A / A' use
  * equal-nonzero tiles of different widths (skewed columns; [10],[11] are then nominal). */
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]);
+/* Diagnostics: order-sensitive 64-bit checksums of every device array of the two layouts
+ * (out[0..16) CSR(A): row pointers, columns, values, row blocks, the four long-row tables, the
+ * sweep's pk / tv / wave rows / entry offsets / step offsets / step tiles / workgroup steps, the
+ * plan's scalars; out[16..32) the same for CSR(A')).  Two handles with equal checksums hold
+ * bit-identical layouts: how the device-side layout construction is held to the host builders. */
+int pdhg_layout_checksums(pdhg_handle *h, uint64_t out[32]);
 /* Measurement only: best-of-`reps` rate of a[i] = b[i] + s*c[i] over `len`
  * doubles (len % 4 == 0) on this handle's device and stream (24*len bytes per pass), in GB/s --
  * the box's own streaming ceiling to put beside the 8 TB/s spec figure. */

@@ -169,6 +169,13 @@ function rccl_info()
           path = unsafe_string(pointer(path)))
 end
 
+"Checksums of every device array of both layouts (`pdhg_layout_checksums`): equal checksums, bit-identical layouts."
+function layout_checksums(s::HipSolverState)
+  out = zeros(UInt64, 32)
+  check(ccall((:pdhg_layout_checksums, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt64}), s.handle, out))
+  return out
+end
+
 "HIP-event bracket of empty launches: (ms for one, ms per further launch in the same bracket) (`pdhg_measure_launch_overhead`)."
 function measure_launch_overhead(s::HipSolverState, reps::Integer = 20)
   out = zeros(2)

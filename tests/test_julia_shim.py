@@ -43,6 +43,7 @@ _C2JL = {
     "double*": {"Ptr{Float64}", "Ref{Float64}"},
     "int64_t*": {"Ptr{Int64}", "Ref{Int64}"},
     "int*": {"Ptr{Cint}", "Ref{Cint}"},
+    "uint64_t*": {"Ptr{UInt64}", "Ref{UInt64}"},
     "pdhg_handle*": {"Ptr{Cvoid}"},
     "pdhg_handle**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
     "void*": {"Ptr{Cvoid}", "Ptr{UInt8}"},
