@@ -556,10 +556,18 @@ void row_nnz_prefix(int64_t m, int64_t n, const int64_t *colptr, const int64_t *
                     std::vector<int64_t> &prefix) {
   const int64_t nnz = colptr[n] - base;
   prefix.assign((size_t)m + 1, 0);
-  for (int64_t k = 0; k < nnz; ++k) {
-    const int64_t r = rowval[k] - base;
-    if (r >= 0 && r < m) prefix[(size_t)r + 1] += 1;
-  }
+  // integer counts: host threads over entry ranges with relaxed atomic increments give the same
+  // numbers as the serial loop (2.2 G entries: ~5 s serial)
+  int64_t *cnt = prefix.data();
+  const int64_t grain = 1 << 22;
+  const int parts = (int)std::min<int64_t>(1 << 20, std::max<int64_t>(1, (nnz + grain - 1) / grain));
+  parallel_ranges(parts, 1, [&](int pb, int pe) {
+    const int64_t kb = nnz * pb / parts, ke = nnz * pe / parts;
+    for (int64_t k = kb; k < ke; ++k) {
+      const int64_t r = rowval[k] - base;
+      if (r >= 0 && r < m) __atomic_fetch_add(&cnt[r + 1], (int64_t)1, __ATOMIC_RELAXED);
+    }
+  });
   for (int64_t i = 0; i < m; ++i) prefix[(size_t)i + 1] += prefix[(size_t)i];
 }
 

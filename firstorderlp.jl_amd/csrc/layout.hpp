@@ -126,7 +126,7 @@ inline int tile_width_cap(int64_t rows) {
 // cnt16_kernel, tw_fill_kernel) and everything else is the code below, unchanged: same plan, same
 // tables, bit-identical layout.  Returns 1 (nothing built, D untouched) when the device mode does
 // not cover the case -- equal-nonzero tiles of different widths, more than 1024 tiles, a count
-// matrix beyond 32M cells: the caller then fetches the entries and calls the host mode.
+// matrix beyond 256M cells: the caller then fetches the entries and calls the host mode.
 int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec *col_p,
                 const dvec *val_p, int tile_cols, bool relaxed) {
   const bool on_device = col_p == nullptr;
@@ -278,7 +278,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     ~DevTmp() { if (*p) (void)hipFree(*p); }
   } tmp_wave_rows{(void **)&d_wave_rows}, tmp_cell_cnt{(void **)&d_cell_cnt};
   if (on_device) {
-    if ((int64_t)nwaves * ntiles > (32LL << 20)) return 1;
+    if ((int64_t)nwaves * ntiles > (256LL << 20)) return 1;     // the count matrix travels to the host: <= 1 GiB
     cell_cnt.resize((size_t)std::max(nwaves, 1) * ntiles);
     dev_max_run.assign((size_t)std::max(grid, 1), 0);
     int rc2;
