@@ -28,6 +28,7 @@ struct CsrDev {
   int *long_row = nullptr, *long_chunk_ptr = nullptr, *chunk_row = nullptr, *chunk_off = nullptr;
   int *chunk_lidx = nullptr;                 // [nchunks] index of the chunk's row in long_row
   unsigned long long *long_ticket = nullptr; // [nlong] chunks of the row completed, over all one-launch trials
+  unsigned long long coop_uses = 0;          // one-launch trials that have run this layout's product (the tickets' base)
   double *chunk_partial = nullptr;
   int64_t max_row_nnz = 0;
   // tiled-sweep layout (optional)

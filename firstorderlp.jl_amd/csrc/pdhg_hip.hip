@@ -151,7 +151,7 @@ struct pdhg_handle {
   int coop_grid = 0;                    // workgroups of the persistent launch (multiple of 8, all co-resident)
   unsigned coop_nxcd = 0;               // XCDs that hold workgroups of such a launch
   unsigned coop_xcd_cnt[8] = {0};       // ... and how many each
-  unsigned long long coop_launches = 0;
+  unsigned long long coop_launches = 0, coop_epoch = 0;   // launches / grid barriers of the one-launch kernel so far
   GridSync *gsync = nullptr;
   unsigned long long *coop_trace = nullptr;   // PDHG_COOP_TRACE=1: phase stamps of the last launch
   int graph_mode = -1;                  // -1 undecided, 0 off, 1 on
@@ -492,15 +492,16 @@ int coop_prepare(pdhg_handle *h);
 bool coop_eligible(pdhg_handle *h) {
   if (h->coop_mode < 0) {
     const char *ev = getenv("PDHG_COOP");
-    bool on = !h->grp && !h->has_q && !h->A.tiled && !h->At.tiled && h->A.slabs.empty() && h->At.slabs.empty() &&
+    bool on = !h->grp && !h->A.tiled && !h->At.tiled && h->A.slabs.empty() && h->At.slabs.empty() &&
               h->n > 0 && h->m > 0;
+    if (h->has_q) on = on && !h->Q.tiled && !h->Qt.tiled && h->Q.slabs.empty() && h->Qt.slabs.empty();
     if (ev) on = on && ev[0] != '0';
     const char *gv = getenv("PDHG_GRAPH");             // PDHG_GRAPH=0: separate launches, no one-launch path of either kind
     if (gv) on = on && gv[0] != '0';
     h->coop_mode = on ? 1 : 0;
     if (on && coop_prepare(h) != 0) h->coop_mode = 0;  // too many items for one co-resident grid, or no census: graph / plain path
   }
-  return h->coop_mode == 1 && !h->has_q && !h->profile;
+  return h->coop_mode == 1 && !h->profile;
 }
 
 // grid of the persistent launch + the census of workgroups per XCD (once per handle)
@@ -516,7 +517,8 @@ int coop_prepare(pdhg_handle *h) {
   int cap = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
   if (const char *ev = getenv("PDHG_COOP_WGS")) cap = std::max(8, std::min(cap, atoi(ev) / 8 * 8));
   // one item per workgroup and phase where the device can hold that many: row blocks from the front, long-row chunks from the end
-  const int items = std::max(h->A.grid + h->A.nchunks, h->At.grid + h->At.nchunks);
+  int items = std::max(h->A.grid + h->A.nchunks, h->At.grid + h->At.nchunks);
+  if (h->has_q) items = std::max(items, std::max(h->Q.grid + h->Q.nchunks, h->A.grid + h->A.nchunks + h->Qt.grid + h->Qt.nchunks));
   h->coop_grid = std::min(cap, std::max(8, (items + 7) / 8 * 8));
   // More items than co-resident workgroups: the persistent kernel would walk several row blocks per workgroup at
   // 5 workgroups per CU, where the separate stream kernels keep 8 per CU in flight -- measured slower (PageRank-1M,
@@ -549,7 +551,7 @@ int coop_prepare(pdhg_handle *h) {
   return 0;
 }
 
-TrialProduct trial_product(pdhg_handle *h, const CsrDev &D, const double *xin, const EpiArgs &e) {
+TrialProduct trial_product(pdhg_handle *h, CsrDev &D, const double *xin, const EpiArgs &e) {
   TrialProduct P{};
   P.M = D.view();
   P.blks = D.blks; P.nblk = D.nblk; P.per_xcd = D.per_xcd; P.grid = D.grid; P.remap = h->remap ? 1 : 0;
@@ -558,6 +560,8 @@ TrialProduct trial_product(pdhg_handle *h, const CsrDev &D, const double *xin, c
   P.long_ticket = D.long_ticket;
   P.long_row = D.long_row; P.long_chunk_ptr = D.long_chunk_ptr;
   P.xin = xin; P.e = e;
+  P.uses = D.coop_uses;
+  D.coop_uses += 1;
   return P;
 }
 
@@ -595,6 +599,22 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
   a.sp.ptr[3] = h->pAt + 2 * h->pAt_stride;   a.sp.count[3] = h->At.slots();
   a.sp.ptr[4] = h->pQ;                        a.sp.count[4] = 0;
   a.sp.out = nullptr;
+  a.has_q = h->has_q ? 1 : 0;
+  a.epoch = h->coop_epoch;
+  h->coop_epoch += 2;
+  if (h->has_q) {
+    a.q_blocks = h->ew_grid_n;
+    a.sp.count[4] = h->ew_grid_n;
+    a.qx = h->qx; a.dx = h->tmp_n; a.qtdx = h->tmp_n2; a.pq = h->pQ;
+    EpiArgs qe{};
+    qe.out = h->tmp_n2;
+    a.Qtdx = trial_product(h, h->Qt, h->tmp_n, qe);
+    if (!xbar_only) {
+      qe.out = h->qx;
+      a.Qx = trial_product(h, h->Q, h->x, qe);
+      h->coop_epoch += 1;
+    }
+  }
   a.seq_dev = h->seq_dev; a.res_host = h->res_host; a.sync = h->gsync;
   h->seq_expected += 1;
   a.launch = h->coop_launches; a.seq = h->seq_expected; a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
@@ -1797,6 +1817,13 @@ int pdhg_set_objective_matrix(pdhg_handle *h0, int64_t q_nnz, const int64_t *q_c
   }
   for (int i = 0; i < L.count; ++i) L.p[i]->matrix_version += 1;
   FOR_SHARDS(L, h) {   // the objective matrix is replicated on every shard (it acts on full n-vectors)
+    // the launch paths were decided for the problem without (or with another) Q: decide again at the next trial
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->gsync) { (void)hipFree(h->gsync); h->gsync = nullptr; }
+    if (h->coop_trace) { (void)hipFree(h->coop_trace); h->coop_trace = nullptr; }
+    h->coop_mode = -1; h->coop_launches = 0; h->coop_epoch = 0;
+    h->graph_mode = -1;
+    graph_destroy(h->tgraph[0]); graph_destroy(h->tgraph[1]);
     if (h->has_q) { free_csr_dev(h->Q); free_csr_dev(h->Qt); h->has_q = false; }
     if (all_zero) continue;  // iszero(objective_matrix): LP path (pdhg.jl:536)
     if ((rc = build_csr_dev(h->Q, (int)h->n, (int)h->n, rowptr, col, val, h->remap))) return rc;
@@ -2946,7 +2973,7 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   if (!h) return fail(-1, "null handle");
   info[12] = (int64_t)h->A.slabs.size(); info[13] = (int64_t)h->At.slabs.size();
   // 2: one persistent kernel per trial (trial_kernel.hpp), 1: one graph launch, 0: separate launches
-  info[14] = (coop_eligible(h) || (h->coop_mode == 1 && !h->has_q)) ? 2 : ((graph_eligible(h) || (h->graph_mode == 1 && !h->has_q)) ? 1 : 0);
+  info[14] = (coop_eligible(h) || h->coop_mode == 1) ? 2 : ((graph_eligible(h) || (h->graph_mode == 1 && !h->has_q)) ? 1 : 0);
   info[15] = (h->A.tiled && h->A.var_tiles ? 1 : 0) + (h->At.tiled && h->At.var_tiles ? 2 : 0);
   info[0] = h->A.nblk; info[1] = h->A.nlong; info[2] = h->A.nchunks; info[3] = h->A.max_row_nnz;
   info[4] = h->At.nblk; info[5] = h->At.nlong; info[6] = h->At.nchunks; info[7] = h->At.max_row_nnz;

@@ -113,6 +113,7 @@ struct TrialProduct {
   unsigned long long *long_ticket;
   const double *xin;
   EpiArgs e;
+  unsigned long long uses;    // one-launch trials that have run this product before (its long rows' tickets count up)
 };
 
 struct TrialKernelArgs {
@@ -124,6 +125,12 @@ struct TrialKernelArgs {
   double avg_w;
   double *sum_x;
   TrialProduct A, T;
+  // QP (pdhg.jl:536-541; saddle_point.jl:1093-1100): Q x before the primal step, 0.5 dx'Q dx beside the other sums
+  int has_q, q_blocks;           // q_blocks: blocks of the dot-product partials (the separate dot_kernel's grid)
+  TrialProduct Qx, Qtdx;         // MODE_PLAIN: qx = Q x ; tmp_n2 = Q' dx
+  const double *qx;
+  double *dx, *qtdx, *pq;        // dx = x' - x, Q' dx, partials of dx . (Q' dx)
+  unsigned long long epoch;      // grid barriers this handle has passed so far
   FinalSpec sp;
   unsigned long long *seq_dev;
   volatile double *res_host;
@@ -170,8 +177,9 @@ __device__ __forceinline__ void product_prefetch(const TrialProduct &P, Prefetch
 }
 
 template <int MODE>
-__device__ __forceinline__ void product_phase(const TrialProduct &P, unsigned long long launch, int relaxed,
+__device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed,
                                               Prefetched &f, double *prod, double (*red)[TPB / WAVE]) {
+  const unsigned long long launch = P.uses;
   const int w = blockIdx.x, nwg = gridDim.x;
   __shared__ int finish_row;
   StreamRegs &g = f.g;
@@ -223,22 +231,44 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(Tri
   const int w = blockIdx.x, nwg = gridDim.x;
 #define PDHG_STAMP(k) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)w * 8 + (k)] = wall_clock64(); } while (0)
   PDHG_STAMP(0);
+  Prefetched f;
+  unsigned long long epoch = a.epoch;
+  if (a.has_q && !a.xbar_only) {
+    // ---- QP, phase -1: Q x (the gradient's quadratic term), then a barrier of its own
+    f.kind = 0;
+    product_phase<MODE_PLAIN>(a.Qx, a.relaxed, f, prod, red);
+    grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
+  }
   // ---- phase 0: x' and xbar (elementwise; any distribution over the workgroups gives the same bits)
   if (a.xbar_only) xbar_body(a.n, a.x, a.x_next, a.theta, a.xbar, w, nwg);
+  else if (a.has_q) primal_body<true, true>(a.n, a.x, a.c, a.aty, a.qx, a.lb, a.ub, a.tau, a.theta, a.x_next, a.xbar, a.avg_w, a.sum_x, w, nwg);
   else primal_body<false, true>(a.n, a.x, a.c, a.aty, nullptr, a.lb, a.ub, a.tau, a.theta, a.x_next, a.xbar, a.avg_w, a.sum_x, w, nwg);
-  Prefetched f;
+  // dx for the interaction term.  After the primal step every thread reads back the x' it wrote itself (same
+  // element mapping); on the Malitsky-Pock retries x' is an earlier kernel's output.
+  if (a.has_q) diff_pairs_body(a.n, a.x_next, a.x, a.dx, w, nwg);
   product_prefetch(a.A, f);                                      // static data: requested before the barrier
   PDHG_STAMP(1);
-  grid_barrier(a.sync, 2 * a.launch + 1, a.nxcd, a.xcd_cnt);
+  grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
   PDHG_STAMP(2);
   // ---- phase 1: y' = proj(y + sigma (b - A xbar)), sum dy^2   (K3+K4)
-  product_phase<MODE_DUAL>(a.A, a.launch, a.relaxed, f, prod, red);
+  product_phase<MODE_DUAL>(a.A, a.relaxed, f, prod, red);
+  if (a.has_q) {                                                 // Q' dx: independent of A xbar, same phase
+    Prefetched none;
+    none.kind = 0;
+    product_phase<MODE_PLAIN>(a.Qtdx, a.relaxed, none, prod, red);
+  }
   product_prefetch(a.T, f);
   PDHG_STAMP(3);
-  grid_barrier(a.sync, 2 * a.launch + 2, a.nxcd, a.xcd_cnt);
+  grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
   PDHG_STAMP(4);
   // ---- phase 2: A'y' and the interaction sums   (K5+K6)
-  product_phase<MODE_ATY>(a.T, a.launch, a.relaxed, f, prod, red);
+  product_phase<MODE_ATY>(a.T, a.relaxed, f, prod, red);
+  if (a.has_q) {                                                 // partials of dx . (Q' dx), block by block as dot_kernel does
+    for (int b = w; b < a.q_blocks; b += nwg) {
+      __syncthreads();
+      dot_body(a.n, a.qtdx, a.dx, a.pq, b, a.q_blocks, red, true);
+    }
+  }
   PDHG_STAMP(5);
   // ---- second stage: the workgroup that finishes last adds the block partials (K6b)
   __syncthreads();

@@ -102,11 +102,25 @@ __global__ __launch_bounds__(TPB) void xbar_kernel(int n, const double *__restri
 }
 
 // dx = x' - x  (for the QP interaction term 0.5*dx'Q dx, pdhg.jl:536-541)
+__device__ __forceinline__ void diff_body(int n, const double *a, const double *b, double *out, int bid, int nb) {
+  const int stride = nb * TPB;
+  for (int j = bid * TPB + threadIdx.x; j < n; j += stride) out[j] = a[j] - b[j];
+}
+// the same with primal_body's element-to-thread mapping (pairs 2p, 2p + 1; the odd tail on block 0, thread 0):
+// inside the one-launch trial kernel every thread then reads back only the x' it has just written itself
+__device__ __forceinline__ void diff_pairs_body(int n, const double *a, const double *b, double *out, int bid, int nb) {
+  const int npair = n >> 1;
+  const int stride = nb * TPB;
+  for (int p = bid * TPB + threadIdx.x; p < npair; p += stride) {
+    out[2 * p] = a[2 * p] - b[2 * p];
+    out[2 * p + 1] = a[2 * p + 1] - b[2 * p + 1];
+  }
+  if ((n & 1) && bid == 0 && threadIdx.x == 0) out[n - 1] = a[n - 1] - b[n - 1];
+}
 __global__ __launch_bounds__(TPB) void diff_kernel(int n, const double *__restrict__ a,
                                                    const double *__restrict__ b,
                                                    double *__restrict__ out) {
-  const int stride = gridDim.x * TPB;
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) out[j] = a[j] - b[j];
+  diff_body(n, a, b, out, blockIdx.x, gridDim.x);
 }
 
 // Reductions over the replicated n-vectors (row-partitioned form, after the
@@ -133,16 +147,23 @@ __global__ __launch_bounds__(TPB) void interaction_kernel(
   }
 }
 
-// dot(a, b) partials (QP term)
+// dot(a, b) partials (QP term): block `bid` of `nb` writes partials[bid]
+__device__ __forceinline__ void dot_body(int n, const double *a, const double *b, double *partials, int bid, int nb,
+                                         double (*red)[TPB / WAVE], bool agent_store) {
+  double acc[3] = {0.0, 0.0, 0.0};
+  const int stride = nb * TPB;
+  for (int j = bid * TPB + threadIdx.x; j < n; j += stride) acc[0] += a[j] * b[j];
+  block_sum<1, TPB>(acc, red);
+  if (threadIdx.x == 0) {
+    if (agent_store) __hip_atomic_store(partials + bid, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else partials[bid] = acc[0];
+  }
+}
 __global__ __launch_bounds__(TPB) void dot_kernel(int n, const double *__restrict__ a,
                                                   const double *__restrict__ b,
                                                   double *__restrict__ partials) {
   __shared__ double red[3][TPB / WAVE];
-  double acc[3] = {0.0, 0.0, 0.0};
-  const int stride = gridDim.x * TPB;
-  for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) acc[0] += a[j] * b[j];
-  block_sum<1, TPB>(acc, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+  dot_body(n, a, b, partials, blockIdx.x, gridDim.x, red, false);
 }
 
 // K7: sum_x += w*x', sum_y += w*y'      saddle_point.jl:258-259, 271

@@ -144,3 +144,47 @@ def test_two_handles_driving_one_kernel_trials_from_two_threads(gpu_required, mo
     assert not errors, errors
     for r in results:
         assert r is not None and np.array_equal(r[0], ref[0]) and r[1:] == ref[1:]
+
+
+def _random_qp(m=4000, n=3000, seed=4):
+    """random_lp plus a sparse positive semidefinite objective matrix Q = B'B + diag."""
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd.quadratic_programming import QuadraticProgrammingProblem
+    p = random_lp(m, n, 7, seed=seed)
+    B = sp.random(n // 3, n, density=3.0 / n, format="csr", random_state=seed + 1)
+    Q = (B.T @ B + sp.diags(np.linspace(0.0, 0.5, n))).tocsc()
+    Q.sort_indices()
+    return QuadraticProgrammingProblem(
+        variable_lower_bound=p.variable_lower_bound, variable_upper_bound=p.variable_upper_bound,
+        objective_matrix=Q, objective_vector=p.objective_vector, objective_constant=0.0,
+        constraint_matrix=p.constraint_matrix, right_hand_side=p.right_hand_side, num_equalities=p.num_equalities)
+
+
+@pytest.mark.parametrize("policy", ["adaptive", "malitsky_pock"])
+def test_qp_through_the_one_kernel_trial_is_bitwise_the_plain_path(gpu_required, monkeypatch, policy):
+    """QPs (pdhg.jl:536-541, saddle_point.jl:1093-1100): the one-launch kernel gets a phase for Q x in front of
+    the primal step and computes Q'dx and dx.(Q'dx) beside the two constraint-matrix products."""
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import MalitskyPockStepsizeParameters
+    p = _random_qp()
+    runs = {}
+    for path in ("plain", "one_kernel"):
+        monkeypatch.setenv("PDHG_GRAPH", "0" if path == "plain" else "1")
+        monkeypatch.setenv("PDHG_COOP", "1" if path == "one_kernel" else "0")
+        eng = HipPdhgEngine.from_problem(p)
+        assert eng.layout_info()["trial_graph"] == (2 if path == "one_kernel" else 0)
+        step, pw = H.initial_step_and_weight(p)
+        if policy == "adaptive":
+            st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+            pol = AdaptiveStepsizeParams(0.3, 0.6)
+        else:
+            st = PdhgSolverState(eng, step_size=step, primal_weight=pw, ratio_step_sizes=1.0)
+            pol = MalitskyPockStepsizeParameters(downscaling_factor=0.7, breaking_factor=0.99, interpolation_coefficient=1.0)
+        steps = []
+        for _ in range(60):
+            take_step(pol, st)
+            steps.append(st.step_size)
+        runs[path] = (np.array(steps), *eng.get_current(), *eng.get_average(), st.total_number_iterations)
+        eng.close()
+    assert runs["plain"][-1] >= 60
+    for a, b in zip(runs["plain"], runs["one_kernel"]):
+        assert np.array_equal(a, b)
