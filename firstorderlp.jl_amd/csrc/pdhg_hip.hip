@@ -419,24 +419,34 @@ __global__ __launch_bounds__(FINAL_TPB) void final_reduce_host_kernel(FinalSpec 
 }
 
 template <typename... Args>
-hipError_t graph_add_kernel(hipGraph_t g, hipGraphNode_t *node, const std::vector<hipGraphNode_t> &deps,
-                            const void *func, dim3 grid, dim3 block, Args... args) {
+hipError_t graph_add_kernel_lds(hipGraph_t g, hipGraphNode_t *node, const std::vector<hipGraphNode_t> &deps,
+                                const void *func, dim3 grid, dim3 block, size_t lds, Args... args) {
   void *params[] = {(void *)&args...};
   hipKernelNodeParams p{};
   p.func = const_cast<void *>(func);
-  p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0;
+  p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = (unsigned)lds;
   p.kernelParams = params; p.extra = nullptr;
   return hipGraphAddKernelNode(node, g, deps.empty() ? nullptr : deps.data(), deps.size(), &p);
 }
 template <typename... Args>
-hipError_t graph_set_kernel(hipGraphExec_t exec, hipGraphNode_t node, const void *func, dim3 grid, dim3 block,
-                            Args... args) {
+hipError_t graph_add_kernel(hipGraph_t g, hipGraphNode_t *node, const std::vector<hipGraphNode_t> &deps,
+                            const void *func, dim3 grid, dim3 block, Args... args) {
+  return graph_add_kernel_lds(g, node, deps, func, grid, block, 0, args...);
+}
+template <typename... Args>
+hipError_t graph_set_kernel_lds(hipGraphExec_t exec, hipGraphNode_t node, const void *func, dim3 grid, dim3 block,
+                                size_t lds, Args... args) {
   void *params[] = {(void *)&args...};
   hipKernelNodeParams p{};
   p.func = const_cast<void *>(func);
-  p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0;
+  p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = (unsigned)lds;
   p.kernelParams = params; p.extra = nullptr;
   return hipGraphExecKernelNodeSetParams(exec, node, &p);
+}
+template <typename... Args>
+hipError_t graph_set_kernel(hipGraphExec_t exec, hipGraphNode_t node, const void *func, dim3 grid, dim3 block,
+                            Args... args) {
+  return graph_set_kernel_lds(exec, node, func, grid, block, 0, args...);
 }
 
 // pinned, host-coherent result word of the one-launch paths: [0..5) sums, [6] error, [7] sequence number
@@ -644,8 +654,11 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
 bool graph_eligible(pdhg_handle *h) {
   if (h->graph_mode < 0) {
     const char *ev = getenv("PDHG_GRAPH");
-    // stream layouts only: with the tiled sweep a trial runs for a millisecond and launch gaps are noise
-    bool on = !h->grp && !h->has_q && !h->A.tiled && !h->At.tiled && h->n > 0;
+    // stream layouts only.  The sweep can run as graph nodes too (PDHG_GRAPH_TILED=1) but gains nothing: with the
+    // take_step loop in C the separate launches already overlap the kernels -- random 1M x 1M 5 709 it/s as a graph
+    // against 5 637, 4M x 4M 1 667 / 1 672, config S 611 / 613 (profiles/r03_trial_kernel.txt).
+    const bool tiled_ok = getenv("PDHG_GRAPH_TILED") != nullptr;
+    bool on = !h->grp && !h->has_q && h->n > 0 && (tiled_ok || (!h->A.tiled && !h->At.tiled));
     if (ev) on = on && ev[0] != '0';
     h->graph_mode = on ? 1 : 0;
   }
@@ -672,6 +685,15 @@ struct GraphArgs {
   }
 };
 
+// the sweep kernel of a layout for graph nodes: function pointer (with the dynamic-LDS opt-in done)
+template <int MODE>
+int tiled_node_func(pdhg_handle *h, const CsrDev &D, const void **fn, size_t *lds) {
+  *lds = tiled_lds_bytes(D);
+  *fn = D.tw_mode == 1 ? (const void *)spmv_tiled_kernel<MODE, 1>
+                       : (D.tw_mode == 2 ? (const void *)spmv_tiled_kernel<MODE, 2> : (const void *)spmv_tiled_kernel<MODE, 0>);
+  return ensure_lds_limit(h, MODE, D.tw_mode, *lds, *fn);
+}
+
 // nodes of one fused SpMV: stream kernel (one node) or its column-slab passes (a chain),
 // beside the long-row pair.  `done` receives the nodes the next stage must wait for;
 // main_node / long_node (optional) receive the nodes that carry the epilogue's scalars.
@@ -680,7 +702,21 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
                    const std::vector<hipGraphNode_t> &deps, std::vector<hipGraphNode_t> &done,
                    hipGraphNode_t *main_node, hipGraphNode_t *long_node) {
   const int rm = h->remap ? 1 : 0, rx = h->relaxed ? 1 : 0;
-  if (!D.slabs.empty()) {
+  if (D.tiled) {
+    if (D.grid > 0) {
+      const void *fn;
+      size_t lds;
+      int rc = tiled_node_func<MODE>(h, D, &fn, &lds);
+      if (rc) return rc;
+      hipGraphNode_t nd = nullptr;
+      HIP_TRY(graph_add_kernel_lds(graph, &nd, deps, fn, dim3(D.grid), dim3(TW_WPB * WAVE), lds, (const int2 *)D.wave_rows,
+                                   (const int *)D.wave_ent, (const int *)D.wave_step_off, (const int *)D.step_tile,
+                                   (const int *)D.wg_step_off, D.nwaves, D.tile_shift, D.tw_rows, (const unsigned *)D.pk,
+                                   (const double *)D.tv, xin, e));
+      if (main_node) *main_node = nd;
+      done.push_back(nd);
+    }
+  } else if (!D.slabs.empty()) {
     const int P = (int)D.slabs.size();
     std::vector<hipGraphNode_t> prev = deps;
     for (int p = 0; p < P; ++p) {
@@ -728,7 +764,16 @@ int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &du
   const CsrDev &A = h->A;
   const int rm = h->remap ? 1 : 0, rx = h->relaxed ? 1 : 0;
   if (G.n_dual) {
-    if (!A.slabs.empty()) {
+    if (A.tiled) {
+      const void *fn;
+      size_t lds;
+      int rc = tiled_node_func<MODE_DUAL>(h, A, &fn, &lds);
+      if (rc) return rc;
+      HIP_TRY(graph_set_kernel_lds(G.exec, G.n_dual, fn, dim3(A.grid), dim3(TW_WPB * WAVE), lds, (const int2 *)A.wave_rows,
+                                   (const int *)A.wave_ent, (const int *)A.wave_step_off, (const int *)A.step_tile,
+                                   (const int *)A.wg_step_off, A.nwaves, A.tile_shift, A.tw_rows, (const unsigned *)A.pk,
+                                   (const double *)A.tv, (const double *)h->xbar, dual_epi));
+    } else if (!A.slabs.empty()) {
       const SlabDev &S = A.slabs.back();
       EpiArgs le = dual_epi;
       le.init = A.slab_partial;
