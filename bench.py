@@ -118,7 +118,18 @@ def shard_for_rank(args, workload, ctx):
     from firstorderlp_jl_amd import HipPdhgEngine
     from firstorderlp_jl_amd.distributed import row_shard_of
     dist, rank, world = ctx["dist"], ctx["rank"], ctx["world"]
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    # where the slices travel: shared memory if it is large enough (a container's /dev/shm may be 64 MB), else a
+    # temporary directory on disk -- every rank evaluates the same rule on the same machine
+    need = 20 * (args.m if workload == "random" else args.pagerank_nodes) * max(args.nnz_per_row, 12) + 40 * args.n * world + (64 << 20)
+    base = tempfile.gettempdir()
+    for cand in ("/dev/shm", tempfile.gettempdir(), ROOT):
+        try:
+            st = os.statvfs(cand)
+            if os.access(cand, os.W_OK) and st.f_bavail * st.f_frsize > need:
+                base = cand
+                break
+        except OSError:
+            continue
     tag = os.environ.get("MASTER_PORT", "0")
     path = lambda r: os.path.join(base, f"pdhg_bench_{tag}_{workload}_rank{r}.pkl")   # noqa: E731
     if rank == 0:

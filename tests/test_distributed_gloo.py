@@ -336,3 +336,62 @@ def test_qp_row_partitioned_matches_unsharded_oracle():
         assert abs(rstep - state.step_size) <= 1e-12 * state.step_size
         np.testing.assert_allclose(rx, x, rtol=1e-11, atol=1e-11)
         np.testing.assert_allclose(ry, y, rtol=1e-11, atol=1e-11)
+
+
+# ---- bench.py's N > 1 harness: generate once, cut with the library's partition, one slice per rank ----
+
+def _bench_shard_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import argparse
+    import folp_loader
+    folp_loader.load()
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        args = argparse.Namespace(m=3000, n=2500, nnz_per_row=7, seed=11, pagerank_nodes=4000)
+        ctx = {"dist": dist, "rank": rank, "world": world}
+        shard, meta = bench.shard_for_rank(args, "random", ctx)
+        q.put((rank, meta, shard["row_bounds"].tolist(), shard["constraint_rows"].tocsr(), shard["right_hand_side_rows"],
+               shard["objective_vector"], shard["num_equalities"], shard["m_global"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_generates_once_and_every_rank_gets_only_its_rows(world):
+    """`bench.py --gpus N` (what the driver's scaling run launches): rank 0 generates the LP, cuts it with
+    pdhg_partition_rows (host-only) and ships one slice per rank through files; the slices must tile
+    the matrix exactly and carry the global vectors.  Runs on CPU: nothing here needs a GPU."""
+    import scipy.sparse as sp
+    sys.path.insert(0, ROOT)
+    from firstorderlp_jl_amd.generators import random_lp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29730 + world
+    procs = [ctx.Process(target=_bench_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    p = random_lp(3000, 2500, 7, seed=11)
+    A = p.constraint_matrix.tocsr()
+    bounds = got[0][2]
+    assert bounds[0] == 0 and bounds[-1] == 3000 and len(bounds) == world + 1
+    for rank, meta, b, rows, rhs, c, num_eq, m_global in got:
+        assert b == bounds and m_global == 3000 and num_eq == p.num_equalities
+        assert meta["m"] == 3000 and meta["n"] == 2500 and meta["nnz"] == A.nnz
+        lo, hi = bounds[rank], bounds[rank + 1]
+        assert rows.shape == (hi - lo, 2500)
+        assert (rows != A[lo:hi]).nnz == 0
+        assert np.array_equal(rhs, p.right_hand_side[lo:hi]) and np.array_equal(c, p.objective_vector)
+    stacked = sp.vstack([g[3] for g in got]).tocsr()
+    assert (stacked != A).nnz == 0
+    # nnz-balanced: no rank holds more than its share plus one row's worth
+    per_rank = [g[3].nnz for g in got]
+    assert max(per_rank) <= A.nnz / world + A.getnnz(axis=1).max() + 1
