@@ -60,6 +60,85 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// ---- double-double accumulation of the step-acceptance sums -----------------------------------
+// The three sums of a trial (dx.(A'y' - A'y), |dx|^2, |dy|^2; pdhg.jl:527-549) are accumulated as unevaluated
+// pairs hi + lo (TwoSum: the rounding error of every addition is kept in lo), per lane, through the wave and
+// block trees and the second stage, and rounded to one double at the very end.  The result is the correctly
+// rounded exact sum of the (double) terms except with probability ~1e-14 per sum, WHATEVER THE ORDER of the
+// additions -- so it does not depend on tile widths, grid sizes or launch paths, and a CPU run that adds the
+// same terms the same way (the oracle's exact-sums mode, test infrastructure) gets the same bits: free-running
+// trajectories then agree bitwise with the CPU restatement instead of drifting apart through the
+// discontinuous step-size rule.  Cost: ~7 flops per row and quantity; not measurable.
+struct Acc3 {
+  double hi[3];
+  double lo[3];
+};
+__device__ __forceinline__ Acc3 acc3_zero() { return Acc3{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}; }
+// (hi, lo) += t
+__device__ __forceinline__ void dd_add(double &hi, double &lo, double t) {
+  const double s = hi + t;
+  const double bb = s - hi;
+  const double e = (hi - (s - bb)) + (t - bb);
+  hi = s;
+  lo = lo + e;
+}
+// (hi, lo) += (bh, bl), renormalised
+__device__ __forceinline__ void dd_add_dd(double &hi, double &lo, double bh, double bl) {
+  const double s = hi + bh;
+  const double bb = s - hi;
+  const double e = (hi - (s - bb)) + (bh - bb);
+  const double l = (lo + bl) + e;
+  const double h2 = s + l;
+  lo = l - (h2 - s);
+  hi = h2;
+}
+// a double moved across lanes by DPP (two 32-bit moves); lanes without a source, or outside row_mask, receive 0.0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// Wave-wide double-double sum; the total ends in LANE 63.  DPP moves instead of ds_bpermute shuffles (the six
+// steps of a shuffle tree over two doubles were ~0.8 us per block on the one-launch trial's critical path):
+// inclusive sums inside each row of 16 lanes (row_shr 1, 2, 4, 8), then lane 15 of rows 0 / 2 into rows 1 / 3
+// (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31).  Adding the 0.0 a lane without a source
+// receives is exact.
+__device__ __forceinline__ void wave_sum_dd(double &hi, double &lo) {
+#define PDHG_DD_STEP(CTRL, MASK) do { const double bh = dpp_move<CTRL, MASK>(hi), bl = dpp_move<CTRL, MASK>(lo); dd_add_dd(hi, lo, bh, bl); } while (0)
+  PDHG_DD_STEP(0x111, 0xF);   // row_shr:1
+  PDHG_DD_STEP(0x112, 0xF);   // row_shr:2
+  PDHG_DD_STEP(0x114, 0xF);   // row_shr:4
+  PDHG_DD_STEP(0x118, 0xF);   // row_shr:8
+  PDHG_DD_STEP(0x142, 0xA);   // row_bcast:15 into rows 1 and 3
+  PDHG_DD_STEP(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
+#undef PDHG_DD_STEP
+}
+// Deterministic block reduction of NQ double-double accumulators; thread 0 returns the totals in acc.
+// `red` is LDS [6][THREADS / WAVE] (hi rows 0..2, lo rows 3..5).
+template <int NQ, int THREADS>
+__device__ __forceinline__ void block_sum_dd(Acc3 &acc, double (*red)[THREADS / WAVE]) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wid = threadIdx.x / WAVE;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double h = acc.hi[q], l = acc.lo[q];
+    wave_sum_dd(h, l);
+    if (lane == WAVE - 1) { red[q][wid] = h; red[3 + q][wid] = l; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double h = 0.0, l = 0.0;
+#pragma unroll
+      for (int w = 0; w < THREADS / WAVE; ++w) dd_add_dd(h, l, red[q][w], red[3 + q][w]);
+      acc.hi[q] = h;
+      acc.lo[q] = l;
+    }
+  }
+}
+
 // Deterministic block reduction of up to 3 per-thread accumulators; thread 0
 // of the block returns the totals in acc[].  `red` is LDS [3][TPB/WAVE].
 template <int NQ, int THREADS>

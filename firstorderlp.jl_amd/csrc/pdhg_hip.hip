@@ -216,7 +216,7 @@ int ensure_lds_limit(pdhg_handle *h, int mode, int chunk_mode, size_t lds, const
 // per CU gather from more tiles at once -- 10M-nnz-per-million-rows LPs of 5.3M-6.5M rows ran
 // at 10 ps per nonzero, against 7.0 at 5M and 7.7 at 7M (profiles/r02_locality.txt).
 size_t tiled_lds_bytes(const CsrDev &D) {
-  const size_t need = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 3 * TW_WPB + (D.tw_mode == 1 ? TW_WPB * WAVE : 0));
+  const size_t need = sizeof(double) * ((size_t)TW_WPB * D.tw_rows + 6 * TW_WPB + (D.tw_mode == 1 ? TW_WPB * WAVE : 0));
   return std::max(need, D.tw_lds_floor);
 }
 
@@ -345,7 +345,7 @@ int launch_dual(pdhg_handle *h, double sigma) {
   ProfScope ps(h, PDHG_K_SPMV_DUAL);
   EpiArgs e{};
   e.y = h->y; e.b = h->b; e.y_next = h->y_next; e.sigma = sigma; e.num_eq = (int)h->num_eq;
-  e.partials = h->pA; e.stride = h->A.slots();
+  e.partials = h->pA; e.stride = h->A.slots(); e.lo_offset = h->A.slots();
   if (h->pend_y) { e.sum_y = h->sum_y; e.avg_w = h->pend_w; }
   const int rc = launch_spmv<MODE_DUAL, 0>(h, h->A, h->xbar, e);
   if (!rc) h->pend_y = false;
@@ -356,7 +356,7 @@ int launch_aty_fused(pdhg_handle *h) {
   ProfScope ps(h, PDHG_K_SPMV_ATY);
   EpiArgs e{};
   e.x = h->x; e.x_next = h->x_next; e.aty = h->aty; e.aty_next = h->aty_next;
-  e.partials = h->pAt; e.stride = h->pAt_stride;
+  e.partials = h->pAt; e.stride = h->pAt_stride; e.lo_offset = 3 * h->pAt_stride;
   return launch_spmv<MODE_ATY, 1>(h, h->At, h->y_next, e);
 }
 
@@ -393,6 +393,9 @@ int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int,
   sp.ptr[2] = p_dy;                   sp.count[2] = n_dy;
   sp.ptr[3] = p_int + 2 * stride_int; sp.count[3] = n_int;
   sp.ptr[4] = h->pQ;                  sp.count[4] = q_count;
+  for (int q : {0, 1, 3}) sp.ptr_lo[q] = sp.ptr[q] + 3 * stride_int;
+  sp.ptr_lo[2] = p_dy + h->A.slots();
+  sp.ptr_lo[4] = h->pQ + h->ew_grid_n;
   sp.out = h->scal_dev;
   hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, sp);
   HIP_TRY(hipGetLastError());
@@ -596,18 +599,21 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
   a.avg_w = h->pend_w; a.sum_x = (h->pend_x && !xbar_only) ? h->sum_x : nullptr;
   EpiArgs de{};
   de.y = h->y; de.b = h->b; de.y_next = h->y_next; de.sigma = primal_weight * step_size; de.num_eq = (int)h->num_eq;
-  de.partials = h->pA; de.stride = h->A.slots();
+  de.partials = h->pA; de.stride = h->A.slots(); de.lo_offset = h->A.slots();
   if (h->pend_y) { de.sum_y = h->sum_y; de.avg_w = h->pend_w; }
   a.A = trial_product(h, h->A, h->xbar, de);
   EpiArgs te{};
   te.x = h->x; te.x_next = h->x_next; te.aty = h->aty; te.aty_next = h->aty_next;
-  te.partials = h->pAt; te.stride = h->pAt_stride;
+  te.partials = h->pAt; te.stride = h->pAt_stride; te.lo_offset = 3 * h->pAt_stride;
   a.T = trial_product(h, h->At, h->y_next, te);
   a.sp.ptr[0] = h->pAt;                       a.sp.count[0] = h->At.slots();
   a.sp.ptr[1] = h->pAt + h->pAt_stride;       a.sp.count[1] = h->At.slots();
   a.sp.ptr[2] = h->pA;                        a.sp.count[2] = h->A.slots();
   a.sp.ptr[3] = h->pAt + 2 * h->pAt_stride;   a.sp.count[3] = h->At.slots();
   a.sp.ptr[4] = h->pQ;                        a.sp.count[4] = 0;
+  for (int q : {0, 1, 3}) a.sp.ptr_lo[q] = a.sp.ptr[q] + 3 * h->pAt_stride;
+  a.sp.ptr_lo[2] = h->pA + h->A.slots();
+  a.sp.ptr_lo[4] = h->pQ + h->ew_grid_n;
   a.sp.out = nullptr;
   a.has_q = h->has_q ? 1 : 0;
   a.epoch = h->coop_epoch;
@@ -680,7 +686,7 @@ struct GraphArgs {
   GraphArgs(pdhg_handle *h_, double sigma) : h(h_), n((int)h_->n), primal_grid(ew_grid((h_->n + 1) / 2)) {
     dual_epi = EpiArgs{};
     dual_epi.y = h->y; dual_epi.b = h->b; dual_epi.y_next = h->y_next; dual_epi.sigma = sigma;
-    dual_epi.num_eq = (int)h->num_eq; dual_epi.partials = h->pA; dual_epi.stride = h->A.slots();
+    dual_epi.num_eq = (int)h->num_eq; dual_epi.partials = h->pA; dual_epi.stride = h->A.slots(); dual_epi.lo_offset = h->A.slots();
     if (h->pend_y) { dual_epi.sum_y = h->sum_y; dual_epi.avg_w = h->pend_w; }
   }
 };
@@ -815,7 +821,7 @@ int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double t
   const CsrDev &T = h->At;
   EpiArgs te{};
   te.x = h->x; te.x_next = h->x_next; te.aty = h->aty; te.aty_next = h->aty_next;
-  te.partials = h->pAt; te.stride = h->pAt_stride;
+  te.partials = h->pAt; te.stride = h->pAt_stride; te.lo_offset = 3 * h->pAt_stride;
   {
     int rc = graph_add_spmv<MODE_ATY, 1>(h, G.graph, T, h->y_next, te, dual_done, aty_done, nullptr, nullptr);
     if (rc) return rc;
@@ -828,6 +834,9 @@ int graph_build(pdhg_handle *h, pdhg_handle::TrialGraph &G, double tau, double t
   sp.ptr[2] = h->pA;                        sp.count[2] = A.slots();
   sp.ptr[3] = h->pAt + 2 * h->pAt_stride;   sp.count[3] = T.slots();
   sp.ptr[4] = h->pQ;                        sp.count[4] = 0;
+  for (int q : {0, 1, 3}) sp.ptr_lo[q] = sp.ptr[q] + 3 * h->pAt_stride;
+  sp.ptr_lo[2] = h->pA + A.slots();
+  sp.ptr_lo[4] = h->pQ + h->ew_grid_n;
   sp.out = nullptr;
   hipGraphNode_t fin = nullptr;
   HIP_TRY(graph_add_kernel(G.graph, &fin, aty_done, (const void *)final_reduce_host_kernel, dim3(1), dim3(FINAL_TPB), sp,
@@ -1344,9 +1353,10 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   CK(alloc_zero(&h->tmp_n, n_alloc)); CK(alloc_zero(&h->tmp_m, m));
   h->ew_grid_n = ew_grid(n); h->ew_grid_m = ew_grid(m); h->ew_grid_nm = ew_grid(std::max(n, m));
   h->pAt_stride = std::max(h->At.slots(), h->ew_grid_n);
-  CK(alloc_zero(&h->pA, std::max(h->A.slots(), 1)));
-  CK(alloc_zero(&h->pAt, 3 * (int64_t)std::max(h->pAt_stride, 1)));
-  CK(alloc_zero(&h->pQ, h->ew_grid_n));
+  // block partials are double-double: hi parts, then lo parts
+  CK(alloc_zero(&h->pA, 2 * (int64_t)std::max(h->A.slots(), 1)));
+  CK(alloc_zero(&h->pAt, 6 * (int64_t)std::max(h->pAt_stride, 1)));
+  CK(alloc_zero(&h->pQ, 2 * (int64_t)h->ew_grid_n));
   CK(alloc_zero(&h->scal_dev, SCAL_MAX));
   {
     hipError_t e = hipHostMalloc((void **)&h->scal_host, sizeof(double) * SCAL_MAX * DIST_MAX_WORLD, hipHostMallocDefault);

@@ -30,9 +30,10 @@ struct EpiArgs {
   const double *x_next;
   const double *aty;
   double *aty_next;
-  // block partials: partials[q*stride + slot]
+  // block partials, double-double: hi at partials[q*stride + slot], lo at partials[lo_offset + q*stride + slot]
+  // (lo_offset = number of quantities * stride)
   double *partials;
-  int stride;
+  int stride, lo_offset;
   // column-slab passes of the stream layout: the row sums so far (read when INIT)
   const double *init;
   // MODE_DUAL: the deferred K7 of the previous accept, sum_y += avg_w * y (nullptr: none)
@@ -42,7 +43,7 @@ struct EpiArgs {
 
 template <int MODE>
 __device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
-                                             double (&acc)[3]) {
+                                             Acc3 &acc) {
   if (MODE == MODE_PLAIN) {
     e.out[r] = s;
   } else if (MODE == MODE_DUAL) {
@@ -60,15 +61,15 @@ __device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
     if (r >= e.num_eq) yn = jl_max(yn, 0.0);
     e.y_next[r] = yn;
     const double dy = yn - yo;                       // pdhg.jl:535
-    acc[0] += dy * dy;
+    dd_add(acc.hi[0], acc.lo[0], dy * dy);
   } else {
     // next_dual_product = A' * next_dual            pdhg.jl:492
     e.aty_next[r] = s;
     const double dx = e.x_next[r] - e.x[r];          // pdhg.jl:534
     const double dd = s - e.aty[r];                  // pdhg.jl:543
-    acc[0] += dx * dd;
-    acc[1] += dx * dx;
-    acc[2] += dd * dd;
+    dd_add(acc.hi[0], acc.lo[0], dx * dd);
+    dd_add(acc.hi[1], acc.lo[1], dx * dx);
+    dd_add(acc.hi[2], acc.lo[2], dd * dd);
   }
 }
 
@@ -132,9 +133,12 @@ constexpr int RELAXED_MIN_ROW = 256;
 // (bitwise reproducible), but not the sequential one: |result - sequential| <= 1e-13 * sum |a x|,
 // the bar the rows beyond BLOCK_NNZ have always had.  The row stays OWNED by the lane that
 // would have added it (epilogue, partial sums): nothing else changes.
-template <int MODE, bool INIT>
+// PIPE: the two-register-set software pipeline of the strict per-lane row sum (32 VGPRs).  The one-launch trial
+// kernel, which keeps a prefetched item's 24 registers alive across its phases, runs the plain 8-at-a-time loop
+// instead (same order of additions, hence the same bits) to stay within 96 VGPRs.
+template <int MODE, bool INIT, bool PIPE = true>
 __device__ __forceinline__ void stream_block_finish(const CsrView &A, const double *xin, const StreamRegs &g,
-                                                    const EpiArgs &e, int relaxed, double (&acc)[3], double *prod) {
+                                                    const EpiArgs &e, int relaxed, Acc3 &acc, double *prod) {
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int k0 = g.k0, k1 = g.k1;
@@ -164,7 +168,13 @@ __device__ __forceinline__ void stream_block_finish(const CsrView &A, const doub
       // lane, so its LDS reads are software-pipelined: the next 8 products are
       // requested before the current 8 are added, which leaves the chain at the
       // latency of the adds alone.
-      if (k + 8 <= ke) {
+      if (!PIPE) {
+        for (; k + 8 <= ke; k += 8) {
+          const double t0 = prod[k], t1 = prod[k + 1], t2 = prod[k + 2], t3 = prod[k + 3];
+          const double t4 = prod[k + 4], t5 = prod[k + 5], t6 = prod[k + 6], t7 = prod[k + 7];
+          s = s + t0; s = s + t1; s = s + t2; s = s + t3; s = s + t4; s = s + t5; s = s + t6; s = s + t7;
+        }
+      } else if (k + 8 <= ke) {
 #define LD8(p, q) const double p##0 = prod[q], p##1 = prod[(q) + 1], p##2 = prod[(q) + 2], p##3 = prod[(q) + 3], \
                                p##4 = prod[(q) + 4], p##5 = prod[(q) + 5], p##6 = prod[(q) + 6], p##7 = prod[(q) + 7]
 #define ADD8(p) s = s + p##0; s = s + p##1; s = s + p##2; s = s + p##3; s = s + p##4; s = s + p##5; s = s + p##6; s = s + p##7
@@ -220,10 +230,10 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
     CsrView A, const double *__restrict__ xin, const int2 *__restrict__ blks,
     int nblk, int per_xcd, int remap, int relaxed, EpiArgs e) {
   __shared__ double prod[BLOCK_NNZ];
-  __shared__ double red[3][TPB / WAVE];
+  __shared__ double red[6][TPB / WAVE];
   const int b = blockIdx.x;
   const int blk = remap ? ((b & (NUM_XCD - 1)) * per_xcd + (b >> 3)) : b;
-  double acc[3] = {0.0, 0.0, 0.0};
+  Acc3 acc = acc3_zero();
   const bool active = remap ? ((b >> 3) < per_xcd && blk < nblk) : (blk < nblk);
   if (active) {
     StreamRegs g;
@@ -232,10 +242,13 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
   }
   constexpr int NQ = ModeNQ<MODE>::value;
   if (NQ > 0) {
-    block_sum<NQ, TPB>(acc, red);
+    block_sum_dd<NQ, TPB>(acc, red);
     if (threadIdx.x == 0) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) e.partials[q * e.stride + b] = acc[q];
+      for (int q = 0; q < NQ; ++q) {
+        e.partials[q * e.stride + b] = acc.hi[q];
+        e.partials[e.lo_offset + q * e.stride + b] = acc.lo[q];
+      }
     }
   }
 }
@@ -405,14 +418,14 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   constexpr int U = TW_U;   // 64-entry chunks held in registers per (wave, tile)
   constexpr int D = 3;      // entry loads run D tiles ahead of the accumulate
   constexpr int R = D + 1;  // register ring (statically indexed: the tile loop is unrolled R times)
-  extern __shared__ double tw_lds[];  // [TW_WPB][TW_ROWS] accumulators, then red[3][TW_WPB]
+  extern __shared__ double tw_lds[];  // [TW_WPB][TW_ROWS] accumulators, then red[6][TW_WPB]
   double(*red)[TW_WPB] = reinterpret_cast<double(*)[TW_WPB]>(tw_lds + TW_WPB * TW_ROWS);
   const int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x / WAVE;
-  double *scratch = tw_lds + TW_WPB * TW_ROWS + 3 * TW_WPB + wid * WAVE;   // CH == 1 only: 64 doubles per wave
+  double *scratch = tw_lds + TW_WPB * TW_ROWS + 6 * TW_WPB + wid * WAVE;   // CH == 1 only: 64 doubles per wave
   const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * TW_WPB + wid);
   const bool live = w < nwaves;
-  double acc3[3] = {0.0, 0.0, 0.0};
+  Acc3 acc3 = acc3_zero();
   double *acc = tw_lds + wid * TW_ROWS;
   int2 rr = make_int2(0, 0);
   if (live) rr = wave_rows[w];
@@ -515,10 +528,13 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   for (int r = lane; r < nrows; r += WAVE) row_epilogue<MODE>(e, rr.x + r, acc[r], acc3);
   constexpr int NQ = ModeNQ<MODE>::value;
   if (NQ > 0) {
-    block_sum<NQ, TW_THREADS>(acc3, red);
+    block_sum_dd<NQ, TW_THREADS>(acc3, red);
     if (threadIdx.x == 0) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) e.partials[q * e.stride + blockIdx.x] = acc3[q];
+      for (int q = 0; q < NQ; ++q) {
+        e.partials[q * e.stride + blockIdx.x] = acc3.hi[q];
+        e.partials[e.lo_offset + q * e.stride + blockIdx.x] = acc3.lo[q];
+      }
     }
   }
 }
@@ -589,14 +605,19 @@ __device__ __forceinline__ void long_final_row(int l, const int *long_row, const
   for (int c = c0 + lane; c < c1; c += WAVE) s = s + chunk_partial[c];
   s = wave_sum(s);
   if (lane == 0) {
-    double acc[3] = {0.0, 0.0, 0.0};
+    Acc3 acc = acc3_zero();
     row_epilogue<MODE>(e, long_row[l], s, acc);
     constexpr int NQ = ModeNQ<MODE>::value;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       double *dst = e.partials + q * e.stride + slot_base + l;
-      if (AGENT) __hip_atomic_store(dst, acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else *dst = acc[q];
+      if (AGENT) {
+        __hip_atomic_store(dst, acc.hi[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + e.lo_offset, acc.lo[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        *dst = acc.hi[q];
+        dst[e.lo_offset] = acc.lo[q];
+      }
     }
   }
 }

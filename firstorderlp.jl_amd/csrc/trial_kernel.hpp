@@ -59,7 +59,10 @@ __global__ __launch_bounds__(TPB) void xcd_register_kernel(GridSync *s) {
 }
 
 #ifndef PDHG_TRIAL_WAVES_PER_EU
-#define PDHG_TRIAL_WAVES_PER_EU 5
+#define PDHG_TRIAL_WAVES_PER_EU 4
+#endif
+#ifndef PDHG_TRIAL_PIPE
+#define PDHG_TRIAL_PIPE true
 #endif
 constexpr unsigned long long RESULT_CHECK_SALT = 0x9E3779B97F4A7C15ull;
 constexpr long GRID_SPIN_LIMIT = 4000000L;   // x s_sleep(1): ~0.1 s
@@ -206,16 +209,19 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed
     __syncthreads();                   // `prod` and `red` are free again
     int blk;
     const bool active = product_block_of(P, b, &blk);
-    double acc[3] = {0.0, 0.0, 0.0};
+    Acc3 acc = acc3_zero();
     if (active) {
       if (!(pre && b == w)) stream_block_load(P.M, P.blks[blk], g);
-      stream_block_finish<MODE, false>(P.M, P.xin, g, P.e, relaxed, acc, prod);
+      stream_block_finish<MODE, false, PDHG_TRIAL_PIPE>(P.M, P.xin, g, P.e, relaxed, acc, prod);
     }
     if (NQ > 0) {
-      block_sum<NQ, TPB>(acc, red);
+      block_sum_dd<NQ, TPB>(acc, red);
       if (threadIdx.x == 0) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) store_agent(P.e.partials + q * P.e.stride + b, acc[q]);
+        for (int q = 0; q < NQ; ++q) {
+          store_agent(P.e.partials + q * P.e.stride + b, acc.hi[q]);
+          store_agent(P.e.partials + P.e.lo_offset + q * P.e.stride + b, acc.lo[q]);
+        }
       }
     }
   }
@@ -226,7 +232,7 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed
 // 2.4k against 4.4k: profiles/r03_trial_kernel.txt).
 __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(TrialKernelArgs a) {
   __shared__ double prod[BLOCK_NNZ];
-  __shared__ double red[3][TPB / WAVE];
+  __shared__ double red[6][TPB / WAVE];
   __shared__ int done_flag;
   const int w = blockIdx.x, nwg = gridDim.x;
 #define PDHG_STAMP(k) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)w * 8 + (k)] = wall_clock64(); } while (0)

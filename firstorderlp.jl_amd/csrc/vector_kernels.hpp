@@ -129,40 +129,47 @@ __global__ __launch_bounds__(TPB) void interaction_kernel(
     int n, const double *__restrict__ x, const double *__restrict__ x_next,
     const double *__restrict__ aty, const double *__restrict__ aty_next,
     double *__restrict__ partials, int pstride) {
-  __shared__ double red[3][TPB / WAVE];
-  double acc[3] = {0.0, 0.0, 0.0};
+  __shared__ double red[6][TPB / WAVE];
+  Acc3 acc = acc3_zero();
   const int stride = gridDim.x * TPB;
   for (int j = blockIdx.x * TPB + threadIdx.x; j < n; j += stride) {
     const double dx = x_next[j] - x[j];
     const double dd = aty_next[j] - aty[j];
-    acc[0] += dx * dd;
-    acc[1] += dx * dx;
-    acc[2] += dd * dd;
+    dd_add(acc.hi[0], acc.lo[0], dx * dd);
+    dd_add(acc.hi[1], acc.lo[1], dx * dx);
+    dd_add(acc.hi[2], acc.lo[2], dd * dd);
   }
-  block_sum<3, TPB>(acc, red);
+  block_sum_dd<3, TPB>(acc, red);
   if (threadIdx.x == 0) {
-    partials[0 * pstride + blockIdx.x] = acc[0];
-    partials[1 * pstride + blockIdx.x] = acc[1];
-    partials[2 * pstride + blockIdx.x] = acc[2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      partials[q * pstride + blockIdx.x] = acc.hi[q];
+      partials[(3 + q) * pstride + blockIdx.x] = acc.lo[q];
+    }
   }
 }
 
-// dot(a, b) partials (QP term): block `bid` of `nb` writes partials[bid]
+// dot(a, b) partials (QP term), double-double: block `bid` of `nb` writes partials[bid] (hi) and partials[nb + bid] (lo)
 __device__ __forceinline__ void dot_body(int n, const double *a, const double *b, double *partials, int bid, int nb,
                                          double (*red)[TPB / WAVE], bool agent_store) {
-  double acc[3] = {0.0, 0.0, 0.0};
+  Acc3 acc = acc3_zero();
   const int stride = nb * TPB;
-  for (int j = bid * TPB + threadIdx.x; j < n; j += stride) acc[0] += a[j] * b[j];
-  block_sum<1, TPB>(acc, red);
+  for (int j = bid * TPB + threadIdx.x; j < n; j += stride) dd_add(acc.hi[0], acc.lo[0], a[j] * b[j]);
+  block_sum_dd<1, TPB>(acc, red);
   if (threadIdx.x == 0) {
-    if (agent_store) __hip_atomic_store(partials + bid, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else partials[bid] = acc[0];
+    if (agent_store) {
+      __hip_atomic_store(partials + bid, acc.hi[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(partials + nb + bid, acc.lo[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      partials[bid] = acc.hi[0];
+      partials[nb + bid] = acc.lo[0];
+    }
   }
 }
 __global__ __launch_bounds__(TPB) void dot_kernel(int n, const double *__restrict__ a,
                                                   const double *__restrict__ b,
                                                   double *__restrict__ partials) {
-  __shared__ double red[3][TPB / WAVE];
+  __shared__ double red[6][TPB / WAVE];
   dot_body(n, a, b, partials, blockIdx.x, gridDim.x, red, false);
 }
 
@@ -194,35 +201,42 @@ __global__ __launch_bounds__(TPB) void div_kernel(int n, const double *__restric
 // Second-stage, fixed-order sum of the block partials.  One workgroup.
 // spec[q] = {ptr, count}; out[q] = sum(ptr[0..count)).  count==0 -> 0.
 struct FinalSpec {
-  const double *ptr[5];
+  const double *ptr[5];     // hi parts of the block partials
+  const double *ptr_lo[5];  // lo parts
   int count[5];
   double *out;     // 5 doubles (host-mapped or device)
 };
-// The five sums: quantity q is summed by three "virtual waves" 3q..3q+2 (fixed order:
-// strided per-lane sums, wave shuffle tree, then the three wave totals left to right).  A
-// workgroup of NW waves runs virtual wave v on wave v mod NW: the separate final kernels have
-// 16 waves (one virtual wave each), the one-launch trial kernel 4 -- the arithmetic, hence the
-// bits, are the same.  Thread 0 ends with all five in res[].
+// The five sums, each a double-double sum of its block partials: quantity q is summed by three
+// "virtual waves" 3q..3q+2 (strided per-lane sums, wave shuffle tree, then the three wave totals
+// left to right -- a fixed order, although the double-double result does not depend on it except
+// with negligible probability).  A workgroup of NW waves runs virtual wave v on wave v mod NW: the
+// separate final kernels have 16 waves (one virtual wave each), the one-launch trial kernel 4 --
+// the arithmetic, hence the bits, are the same.  Thread 0 ends with all five, rounded to one
+// double each, in res[].
+#ifndef PDHG_FINAL_BATCH
+#define PDHG_FINAL_BATCH 4
+#endif
 template <int NW>
 __device__ __forceinline__ void final_reduce_body(const FinalSpec &sp, double (&res)[5]) {
-  __shared__ double wsum[16];
+  __shared__ double wsum[16], wsum_lo[16];
   const int wid = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   constexpr int VPW = (15 + NW - 1) / NW;        // virtual waves per physical wave
-  constexpr int B = 4;                           // loads in flight per lane and virtual wave
+  constexpr int B = PDHG_FINAL_BATCH;            // load pairs in flight per lane and virtual wave (registers: 2 * VPW * B doubles)
   // The partials come from other CUs' stores: every load is a trip to memory.  All of a
   // physical wave's first B loads per virtual wave are requested before anything is added
-  // (one round trip instead of VPW); the sums keep the ascending order of a plain loop.
-  double t[VPW][B];
+  // (one round trip instead of VPW).
+  double th[VPW][B], tl[VPW][B];
 #pragma unroll
   for (int j = 0; j < VPW; ++j) {
     const int v = wid + j * NW;
     const int q = v < 15 ? v / 3 : 0, sub = v % 3;
-    const double *p = sp.ptr[q];
+    const double *p = sp.ptr[q], *pl = sp.ptr_lo[q];
     const int cnt = v < 15 ? sp.count[q] : 0;
 #pragma unroll
     for (int u = 0; u < B; ++u) {
       const int i = sub * WAVE + lane + u * 3 * WAVE;
-      t[j][u] = i < cnt ? p[i] : 0.0;
+      th[j][u] = i < cnt ? p[i] : 0.0;
+      tl[j][u] = i < cnt ? pl[i] : 0.0;
     }
   }
 #pragma unroll
@@ -230,31 +244,37 @@ __device__ __forceinline__ void final_reduce_body(const FinalSpec &sp, double (&
     const int v = wid + j * NW;
     if (v < 15) {                                 // wave-uniform
       const int q = v / 3, sub = v % 3;
-      const double *p = sp.ptr[q];
+      const double *p = sp.ptr[q], *pl = sp.ptr_lo[q];
       const int cnt = sp.count[q];
-      double acc = 0.0;
+      double hi = 0.0, lo = 0.0;
 #pragma unroll
       for (int u = 0; u < B; ++u)
-        if (sub * WAVE + lane + u * 3 * WAVE < cnt) acc += t[j][u];
+        if (sub * WAVE + lane + u * 3 * WAVE < cnt) dd_add_dd(hi, lo, th[j][u], tl[j][u]);
       for (int i0 = sub * WAVE + lane + B * 3 * WAVE; i0 < cnt; i0 += B * 3 * WAVE) {
-        double r[B];
+        double rh[B], rl[B];
 #pragma unroll
         for (int u = 0; u < B; ++u) {
           const int i = i0 + u * 3 * WAVE;
-          r[u] = i < cnt ? p[i] : 0.0;
+          rh[u] = i < cnt ? p[i] : 0.0;
+          rl[u] = i < cnt ? pl[i] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < B; ++u)
-          if (i0 + u * 3 * WAVE < cnt) acc += r[u];
+          if (i0 + u * 3 * WAVE < cnt) dd_add_dd(hi, lo, rh[u], rl[u]);
       }
-      acc = wave_sum(acc);
-      if (lane == 0) wsum[v] = acc;
+      wave_sum_dd(hi, lo);
+      if (lane == WAVE - 1) { wsum[v] = hi; wsum_lo[v] = lo; }
     }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) res[k] = (wsum[3 * k] + wsum[3 * k + 1]) + wsum[3 * k + 2];
+    for (int k = 0; k < 5; ++k) {
+      double hi = wsum[3 * k], lo = wsum_lo[3 * k];
+      dd_add_dd(hi, lo, wsum[3 * k + 1], wsum_lo[3 * k + 1]);
+      dd_add_dd(hi, lo, wsum[3 * k + 2], wsum_lo[3 * k + 2]);
+      res[k] = hi + lo;
+    }
   }
 }
 

@@ -48,6 +48,9 @@ def lib():
         _lib.oracle_get_numerical_error.restype = ctypes.c_int
         _lib.oracle_get_numerical_error.argtypes = [ctypes.c_void_p]
         _lib.oracle_set_numerical_error.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.oracle_set_exact_sums.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.oracle_get_exact_sums.restype = ctypes.c_int
+        _lib.oracle_get_exact_sums.argtypes = [ctypes.c_void_p]
         _lib.oracle_get_total_number_iterations.restype = ctypes.c_int64
         _lib.oracle_get_total_number_iterations.argtypes = [ctypes.c_void_p]
         _lib.oracle_take_step_adaptive.argtypes = [ctypes.c_void_p,
@@ -168,6 +171,10 @@ class OracleState:
     numerical_error = property(
         lambda s: bool(s._L.oracle_get_numerical_error(s._h)),
         lambda s, v: s._L.oracle_set_numerical_error(s._h, int(bool(v))))
+    # test aid (not the reference's arithmetic): the three step-acceptance sums in double-double,
+    # i.e. exactly rounded and independent of the order of the additions -- what the HIP library does
+    exact_sums = property(lambda s: bool(s._L.oracle_get_exact_sums(s._h)),
+                          lambda s, v: s._L.oracle_set_exact_sums(s._h, int(bool(v))))
     total_number_iterations = property(
         lambda s: int(s._L.oracle_get_total_number_iterations(s._h)))
 
@@ -301,6 +308,10 @@ class OmpCpuState:
         return self._L.omp_take_step_adaptive(self._h, reduction_exponent, growth_exponent)
 
     step_size = property(lambda s: s._L.omp_get_step_size(s._h))
+    # test aid (not the reference's arithmetic): the three step-acceptance sums in double-double,
+    # i.e. exactly rounded and independent of the order of the additions -- what the HIP library does
+    exact_sums = property(lambda s: bool(s._L.oracle_get_exact_sums(s._h)),
+                          lambda s, v: s._L.oracle_set_exact_sums(s._h, int(bool(v))))
     total_number_iterations = property(lambda s: int(s._L.omp_get_total_iterations(s._h)))
 
     def xy(self):

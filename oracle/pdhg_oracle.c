@@ -58,6 +58,7 @@ typedef struct {
 
   double step_size, primal_weight;
   int numerical_error;
+  int exact_sums; /* test aid, NOT the reference's arithmetic: see oracle_set_exact_sums */
   double cumulative_kkt_passes;
   int64_t total_number_iterations;
   double ratio_step_sizes;
@@ -120,6 +121,24 @@ static double sumsq(const double *v, int64_t len) {
   }
   return s;
 }
+/* (hi, lo) += t, TwoSum: the rounding error of the addition goes to lo */
+static inline void dd_add(double *hi, double *lo, double t) {
+  const double s = *hi + t;
+  const double bb = s - *hi;
+  const double e = (*hi - (s - bb)) + (t - bb);
+  *hi = s;
+  *lo = *lo + e;
+}
+/* sum of a[i] * b[i] (each product rounded to a double), accumulated in double-double */
+static double dd_dot(const double *a, const double *b, int64_t len) {
+  double hi = 0.0, lo = 0.0;
+  for (int64_t i = 0; i < len; ++i) {
+    const double p = a[i] * b[i];
+    dd_add(&hi, &lo, p);
+  }
+  return hi + lo;
+}
+
 static double dot_seq(const double *a, const double *b, int64_t len) {
   double s = 0.0;
   for (int64_t i = 0; i < len; ++i) {
@@ -219,6 +238,16 @@ double oracle_get_ratio_step_sizes(const oracle_state *s) { return s->ratio_step
 void oracle_set_ratio_step_sizes(oracle_state *s, double v) { s->ratio_step_sizes = v; }
 int oracle_get_numerical_error(const oracle_state *s) { return s->numerical_error; }
 void oracle_set_numerical_error(oracle_state *s, int v) { s->numerical_error = v; }
+/* Exact-sums mode (test aid).  The reference takes the three step-acceptance sums with BLAS
+ * dot / nrm2 (pdhg.jl:540-547), whose summation order is implementation-defined; the default here is
+ * the plain sequential loop.  With exact_sums != 0 the same TERMS (each product rounded to a double
+ * first) are added in double-double arithmetic and rounded once at the end: the correctly rounded
+ * exact sum (up to a ~1e-14 chance per sum), which no longer depends on the order of the additions.
+ * The HIP library accumulates these sums the same way, so in this mode the two produce bitwise
+ * identical scalars, hence -- everything else being bit-exact -- bitwise identical free-running
+ * trajectories (tests/test_gpu_exact_sums.py). */
+void oracle_set_exact_sums(oracle_state *s, int v) { s->exact_sums = v; }
+int oracle_get_exact_sums(const oracle_state *s) { return s->exact_sums; }
 double oracle_get_cumulative_kkt_passes(const oracle_state *s) { return s->cumulative_kkt_passes; }
 void oracle_set_cumulative_kkt_passes(oracle_state *s, double v) { s->cumulative_kkt_passes = v; }
 int64_t oracle_get_total_number_iterations(const oracle_state *s) { return s->total_number_iterations; }
@@ -357,28 +386,33 @@ void oracle_interaction_and_movement(oracle_state *s, const double *x_next,
      * dx'*Q is the adjoint-vector x CSC product = per-column dots. */
     oracle_spmv_t(s->n, s->n, s->q_colptr, s->q_rowval, s->q_nzval, s->tmp_n,
                   s->tmp_n2);
-    primal_objective_interaction = 0.5 * dot_seq(s->tmp_n2, s->tmp_n, s->n);
+    primal_objective_interaction = 0.5 * (s->exact_sums ? dd_dot(s->tmp_n2, s->tmp_n, s->n)
+                                                        : dot_seq(s->tmp_n2, s->tmp_n, s->n));
   }
-  double pdi = 0.0;
+  double pdi = 0.0, pdi_lo = 0.0;
   for (int64_t j = 0; j < s->n; ++j) {
     const double dd = aty_next[j] - s->aty[j];
     const double p = s->tmp_n[j] * dd;
-    pdi = pdi + p;
+    if (s->exact_sums) dd_add(&pdi, &pdi_lo, p);
+    else pdi = pdi + p;
   }
-  const double ssx = sumsq(s->tmp_n, s->n);
-  const double ssy = sumsq(s->tmp_m, s->m);
+  if (s->exact_sums) pdi = pdi + pdi_lo;
+  const double ssx = s->exact_sums ? dd_dot(s->tmp_n, s->tmp_n, s->n) : sumsq(s->tmp_n, s->n);
+  const double ssy = s->exact_sums ? dd_dot(s->tmp_m, s->tmp_m, s->m) : sumsq(s->tmp_m, s->m);
   const double nx = sqrt(ssx), ny = sqrt(ssy);
   *interaction = fabs(pdi) + fabs(primal_objective_interaction);
   *movement = 0.5 * s->primal_weight * (nx * nx) +
               (0.5 / s->primal_weight) * (ny * ny);
   if (raw) {
     /* raw[3] = sum (A'y' - A'y)^2 (Malitsky-Pock test, pdhg.jl:615) */
-    double ssd = 0.0;
+    double ssd = 0.0, ssd_lo = 0.0;
     for (int64_t j = 0; j < s->n; ++j) {
       const double dd = aty_next[j] - s->aty[j];
       const double p = dd * dd;
-      ssd = ssd + p;
+      if (s->exact_sums) dd_add(&ssd, &ssd_lo, p);
+      else ssd = ssd + p;
     }
+    if (s->exact_sums) ssd = ssd + ssd_lo;
     raw[0] = pdi; raw[1] = ssx; raw[2] = ssy; raw[3] = ssd;
     raw[4] = primal_objective_interaction;
   }
@@ -473,8 +507,8 @@ int oracle_take_step_malitsky_pock(oracle_state *s, double downscaling_factor,
     for (int64_t i = 0; i < s->m; ++i) s->tmp_m[i] = s->y_next[i] - s->y[i];
     for (int64_t j = 0; j < s->n; ++j) s->tmp_n[j] = s->aty_next[j] - s->aty[j];
     s->cumulative_kkt_passes += 0.5;
-    const double n_dp = sqrt(sumsq(s->tmp_n, s->n));
-    const double n_dd = sqrt(sumsq(s->tmp_m, s->m));
+    const double n_dp = sqrt(s->exact_sums ? dd_dot(s->tmp_n, s->tmp_n, s->n) : sumsq(s->tmp_n, s->n));
+    const double n_dd = sqrt(s->exact_sums ? dd_dot(s->tmp_m, s->tmp_m, s->m) : sumsq(s->tmp_m, s->m));
     if (step_size * n_dp <= breaking_factor * n_dd) {
       if (s->sum_x_count == 0) {
         oracle_add_to_primal_average(s, s->x, step_size * ratio_step_sizes);
