@@ -29,6 +29,10 @@
  *              we use the sequential form for all lengths)
  *   dot(a,b) : sequential sum a_i*b_i (BLAS ddot order is implementation
  *              defined; sequential is the stand-in)
+ * Test aid beside the literal restatement: oracle_set_exact_sums(1) takes the three
+ * step-acceptance sums (pdhg.jl:540-547) in double-double instead -- the correctly rounded
+ * exact sum of the same terms, independent of summation order.  Off by default; every KAT and
+ * golden vector is produced with it off.
  *
  * Index convention here: 0-based int64 CSC (the Python wrapper converts).
  */
