@@ -221,7 +221,9 @@ __device__ __forceinline__ void final_reduce_body(const FinalSpec &sp, double (&
   __shared__ double wsum[16], wsum_lo[16];
   const int wid = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   constexpr int VPW = (15 + NW - 1) / NW;        // virtual waves per physical wave
-  constexpr int B = PDHG_FINAL_BATCH;            // load pairs in flight per lane and virtual wave (registers: 2 * VPW * B doubles)
+  // load pairs in flight per lane and virtual wave (registers: 2 * VPW * B doubles).  The 4-wave form (trial kernel) takes 5:
+  // a one-launch LP has up to ~1000 block partials per quantity, i.e. 5 per lane and virtual wave -- one trip to memory
+  constexpr int B = NW >= 16 ? PDHG_FINAL_BATCH : PDHG_FINAL_BATCH + 1;
   // The partials come from other CUs' stores: every load is a trip to memory.  All of a
   // physical wave's first B loads per virtual wave are requested before anything is added
   // (one round trip instead of VPW).
