@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--shards", type=int, default=0,
                     help="dev: run K row shards inside this one process on the one GPU (peer-kernel back end); "
                          "timings then show the sharded pipeline's total work, not a multi-GPU rate")
+    ap.add_argument("--per-step-calls", action="store_true",
+                    help="one host call per take_step in the timed region (pdhg_take_step_adaptive) instead of one "
+                         "call for the K steps (pdhg_take_steps_adaptive, what optimize() issues between evaluations)")
     ap.add_argument("--plain-launches", action="store_true",
                     help="measurement aid: every kernel as its own launch, in stream order (PDHG_GRAPH=0), also in the timed "
                          "region -- the same kernels the one-launch paths run.  A rocprofv3 kernel trace of this command "
@@ -164,7 +167,7 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
     import torch
     from firstorderlp_jl_amd import _lib
     from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
-        AdaptiveStepsizeParams, PdhgSolverState, take_step)
+        AdaptiveStepsizeParams, PdhgSolverState, take_step, take_steps)
     pkg, dist, rank, world, local_rank = ctx["pkg"], ctx["dist"], ctx["rank"], ctx["world"], ctx["local_rank"]
 
     t0 = time.time()
@@ -205,13 +208,23 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        take_step(policy, state)
+    def run_steps(k):
+        # optimize() runs the take_steps between two termination evaluations as one
+        # library call (take_steps -> pdhg_take_steps_adaptive); so does the timed region.
+        # --per-step-calls: one host call per take_step instead.
+        if args.per_step_calls:
+            for _ in range(k):
+                take_step(policy, state)
+            return
+        done = 0
+        while done < k:
+            done += take_steps(policy, state, k - done)
+
+    run_steps(warmup)
     barrier()
     trials0 = state.total_number_iterations
     t0 = time.perf_counter()
-    for _ in range(steps):
-        take_step(policy, state)
+    run_steps(steps)
     barrier()
     elapsed = time.perf_counter() - t0
     trials = state.total_number_iterations - trials0
@@ -371,6 +384,8 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         "layout_products": [eng.kernel_name(_lib.K_SPMV_DUAL), eng.kernel_name(_lib.K_SPMV_ATY)],
         "launch_path": {2: "one persistent kernel per trial (trial_kernel)", 1: "one HIP-graph launch per trial",
                         0: "separate launches"}.get(eng.layout_info().get("trial_graph"), "?"),
+        "host_calls": "one per take_step (pdhg_take_step_adaptive)" if args.per_step_calls
+                      else "one for the K steps (pdhg_take_steps_adaptive, as optimize() issues them between evaluations)",
         "setup_sec": {"generate": round(t_gen, 1), "create_upload": round(t_create, 1)},
     }
     if issue_stats is not None:

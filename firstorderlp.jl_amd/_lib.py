@@ -25,7 +25,7 @@ LINK_FLAGS = ["-ldl"]
 EXPORTS = [
     "pdhg_last_error", "pdhg_abi_version", "pdhg_create",
     "pdhg_set_objective_matrix", "pdhg_destroy", "pdhg_trial_step",
-    "pdhg_trial_primal", "pdhg_trial_dual", "pdhg_accept", "pdhg_take_step_adaptive",
+    "pdhg_trial_primal", "pdhg_trial_dual", "pdhg_accept", "pdhg_take_step_adaptive", "pdhg_take_steps_adaptive",
     "pdhg_add_current_primal_to_average", "pdhg_get_average_info",
     "pdhg_get_average", "pdhg_reset_average", "pdhg_restart_to_average",
     "pdhg_get_current", "pdhg_set_current", "pdhg_get_trial", "pdhg_spmv",
@@ -39,7 +39,7 @@ EXPORTS = [
     "pdhg_measure_launch_overhead", "pdhg_layout_checksums",
 ]
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 UNIQUE_ID_BYTES = 128
 (K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_ALLGATHER, K_REDUCE_SCATTER,
  K_INTERACTION, K_COUNT) = range(9)
@@ -113,6 +113,8 @@ def lib():
     L.pdhg_accept.argtypes = [_vp, d]
     L.pdhg_take_step_adaptive.restype = i32
     L.pdhg_take_step_adaptive.argtypes = [_vp, d, d, _dp, d, _ip, _dp, ctypes.POINTER(i32)]
+    L.pdhg_take_steps_adaptive.restype = i32
+    L.pdhg_take_steps_adaptive.argtypes = [_vp, i64, d, d, _dp, d, _ip, _dp, ctypes.POINTER(i32), _ip]
     L.pdhg_add_current_primal_to_average.restype = i32
     L.pdhg_add_current_primal_to_average.argtypes = [_vp, d]
     L.pdhg_get_average_info.restype = i32

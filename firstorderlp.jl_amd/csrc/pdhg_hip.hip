@@ -1543,7 +1543,7 @@ int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colpt
 extern "C" {
 
 const char *pdhg_last_error(void) { return g_last_error.c_str(); }
-int pdhg_abi_version(void) { return 6; }
+int pdhg_abi_version(void) { return 7; }
 
 // The kernels behind one fused product, as rocprofv3 prints them (template arguments <MODE,
 // INIT, TAG> / <MODE, CH> / <TAG>; MODE 0 plain, 1 dual epilogue, 2 A'y epilogue; TAG 0 = A,
@@ -2184,6 +2184,26 @@ int pdhg_take_step_adaptive(pdhg_handle *h, double reduction_exponent, double gr
                     ? NAN : ((first_term < second_term) ? first_term : second_term);
   }
   *step_size_io = step_size;
+  return 0;
+}
+
+/* `n_steps` consecutive take_steps (the iterations optimize() runs between two termination
+ * evaluations, pdhg.jl:862-1046: nothing but take_step happens there).  Stops after the step that
+ * raised numerical_error, like the reference's loop does at the top of the next iteration. */
+int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_exponent, double growth_exponent,
+                             double *step_size_io, double primal_weight, int64_t *total_number_iterations_io,
+                             double *cumulative_kkt_passes_io, int *numerical_error_out, int64_t *steps_done_out) {
+  if (!steps_done_out) return fail(-1, "null argument");
+  if (n_steps < 0) return fail(-2, "pdhg_take_steps_adaptive: n_steps < 0");
+  *steps_done_out = 0;
+  if (numerical_error_out) *numerical_error_out = 0;
+  for (int64_t s = 0; s < n_steps; ++s) {
+    const int rc = pdhg_take_step_adaptive(h, reduction_exponent, growth_exponent, step_size_io, primal_weight,
+                                           total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out);
+    if (rc) return rc;
+    *steps_done_out = s + 1;
+    if (*numerical_error_out) break;
+  }
   return 0;
 }
 

@@ -209,6 +209,20 @@ class HipPdhgEngine:
             ctypes.byref(it), ctypes.byref(kkt), ctypes.byref(err)))
         return ss.value, it.value, kkt.value, bool(err.value)
 
+    def take_steps_adaptive(self, n_steps, reduction_exponent, growth_exponent, step_size, primal_weight,
+                            total_number_iterations, cumulative_kkt_passes):
+        """pdhg_take_steps_adaptive: `n_steps` take_steps in one call.  Returns (step_size,
+        total_number_iterations, cumulative_kkt_passes, numerical_error, steps_done)."""
+        ss = ctypes.c_double(step_size)
+        it = ctypes.c_int64(total_number_iterations)
+        kkt = ctypes.c_double(cumulative_kkt_passes)
+        err = ctypes.c_int(0)
+        done = ctypes.c_int64(0)
+        _lib.check(self._L.pdhg_take_steps_adaptive(
+            self._h, int(n_steps), reduction_exponent, growth_exponent, ctypes.byref(ss), primal_weight,
+            ctypes.byref(it), ctypes.byref(kkt), ctypes.byref(err), ctypes.byref(done)))
+        return ss.value, it.value, kkt.value, bool(err.value), done.value
+
     def add_current_primal_to_average(self, weight):
         _lib.check(self._L.pdhg_add_current_primal_to_average(self._h, weight))
 

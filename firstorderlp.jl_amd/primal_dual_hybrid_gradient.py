@@ -190,6 +190,32 @@ def take_step(step_params, solver_state, is_lp=True):
     raise TypeError(f"unknown step size policy {type(step_params)}")
 
 
+def take_steps(step_params, solver_state, n_steps, is_lp=True):
+    """`n_steps` consecutive take_step calls -- the iterations optimize() runs between
+    two termination evaluations (pdhg.jl:862-1046: nothing else happens on them).
+    With the HIP engine and the adaptive rule they are one library call
+    (pdhg_take_steps_adaptive; the same statements, so the same scalars bit for bit).
+    Stops after a step that raised numerical_error.  Returns the steps taken."""
+    eng = solver_state.engine
+    if (isinstance(step_params, AdaptiveStepsizeParams) and hasattr(eng, "take_steps_adaptive")
+            and os.environ.get("PDHG_PY_TAKE_STEP", "0") != "1"):
+        (solver_state.step_size, solver_state.total_number_iterations,
+         solver_state.cumulative_kkt_passes, err, done) = eng.take_steps_adaptive(
+            n_steps, step_params.reduction_exponent, step_params.growth_exponent,
+            solver_state.step_size, solver_state.primal_weight,
+            solver_state.total_number_iterations, solver_state.cumulative_kkt_passes)
+        if err:
+            solver_state.numerical_error = True
+        return done
+    done = 0
+    while done < n_steps:
+        take_step(step_params, solver_state, is_lp)
+        done += 1
+        if solver_state.numerical_error:
+            break
+    return done
+
+
 # ==============================================================================
 # optimize(): the reference's outer loop (pdhg.jl:782-1049) on the host, with
 # every n-/m-length vector operation behind ``engine``.
@@ -482,8 +508,17 @@ def _optimize(params, original_problem, engine_factory, created):
             # RESTART_TO_AVERAGE: A'y was recomputed inside
             # engine.restart_to_average() (pdhg.jl:1018-1022).
 
+        # This iteration's take_step and those of the iterations up to (not including)
+        # the next one the test above fires on: the reference does nothing else on them.
+        next_evaluation = ((iteration - 1) // termination_evaluation_frequency + 1) * \
+            termination_evaluation_frequency + 1
+        if iteration < 10:
+            next_evaluation = iteration + 1
+        if iteration < iteration_limit + 1:
+            next_evaluation = min(next_evaluation, iteration_limit + 1)
+        batch = next_evaluation - iteration
         time_spent_doing_basic_algorithm_checkpoint = _time.time()
-        take_step(policy, solver_state, is_lp)
+        iteration += take_steps(policy, solver_state, batch, is_lp) - 1
         time_spent_doing_basic_algorithm += \
             _time.time() - time_spent_doing_basic_algorithm_checkpoint
 

@@ -123,6 +123,17 @@ int pdhg_take_step_adaptive(pdhg_handle *h, double reduction_exponent, double gr
                             int64_t *total_number_iterations, double *cumulative_kkt_passes,
                             int *numerical_error);
 
+/*
+ * `n_steps` consecutive pdhg_take_step_adaptive calls: what optimize() runs between two
+ * termination evaluations (pdhg.jl:862-1046 does nothing but take_step on those
+ * iterations).  Returns after the step that set *numerical_error (the reference notices
+ * it at the top of the next iteration); *steps_done = take_steps completed.
+ */
+int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_exponent,
+                             double growth_exponent, double *step_size, double primal_weight,
+                             int64_t *total_number_iterations, double *cumulative_kkt_passes,
+                             int *numerical_error, int64_t *steps_done);
+
 /* add_to_primal_solution_weighted_average on the CURRENT x (pdhg.jl:621-627). */
 int pdhg_add_current_primal_to_average(pdhg_handle *h, double weight);
 

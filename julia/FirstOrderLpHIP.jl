@@ -1,4 +1,4 @@
-# FirstOrderLpHIP.jl -- `ccall` shim over libpdhg_hip.so (include/pdhg_hip.h, abi 6).
+# FirstOrderLpHIP.jl -- `ccall` shim over libpdhg_hip.so (include/pdhg_hip.h, abi 7).
 #
 # Drop-in for FirstOrderLp.jl's PDHG path on MI355X:
 #
@@ -26,7 +26,7 @@ using SparseArrays
 import Random
 
 const LIB = get(ENV, "PDHG_HIP_LIB", "libpdhg_hip.so")
-const ABI_VERSION = 6
+const ABI_VERSION = 7
 const POINT_CURRENT = Cint(0)
 const POINT_AVERAGE = Cint(1)
 const POINT_RESTART = Cint(2)
@@ -242,6 +242,22 @@ function take_step_adaptive_native!(s::HipSolverState, reduction_exponent, growt
     s.handle, reduction_exponent, growth_exponent, step, s.primal_weight, its, kkt, err))
   s.step_size = step[]; s.total_number_iterations = its[]; s.cumulative_kkt_passes = kkt[]
   s.numerical_error = s.numerical_error || err[] != 0
+end
+
+"""
+`n_steps` adaptive take_steps in one ccall (pdhg_take_steps_adaptive): the iterations
+optimize() runs between two termination evaluations.  Returns the number of take_steps
+done (fewer than `n_steps` only after a numerical error).
+"""
+function take_steps_adaptive_native!(s::HipSolverState, n_steps::Integer, reduction_exponent, growth_exponent)
+  step = Ref{Float64}(s.step_size); its = Ref{Int64}(s.total_number_iterations)
+  kkt = Ref{Float64}(s.cumulative_kkt_passes); err = Ref{Cint}(0); done = Ref{Int64}(0)
+  check(ccall((:pdhg_take_steps_adaptive, LIB), Cint,
+    (Ptr{Cvoid}, Int64, Float64, Float64, Ref{Float64}, Float64, Ref{Int64}, Ref{Float64}, Ref{Cint}, Ref{Int64}),
+    s.handle, n_steps, reduction_exponent, growth_exponent, step, s.primal_weight, its, kkt, err, done))
+  s.step_size = step[]; s.total_number_iterations = its[]; s.cumulative_kkt_passes = kkt[]
+  s.numerical_error = s.numerical_error || err[] != 0
+  return done[]
 end
 
 "take_step(::AdaptiveStepsizeParams, ...) -- pdhg.jl:653-731 with the vector work on the GPU."

@@ -27,7 +27,7 @@ def test_header_symbols_all_exported():
     L = ctypes.CDLL(_lib.LIB_PATH)       # loads without a GPU
     for name in declared:
         assert hasattr(L, name), f"{name} not exported by libpdhg_hip.so"
-    assert _lib.lib().pdhg_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib().pdhg_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_create_fails_loudly_without_gpu():
@@ -125,3 +125,25 @@ def test_julia_min_propagates_nan():
     assert julia_min(1.0, 2.0) == 1.0 and julia_min(2.0, 1.0) == 1.0
     assert math.isnan(julia_min(math.nan, 1.0)) and math.isnan(julia_min(1.0, math.nan))
     assert julia_min(math.inf, 3.0) == 3.0
+
+
+def test_take_steps_host_loop_stops_on_numerical_error():
+    """take_steps with an engine that has no batched entry point: the plain loop, ending
+    on the step that set numerical_error (what optimize() relies on between evaluations)."""
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (ConstantStepsizeParams,
+                                                                 PdhgSolverState, take_steps)
+
+    class Eng:
+        calls = 0
+
+        def trial_step(self, *a):
+            Eng.calls += 1
+            return [0.0] * 5
+
+        def accept(self, w):
+            pass
+
+    st = PdhgSolverState(Eng(), step_size=0.5, primal_weight=1.0)
+    assert take_steps(ConstantStepsizeParams(), st, 7) == 7 and Eng.calls == 7
+    st.numerical_error = True
+    assert take_steps(ConstantStepsizeParams(), st, 7) == 1

@@ -188,3 +188,35 @@ def test_qp_through_the_one_kernel_trial_is_bitwise_the_plain_path(gpu_required,
     assert runs["plain"][-1] >= 60
     for a, b in zip(runs["plain"], runs["one_kernel"]):
         assert np.array_equal(a, b)
+
+
+def test_batched_take_steps_equal_single_calls(gpu_required):
+    """pdhg_take_steps_adaptive(n) == n x pdhg_take_step_adaptive, bit for bit, including
+    the early return on the step that reaches movement == 0."""
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import take_steps
+    policy = AdaptiveStepsizeParams(0.3, 0.6)
+    for p, n in ((random_lp(3000, 2500, 6, seed=3), 75), (H.example_cc_lp(), 200)):
+        step, pw = H.initial_step_and_weight(p)
+        one = HipPdhgEngine.from_problem(p)
+        s1 = PdhgSolverState(one, step_size=step, primal_weight=pw)
+        done1 = 0
+        while done1 < n and not s1.numerical_error:
+            take_step(policy, s1)
+            done1 += 1
+        many = HipPdhgEngine.from_problem(p)
+        s2 = PdhgSolverState(many, step_size=step, primal_weight=pw)
+        done2 = take_steps(policy, s2, n)
+        assert done2 == done1
+        assert s2.numerical_error == s1.numerical_error
+        assert (s2.step_size, s2.total_number_iterations, s2.cumulative_kkt_passes) == \
+            (s1.step_size, s1.total_number_iterations, s1.cumulative_kkt_passes)
+        for a, b in zip(one.get_current() + one.get_average(), many.get_current() + many.get_average()):
+            assert np.array_equal(a, b)
+        one.close()
+        many.close()
+    eng = HipPdhgEngine.from_problem(H.example_lp())
+    st = PdhgSolverState(eng, step_size=0.1, primal_weight=1.0)
+    assert take_steps(policy, st, 0) == 0 and st.total_number_iterations == 0
+    with pytest.raises(Exception):
+        eng.take_steps_adaptive(-1, 0.3, 0.6, 0.1, 1.0, 0, 0.0)
+    eng.close()
