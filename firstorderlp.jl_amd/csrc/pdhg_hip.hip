@@ -159,6 +159,7 @@ struct pdhg_handle {
   unsigned long long *seq_dev = nullptr;   // launch counter, incremented by the final kernel
   volatile double *res_host = nullptr;     // pinned, coherent: 5 results + [7] = sequence number
   unsigned long long seq_expected = 0;
+  int coop_fallbacks = 0;                   // trials repeated on the other paths after a barrier time-out
   double res_error = 0.0;                   // error word of the last checked result read
   // host-side breakdown of graph trials (PDHG_VERBOSE): seconds in node updates, in hipGraphLaunch, waiting
   double t_set = 0.0, t_launch = 0.0, t_wait = 0.0;
@@ -501,6 +502,7 @@ int wait_result_word(pdhg_handle *h, double out[5], bool checked = false) {
 // ---- the trial step as ONE persistent kernel (trial_kernel.hpp) -----------------------------
 
 int coop_prepare(pdhg_handle *h);
+bool graph_eligible(pdhg_handle *h);
 
 bool coop_eligible(pdhg_handle *h) {
   if (h->coop_mode < 0) {
@@ -529,10 +531,13 @@ int coop_prepare(pdhg_handle *h) {
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));
   int cap = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
   if (const char *ev = getenv("PDHG_COOP_WGS")) cap = std::max(8, std::min(cap, atoi(ev) / 8 * 8));
+  // test knob: pretend the device holds this many workgroups (more than it does: the barriers cannot complete)
+  const char *pretend = getenv("PDHG_COOP_TEST_PRETEND_WGS");
+  if (pretend) cap = std::max(8, atoi(pretend) / 8 * 8);
   // one item per workgroup and phase where the device can hold that many: row blocks from the front, long-row chunks from the end
   int items = std::max(h->A.grid + h->A.nchunks, h->At.grid + h->At.nchunks);
   if (h->has_q) items = std::max(items, std::max(h->Q.grid + h->Q.nchunks, h->A.grid + h->A.nchunks + h->Qt.grid + h->Qt.nchunks));
-  h->coop_grid = std::min(cap, std::max(8, (items + 7) / 8 * 8));
+  h->coop_grid = pretend ? cap : std::min(cap, std::max(8, (items + 7) / 8 * 8));
   // More items than co-resident workgroups: the persistent kernel would walk several row blocks per workgroup at
   // 5 workgroups per CU, where the separate stream kernels keep 8 per CU in flight -- measured slower (PageRank-1M,
   // 4 552 items on 1 280 workgroups: 4 380 it/s against 4 620 as a graph of slab passes).  Leave those to the graph.
@@ -636,6 +641,13 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
   a.launch = h->coop_launches; a.seq = h->seq_expected; a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
   a.trace = h->coop_trace;
   for (int x = 0; x < 8; ++x) a.xcd_cnt[x] = h->coop_xcd_cnt[x];
+  // test knob: raise the barriers' error word in front of launch number k, as a time-out in it would (the launch
+  // then runs without synchronisation and reports the error; the recovery below is what is being tested)
+  static const long break_at = getenv("PDHG_COOP_TEST_BREAK_AT") ? atol(getenv("PDHG_COOP_TEST_BREAK_AT")) : -1;
+  if (break_at >= 0 && (long)h->coop_launches == break_at) {
+    static const unsigned long long nine = 9ull;
+    HIP_TRY(hipMemcpyAsync(&h->gsync->error[0], &nine, sizeof nine, hipMemcpyHostToDevice, h->stream));
+  }
   h->coop_launches += 1;
   const auto c1 = std::chrono::steady_clock::now();
   hipLaunchKernelGGL(trial_kernel, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
@@ -650,9 +662,18 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
   h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
   if (rc) return rc;
   if (h->res_error != 0.0) {
-    h->coop_mode = 0;                 // the barrier counters are out of step now: never again on this handle
-    return fail(996, "one-launch trial: a grid barrier timed out (are all workgroups co-resident? is the device shared?); "
-                     "set PDHG_COOP=0 to use the graph path");
+    // A grid barrier ran into its spin limit: the workgroups were not all co-resident (another process runs a
+    // persistent kernel on this device, or a debugger / profiler serialises dispatch).  Once the error word is up no
+    // workgroup waits any more, every workgroup still runs every phase, so the launch has ended and the elementwise
+    // work that does not depend on the barriers -- the deferred average update it carried -- is applied exactly once.
+    // x', y', A'y' and the sums are not trustworthy: the caller repeats the trial on the graph / plain path (its
+    // inputs x, y, A'y are untouched), and this handle stays there (the barrier counters are out of step now).
+    h->coop_mode = 0;
+    h->coop_fallbacks += 1;
+    fprintf(stderr, "[pdhg_hip] one-launch trial: a grid barrier timed out (code %g; is the device shared with another "
+                    "persistent kernel?) -- this handle uses the %s path from here on\n", h->res_error,
+            graph_eligible(h) ? "graph" : "separate-launch");
+    return 1;
   }
   return 0;
 }
@@ -2096,7 +2117,9 @@ int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight, doub
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
-  if (!L.g && coop_eligible(h)) return coop_trial(h, step_size, primal_weight, theta, true, out);   // Malitsky-Pock retries: xbar + the dual half
+  if (!L.g && coop_eligible(h)) {         // Malitsky-Pock retries: xbar + the dual half
+    if ((rc = coop_trial(h, step_size, primal_weight, theta, true, out)) != 1) return rc;    // 1: not run / timed out, repeat below
+  }
   if (L.g && L.g->pool && !L.p[0]->profile) return trial_group_mt(L, TrialArgs{step_size, primal_weight, theta, false}, out);
   FOR_SHARDS(L, s) { if ((rc = launch_xbar(s, theta))) return rc; }
   if (L.g) return trial_dual_group(L, step_size, primal_weight, out);
@@ -2108,7 +2131,9 @@ int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, doub
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
-  if (!L.g && coop_eligible(h)) return coop_trial(h, step_size, primal_weight, theta, false, out);
+  if (!L.g && coop_eligible(h)) {
+    if ((rc = coop_trial(h, step_size, primal_weight, theta, false, out)) != 1) return rc;   // 1: not run / timed out, repeat below
+  }
   if (!L.g && graph_eligible(h)) return graph_trial(h, step_size, primal_weight, theta, out);
   if (L.g && L.g->pool && !L.p[0]->profile) return trial_group_mt(L, TrialArgs{step_size, primal_weight, theta, true}, out);
   FOR_SHARDS(L, s) { if ((rc = launch_primal(s, step_size / primal_weight, theta, true))) return rc; }

@@ -356,8 +356,11 @@ const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id);
 /* Layout statistics (diagnostics): [0..3] CSR(A) {row blocks, long rows, long
  * chunks, max row nnz}, [4..7] same for CSR(A'), [8],[9] tiled-sweep waves of
  * A / A' (0 = stream layout), [10],[11] their tile widths in columns, [12],[13]
- * column-slab passes of A / A' (0 = single pass), [14] 1 when pdhg_trial_step runs as one
- * graph launch (small / medium LPs; not while profiling), [15] bit 0 / bit 1: A / A' use
+ * column-slab passes of A / A' (0 = single pass), [14] how pdhg_trial_step is launched: 2 one
+ * persistent kernel per trial, 1 one graph launch (small / medium LPs; not while
+ * profiling), 0 separate launches.  A handle leaves 2 for good when a grid barrier of
+ * the persistent kernel times out (device shared with another persistent kernel): that
+ * trial is repeated on the other path, with a line on stderr, [15] bit 0 / bit 1: A / A' use
  * equal-nonzero tiles of different widths (skewed columns; [10],[11] are then nominal). */
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]);
 /* Diagnostics: order-sensitive 64-bit checksums of every device array of the two layouts

@@ -220,3 +220,75 @@ def test_batched_take_steps_equal_single_calls(gpu_required):
     with pytest.raises(Exception):
         eng.take_steps_adaptive(-1, 0.3, 0.6, 0.1, 1.0, 0, 0.0)
     eng.close()
+
+
+def test_barrier_timeout_falls_back_to_the_graph_path(gpu_required, monkeypatch, capfd):
+    """A persistent trial kernel whose workgroups are not all co-resident (here: a grid four
+    times what the device holds) cannot complete its grid barriers.  Every spin is bounded;
+    the trial is repeated on the graph path and the handle stays there -- with the same
+    results as a handle that never used the persistent kernel."""
+    p = random_lp(3000, 2500, 6, seed=11)
+    ref = _trajectory(p, 12, monkeypatch, graph=True, native=True)
+    monkeypatch.setenv("PDHG_GRAPH", "1")
+    monkeypatch.setenv("PDHG_COOP", "1")
+    monkeypatch.setenv("PDHG_PY_TAKE_STEP", "0")
+    monkeypatch.setenv("PDHG_COOP_TEST_PRETEND_WGS", "8192")
+    eng = HipPdhgEngine.from_problem(p)
+    assert eng.layout_info()["trial_graph"] == 2
+    step, pw = H.initial_step_and_weight(p)
+    st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    sizes = []
+    for _ in range(12):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+        sizes.append(st.step_size)
+    assert eng.layout_info()["trial_graph"] == 1
+    assert "timed out" in capfd.readouterr().err
+    x, y = eng.get_current()
+    xa, ya = eng.get_average()
+    for a, b in zip(ref, (np.array(sizes), x, y, xa, ya, st.total_number_iterations, st.cumulative_kkt_passes)):
+        assert np.array_equal(a, b)
+    eng.close()
+
+
+def test_barrier_error_mid_run_keeps_the_deferred_average(gpu_required):
+    """The failing launch carries the previous step's deferred average update (lazy K7); the
+    repeat on the graph path must not apply it twice nor lose it.  Run in a child process:
+    the knob is read once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import folp_loader
+folp_loader.load()
+from firstorderlp_jl_amd import HipPdhgEngine
+from firstorderlp_jl_amd.generators import random_lp
+from firstorderlp_jl_amd.primal_dual_hybrid_gradient import AdaptiveStepsizeParams, PdhgSolverState, take_step
+from tests import helpers as H
+p = random_lp(3000, 2500, 6, seed=11)
+def run(env):
+    os.environ.update(env)
+    eng = HipPdhgEngine.from_problem(p)
+    kind = eng.layout_info()["trial_graph"]
+    step, pw = H.initial_step_and_weight(p)
+    st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    for _ in range(30):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+    out = eng.get_current() + eng.get_average() + (np.array([st.step_size, st.total_number_iterations]),)
+    after = eng.layout_info()["trial_graph"]
+    eng.close()
+    return kind, after, out
+k0, a0, ref = run({"PDHG_COOP": "0"})
+k1, a1, got = run({"PDHG_COOP": "1"})
+assert (k0, a0, k1, a1) == (1, 1, 2, 1), (k0, a0, k1, a1)
+for a, b in zip(ref, got):
+    assert np.array_equal(a, b)
+print("same")
+'''
+    import os
+    env = dict(os.environ, PDHG_COOP_TEST_BREAK_AT="7", PDHG_ROW_ORDER="strict", PDHG_GRAPH="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "same" in r.stdout, r.stdout + r.stderr
+    assert "timed out" in r.stderr
