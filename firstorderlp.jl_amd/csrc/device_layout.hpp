@@ -87,6 +87,41 @@ int device_exclusive_scan(const int *in, int *out, int64_t n, int *total, hipStr
   return 0;
 }
 
+// ---------------------------------------------------------------- column slabs of a stream layout
+
+// cnt[r] = entries of row r with c0 <= column < c1; rows that are long in the full matrix (the long-row
+// path's) and the extra slot cnt[rows] count 0, so that the exclusive scan of cnt[0..rows] is the slab's
+// row-pointer array.  One thread per row: a one-time pass, rows are short here by construction.
+__global__ __launch_bounds__(TPB) void slab_count_kernel(int rows, const int *__restrict__ rowptr,
+                                                         const int *__restrict__ col, int c0, int c1, int max_row,
+                                                         int *__restrict__ cnt) {
+  for (int r = blockIdx.x * TPB + threadIdx.x; r <= rows; r += gridDim.x * TPB) {
+    int c = 0;
+    if (r < rows) {
+      const int b = rowptr[r], e = rowptr[r + 1];
+      if (e - b <= max_row)
+        for (int k = b; k < e; ++k) { const int j = col[k]; c += (j >= c0 && j < c1); }
+    }
+    cnt[r] = c;
+  }
+}
+
+// the slab's entries, every row in its original order (what the host builder's loop writes)
+__global__ __launch_bounds__(TPB) void slab_fill_kernel(int rows, const int *__restrict__ rowptr,
+                                                        const int *__restrict__ col, const double *__restrict__ val,
+                                                        int c0, int c1, int max_row, const int *__restrict__ slab_rowptr,
+                                                        int *__restrict__ sc, double *__restrict__ sv) {
+  for (int r = blockIdx.x * TPB + threadIdx.x; r < rows; r += gridDim.x * TPB) {
+    const int b = rowptr[r], e = rowptr[r + 1];
+    if (e - b > max_row) continue;
+    int q = slab_rowptr[r];
+    for (int k = b; k < e; ++k) {
+      const int j = col[k];
+      if (j >= c0 && j < c1) { sc[q] = j; sv[q] = val[k]; ++q; }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- peer masks
 
 // lanes of the wave whose `key` equals this lane's, among the lanes in `valid`: one ballot per key bit
@@ -241,12 +276,18 @@ __global__ __launch_bounds__(TPB) void ingest_entries_kernel(const int64_t *__re
 
 // ---------------------------------------------------------------- the tiled sweep's tables
 
-// Per wave: entries per tile (uniform tile width) and the longest same-row run inside one tile.
+// Tile of column c: uniform width tile_cols, or (map16 != nullptr: tiles of equal nonzeros and different
+// widths, build_tiled) the tile of its 16-column group.
+__device__ __forceinline__ int tw_tile_of(int c, int tile_cols, const int *__restrict__ map16) {
+  return map16 ? map16[c >> 4] : c / tile_cols;
+}
+
+// Per wave: entries per tile and the longest same-row run inside one tile.
 // One lane per row (order is irrelevant for counts): cnt[w * ntiles + t].
 __global__ __launch_bounds__(TPB) void tw_count_kernel(const int2 *__restrict__ wave_rows, int nwaves,
                                                        const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                       int tile_cols, int ntiles, int *__restrict__ cnt,
-                                                       int *__restrict__ max_run_of_wg) {
+                                                       int tile_cols, const int *__restrict__ map16, int ntiles,
+                                                       int *__restrict__ cnt, int *__restrict__ max_run_of_wg) {
   extern __shared__ int tw_hist[];            // [TPB / WAVE][ntiles]
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
   const int w = blockIdx.x * (TPB / WAVE) + wid;
@@ -259,7 +300,7 @@ __global__ __launch_bounds__(TPB) void tw_count_kernel(const int2 *__restrict__ 
     for (int r = rr.x + lane; r < rr.y; r += WAVE) {
       int run = 0, run_tile = -1;
       for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-        const int t = col[k] / tile_cols;
+        const int t = tw_tile_of(col[k], tile_cols, map16);
         run = (t == run_tile) ? run + 1 : 1;
         run_tile = t;
         max_run = max(max_run, run);
@@ -293,7 +334,8 @@ __global__ __launch_bounds__(TPB) void cnt16_kernel(int rows, const int *__restr
 __global__ __launch_bounds__(TPB) void tw_fill_kernel(const int2 *__restrict__ wave_rows, int nwaves,
                                                       const int64_t *__restrict__ wave_base,
                                                       const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                      const double *__restrict__ val, int tile_cols, int ntiles,
+                                                      const double *__restrict__ val, int tile_cols,
+                                                      const int *__restrict__ map16, const int *__restrict__ tstart, int ntiles,
                                                       int tile_bits, int tile_shift, const int *__restrict__ cnt,
                                                       unsigned *__restrict__ pk, double *__restrict__ tv) {
   extern __shared__ int tw_cur[];             // [TPB / WAVE][ntiles]
@@ -324,7 +366,7 @@ __global__ __launch_bounds__(TPB) void tw_fill_kernel(const int2 *__restrict__ w
     const bool ok = k < k1;
     const unsigned long long valid = __ballot(ok);
     const int c = ok ? col[k] : 0;
-    const int t = c / tile_cols;
+    const int t = ok ? tw_tile_of(c, tile_cols, map16) : 0;
     // the entry's row: last r in [r0, r1) with rowptr[r] <= k
     int lo = rr.x, hi = rr.y;
     while (ok && hi - lo > 1) {
@@ -339,7 +381,7 @@ __global__ __launch_bounds__(TPB) void tw_fill_kernel(const int2 *__restrict__ w
     if (ok && rank == 0) cur[t] = cur[t] + __popcll(peers);
     __builtin_amdgcn_wave_barrier();
     if (ok) {
-      pk[base + pos] = ((unsigned)(lo - rr.x) << tile_shift) | (unsigned)(c - t * tile_cols);
+      pk[base + pos] = ((unsigned)(lo - rr.x) << tile_shift) | (unsigned)(c - (tstart ? tstart[t] : t * tile_cols));
       tv[base + pos] = val[k];
     }
   }

@@ -180,7 +180,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     const char *vt = getenv("PDHG_VAR_TILES");                   // 0 / 1 force
     bool variable = nt0 > 1 && (double)fullest > 1.5 * (double)total / (double)nt0;
     if (vt) variable = vt[0] != '0' && nt0 > 1;
-    if (on_device && (variable || nt0 > 1024)) return 1;      // host mode handles these
+    if (on_device && nt0 > 1024) return 1;                    // host mode handles these
     if (!variable) {
       for (int t = 0; t <= nt0; ++t) tstart.push_back((int)std::min<int64_t>(D.cols, (int64_t)t * tile_cols));
     } else {
@@ -204,6 +204,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     }
   }
   const int ntiles = (int)tstart.size() - 1;
+  if (on_device && ntiles > 1024) return 1;                   // the kernels keep one counter per tile and wave in LDS
   int widest = 1;
   for (int t = 0; t < ntiles; ++t) widest = std::max(widest, tstart[(size_t)t + 1] - tstart[(size_t)t]);
   // the column field of an entry is wide enough for the widest tile (any width, not only powers of two)
@@ -278,6 +279,13 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     void **p;
     ~DevTmp() { if (*p) (void)hipFree(*p); }
   } tmp_wave_rows{(void **)&d_wave_rows}, tmp_cell_cnt{(void **)&d_cell_cnt};
+  int *d_map16 = nullptr, *d_tstart = nullptr;                // tiles of different widths: the kernels' lookup tables
+  DevTmp tmp_map16{(void **)&d_map16}, tmp_tstart{(void **)&d_tstart};
+  if (on_device && !uniform) {
+    int rc2;
+    if ((rc2 = upload(&d_map16, map16))) return rc2;
+    if ((rc2 = upload(&d_tstart, tstart))) return rc2;
+  }
   if (on_device) {
     if ((int64_t)nwaves * ntiles > (256LL << 20)) return 1;     // the count matrix travels to the host: <= 1 GiB
     cell_cnt.resize((size_t)std::max(nwaves, 1) * ntiles);
@@ -291,8 +299,8 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     if (nwaves > 0) {
       const int wpb = TPB / WAVE;
       hipLaunchKernelGGL(tw_count_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(TPB), sizeof(int) * wpb * ntiles, nullptr,
-                         (const int2 *)d_wave_rows, nwaves, (const int *)D.rowptr, (const int *)D.col, tile_cols, ntiles,
-                         d_cell_cnt, d_mr);
+                         (const int2 *)d_wave_rows, nwaves, (const int *)D.rowptr, (const int *)D.col, tile_cols,
+                         (const int *)d_map16, ntiles, d_cell_cnt, d_mr);
       HIP_TRY(hipMemcpy(cell_cnt.data(), d_cell_cnt, sizeof(int) * cell_cnt.size(), hipMemcpyDeviceToHost));
     }
     hipError_t e = hipMemcpy(dev_max_run.data(), d_mr, sizeof(int) * dev_max_run.size(), hipMemcpyDeviceToHost);
@@ -464,7 +472,8 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
       const int wpb = TPB / WAVE;
       hipLaunchKernelGGL(tw_fill_kernel, dim3((nwaves + wpb - 1) / wpb), dim3(TPB), sizeof(int) * wpb * ntiles, nullptr,
                          (const int2 *)D.wave_rows, nwaves, (const int64_t *)d_base, (const int *)D.rowptr, (const int *)D.col,
-                         (const double *)D.val, tile_cols, ntiles, tile_bits, tile_shift, (const int *)d_cell_cnt, D.pk, D.tv);
+                         (const double *)D.val, tile_cols, (const int *)d_map16, (const int *)d_tstart, ntiles, tile_bits,
+                         tile_shift, (const int *)d_cell_cnt, D.pk, D.tv);
       hipError_t e = hipDeviceSynchronize();
       (void)hipFree(d_base);
       HIP_TRY(e);
@@ -549,6 +558,41 @@ int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, c
   return 0;
 }
 
+// The same slabs from D.rowptr / D.col / D.val in HBM (device_layout.hpp: count, scan, fill); only each slab's
+// row pointers travel back, for the row blocks.  Bit-identical to build_slabs (same entries, same order, same blocks).
+int build_slabs_device(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, bool remap, int P) {
+  const int width = (cols + P - 1) / P;
+  const int grid = (int)std::min<int64_t>(((int64_t)rows + 1 + TPB - 1) / TPB, 1 << 16);
+  int rc;
+  for (int p = 0; p < P; ++p) {
+    const int c0 = p * width, c1 = std::min(cols, (p + 1) * width);
+    SlabDev S;
+    HIP_TRY(hipMalloc((void **)&S.rowptr, sizeof(int) * ((size_t)rows + 1)));
+    hipLaunchKernelGGL(slab_count_kernel, dim3(grid), dim3(TPB), 0, nullptr, rows, D.rowptr, D.col, c0, c1, BLOCK_NNZ, S.rowptr);
+    HIP_TRY(hipGetLastError());
+    if ((rc = device_exclusive_scan(S.rowptr, S.rowptr, (int64_t)rows + 1, nullptr, nullptr))) return rc;
+    std::vector<int> rp((size_t)rows + 1);
+    HIP_TRY(hipMemcpy(rp.data(), S.rowptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost));
+    S.nnz = rp[(size_t)rows];
+    HIP_TRY(hipMalloc((void **)&S.col, sizeof(int) * (size_t)std::max<int64_t>(S.nnz, 1)));
+    HIP_TRY(hipMalloc((void **)&S.val, sizeof(double) * (size_t)std::max<int64_t>(S.nnz, 1)));
+    hipLaunchKernelGGL(slab_fill_kernel, dim3(grid), dim3(TPB), 0, nullptr, rows, D.rowptr, D.col, D.val, c0, c1, BLOCK_NNZ,
+                       S.rowptr, S.col, S.val);
+    HIP_TRY(hipGetLastError());
+    std::vector<int2> blks;
+    make_row_blocks(rows, rp, rowptr, blks);
+    S.nblk = (int)blks.size();
+    S.per_xcd = (S.nblk + NUM_XCD - 1) / NUM_XCD;
+    S.grid = remap ? S.per_xcd * NUM_XCD : S.nblk;
+    if ((rc = upload(&S.blks, blks))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    D.slabs.push_back(S);
+  }
+  if ((rc = alloc_zero(&D.slab_partial, rows))) return rc;
+  D.grid = D.slabs.back().grid;      // the last pass runs the epilogue and writes the block partials
+  return 0;
+}
+
 // Everything of a CsrDev that follows from the row pointers alone: row blocks, the long-row
 // tables and their buffers.  (Host loops over the rows; the per-nonzero arrays are not touched.)
 int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, bool remap) {
@@ -624,9 +668,8 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
 }
 
 // The same with D.rowptr / D.col / D.val ALREADY in HBM (device_layout.hpp): tables from the row
-// pointers, the sweep's layout by the device kernels.  Cases the device mode does not cover (tiles of
-// different widths, very many tiles; column slabs, which are built from host arrays) fetch the
-// entries back once and take the host builders.
+// pointers, the sweep's layout and the column slabs by the device kernels.  Cases the device mode does not
+// cover (tiles of different widths, very many tiles) fetch the entries back once and take the host builders.
 int build_csr_dev_resident(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, bool remap,
                            int tile_cols, bool relaxed) {
   int rc;
@@ -661,8 +704,9 @@ int build_csr_dev_resident(CsrDev &D, int rows, int cols, const std::vector<int>
     const int P = (int)std::ceil(vec_bytes / slab_bytes);
     const bool slabs = !(off && off[0] == '0') && vec_bytes > 1.25 * slab_bytes && D.nnz >= (1 << 20) && P >= 2 && P <= 4;
     if (slabs) {
-      if ((rc = fetch())) return rc;
-      if ((rc = build_slabs(D, rows, cols, rowptr, col, val, remap))) return rc;
+      if (fetched) rc = build_slabs(D, rows, cols, rowptr, col, val, remap);
+      else rc = build_slabs_device(D, rows, cols, rowptr, remap, P);
+      if (rc) return rc;
     }
   }
   return 0;

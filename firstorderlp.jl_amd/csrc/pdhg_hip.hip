@@ -133,6 +133,8 @@ struct pdhg_handle {
   double *dm_buf = nullptr;        // [m_global] row-gather buffer (group only)
   // scalar results: scal_dev[SCAL_MAX] on the device, scal_all[world*SCAL_MAX] (RCCL gather), pinned scal_host
   double *scal_dev = nullptr, *scal_all = nullptr, *scal_host = nullptr;
+  double *ev_host = nullptr;                // pinned result words of the evaluation reductions (ev_finish)
+  unsigned long long ev_seq = 0;
 
   // ---- one trial step as ONE graph launch (small / medium problems: stream layouts,
   // where the ~8 launches and the result copy cost as much as the kernels).  Two
@@ -1440,6 +1442,7 @@ void destroy_shard(pdhg_handle *h) {
   if (h->coop_trace) (void)hipFree(h->coop_trace);
   if (h->res_host) (void)hipHostFree((void *)h->res_host);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
+  if (h->ev_host) (void)hipHostFree(h->ev_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -2401,9 +2404,42 @@ static int ev_alloc(pdhg_handle *h) {
 // second stage of every shard's block partials (ns sums then nm maxes), then the
 // combination over ranks in rank order
 static int ev_finish(const Shards &L, int ns, int nm, double *out) {
+  static const bool host_word = !(getenv("PDHG_EVAL_HOST_WORD") && getenv("PDHG_EVAL_HOST_WORD")[0] == '0');
+  if (!L.g && host_word) {
+    // one handle: the second stage publishes into pinned memory and the host polls (see multi_final_kernel)
+    pdhg_handle *h = L.p[0];
+    const int k = ns + nm;
+    if (k > EV_HOST_SLOTS) return fail(-1, "too many scalars in one reduction");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->ev_host) {
+      HIP_TRY(hipHostMalloc((void **)&h->ev_host, (EV_HOST_SLOTS + 2) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+      memset(h->ev_host, 0, (EV_HOST_SLOTS + 2) * sizeof(double));
+    }
+    const unsigned long long seq = ++h->ev_seq;
+    hipLaunchKernelGGL(multi_final_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->ev_partials, h->ev_grid,
+                       h->ev_grid, ns, nm, h->scal_dev, h->ev_host, seq);
+    HIP_TRY(hipGetLastError());
+    const volatile unsigned long long *bits = reinterpret_cast<const volatile unsigned long long *>(h->ev_host);
+    auto ready = [&]() -> bool {
+      if (bits[EV_HOST_SEQ] != seq) return false;
+      unsigned long long w[EV_HOST_SLOTS];
+      unsigned long long ck = EV_CHECK_SALT ^ seq ^ ((unsigned long long)k << 56);
+      for (int q = 0; q < k; ++q) { w[q] = bits[q]; ck ^= w[q] * (2ull * (unsigned long long)q + 1ull); }
+      if (ck != bits[EV_HOST_CK]) return false;
+      for (int q = 0; q < k; ++q) memcpy(&out[q], &w[q], 8);
+      return true;
+    };
+    for (long spin = 0; spin < 40000000L; ++spin) {
+      if (ready()) return 0;
+      if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (ready()) return 0;
+    return fail(998, "evaluation reduction finished without publishing its results");
+  }
   FOR_SHARDS(L, h) {
     hipLaunchKernelGGL(multi_final_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->ev_partials, h->ev_grid,
-                       h->ev_grid, ns, nm, h->scal_dev);
+                       h->ev_grid, ns, nm, h->scal_dev, (double *)nullptr, 0ull);
     HIP_TRY(hipGetLastError());
   }
   return combine_scalars(L, ns + nm, ns, out);
@@ -3061,6 +3097,19 @@ int pdhg_layout_checksums(pdhg_handle *h, uint64_t out[32]) {
       unsigned long long v = 0;
       if ((rc = device_checksum(parts[q].p, parts[q].words, &v, h->stream))) return rc;
       out[16 * k + q] = v;
+    }
+    // a stream layout's column slabs ride in the sweep's (then unused) slots: row pointers, columns, values, row blocks
+    if (!D.tiled) {
+      for (size_t s = 0; s < D.slabs.size(); ++s) {
+        const SlabDev &S = D.slabs[s];
+        const struct { const void *p; int64_t words; } sp4[4] = {
+            {S.rowptr, (int64_t)D.rows + 1}, {S.col, S.nnz}, {S.val, 2 * S.nnz}, {S.blks, 2 * (int64_t)S.nblk}};
+        for (int q = 0; q < 4; ++q) {
+          unsigned long long v = 0;
+          if ((rc = device_checksum(sp4[q].p, sp4[q].words, &v, h->stream))) return rc;
+          out[16 * k + 8 + q] += v * (2ull * s + 3ull);
+        }
+      }
     }
     // the plan's scalars ride in the last slot
     out[16 * k + 15] = (uint64_t)D.tiled + 2ull * (uint64_t)D.tw_mode + 8ull * (uint64_t)D.tile_shift + 1024ull * (uint64_t)D.tw_rows +

@@ -366,7 +366,8 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]);
 /* Diagnostics: order-sensitive 64-bit checksums of every device array of the two layouts
  * (out[0..16) CSR(A): row pointers, columns, values, row blocks, the four long-row tables, the
  * sweep's pk / tv / wave rows / entry offsets / step offsets / step tiles / workgroup steps, the
- * plan's scalars; out[16..32) the same for CSR(A')).  Two handles with equal checksums hold
+ * plan's scalars; a stream layout's column slabs -- row pointers, columns, values, row blocks --
+ * in the first four of the sweep's slots; out[16..32) the same for CSR(A')).  Two handles with equal checksums hold
  * bit-identical layouts: how the device-side layout construction is held to the host builders. */
 int pdhg_layout_checksums(pdhg_handle *h, uint64_t out[32]);
 /* Measurement only: best-of-`reps` rate of a[i] = b[i] + s*c[i] over `len`

@@ -66,6 +66,9 @@ CASES = {
     "long_rows_forced_sweep": (lambda: _with_structure(60_000, 50_000, 8, seed=9, dense_rows=3, dense_cols=2),
                                {"PDHG_SPMV": "tiled", "PDHG_TILE_COLS": "8192"}),
     "pagerank_slabs": (lambda: pagerank_lp(150_000, seed=4), {"PDHG_SLAB_MB": "0.4"}),
+    "pagerank_var_tiles": (lambda: pagerank_lp(150_000, seed=4), {"PDHG_SPMV": "tiled", "PDHG_TILE_COLS": "8192"}),
+    "var_tiles_forced": (lambda: random_lp(90_000, 80_000, 9, seed=6), {"PDHG_SPMV": "tiled", "PDHG_TILE_COLS": "4096",
+                                                                        "PDHG_VAR_TILES": "1"}),
     "wide": (lambda: random_lp(40_000, 900_000, 12, seed=3), {}),
     "tall": (lambda: random_lp(900_000, 40_000, 5, seed=3), {}),
 }
@@ -78,6 +81,10 @@ def test_device_built_layouts_are_bit_identical_to_the_host_builders(gpu_require
     got = _both(p, monkeypatch, **env)
     (ck_h, info_h, eng_h), (ck_d, info_d, eng_d) = got["0"], got["1"]
     assert info_h == info_d, (info_h, info_d)
+    if name.endswith("var_tiles") or name.startswith("var_tiles"):
+        assert info_d["var_tiles"] != 0 and info_d["A_tiled_waves"] > 0          # tiles of different widths, built on the device
+    if name == "pagerank_slabs":
+        assert info_d["A_slabs"] >= 2 and info_d["At_slabs"] >= 2      # their arrays ride in the sweep's checksum slots
     labels = ["rowptr", "col", "val", "blks", "long_row", "long_chunk_ptr", "chunk_row", "chunk_off", "pk", "tv",
               "wave_rows", "wave_ent", "wave_step_off", "step_tile", "wg_step_off", "plan"]
     bad = [("A" if q < 16 else "At") + "." + labels[q % 16] for q in range(32) if ck_h[q] != ck_d[q]]

@@ -5,12 +5,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import folp_loader
 pkg = folp_loader.load()
-from firstorderlp_jl_amd.generators import random_lp
+from firstorderlp_jl_amd.generators import random_lp, l1_svm_rcv1_like_lp, pagerank_lp
 from firstorderlp_jl_amd.primal_dual_hybrid_gradient import AdaptiveStepsizeParams, PdhgSolverState, take_step
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-p = random_lp(n, n, 10, 12345)
+arg = sys.argv[1] if len(sys.argv) > 1 else "10000000"
+if arg == "l1svm":
+    p = l1_svm_rcv1_like_lp()
+elif arg == "pagerank":
+    p = pagerank_lp(1_000_000)
+else:
+    p = random_lp(int(arg), int(arg), 10, 12345)
 eng = pkg.HipPdhgEngine.from_problem(p)
-m = n
+m, n = p.num_constraints, p.num_variables
 eng.set_original_problem(np.ones(m), np.ones(n), p.objective_vector, p.right_hand_side,
                          p.variable_lower_bound, p.variable_upper_bound)
 st = PdhgSolverState(eng, step_size=1.0 / np.abs(p.constraint_matrix.data).max(), primal_weight=1.0)
