@@ -114,6 +114,27 @@ __device__ __forceinline__ void wave_sum_dd(double &hi, double &lo) {
   PDHG_DD_STEP(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
 #undef PDHG_DD_STEP
 }
+// The same tree for one double (sum) and for a max of NON-NEGATIVE values; the total ends in LANE 63.  A shuffle
+// tree costs six dependent LDS-crossbar round trips per quantity (~0.35 us measured on the evaluation kernels,
+// which reduce up to 30 quantities per workgroup); these are VALU moves.
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_move<0x111, 0xF>(v);
+  v += dpp_move<0x112, 0xF>(v);
+  v += dpp_move<0x114, 0xF>(v);
+  v += dpp_move<0x118, 0xF>(v);
+  v += dpp_move<0x142, 0xA>(v);
+  v += dpp_move<0x143, 0xC>(v);
+  return v;
+}
+__device__ __forceinline__ double wave_max_nonneg_dpp(double v) {
+  v = fmax(v, dpp_move<0x111, 0xF>(v));
+  v = fmax(v, dpp_move<0x112, 0xF>(v));
+  v = fmax(v, dpp_move<0x114, 0xF>(v));
+  v = fmax(v, dpp_move<0x118, 0xF>(v));
+  v = fmax(v, dpp_move<0x142, 0xA>(v));
+  v = fmax(v, dpp_move<0x143, 0xC>(v));
+  return v;
+}
 // Deterministic block reduction of NQ double-double accumulators; thread 0 returns the totals in acc.
 // `red` is LDS [6][THREADS / WAVE] (hi rows 0..2, lo rows 3..5).
 template <int NQ, int THREADS>

@@ -9,7 +9,7 @@ namespace {
 // iterations): plain SpMVs into temporaries followed by elementwise kernels
 // with multi-quantity sum/max reductions.  Simplicity over fusion here: the
 // extra vector passes are noise at this cadence.
-constexpr int EV_MAXQ = 20;
+constexpr int EV_MAXQ = 32;            // quantities one evaluation reduction may carry (partials: EV_MAXQ x grid)
 
 template <int NS, int NM>
 struct RedAcc {
@@ -32,22 +32,26 @@ template <int NS, int NM>
 __device__ __forceinline__ void block_reduce_store(const RedAcc<NS, NM> &a, double *partials, int stride) {
   __shared__ double red[NS + NM][TPB / WAVE];
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  // DPP trees (common.hpp): the wave's total ends in lane 63
 #pragma unroll
-  for (int q = 0; q < NS; ++q) { const double w = wave_sum(a.s[q]); if (lane == 0) red[q][wid] = w; }
+  for (int q = 0; q < NS; ++q) { const double w = wave_sum_dpp(a.s[q]); if (lane == WAVE - 1) red[q][wid] = w; }
 #pragma unroll
-  for (int q = 0; q < NM; ++q) { const double w = wave_max(a.m[q]); if (lane == 0) red[NS + q][wid] = w; }
+  for (int q = 0; q < NM; ++q) { const double w = wave_max_nonneg_dpp(a.m[q]); if (lane == WAVE - 1) red[NS + q][wid] = w; }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  static_assert(NS + NM <= TPB, "one thread per quantity combines the waves");
+  if (threadIdx.x < NS + NM) {
+    const int q = threadIdx.x;
+    double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < NS; ++q) { double t = 0.0; for (int w = 0; w < TPB / WAVE; ++w) t += red[q][w]; partials[q * stride + blockIdx.x] = t; }
-#pragma unroll
-    for (int q = 0; q < NM; ++q) { double t = 0.0; for (int w = 0; w < TPB / WAVE; ++w) t = fmax(t, red[NS + q][w]); partials[(NS + q) * stride + blockIdx.x] = t; }
+    for (int w = 0; w < TPB / WAVE; ++w) t = (q >= NS) ? fmax(t, red[q][w]) : t + red[q][w];
+    partials[q * stride + blockIdx.x] = t;
   }
 }
 
 // Second stage of the evaluation kernels' block partials: quantity q (ns sums, then nm maxes) belongs to
-// wave q mod 16, which adds / maxes its `count` partials in a fixed order (lane i takes i, i + 64, ...; then
-// the shuffle tree) -- no workgroup barrier between quantities, so 16 of them cost what one does.
+// wave q mod 16, which adds / maxes its `count` partials in a fixed order (lane i takes i, i + 64, ..., eight
+// loads in flight at a time; then the shuffle tree) -- no workgroup barrier between quantities, so 16 of them
+// cost what one does.
 // host_out != nullptr: the results also go straight into pinned host memory, followed by a checksum and the
 // call's sequence number ([EV_HOST_CK], [EV_HOST_SEQ]); the host polls those instead of a device-to-host
 // copy + stream synchronisation (20-30 us per round trip on this runtime, and the trust-region search makes
@@ -66,9 +70,15 @@ __global__ __launch_bounds__(FINAL_TPB) void multi_final_kernel(const double *__
     const double *p = partials + (size_t)q * stride;
     const bool is_max = q >= ns;
     double v = 0.0;
-    for (int i = lane; i < count; i += WAVE) v = is_max ? fmax(v, p[i]) : v + p[i];
-    v = is_max ? wave_max(v) : wave_sum(v);
-    if (lane == 0) { out[q] = v; res[q] = v; }
+    for (int base = lane; base < count; base += 8 * WAVE) {
+      double t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = (base + j * WAVE < count) ? p[base + j * WAVE] : 0.0;   // partials of maxes are >= 0
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v = is_max ? fmax(v, t[j]) : v + t[j];
+    }
+    v = is_max ? wave_max_nonneg_dpp(v) : wave_sum_dpp(v);
+    if (lane == WAVE - 1) { out[q] = v; res[q] = v; }
   }
   if (host_out) {
     __syncthreads();
@@ -170,20 +180,29 @@ __global__ __launch_bounds__(TPB) void dist2_kernel(int n, int m, const double *
 // problem at point z = (x, y): gradient g = [c - A'y ; -(b - A x)], direction
 // d = -g/w (0 if the bound blocks it), breakpoint thr (trust_region_utils.jl:86-110).
 // range: 0 both blocks (EUCLIDEAN_NORM), 1 primal only, 2 dual only (MAX_NORM halves).
-// sums: 0 c.x, 1 x.(A'y), 2 y.b, 3 sum_{thr=inf} w d^2, 4 sum g^2 (in range),
-//       5 sum w d^2 (in range), 6 sum g.d primal, 7 sum g.d dual, 8 sum x^2, 9 sum y^2, 10 x.(Q x)
+// Per element the search needs three numbers, written here: thr, wd2 = w d^2 and gd = g d --
+//   radius^2(t) = sum_{thr <= t} wd2 thr^2 + t^2 sum_{thr > t} wd2
+//   value(t)    = sum g (clamp(z + t d) - z) = sum_{thr <= t} gd thr + t sum_{thr > t} gd
+// (clamp(z + t d) - z = d min(t, thr) for a direction that moves towards its bound), so every
+// probe of the search yields the value at its t as well and no pass over x, y, the bounds and g
+// is needed once t* is known.
+// sums: 0 c.x, 1 x.(A'y), 2 y.b, 3 sum_{thr=inf} wd2, 4 sum g^2 (in range),
+//       5 sum wd2 (in range), 6 sum gd primal, 7 sum gd dual, 8 sum x^2, 9 sum y^2, 10 x.(Q x),
+//       11 sum_{thr finite} wd2 thr^2, 12 / 13 sum_{thr finite} gd thr (primal / dual),
+//       14 / 15 sum_{thr=inf} gd (primal / dual)      [11-15: the probe at t = max finite thr]
 // maxs: 0 max finite thr (in range)
 // qx_s = Q x at the point (NULL for an LP): the primal gradient is Q x + c - A'y.
+constexpr int TR_SETUP_NS = 16;
 __global__ __launch_bounds__(TPB) void tr_setup_kernel(int n, int m, int ne, const double *__restrict__ px,
                                                        const double *__restrict__ py, const double *__restrict__ aty_s,
                                                        const double *__restrict__ qx_s,
                                                        const double *__restrict__ ax_s, const double *__restrict__ c_s,
                                                        const double *__restrict__ b_s, const double *__restrict__ lb_s,
                                                        const double *__restrict__ ub_s, double wp, double wd, int range,
-                                                       double *__restrict__ gvec, double *__restrict__ dir,
+                                                       double *__restrict__ gdv, double *__restrict__ wd2v,
                                                        double *__restrict__ thr, double *__restrict__ partials,
                                                        int stride) {
-  RedAcc<11, 1> a;
+  RedAcc<TR_SETUP_NS, 1> a;
   const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
   for (int k = tid; k < n + m; k += st) {
     const bool primal = k < n;
@@ -206,61 +225,57 @@ __global__ __launch_bounds__(TPB) void tr_setup_kernel(int n, int m, int ne, con
       else if (d < 0.0) t = (lo - z) / d;
       else t = 0.0;
     }
-    gvec[k] = g; dir[k] = d; thr[k] = t;
+    const double wd2 = w * d * d, gd = g * d;
+    gdv[k] = gd; wd2v[k] = wd2; thr[k] = t;
     if (in_range) {
       a.s[4] += g * g;
-      a.s[5] += w * d * d;
-      if (primal) a.s[6] += g * d; else a.s[7] += g * d;
-      if (isinf(t)) a.s[3] += w * d * d; else a.m[0] = fmax(a.m[0], t);
+      a.s[5] += wd2;
+      if (primal) a.s[6] += gd; else a.s[7] += gd;
+      if (isinf(t)) {
+        a.s[3] += wd2;
+        if (primal) a.s[14] += gd; else a.s[15] += gd;
+      } else {
+        a.m[0] = fmax(a.m[0], t);
+        if (wd2 != 0.0) {
+          a.s[11] += wd2 * t * t;
+          if (primal) a.s[12] += gd * t; else a.s[13] += gd * t;
+        }
+      }
     }
   }
-  block_reduce_store<11, 1>(a, partials, stride);
+  block_reduce_store<TR_SETUP_NS, 1>(a, partials, stride);
 }
 
-// radius^2 as a function of the step t at K probe values:
-//   low_k = sum_{thr <= t_k} w d^2 thr^2 ,  high_k = sum_{thr > t_k} w d^2
-constexpr int TR_K = 7;
+// radius^2 and the value as functions of the step t at K probe values, per probe q (6 sums):
+//   low = sum_{thr <= t_q} wd2 thr^2, high = sum_{thr > t_q} wd2,
+//   vlow / vhigh = sum_{thr <= t_q} gd thr / sum_{thr > t_q} gd, primal block then dual block
+constexpr int TR_K = 5, TR_Q = 6;
+static_assert(TR_K * TR_Q <= EV_MAXQ && TR_SETUP_NS + 1 <= EV_MAXQ, "evaluation partials are sized for EV_MAXQ quantities");
 struct TrProbes { double t[TR_K]; };
-__global__ __launch_bounds__(TPB) void tr_probe_kernel(int n, int total, const double *__restrict__ dir,
-                                                       const double *__restrict__ thr, double wp, double wd,
-                                                       TrProbes pr, double *__restrict__ partials, int stride) {
-  RedAcc<2 * TR_K, 0> a;
-  for (int k = blockIdx.x * TPB + threadIdx.x; k < total; k += gridDim.x * TPB) {
-    const double d = dir[k];
-    if (d == 0.0) continue;
-    const double w = (k < n) ? wp : wd;
-    const double t = thr[k];
-    const double wd2 = w * d * d;
+template <int BASE>
+__device__ __forceinline__ void tr_probe_range(int k0, int k1, const double *__restrict__ thr,
+                                               const double *__restrict__ wd2v, const double *__restrict__ gdv,
+                                               const TrProbes &pr, RedAcc<TR_Q * TR_K, 0> &a) {
+  for (int k = k0 + blockIdx.x * TPB + threadIdx.x; k < k1; k += gridDim.x * TPB) {
+    const double wd2 = wd2v[k];
+    if (wd2 == 0.0) continue;          // d == 0: blocked by its bound, or outside the range
+    const double t = thr[k], gd = gdv[k];
     const double lowc = wd2 * t * t;   // inf for thr = inf: never selected below
+    const double vlow = gd * t;
 #pragma unroll
     for (int q = 0; q < TR_K; ++q) {
-      if (t <= pr.t[q]) a.s[2 * q] += lowc; else a.s[2 * q + 1] += wd2;
+      if (t <= pr.t[q]) { a.s[TR_Q * q] += lowc; a.s[TR_Q * q + BASE] += vlow; }
+      else { a.s[TR_Q * q + 1] += wd2; a.s[TR_Q * q + BASE + 1] += gd; }
     }
   }
-  block_reduce_store<2 * TR_K, 0>(a, partials, stride);
 }
-
-// value parts sum g_i (clamp(z_i + t d_i) - z_i), primal block and dual block
-__global__ __launch_bounds__(TPB) void tr_value_kernel(int n, int m, int ne, const double *__restrict__ px,
-                                                       const double *__restrict__ py, const double *__restrict__ lb_s,
-                                                       const double *__restrict__ ub_s, const double *__restrict__ gvec,
-                                                       const double *__restrict__ dir, double t,
-                                                       double *__restrict__ partials, int stride) {
-  RedAcc<2, 0> a;
-  const int tid = blockIdx.x * TPB + threadIdx.x, st = gridDim.x * TPB;
-  for (int k = tid; k < n + m; k += st) {
-    const bool primal = k < n;
-    const int i = primal ? k : k - n;
-    const double d = dir[k];
-    if (d == 0.0) continue;
-    const double z = primal ? px[i] : py[i];
-    const double lo = primal ? lb_s[i] : ((i < ne) ? -INFINITY : 0.0);
-    const double hi = primal ? ub_s[i] : INFINITY;
-    const double cand = fmin(fmax(z + t * d, lo), hi);   // clamp.(center + t*direction, lb, ub)
-    const double v = gvec[k] * (cand - z);
-    if (primal) a.s[0] += v; else a.s[1] += v;
-  }
-  block_reduce_store<2, 0>(a, partials, stride);
+__global__ __launch_bounds__(TPB) void tr_probe_kernel(int n, int total, const double *__restrict__ thr,
+                                                       const double *__restrict__ wd2v, const double *__restrict__ gdv,
+                                                       TrProbes pr, double *__restrict__ partials, int stride) {
+  RedAcc<TR_Q * TR_K, 0> a;
+  tr_probe_range<2>(0, n, thr, wd2v, gdv, pr, a);
+  tr_probe_range<4>(n, total, thr, wd2v, gdv, pr, a);
+  block_reduce_store<TR_Q * TR_K, 0>(a, partials, stride);
 }
 
 }  // namespace

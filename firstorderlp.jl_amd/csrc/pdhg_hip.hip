@@ -102,7 +102,7 @@ struct pdhg_handle {
   uint64_t restart_version = 1, matrix_version = 1, ev_rkey = 0;
   uint64_t state_version = 1;                      // bumped by everything that moves x, y, the sums or A
   uint64_t ev_cversion[2] = {0, 0}, avg_version = 0;
-  double *tr_g = nullptr, *tr_dir = nullptr, *tr_thr = nullptr;  // n+m each
+  double *tr_g = nullptr, *tr_dir = nullptr, *tr_thr = nullptr;  // n+m each: g d, w d^2, breakpoint (tr_setup_kernel)
   double *ev_partials = nullptr;
   double *ev_xg = nullptr;                         // [n_alloc] full x at the evaluated point (group only)
   // the point being evaluated and its products (set by point_products)
@@ -2385,7 +2385,13 @@ int pdhg_spmv_t(pdhg_handle *h0, const double *y, double *out) {
 static int ev_alloc(pdhg_handle *h) {
   if (h->ev_partials) return 0;
   int rc;
-  h->ev_grid = ew_grid(std::max(h->n, h->m) + 1);
+  {
+    // the evaluation kernels reduce up to 30 quantities per workgroup and a second stage reads every workgroup's
+    // partials: two elements per thread and at most 1024 workgroups measured best (L1-SVM 229K elements: 448
+    // workgroups 67 us per trust-region call against 82 with 895; 2M elements: 977 workgroups 123 us against 147 with 2048)
+    static const int per_thread = getenv("PDHG_EV_ELEMS") ? std::max(1, atoi(getenv("PDHG_EV_ELEMS"))) : 2;
+    h->ev_grid = std::min(1024, ew_grid((h->n + h->m + per_thread) / per_thread));
+  }
   if ((rc = alloc_zero(&h->ev_partials, (int64_t)EV_MAXQ * h->ev_grid))) return rc;
   if ((rc = alloc_zero(&h->ev_ax, h->m))) return rc;
   if ((rc = alloc_zero(&h->ev_aty, h->n_alloc))) return rc;
@@ -2404,6 +2410,7 @@ static int ev_alloc(pdhg_handle *h) {
 // second stage of every shard's block partials (ns sums then nm maxes), then the
 // combination over ranks in rank order
 static int ev_finish(const Shards &L, int ns, int nm, double *out) {
+  if (ns + nm > EV_MAXQ) return fail(-1, "too many scalars in one reduction");
   static const bool host_word = !(getenv("PDHG_EVAL_HOST_WORD") && getenv("PDHG_EVAL_HOST_WORD")[0] == '0');
   if (!L.g && host_word) {
     // one handle: the second stage publishes into pinned memory and the host polls (see multi_final_kernel)
@@ -2642,17 +2649,17 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
     hipLaunchKernelGGL(tr_setup_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)h->m,
                        (int)h->num_eq, h->pt_x + o, h->pt_y, h->pt_aty + o, h->pt_qx ? h->pt_qx + o : nullptr, h->pt_ax,
                        h->c + o, h->b, h->lb + o, h->ub + o, wp, wd, range,
-                       h->tr_g, h->tr_dir, h->tr_thr, h->ev_partials, h->ev_grid);
+                       h->tr_g, h->tr_dir, h->tr_thr, h->ev_partials, h->ev_grid);   // tr_g: g d, tr_dir: w d^2
     HIP_TRY(hipGetLastError());
   }
   double r[EV_MAXQ];
-  if ((rc = ev_finish(L, 11, 1, r))) return rc;
+  if ((rc = ev_finish(L, TR_SETUP_NS, 1, r))) return rc;
   // compute_lagrangian_value (saddle_point.jl:1109-1120) without objective_constant
   out[0] = 0.5 * r[10] + r[0] - r[1] + r[2];
   out[1] = out[2] = 0.0;
   out[3] = r[8]; out[4] = r[9];
   out[5] = 0.0; out[6] = 0.0; out[7] = 0.0;
-  const double hinf = r[3], g2 = r[4], wd2_all = r[5], tmax = r[11];
+  const double hinf = r[3], g2 = r[4], wd2_all = r[5], tmax = r[TR_SETUP_NS];
   const double r2 = radius * radius;
   if (approximate) {
     // approximately_solve_bound_constrained_trust_region (trust_region_utils.jl:194-224)
@@ -2666,28 +2673,33 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
   // reference eliminates breakpoints by repeated medians (trust_region_utils.jl:112-165);
   // here: TR_K-ary search over the IEEE bit patterns of t in [0, max finite
   // breakpoint] until no breakpoint lies strictly inside the bracket, then the
-  // same closed form (trust_region_utils.jl:167-175).
-  auto probe = [&](const TrProbes &pr, double *lowhigh) -> int {
+  // same closed form (trust_region_utils.jl:167-175).  Every probe carries the value sums of its t
+  // (tr_probe_kernel), and the set-up pass those of t = tmax, so t* needs no pass of its own:
+  //   value(t*) = vlow + t* vhigh  at the bracket's lower end (no breakpoint lies in between).
+  struct End { double low, high, v[4]; };     // v: vlow primal, vhigh primal, vlow dual, vhigh dual
+  auto end_of = [](const double *p6) { return End{p6[0], p6[1], {p6[2], p6[3], p6[4], p6[5]}}; };
+  auto probe = [&](const TrProbes &pr, double *sums) -> int {
     FOR_SHARDS(L, h) {
       hipLaunchKernelGGL(tr_probe_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)(h->cn + h->m),
-                         h->tr_dir, h->tr_thr, wp, wd, pr, h->ev_partials, h->ev_grid);
+                         h->tr_thr, h->tr_dir, h->tr_g, pr, h->ev_partials, h->ev_grid);
       HIP_TRY(hipGetLastError());
     }
-    return ev_finish(L, 2 * TR_K, 0, lowhigh);
+    return ev_finish(L, TR_Q * TR_K, 0, sums);
   };
-  double lh[2 * TR_K];
+  double lh[TR_Q * TR_K];
   TrProbes pr;
-  for (int q = 0; q < TR_K; ++q) pr.t[q] = tmax;
-  if ((rc = probe(pr, lh))) return rc;
-  int passes = 1;
+  int passes = 0;                            // probe passes (the set-up pass evaluates t = tmax itself)
   double tstar;
-  if (lh[0] + tmax * tmax * lh[1] <= r2) {
+  End at{0.0, 0.0, {0.0, 0.0, 0.0, 0.0}};    // the sums that t* is computed from
+  const End at_tmax{r[11], hinf, {r[12], r[14], r[13], r[15]}};
+  if (at_tmax.low + tmax * tmax * at_tmax.high <= r2) {
     // every finite breakpoint is reached before the radius
     if (hinf <= 0.0) tstar = tmax;                       // "all bounds hit" special case
-    else tstar = sqrt((r2 - lh[0]) / hinf);
+    else tstar = sqrt((r2 - at_tmax.low) / hinf);
+    at = at_tmax;
   } else {
     uint64_t lo = 0, hi = d2bits(tmax);
-    double low_lo = 0.0, high_lo = 0.0;
+    End lo_end = at;
     bool have_lo = false;
     bool exact = false;
     tstar = 0.0;
@@ -2699,9 +2711,9 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
       // t' = sqrt((r2 - low)/high).  If no breakpoint lies in (lo, t'] the
       // probe returns the same (low, high) and t' is the exact answer -- this
       // fixed-point step usually lands within a few passes; the remaining
-      // probes keep a guaranteed 8-ary bracket in IEEE bit space.
-      if (have_lo && high_lo > 0.0) {
-        const double cand = sqrt(fmax(r2 - low_lo, 0.0) / high_lo);
+      // probes keep a guaranteed bracket in IEEE bit space.
+      if (have_lo && lo_end.high > 0.0) {
+        const double cand = sqrt(fmax(r2 - lo_end.low, 0.0) / lo_end.high);
         const uint64_t cb = d2bits(cand);
         if (cb > lo && cb < hi) { pb[0] = cb; pr.t[0] = cand; q0 = 1; }
       }
@@ -2714,35 +2726,29 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
       }
       if ((rc = probe(pr, lh))) return rc;
       ++passes;
-      if (q0 == 1 && lh[0] == low_lo && lh[1] == high_lo) { tstar = pr.t[0]; exact = true; break; }
+      if (q0 == 1 && lh[0] == lo_end.low && lh[1] == lo_end.high) { tstar = pr.t[0]; exact = true; break; }
       uint64_t nlo = lo, nhi = hi;
       for (int q = 0; q < TR_K; ++q) {
-        const double f = lh[2 * q] + pr.t[q] * pr.t[q] * lh[2 * q + 1];
-        if (f <= r2) { if (pb[q] > nlo) { nlo = pb[q]; low_lo = lh[2 * q]; high_lo = lh[2 * q + 1]; have_lo = true; } }
+        const double f = lh[TR_Q * q] + pr.t[q] * pr.t[q] * lh[TR_Q * q + 1];
+        if (f <= r2) { if (pb[q] > nlo) { nlo = pb[q]; lo_end = end_of(lh + TR_Q * q); have_lo = true; } }
         else { if (pb[q] < nhi) nhi = pb[q]; }
       }
       lo = nlo; hi = nhi;
     }
     if (!exact) {
-      if (!have_lo) {  // bracket collapsed at t = 0: evaluate low/high there
+      if (!have_lo) {  // bracket collapsed at t = 0: evaluate the sums there
         for (int q = 0; q < TR_K; ++q) pr.t[q] = 0.0;
         if ((rc = probe(pr, lh))) return rc;
         ++passes;
-        low_lo = lh[0]; high_lo = lh[1];
+        lo_end = end_of(lh);
       }
-      tstar = high_lo > 0.0 ? sqrt(fmax(r2 - low_lo, 0.0) / high_lo) : bits2d(lo);
+      tstar = lo_end.high > 0.0 ? sqrt(fmax(r2 - lo_end.low, 0.0) / lo_end.high) : bits2d(lo);
     }
+    at = lo_end;
   }
-  FOR_SHARDS(L, h) {
-    const int64_t o = h->clo;
-    hipLaunchKernelGGL(tr_value_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)h->m,
-                       (int)h->num_eq, h->pt_x + o, h->pt_y, h->lb + o, h->ub + o, h->tr_g, h->tr_dir, tstar,
-                       h->ev_partials, h->ev_grid);
-    HIP_TRY(hipGetLastError());
-  }
-  double vv[2];
-  if ((rc = ev_finish(L, 2, 0, vv))) return rc;
-  out[1] = vv[0]; out[2] = vv[1]; out[5] = tstar; out[6] = (double)passes;
+  out[1] = at.v[0] + tstar * at.v[1];
+  out[2] = at.v[2] + tstar * at.v[3];
+  out[5] = tstar; out[6] = (double)passes;
   return 0;
 }
 

@@ -298,7 +298,11 @@ int pdhg_get_point(pdhg_handle *h, int point, double *x, double *y);
  * only (the two halves of MAX_NORM).  out[0] = Lagrangian value minus
  * objective_constant, out[1] = sum g_x.(x_tr - x), out[2] = sum g_y.(y_tr - y)
  * (lower bound = L + out[1], upper bound = L - out[2]), out[3] = sum x^2,
- * out[4] = sum y^2, out[5] = t*, out[6] = reduction passes used.
+ * out[4] = sum y^2, out[5] = t*, out[6] = probe passes of the breakpoint search
+ * (after the set-up pass; 0 when every finite breakpoint lies inside the ball).
+ * The two value sums are evaluated as sum g d min(t*, breakpoint) -- the same numbers as
+ * the reference's sum g (clamp(z + t* d) - z) up to rounding -- so that they come out of
+ * the search's own passes.
  */
 int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm,
                             double dual_weight_norm, double radius, int range,
