@@ -386,27 +386,6 @@ int launch_q_interaction(pdhg_handle *h, int *count) {
   return 0;
 }
 
-// second-stage reduction of the trial's block partials into scal_dev[0..5)
-int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int, const double *p_dy, int n_dy,
-                 int q_count) {
-  ProfScope ps(h, PDHG_K_FINAL);
-  FinalSpec sp{};
-  sp.ptr[0] = p_int;                  sp.count[0] = n_int;
-  sp.ptr[1] = p_int + stride_int;     sp.count[1] = n_int;
-  sp.ptr[2] = p_dy;                   sp.count[2] = n_dy;
-  sp.ptr[3] = p_int + 2 * stride_int; sp.count[3] = n_int;
-  sp.ptr[4] = h->pQ;                  sp.count[4] = q_count;
-  for (int q : {0, 1, 3}) sp.ptr_lo[q] = sp.ptr[q] + 3 * stride_int;
-  sp.ptr_lo[2] = p_dy + h->A.slots();
-  sp.ptr_lo[4] = h->pQ + h->ew_grid_n;
-  sp.out = h->scal_dev;
-  hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, sp);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// ---- the trial step as a HIP graph ---------------------------------------------------
-
 // second stage of the block partials straight into pinned host memory, then the launch's
 // sequence number: the host polls that word instead of a device-to-host copy + stream
 // synchronisation (the copy alone is a 4 us kernel on this runtime).
@@ -423,6 +402,32 @@ __global__ __launch_bounds__(FINAL_TPB) void final_reduce_host_kernel(FinalSpec 
     res_host[7] = (double)s;      // exact up to 2^53 launches
   }
 }
+
+// second-stage reduction of the trial's block partials into scal_dev[0..5)
+int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int, const double *p_dy, int n_dy,
+                 int q_count, bool to_host = false) {
+  ProfScope ps(h, PDHG_K_FINAL);
+  FinalSpec sp{};
+  sp.ptr[0] = p_int;                  sp.count[0] = n_int;
+  sp.ptr[1] = p_int + stride_int;     sp.count[1] = n_int;
+  sp.ptr[2] = p_dy;                   sp.count[2] = n_dy;
+  sp.ptr[3] = p_int + 2 * stride_int; sp.count[3] = n_int;
+  sp.ptr[4] = h->pQ;                  sp.count[4] = q_count;
+  for (int q : {0, 1, 3}) sp.ptr_lo[q] = sp.ptr[q] + 3 * stride_int;
+  sp.ptr_lo[2] = p_dy + h->A.slots();
+  sp.ptr_lo[4] = h->pQ + h->ew_grid_n;
+  sp.out = h->scal_dev;
+  if (to_host) {       // results straight into the pinned result word (the caller polls it: wait_result_word)
+    hipLaunchKernelGGL(final_reduce_host_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, sp, h->seq_dev, h->res_host);
+    h->seq_expected += 1;
+  } else {
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, sp);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- the trial step as a HIP graph ---------------------------------------------------
 
 template <typename... Args>
 hipError_t graph_add_kernel_lds(hipGraph_t g, hipGraphNode_t *node, const std::vector<hipGraphNode_t> &deps,
@@ -1929,6 +1934,15 @@ static int trial_dual_single(pdhg_handle *h, double step_size, double primal_wei
   if ((rc = launch_aty_fused(h))) return rc;
   int qcount = 0;
   if ((rc = launch_q_interaction(h, &qcount))) return rc;
+  // The five sums go straight into pinned host memory and the host polls the launch's sequence number there
+  // (as on the graph path) instead of a device-to-host copy + stream synchronisation: ~10 us per trial, which
+  // is 5 % of a 1M x 1M LP's iteration.  While profiling: the copy, so that the event brackets stay simple.
+  static const bool host_word = !(getenv("PDHG_TRIAL_HOST_WORD") && getenv("PDHG_TRIAL_HOST_WORD")[0] == '0');
+  if (host_word && !h->profile) {
+    if ((rc = ensure_result_word(h))) return rc;
+    if ((rc = launch_final(h, h->pAt, h->At.slots(), h->pAt_stride, h->pA, h->A.slots(), qcount, true))) return rc;
+    return wait_result_word(h, out);
+  }
   if ((rc = launch_final(h, h->pAt, h->At.slots(), h->pAt_stride, h->pA, h->A.slots(), qcount))) return rc;
   HIP_TRY(hipMemcpyAsync(h->scal_host, h->scal_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));

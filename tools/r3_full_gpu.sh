@@ -6,8 +6,8 @@ timeout 900 python bench.py > gpurun_out/r3full/bench_default.json 2> gpurun_out
 python -c "
 import json
 d=json.load(open('gpurun_out/r3full/bench_default.json'))
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['frac_net'], d['setup_sec'], d['cpu_baseline']['value'], d.get('cpu_baseline_socket',{}).get('value'))
-for o in d.get('other_configs', []): print(o['config']['workload'][:40], o.get('value'), o.get('roofline', {}).get('frac'), o.get('roofline', {}).get('frac_net'), o.get('launch_path'))
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['setup_sec'], d['cpu_baseline']['value'], d.get('cpu_baseline_socket',{}).get('value'))
+for o in d.get('other_configs', []): print(o['config']['workload'][:40], o.get('value'), o.get('roofline', {}).get('frac'), o.get('launch_path'))
 "
 PDHG_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/r3full/bench_dist_world1.json 2> gpurun_out/r3full/bench_dist_world1.err
 python -c "
