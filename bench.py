@@ -451,7 +451,9 @@ def main():
     if dist is None and not args.no_other_configs and args.workload == "random" and args.shards == 0:
         for wl in ("pagerank", "l1svm"):
             try:
-                r = measure(args, wl, ctx, max(args.steps, 200), max(args.warmup, 20), min(cpu_s, 3.0),
+                # an iteration of these LPs takes 0.05-0.2 ms: 2000 timed steps after 300 untimed ones (each leg states
+                # its own steps / warmup), so that the figure is the steady rate and not the retry-heavy first steps
+                r = measure(args, wl, ctx, max(args.steps, 2000), max(args.warmup, 300), min(cpu_s, 3.0),
                             with_socket=False)
                 r["metric"] = "pdhg_iterations_per_sec"
                 others.append(r)

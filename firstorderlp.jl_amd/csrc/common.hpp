@@ -92,6 +92,15 @@ __device__ __forceinline__ void dd_add_dd(double &hi, double &lo, double bh, dou
   lo = l - (h2 - s);
   hi = h2;
 }
+// A load that cannot be served by a stale line of this CU's L1: agent scope (sc1), served by the L2.  The
+// multi-step trial kernel re-reads vectors that OTHER compute units rewrote since this CU last read them, and a
+// per-workgroup L1 invalidate costs ~50 ns per workgroup and XCD, serialised (tools/grid_barrier_probe).  Relaxed:
+// no wait is attached, the loads pipeline like plain ones.
+template <bool COH>
+__device__ __forceinline__ double ldc(const double *p) {
+  if (COH) return __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
 // a double moved across lanes by DPP (two 32-bit moves); lanes without a source, or outside row_mask, receive 0.0
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_move(double v) {

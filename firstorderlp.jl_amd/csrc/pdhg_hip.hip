@@ -533,7 +533,7 @@ int coop_prepare(pdhg_handle *h) {
   int rc = ensure_result_word(h);
   if (rc) return rc;
   int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trial_kernel, TPB, 0));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trial_kernel<false>, TPB, 0));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));
   int cap = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
@@ -657,7 +657,9 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
   }
   h->coop_launches += 1;
   const auto c1 = std::chrono::steady_clock::now();
-  hipLaunchKernelGGL(trial_kernel, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
+  static const bool coh_single = getenv("PDHG_COOP_COH") && getenv("PDHG_COOP_COH")[0] == '1';   // dev: L1-bypassing loads in the single-trial kernel too
+  if (coh_single) hipLaunchKernelGGL(trial_kernel<true>, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
+  else hipLaunchKernelGGL(trial_kernel<false>, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
   const auto c2 = std::chrono::steady_clock::now();
   h->t_set += std::chrono::duration<double>(c1 - c0).count();

@@ -41,17 +41,17 @@ struct EpiArgs {
   double avg_w;
 };
 
-template <int MODE>
+template <int MODE, bool COH = false>
 __device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
                                              Acc3 &acc) {
   if (MODE == MODE_PLAIN) {
     e.out[r] = s;
   } else if (MODE == MODE_DUAL) {
     // compute_dual_gradient: b .- A*x              saddle_point.jl:1102-1107
-    const double yo = e.y[r];
+    const double yo = ldc<COH>(e.y + r);
     if (e.sum_y) {
       const double t = yo * e.avg_w;
-      e.sum_y[r] = e.sum_y[r] + t;
+      e.sum_y[r] = ldc<COH>(e.sum_y + r) + t;
     }
     const double dg = e.b[r] - s;
     // next_dual = y .+ (pw*step) .* dual_gradient   pdhg.jl:489-490
@@ -65,8 +65,8 @@ __device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
   } else {
     // next_dual_product = A' * next_dual            pdhg.jl:492
     e.aty_next[r] = s;
-    const double dx = e.x_next[r] - e.x[r];          // pdhg.jl:534
-    const double dd = s - e.aty[r];                  // pdhg.jl:543
+    const double dx = ldc<COH>(e.x_next + r) - ldc<COH>(e.x + r);   // pdhg.jl:534
+    const double dd = s - ldc<COH>(e.aty + r);                     // pdhg.jl:543
     dd_add(acc.hi[0], acc.lo[0], dx * dd);
     dd_add(acc.hi[1], acc.lo[1], dx * dx);
     dd_add(acc.hi[2], acc.lo[2], dd * dd);
@@ -136,7 +136,7 @@ constexpr int RELAXED_MIN_ROW = 256;
 // PIPE: the two-register-set software pipeline of the strict per-lane row sum (32 VGPRs).  The one-launch trial
 // kernel, which keeps a prefetched item's 24 registers alive across its phases, runs the plain 8-at-a-time loop
 // instead (same order of additions, hence the same bits) to stay within 96 VGPRs.
-template <int MODE, bool INIT, bool PIPE = true>
+template <int MODE, bool INIT, bool PIPE = true, bool COH = false>
 __device__ __forceinline__ void stream_block_finish(const CsrView &A, const double *xin, const StreamRegs &g,
                                                     const EpiArgs &e, int relaxed, Acc3 &acc, double *prod) {
   const int tid = threadIdx.x;
@@ -146,7 +146,15 @@ __device__ __forceinline__ void stream_block_finish(const CsrView &A, const doub
 #pragma unroll
   for (int i = 0; i < UNROLL; ++i) {
     const int k = k0 + tid + i * TPB;
-    xv[i] = (k < k1) ? xin[g.cidx[i]] : 0.0;
+    if (COH) {
+      // unconditional: a lane without an entry holds column 0 (stream_block_load), a valid address -- an ATOMIC load
+      // under a condition becomes a branch per load, and the waits the compiler puts in front of each serialise the
+      // gathers.  (For plain loads the conditional form measured 1-2 % faster: kept.)
+      const double t = ldc<true>(xin + g.cidx[i]);
+      xv[i] = (k < k1) ? t : 0.0;
+    } else {
+      xv[i] = (k < k1) ? xin[g.cidx[i]] : 0.0;
+    }
   }
 #pragma unroll
   for (int i = 0; i < UNROLL; ++i) {
@@ -218,7 +226,7 @@ __device__ __forceinline__ void stream_block_finish(const CsrView &A, const doub
         if (lane == l) s = s + total;
       }
     }
-    if (have) row_epilogue<MODE>(e, r, s, acc);
+    if (have) row_epilogue<MODE, COH>(e, r, s, acc);
   }
 }
 
@@ -559,13 +567,19 @@ __device__ __forceinline__ void long_chunk_load(const CsrView &A, int r, int off
     g.v[i] = ok ? __builtin_nontemporal_load(A.val + k) : 0.0;
   }
 }
+template <bool COH = false>
 __device__ __forceinline__ double long_chunk_finish(const double *xin, const StreamRegs &g, double (*red)[TPB / WAVE]) {
   double acc[3] = {0.0, 0.0, 0.0};
   double p[UNROLL];
 #pragma unroll
   for (int i = 0; i < UNROLL; ++i) {
     const int k = g.k0 + threadIdx.x + i * TPB;
-    p[i] = (k < g.k1) ? g.v[i] * xin[g.cidx[i]] : 0.0;
+    if (COH) {
+      const double t = ldc<true>(xin + g.cidx[i]);     // unconditional (column 0 for a lane without an entry): see stream_block_finish
+      p[i] = (k < g.k1) ? g.v[i] * t : 0.0;
+    } else {
+      p[i] = (k < g.k1) ? g.v[i] * xin[g.cidx[i]] : 0.0;
+    }
   }
   static_assert(UNROLL == 8 && LONG_CHUNK == UNROLL * TPB, "the chunk sum below is written for 8 products per lane");
   acc[0] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
@@ -596,7 +610,7 @@ __global__ __launch_bounds__(TPB) void spmv_long_partial_kernel(
 // workgroup ends up finishing a long row -- a block of the separate kernel below, or, in the
 // one-launch trial, the workgroup that completed the row's last chunk -- the slots hold the
 // same bits.  Called by all 64 lanes of one wave.  AGENT: write-through stores (trial kernel).
-template <int MODE, bool AGENT>
+template <int MODE, bool AGENT, bool COH = false>
 __device__ __forceinline__ void long_final_row(int l, const int *long_row, const int *long_chunk_ptr,
                                                const double *chunk_partial, const EpiArgs &e, int slot_base) {
   const int lane = threadIdx.x & (WAVE - 1);
@@ -606,7 +620,7 @@ __device__ __forceinline__ void long_final_row(int l, const int *long_row, const
   s = wave_sum(s);
   if (lane == 0) {
     Acc3 acc = acc3_zero();
-    row_epilogue<MODE>(e, long_row[l], s, acc);
+    row_epilogue<MODE, COH>(e, long_row[l], s, acc);
     constexpr int NQ = ModeNQ<MODE>::value;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {

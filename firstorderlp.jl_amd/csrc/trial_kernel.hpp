@@ -179,7 +179,7 @@ __device__ __forceinline__ void product_prefetch(const TrialProduct &P, Prefetch
   }
 }
 
-template <int MODE>
+template <int MODE, bool COH = false>
 __device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed,
                                               Prefetched &f, double *prod, double (*red)[TPB / WAVE]) {
   const unsigned long long launch = P.uses;
@@ -190,7 +190,7 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed
   for (int c = nwg - 1 - w; c < P.nchunks; c += nwg) {
     __syncthreads();
     if (!(f.kind == 2 && c == nwg - 1 - w)) long_chunk_load(P.M, P.chunk_row[c], P.chunk_off[c], f.g);
-    const double part = long_chunk_finish(P.xin, f.g, red);
+    const double part = long_chunk_finish<COH>(P.xin, f.g, red);
     if (threadIdx.x == 0) {
       store_agent(P.chunk_partial + c, part);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,7 +202,7 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed
     }
     __syncthreads();
     if (finish_row >= 0 && threadIdx.x < WAVE)                             // one wave finishes the row
-      long_final_row<MODE, true>(finish_row, P.long_row, P.long_chunk_ptr, P.chunk_partial, P.e, P.grid);
+      long_final_row<MODE, true, COH>(finish_row, P.long_row, P.long_chunk_ptr, P.chunk_partial, P.e, P.grid);
   }
   constexpr int NQ = ModeNQ<MODE>::value;
   for (int b = w; b < P.grid; b += nwg) {
@@ -212,7 +212,7 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed
     Acc3 acc = acc3_zero();
     if (active) {
       if (!(pre && b == w)) stream_block_load(P.M, P.blks[blk], g);
-      stream_block_finish<MODE, false, PDHG_TRIAL_PIPE>(P.M, P.xin, g, P.e, relaxed, acc, prod);
+      stream_block_finish<MODE, false, PDHG_TRIAL_PIPE, COH>(P.M, P.xin, g, P.e, relaxed, acc, prod);
     }
     if (NQ > 0) {
       block_sum_dd<NQ, TPB>(acc, red);
@@ -230,6 +230,7 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed
 // waves per SIMD: the kernel needs 96 VGPRs (5 waves per SIMD, 5 workgroups per CU).  Forcing the 8 of the separate
 // stream kernel (64 VGPRs) spills 132 bytes per lane and is 1.4-2x SLOWER (L1-SVM 8.9k against 12.3k it/s, PageRank-1M
 // 2.4k against 4.4k: profiles/r03_trial_kernel.txt).
+template <bool COH>
 __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(TrialKernelArgs a) {
   __shared__ double prod[BLOCK_NNZ];
   __shared__ double red[6][TPB / WAVE];
@@ -242,13 +243,13 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(Tri
   if (a.has_q && !a.xbar_only) {
     // ---- QP, phase -1: Q x (the gradient's quadratic term), then a barrier of its own
     f.kind = 0;
-    product_phase<MODE_PLAIN>(a.Qx, a.relaxed, f, prod, red);
+    product_phase<MODE_PLAIN, COH>(a.Qx, a.relaxed, f, prod, red);
     grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
   }
   // ---- phase 0: x' and xbar (elementwise; any distribution over the workgroups gives the same bits)
   if (a.xbar_only) xbar_body(a.n, a.x, a.x_next, a.theta, a.xbar, w, nwg);
   else if (a.has_q) primal_body<true, true>(a.n, a.x, a.c, a.aty, a.qx, a.lb, a.ub, a.tau, a.theta, a.x_next, a.xbar, a.avg_w, a.sum_x, w, nwg);
-  else primal_body<false, true>(a.n, a.x, a.c, a.aty, nullptr, a.lb, a.ub, a.tau, a.theta, a.x_next, a.xbar, a.avg_w, a.sum_x, w, nwg);
+  else primal_body<false, true, COH>(a.n, a.x, a.c, a.aty, nullptr, a.lb, a.ub, a.tau, a.theta, a.x_next, a.xbar, a.avg_w, a.sum_x, w, nwg);
   // dx for the interaction term.  After the primal step every thread reads back the x' it wrote itself (same
   // element mapping); on the Malitsky-Pock retries x' is an earlier kernel's output.
   if (a.has_q) diff_pairs_body(a.n, a.x_next, a.x, a.dx, w, nwg);
@@ -257,18 +258,18 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(Tri
   grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
   PDHG_STAMP(2);
   // ---- phase 1: y' = proj(y + sigma (b - A xbar)), sum dy^2   (K3+K4)
-  product_phase<MODE_DUAL>(a.A, a.relaxed, f, prod, red);
+  product_phase<MODE_DUAL, COH>(a.A, a.relaxed, f, prod, red);
   if (a.has_q) {                                                 // Q' dx: independent of A xbar, same phase
     Prefetched none;
     none.kind = 0;
-    product_phase<MODE_PLAIN>(a.Qtdx, a.relaxed, none, prod, red);
+    product_phase<MODE_PLAIN, COH>(a.Qtdx, a.relaxed, none, prod, red);
   }
   product_prefetch(a.T, f);
   PDHG_STAMP(3);
   grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
   PDHG_STAMP(4);
   // ---- phase 2: A'y' and the interaction sums   (K5+K6)
-  product_phase<MODE_ATY>(a.T, a.relaxed, f, prod, red);
+  product_phase<MODE_ATY, COH>(a.T, a.relaxed, f, prod, red);
   if (a.has_q) {                                                 // partials of dx . (Q' dx), block by block as dot_kernel does
     for (int b = w; b < a.q_blocks; b += nwg) {
       __syncthreads();

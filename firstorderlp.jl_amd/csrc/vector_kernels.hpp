@@ -31,7 +31,8 @@ __device__ __forceinline__ void primal_one(double x, double c, double aty,
 }
 
 // Workgroup `bid` of `nb` (grid-stride; elementwise, so the distribution does not matter for the bits).
-template <bool HAS_Q, bool WRITE_XBAR>
+// COH: A'y was written by other compute units since this one last read it (multi-step trial kernel): coherent loads
+template <bool HAS_Q, bool WRITE_XBAR, bool COH = false>
 __device__ __forceinline__ void primal_body(
     int n, const double *x, const double *c, const double *aty, const double *qx,
     const double *lb, const double *ub, double tau, double theta, double *x_next, double *xbar,
@@ -50,7 +51,9 @@ __device__ __forceinline__ void primal_body(
       reinterpret_cast<double2 *>(sum_x)[p] = sv;
     }
     const double2 cv = reinterpret_cast<const double2 *>(c)[p];
-    const double2 av = reinterpret_cast<const double2 *>(aty)[p];
+    double2 av;
+    if (COH) { av.x = ldc<true>(aty + 2 * p); av.y = ldc<true>(aty + 2 * p + 1); }
+    else av = reinterpret_cast<const double2 *>(aty)[p];
     const double2 lv = reinterpret_cast<const double2 *>(lb)[p];
     const double2 uv = reinterpret_cast<const double2 *>(ub)[p];
     double2 qv = {0.0, 0.0};
@@ -68,7 +71,7 @@ __device__ __forceinline__ void primal_body(
       const double t = x[j] * avg_w;
       sum_x[j] = sum_x[j] + t;
     }
-    primal_one<HAS_Q, WRITE_XBAR>(x[j], c[j], aty[j], HAS_Q ? qx[j] : 0.0, lb[j], ub[j], tau, theta, xn, xb);
+    primal_one<HAS_Q, WRITE_XBAR>(x[j], c[j], ldc<COH>(aty + j), HAS_Q ? qx[j] : 0.0, lb[j], ub[j], tau, theta, xn, xb);
     x_next[j] = xn;
     if (WRITE_XBAR) xbar[j] = xb;
   }
