@@ -92,6 +92,40 @@ __device__ __forceinline__ void dd_add_dd(double &hi, double &lo, double bh, dou
   lo = l - (h2 - s);
   hi = h2;
 }
+// The scalar part of take_step(::AdaptiveStepsizeParams) after one trial (pdhg.jl:527-549, 691-729), ONE definition
+// for the host loop (pdhg_take_step_adaptive) and for the kernel that takes several steps per launch
+// (steps_kernel): the same expression trees, IEEE sqrt / divide on both sides, -ffp-contract=off, so the same bits
+// (tests/test_gpu_device_loop.py checks the device's sqrt and divide against the host's on random inputs, and whole
+// trajectories).  raw: the trial's five sums with raw[4] = 0.5 dx'Q dx already; pow_red / pow_growth:
+// (total_number_iterations + 1)^-reduction_exponent / ^-growth_exponent, computed by the HOST's pow on both paths.
+struct StepRule {
+  int accept, numerical_error;
+  double next_step;
+};
+__host__ __device__ inline StepRule adaptive_step_rule(const double raw[5], double primal_weight, double step_size,
+                                                       double pow_red, double pow_growth) {
+  StepRule r;
+  const double interaction = fabs(raw[0]) + fabs(raw[4]);
+  const double nx = sqrt(raw[1]), ny = sqrt(raw[2]);
+  const double movement = 0.5 * primal_weight * (nx * nx) + (0.5 / primal_weight) * (ny * ny);
+  r.accept = 0;
+  r.numerical_error = 0;
+  r.next_step = step_size;
+  if (movement == 0.0) {       // the algorithm terminates at the beginning of the next iteration
+    r.numerical_error = 1;
+    return r;
+  }
+  const double step_size_limit = interaction > 0 ? movement / interaction : INFINITY;
+  if (step_size <= step_size_limit) r.accept = 1;
+  const double first_term = (1 - pow_red) * step_size_limit;
+  const double second_term = (1 + pow_growth) * step_size;
+  // Julia's min (pdhg.jl:729): a NaN operand gives NaN, so the step size the reference would
+  // carry after a NaN trial is NaN, not the finite operand (`a < b ? a : b` drops the NaN)
+  r.next_step = (first_term != first_term || second_term != second_term)
+                    ? NAN : ((first_term < second_term) ? first_term : second_term);
+  return r;
+}
+
 // A load that cannot be served by a stale line of this CU's L1: agent scope (sc1), served by the L2.  The
 // multi-step trial kernel re-reads vectors that OTHER compute units rewrote since this CU last read them, and a
 // per-workgroup L1 invalidate costs ~50 ns per workgroup and XCD, serialised (tools/grid_barrier_probe).  Relaxed:

@@ -162,6 +162,12 @@ struct pdhg_handle {
   volatile double *res_host = nullptr;     // pinned, coherent: 5 results + [7] = sequence number
   unsigned long long seq_expected = 0;
   int coop_fallbacks = 0;                   // trials repeated on the other paths after a barrier time-out
+  // several take_steps per launch (steps_kernel): control lines, pow tables (device + pinned staging), result words
+  StepsCtl *steps_ctl = nullptr;
+  double *steps_pow_dev = nullptr, *steps_pow_host = nullptr, *steps_res = nullptr;
+  int steps_pow_cap = 0;
+  unsigned long long steps_seq = 0;
+  int64_t steps_launches = 0, steps_trials = 0;
   double res_error = 0.0;                   // error word of the last checked result read
   // host-side breakdown of graph trials (PDHG_VERBOSE): seconds in node updates, in hipGraphLaunch, waiting
   double t_set = 0.0, t_launch = 0.0, t_wait = 0.0;
@@ -683,6 +689,131 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
                     "persistent kernel?) -- this handle uses the %s path from here on\n", h->res_error,
             graph_eligible(h) ? "graph" : "separate-launch");
     return 1;
+  }
+  return 0;
+}
+
+// Up to n_steps adaptive take_steps in ONE launch (steps_kernel, trial_kernel.hpp).  On return *steps_done take_steps
+// have been taken (fewer when the launch ran out of its trial budget, met numerical_error, or a barrier timed out: the
+// caller goes on from the state left).  Returns 1 when nothing could be launched (not eligible).
+int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, double growth_exponent, double *step_size_io,
+               double primal_weight, int64_t *total_number_iterations_io, double *cumulative_kkt_passes_io,
+               int *numerical_error_out, int64_t *steps_done) {
+  *steps_done = 0;
+  if (!coop_eligible(h) || h->has_q || !h->lazy_accept || h->pend_x != h->pend_y) return 1;
+  int rc = coop_prepare(h);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  const int n = (int)std::min<int64_t>(n_steps, 1 << 20);
+  const int max_trials = 2 * n + 64, table_len = max_trials + 256;
+  if (!h->steps_ctl) {
+    HIP_TRY(hipMalloc((void **)&h->steps_ctl, sizeof(StepsCtl)));
+    HIP_TRY(hipMemsetAsync(h->steps_ctl, 0, sizeof(StepsCtl), h->stream));
+    HIP_TRY(hipHostMalloc((void **)&h->steps_res, STEPS_RES_WORDS * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(h->steps_res, 0, STEPS_RES_WORDS * sizeof(double));
+  }
+  if (h->steps_pow_cap < table_len) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->steps_pow_dev) (void)hipFree(h->steps_pow_dev);
+    if (h->steps_pow_host) (void)hipHostFree(h->steps_pow_host);
+    h->steps_pow_dev = h->steps_pow_host = nullptr;
+    h->steps_pow_cap = std::max(table_len, 512);
+    HIP_TRY(hipMalloc((void **)&h->steps_pow_dev, sizeof(double) * 2 * (size_t)h->steps_pow_cap));
+    HIP_TRY(hipHostMalloc((void **)&h->steps_pow_host, sizeof(double) * 2 * (size_t)h->steps_pow_cap + sizeof(FinalSpec) + 64, hipHostMallocDefault));
+  }
+  std::lock_guard<std::mutex> one_at_a_time(coop_device_mutex(h->device));
+  // the t-th trial of the launch runs with total_number_iterations = total + t + 1 and uses k1 = that + 1 (pdhg.jl:713-714)
+  for (int t = 0; t < table_len; ++t) {
+    const double k1 = (double)(*total_number_iterations_io + t + 2);
+    h->steps_pow_host[t] = pow(k1, -reduction_exponent);
+    h->steps_pow_host[table_len + t] = pow(k1, -growth_exponent);
+  }
+  HIP_TRY(hipMemcpyAsync(h->steps_pow_dev, h->steps_pow_host, sizeof(double) * 2 * (size_t)table_len, hipMemcpyHostToDevice, h->stream));
+  StepsKernelArgs a{};
+  a.n = (int)h->n; a.num_eq = (int)h->num_eq;
+  a.xa = h->x; a.xb = h->x_next; a.ya = h->y; a.yb = h->y_next; a.atya = h->aty; a.atyb = h->aty_next;
+  a.c = h->c; a.lb = h->lb; a.ub = h->ub; a.b = h->b;
+  a.xbar = h->xbar; a.sum_x = h->sum_x; a.sum_y = h->sum_y;
+  EpiArgs none{};
+  a.A = trial_product(h, h->A, nullptr, none);
+  a.T = trial_product(h, h->At, nullptr, none);
+  h->A.coop_uses -= 1; h->At.coop_uses -= 1;       // (trial_product counted one use: the launch's own count comes back with the results)
+  a.uses_a = a.A.uses; a.uses_t = a.T.uses;
+  a.pA = h->pA; a.pAt = h->pAt; a.pA_slots = h->A.slots(); a.pAt_stride = h->pAt_stride;
+  FinalSpec sp{};
+  sp.ptr[0] = h->pAt;                       sp.count[0] = h->At.slots();
+  sp.ptr[1] = h->pAt + h->pAt_stride;       sp.count[1] = h->At.slots();
+  sp.ptr[2] = h->pA;                        sp.count[2] = h->A.slots();
+  sp.ptr[3] = h->pAt + 2 * h->pAt_stride;   sp.count[3] = h->At.slots();
+  sp.ptr[4] = h->pQ;                        sp.count[4] = 0;
+  for (int q : {0, 1, 3}) sp.ptr_lo[q] = sp.ptr[q] + 3 * h->pAt_stride;
+  sp.ptr_lo[2] = h->pA + h->A.slots();
+  sp.ptr_lo[4] = h->pQ + h->ew_grid_n;
+  sp.out = nullptr;
+  memcpy(h->steps_pow_host + 2 * (size_t)table_len, &sp, sizeof sp);        // staged behind the pow tables (pinned)
+  HIP_TRY(hipMemcpyAsync(&h->steps_ctl->sp, h->steps_pow_host + 2 * (size_t)table_len, sizeof sp, hipMemcpyHostToDevice, h->stream));
+  a.primal_weight = primal_weight; a.step_size = *step_size_io;
+  a.n_steps = n; a.max_trials = max_trials; a.table_len = table_len;
+  a.pend = h->pend_x ? 1 : 0; a.pend_w = h->pend_w;
+  a.wsum_x = h->sum_x_weights; a.wsum_y = h->sum_y_weights;
+  a.pow_red = h->steps_pow_dev; a.pow_growth = h->steps_pow_dev + table_len;
+  a.epoch = h->coop_epoch;
+  a.sync = h->gsync; a.ctl = h->steps_ctl; a.res_host = h->steps_res;
+  a.seq = ++h->steps_seq;
+  a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
+  a.trace = h->coop_trace;
+  for (int x = 0; x < 8; ++x) a.xcd_cnt[x] = h->coop_xcd_cnt[x];
+  const auto c1 = std::chrono::steady_clock::now();
+  hipLaunchKernelGGL(steps_kernel, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  const auto c2 = std::chrono::steady_clock::now();
+  h->t_launch += std::chrono::duration<double>(c2 - c1).count();
+  // wait for the result words (sequence number + checksum), then for the kernel itself: its counters go on from here
+  const volatile unsigned long long *bits = reinterpret_cast<const volatile unsigned long long *>(h->steps_res);
+  double r[13];
+  auto ready = [&]() -> bool {
+    if (h->steps_res[15] != (double)a.seq) return false;
+    unsigned long long w[13], ck = RESULT_CHECK_SALT;
+    for (int k = 0; k < 13; ++k) { w[k] = bits[k]; ck ^= w[k] * (2ull * (unsigned long long)k + 1ull); }
+    if (ck != bits[13]) return false;
+    for (int k = 0; k < 13; ++k) memcpy(&r[k], &w[k], 8);
+    return r[12] == (double)a.seq;
+  };
+  bool seen = false;
+  for (long spin = 0; spin < 400000000L; ++spin) {
+    if (ready()) { seen = true; break; }
+    if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+  }
+  if (!seen) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!ready()) return fail(998, "multi-step trial kernel finished without publishing its results");
+  }
+  h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
+  const int64_t steps = (int64_t)r[1], trials = (int64_t)r[2];
+  const bool flip = r[3] != 0.0, aborted = r[9] != 0.0 || r[11] != 0.0;
+  h->steps_launches += 1; h->steps_trials += trials; h->n_graph_trials += trials;
+  h->coop_epoch = (unsigned long long)r[10];
+  h->A.coop_uses += (unsigned long long)trials + (aborted ? 1ull : 0ull);
+  h->At.coop_uses += (unsigned long long)trials + (aborted ? 1ull : 0ull);
+  if (flip) { std::swap(h->x, h->x_next); std::swap(h->y, h->y_next); std::swap(h->aty, h->aty_next); }
+  h->pend_x = h->pend_y = r[4] != 0.0;
+  h->pend_w = r[5];
+  h->sum_x_count += steps; h->sum_y_count += steps;
+  h->sum_x_weights = r[6]; h->sum_y_weights = r[7];
+  if (trials > 0 || aborted) h->state_version += 1;     // (bump_version of a single handle)
+  *step_size_io = r[0];
+  *total_number_iterations_io += trials;
+  *cumulative_kkt_passes_io += (double)trials;
+  *steps_done = steps;
+  if (h->steps_res[14] != 0.0 && !aborted)
+    return fail(995, "multi-step trial kernel: more than 256 consecutive rejected trials inside one take_step");
+  if (r[8] != 0.0) { *numerical_error_out = 1; *steps_done = steps + 1; }   // the failing take_step counts as taken (it is not repeated)
+  if (aborted) {
+    h->coop_mode = 0;
+    h->coop_fallbacks += 1;
+    fprintf(stderr, "[pdhg_hip] multi-step trial kernel: a grid barrier timed out (code %g; is the device shared with another "
+                    "persistent kernel?) -- this handle uses the %s path from here on\n", r[11],
+            graph_eligible(h) ? "graph" : "separate-launch");
   }
   return 0;
 }
@@ -1408,7 +1539,7 @@ void destroy_shard(pdhg_handle *h) {
     fprintf(stderr, "[pdhg_hip] %ld graph trials: host us per trial: node updates %.2f, hipGraphLaunch %.2f, wait for the result %.2f\n",
             h->n_graph_trials, 1e6 * h->t_set / h->n_graph_trials, 1e6 * h->t_launch / h->n_graph_trials,
             1e6 * h->t_wait / h->n_graph_trials);
-  if (h->coop_trace && h->coop_launches > 0) {
+  if (h->coop_trace && (h->coop_launches > 0 || h->steps_launches > 0)) {
     // phase timeline of the LAST one-launch trial: per phase, mean and max over the workgroups of its duration (us)
     std::vector<unsigned long long> t((size_t)8 * h->coop_grid);
     if (hipMemcpy(t.data(), h->coop_trace, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1425,9 +1556,11 @@ void destroy_shard(pdhg_handle *h) {
         }
         fprintf(stderr, "    %-38s mean %6.2f us, max %6.2f us; last workgroup out at %6.2f us\n", names[k], sum / h->coop_grid, mx, last_end);
       }
-      unsigned long long fin = 0;
-      for (int w = 0; w < h->coop_grid; ++w) fin = std::max(fin, t[(size_t)w * 8 + 6]);
-      fprintf(stderr, "    second-stage reduction published at %6.2f us\n", 0.01 * (double)(fin - t0));
+      unsigned long long fin = 0, lead = 0;
+      for (int w = 0; w < h->coop_grid; ++w) { fin = std::max(fin, t[(size_t)w * 8 + 6]); lead = std::max(lead, t[(size_t)w * 8 + 7]); }
+      if (lead) fprintf(stderr, "    barrier 3: global phase complete at %6.2f us; decision known to the last workgroup at %6.2f us (multi-step kernel, last trial)\n",
+                        0.01 * (double)(lead - t0), 0.01 * (double)(fin - t0));
+      else fprintf(stderr, "    second-stage reduction published at %6.2f us\n", 0.01 * (double)(fin - t0));
     }
   }
   free_csr_dev(h->A); free_csr_dev(h->At); free_csr_dev(h->Q); free_csr_dev(h->Qt);
@@ -1450,6 +1583,10 @@ void destroy_shard(pdhg_handle *h) {
   if (h->res_host) (void)hipHostFree((void *)h->res_host);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
   if (h->ev_host) (void)hipHostFree(h->ev_host);
+  if (h->steps_ctl) (void)hipFree(h->steps_ctl);
+  if (h->steps_pow_dev) (void)hipFree(h->steps_pow_dev);
+  if (h->steps_pow_host) (void)hipHostFree(h->steps_pow_host);
+  if (h->steps_res) (void)hipHostFree(h->steps_res);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -2206,26 +2343,18 @@ int pdhg_take_step_adaptive(pdhg_handle *h, double reduction_exponent, double gr
     double raw[5];
     int rc = pdhg_trial_step(h, step_size, primal_weight, 1.0, raw);
     if (rc) return rc;
-    const double interaction = fabs(raw[0]) + fabs(raw[4]);
-    const double nx = sqrt(raw[1]), ny = sqrt(raw[2]);
-    const double movement = 0.5 * primal_weight * (nx * nx) + (0.5 / primal_weight) * (ny * ny);
     *cumulative_kkt_passes_io += 1;
-    if (movement == 0.0) {       // the algorithm terminates at the beginning of the next iteration
+    const double k1 = (double)(*total_number_iterations_io + 1);
+    const StepRule rule = adaptive_step_rule(raw, primal_weight, step_size, pow(k1, -reduction_exponent), pow(k1, -growth_exponent));
+    if (rule.numerical_error) {
       *numerical_error_out = 1;
       break;
     }
-    const double step_size_limit = interaction > 0 ? movement / interaction : INFINITY;
-    if (step_size <= step_size_limit) {
+    if (rule.accept) {
       if ((rc = pdhg_accept(h, step_on_entry))) return rc;   // weight = step size on entry (pdhg.jl:512)
       done = true;
     }
-    const double k1 = (double)(*total_number_iterations_io + 1);
-    const double first_term = (1 - pow(k1, -reduction_exponent)) * step_size_limit;
-    const double second_term = (1 + pow(k1, -growth_exponent)) * step_size;
-    // Julia's min (pdhg.jl:729): a NaN operand gives NaN, so the step size the reference would
-    // carry after a NaN trial is NaN, not the finite operand (`a < b ? a : b` drops the NaN)
-    step_size = (first_term != first_term || second_term != second_term)
-                    ? NAN : ((first_term < second_term) ? first_term : second_term);
+    step_size = rule.next_step;
   }
   *step_size_io = step_size;
   return 0;
@@ -2240,12 +2369,32 @@ int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_e
   if (!steps_done_out) return fail(-1, "null argument");
   if (n_steps < 0) return fail(-2, "pdhg_take_steps_adaptive: n_steps < 0");
   *steps_done_out = 0;
-  if (numerical_error_out) *numerical_error_out = 0;
-  for (int64_t s = 0; s < n_steps; ++s) {
+  if (!h || !step_size_io || !total_number_iterations_io || !cumulative_kkt_passes_io || !numerical_error_out)
+    return fail(-1, "null argument");
+  *numerical_error_out = 0;
+  // PDHG_DEVICE_LOOP=1 (stream-layout LPs on one handle): several take_steps per launch (steps_kernel), the rule on
+  // the device.  Bitwise the per-trial launches (tests/test_gpu_device_loop.py) and NOT the default: measured slower --
+  // L1-SVM 58.5 us per step against 50.3, random 100K 50.8 against 44.7 (trial_kernel.hpp says where the time goes).
+  const char *dl_env = getenv("PDHG_DEVICE_LOOP");
+  const bool device_loop = dl_env && dl_env[0] == '1';
+  int64_t s = 0;
+  while (s < n_steps) {
+    if (device_loop && n_steps - s >= 2 && !h->grp && !h->profile && check_handle(h) == 0) {
+      int64_t k = 0;
+      const int rc = coop_steps(h, n_steps - s, reduction_exponent, growth_exponent, step_size_io, primal_weight,
+                                total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out, &k);
+      if (rc != 0 && rc != 1) return rc;
+      if (rc == 0) {
+        s += k;
+        *steps_done_out = s;
+        if (*numerical_error_out) break;
+        if (k > 0) continue;           // (k == 0: trial budget spent on rejections, or a time-out: take the next step singly)
+      }
+    }
     const int rc = pdhg_take_step_adaptive(h, reduction_exponent, growth_exponent, step_size_io, primal_weight,
                                            total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out);
     if (rc) return rc;
-    *steps_done_out = s + 1;
+    *steps_done_out = ++s;
     if (*numerical_error_out) break;
   }
   return 0;

@@ -70,9 +70,12 @@ constexpr long GRID_SPIN_LIMIT = 4000000L;   // x s_sleep(1): ~0.1 s
 // epoch = 1, 2, ... over the life of the handle; nxcd = XCDs that hold workgroups
 // xcd_cnt: workgroups of this launch on each XCD (the census, passed in the kernel arguments: a load of it here
 // would put one more ~1.5 us trip to memory in front of every arrival)
-__device__ __forceinline__ void grid_barrier(GridSync *s, unsigned long long epoch, unsigned nxcd, const unsigned *xcd_cnt) {
+// err_known: the error word as thread 0 read it a little earlier (the multi-step kernel requests it at the start of the
+// phase, off the critical path; ~0ull: read it here)
+__device__ __forceinline__ void grid_barrier(GridSync *s, unsigned long long epoch, unsigned nxcd, const unsigned *xcd_cnt,
+                                             unsigned long long err_known = ~0ull) {
   __syncthreads();       // every wave's workgroup-scope release: its stores have reached the XCD's L2
-  if (threadIdx.x == 0 && __hip_atomic_load(&s->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+  if (threadIdx.x == 0 && (err_known != ~0ull ? err_known : __hip_atomic_load(&s->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
     const unsigned x = xcc_id();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long cnt = xcd_cnt[x];
@@ -179,10 +182,12 @@ __device__ __forceinline__ void product_prefetch(const TrialProduct &P, Prefetch
   }
 }
 
+// xin, e, uses: the operands that change from trial to trial (the single-trial kernel passes P's own)
 template <int MODE, bool COH = false>
-__device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed,
+__device__ __forceinline__ void product_phase(const TrialProduct &P, const double *xin, const EpiArgs &e,
+                                              unsigned long long uses, int relaxed,
                                               Prefetched &f, double *prod, double (*red)[TPB / WAVE]) {
-  const unsigned long long launch = P.uses;
+  const unsigned long long launch = uses;
   const int w = blockIdx.x, nwg = gridDim.x;
   __shared__ int finish_row;
   StreamRegs &g = f.g;
@@ -190,7 +195,7 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed
   for (int c = nwg - 1 - w; c < P.nchunks; c += nwg) {
     __syncthreads();
     if (!(f.kind == 2 && c == nwg - 1 - w)) long_chunk_load(P.M, P.chunk_row[c], P.chunk_off[c], f.g);
-    const double part = long_chunk_finish<COH>(P.xin, f.g, red);
+    const double part = long_chunk_finish<COH>(xin, f.g, red);
     if (threadIdx.x == 0) {
       store_agent(P.chunk_partial + c, part);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,7 +207,7 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed
     }
     __syncthreads();
     if (finish_row >= 0 && threadIdx.x < WAVE)                             // one wave finishes the row
-      long_final_row<MODE, true, COH>(finish_row, P.long_row, P.long_chunk_ptr, P.chunk_partial, P.e, P.grid);
+      long_final_row<MODE, true, COH>(finish_row, P.long_row, P.long_chunk_ptr, P.chunk_partial, e, P.grid);
   }
   constexpr int NQ = ModeNQ<MODE>::value;
   for (int b = w; b < P.grid; b += nwg) {
@@ -212,15 +217,15 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, int relaxed
     Acc3 acc = acc3_zero();
     if (active) {
       if (!(pre && b == w)) stream_block_load(P.M, P.blks[blk], g);
-      stream_block_finish<MODE, false, PDHG_TRIAL_PIPE, COH>(P.M, P.xin, g, P.e, relaxed, acc, prod);
+      stream_block_finish<MODE, false, PDHG_TRIAL_PIPE, COH>(P.M, xin, g, e, relaxed, acc, prod);
     }
     if (NQ > 0) {
       block_sum_dd<NQ, TPB>(acc, red);
       if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          store_agent(P.e.partials + q * P.e.stride + b, acc.hi[q]);
-          store_agent(P.e.partials + P.e.lo_offset + q * P.e.stride + b, acc.lo[q]);
+          store_agent(e.partials + q * e.stride + b, acc.hi[q]);
+          store_agent(e.partials + e.lo_offset + q * e.stride + b, acc.lo[q]);
         }
       }
     }
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(Tri
   if (a.has_q && !a.xbar_only) {
     // ---- QP, phase -1: Q x (the gradient's quadratic term), then a barrier of its own
     f.kind = 0;
-    product_phase<MODE_PLAIN, COH>(a.Qx, a.relaxed, f, prod, red);
+    product_phase<MODE_PLAIN, COH>(a.Qx, a.Qx.xin, a.Qx.e, a.Qx.uses, a.relaxed, f, prod, red);
     grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
   }
   // ---- phase 0: x' and xbar (elementwise; any distribution over the workgroups gives the same bits)
@@ -258,18 +263,18 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(Tri
   grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
   PDHG_STAMP(2);
   // ---- phase 1: y' = proj(y + sigma (b - A xbar)), sum dy^2   (K3+K4)
-  product_phase<MODE_DUAL, COH>(a.A, a.relaxed, f, prod, red);
+  product_phase<MODE_DUAL, COH>(a.A, a.A.xin, a.A.e, a.A.uses, a.relaxed, f, prod, red);
   if (a.has_q) {                                                 // Q' dx: independent of A xbar, same phase
     Prefetched none;
     none.kind = 0;
-    product_phase<MODE_PLAIN, COH>(a.Qtdx, a.relaxed, none, prod, red);
+    product_phase<MODE_PLAIN, COH>(a.Qtdx, a.Qtdx.xin, a.Qtdx.e, a.Qtdx.uses, a.relaxed, none, prod, red);
   }
   product_prefetch(a.T, f);
   PDHG_STAMP(3);
   grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
   PDHG_STAMP(4);
   // ---- phase 2: A'y' and the interaction sums   (K5+K6)
-  product_phase<MODE_ATY, COH>(a.T, a.relaxed, f, prod, red);
+  product_phase<MODE_ATY, COH>(a.T, a.T.xin, a.T.e, a.T.uses, a.relaxed, f, prod, red);
   if (a.has_q) {                                                 // partials of dx . (Q' dx), block by block as dot_kernel does
     for (int b = w; b < a.q_blocks; b += nwg) {
       __syncthreads();
@@ -320,6 +325,282 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(Tri
     PDHG_STAMP(6);
   }
 #undef PDHG_STAMP
+}
+
+
+// ---- several adaptive take_steps per launch (pdhg_take_steps_adaptive) ------------------------------------------
+// Between two termination evaluations the reference's loop is take_step after take_step (pdhg.jl:862-1046), and
+// take_step's scalar part needs nothing but the trial's five sums: so the accept / reject decision and the
+// step-size rule run on the device too (adaptive_step_rule, common.hpp: the host loop's own function, with the two
+// powers of the iteration count looked up in a table the HOST computed), and one launch takes up to n_steps steps.
+// Per trial that removes the launch latency (~5 us), the result's trip to host memory and back (~3 us) and the
+// host's own microseconds, and adds a third grid barrier: the XCD's last arriver -- its L1 and L2 are clean after
+// its acquire -- runs the second-stage reduction and the rule between the barrier's global phase and the release,
+// and leaves the decision in its XCD's control line for the workgroups it releases.  All eight leaders compute
+// the same bits from the same partials.
+//
+// MEASURED, AND NOT THE DEFAULT (PDHG_DEVICE_LOOP=1 turns it on; profiles/r03_trial_kernel.txt).  Bitwise the
+// per-trial launches over thousands of steps, but slower: L1-SVM 58.5 us per step against 50.3 (17.1k against 19.9k
+// it/s), random 100K x 100K 50.8 against 44.7.  The launch it saves is worth ~5 us + ~3 us of result round trip per
+// trial; what it costs is more: (i) the phases up to the end of phase 2 take 41.8 us inside the loop against 35.0 after
+// a launch -- a launch starts every workgroup together, the loop starts each where the previous decision reached
+// it (~4 us of skew that barrier 1 then absorbs), and the coherent loads below add ~2 us; (ii) the third barrier
+// (~2 us to its global phase) and the leaders' second stage, which spills at this kernel's register limit once
+// its address arithmetic is hoisted out of the trial loop: 22 us from "global phase complete" to "every workgroup
+// knows the decision" (9 us with the second stage out of line, but then the call makes the phases' code worse by
+// more than that: PDHG_STEPS_NOINLINE).  Even a free second stage would only tie (41.8 + ~4 us per trial against
+// 46.5).  Kept as a tested, opt-in path: the pieces (one host/device step rule, coherent-load phase bodies, the
+// decision-as-release barrier) are what a future attempt with cheaper barriers would start from.
+//
+// What a multi-trial kernel must add to the single-trial one is L1 coherence ACROSS trials: x', xbar, y', A'y' are
+// rewritten every trial by other compute units than those that read them, and a compute unit's L1 may still hold
+// last trial's lines.  A per-workgroup L1 invalidate serialises in the XCD's L2 (~50 ns per workgroup:
+// profiles/r03_grid_barrier_probe.txt, 5.7 us per trial for 856 workgroups), so instead every load of a vector that
+// another compute unit may have rewritten is an agent-scope load (ldc<true>: served by the L2, which the barrier
+// leaders keep coherent) -- the gathers, the epilogues' operands, A'y in the primal step.  Data a thread re-reads
+// after ITS OWN store (x in the primal step, the running sums) and the static matrix and problem vectors stay plain.
+struct StepsCtl {
+  double slot[8][16];          // per XCD (one 128-byte line), as 64-bit words: [0] epoch << 2 | numerical_error << 1 | accept,
+                               // [1] the next step size's bits, [2] word 0 ^ word 1 ^ salt
+  FinalSpec sp;                // where the block partials are (read by the leaders only: as kernel arguments these 27
+};                             // SGPRs' worth of pointers stay live through every phase and push the kernel into scratch)
+
+struct StepsKernelArgs {
+  int n, num_eq;
+  double *xa, *xb, *ya, *yb, *atya, *atyb;       // the iterate and the trial point: flip 0 -> x = xa, x' = xb, ...
+  const double *c, *lb, *ub, *b;
+  double *xbar, *sum_x, *sum_y;
+  TrialProduct A, T;                              // static parts (xin / e / uses are set per trial)
+  double *pA, *pAt;
+  int pA_slots, pAt_stride;
+  double primal_weight, step_size;
+  int n_steps, max_trials, table_len;
+  int pend;                                       // the accept before this launch left its average update to the next trial
+  double pend_w;
+  double wsum_x, wsum_y;                          // the averages' weight sums (every accept adds the step size on entry)
+  const double *pow_red, *pow_growth;             // entry t: the powers for the launch's t-th trial
+  unsigned long long epoch, uses_a, uses_t;
+  GridSync *sync;
+  StepsCtl *ctl;
+  volatile double *res_host;
+  unsigned long long seq;
+  unsigned nxcd;
+  unsigned xcd_cnt[8];
+  int relaxed;
+  unsigned long long *trace;                      // PDHG_COOP_TRACE: stamps of the launch's last trial, as for trial_kernel ([7]: leaders, global phase done)
+};
+
+// result words: [0] step size, [1] steps taken, [2] trials, [3] flip, [4] pending average update, [5] its weight,
+// [6] / [7] weight sums, [8] numerical_error, [9] aborted on a barrier time-out, [10] barrier epoch, [11] the barriers'
+// error word, [12] sequence number; [13] checksum over [0..12]; [14] ended inside a take_step (table exhausted);
+// [15] sequence number again (what the host polls)
+constexpr int STEPS_RES_WORDS = 16;
+
+// The leaders' second stage, out of line: inlined into the trial loop its loop-invariant address arithmetic is
+// hoisted in front of the loop and kept alive through every phase -- in a kernel at its register limit that is
+// 436 bytes of scratch per lane.
+#ifndef PDHG_STEPS_NOINLINE
+#define PDHG_STEPS_NOINLINE 0
+#endif
+#ifndef PDHG_STEPS_PREFETCH
+#define PDHG_STEPS_PREFETCH 1
+#endif
+#if PDHG_STEPS_NOINLINE
+__device__ __attribute__((noinline)) void steps_second_stage(
+#else
+__device__ __forceinline__ void steps_second_stage(
+#endif
+    const FinalSpec *sp, double *res5_lds) {
+  double res[5];
+  final_reduce_body<TPB / WAVE>(*sp, res);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) res5_lds[k] = res[k];
+  }
+}
+
+__global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(StepsKernelArgs a) {
+  __shared__ double prod[BLOCK_NNZ];
+  __shared__ double red[6][TPB / WAVE];
+  __shared__ int s_leader;
+  __shared__ double s_dec[4];
+  // the doubles of the loop's state live in LDS (thread 0 updates them): as registers they are ten more VGPRs in a
+  // kernel that has none to spare.  [0] step size of the trial, [1] step size on entry of the take_step, [2] weight of
+  // the pending average update, [3] / [4] the averages' weight sums
+  __shared__ double s_st[5];
+  __shared__ double s_pow[2];
+  __shared__ double s_res[5];
+  const int w = blockIdx.x, nwg = gridDim.x;
+  int flip = 0, pend = a.pend, steps = 0, trials = 0, num_err = 0, hw_err = 0, mid = 0;
+  if (threadIdx.x == 0) { s_st[0] = a.step_size; s_st[1] = a.step_size; s_st[2] = a.pend_w; s_st[3] = a.wsum_x; s_st[4] = a.wsum_y; }
+  unsigned long long epoch = a.epoch;
+  Prefetched f;
+  __syncthreads();
+  // the trial budget ends the launch only BETWEEN take_steps (mid: the last trial was rejected -- the host API carries
+  // one step size, not the pair (trial step, step on entry) of an unfinished take_step); the pow tables hold
+  // table_len >= max_trials entries for that
+  while (steps < a.n_steps && (trials < a.max_trials || mid) && trials < a.table_len) {
+    const double step = s_st[0], pend_w = s_st[2];
+#define PDHG_STAMP(k) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)w * 8 + (k)] = wall_clock64(); } while (0)
+    PDHG_STAMP(0);
+    double *x = flip ? a.xb : a.xa, *xn = flip ? a.xa : a.xb;
+    double *y = flip ? a.yb : a.ya, *yn = flip ? a.ya : a.yb;
+    double *aty = flip ? a.atyb : a.atya, *atyn = flip ? a.atya : a.atyb;
+    const double tau = step / a.primal_weight, sigma = a.primal_weight * step;
+    // thread 0 requests, off the critical path, what the barriers and a leader will need: the error word and the
+    // trial's two powers (any workgroup may turn out to be its XCD's leader)
+    unsigned long long err_pref = 0;
+    double pw_r = 0.0, pw_g = 0.0;
+#if PDHG_STEPS_PREFETCH
+    if (threadIdx.x == 0) {
+      err_pref = __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pw_r = a.pow_red[trials]; pw_g = a.pow_growth[trials];
+    }
+#else
+    err_pref = ~0ull;
+#endif
+    // ---- phase 0: x' and xbar (+ the deferred sum_x update of the previous accept)
+    primal_body<false, true, true>(a.n, x, a.c, aty, nullptr, a.lb, a.ub, tau, 1.0, xn, a.xbar, pend_w,
+                                   pend ? a.sum_x : nullptr, w, nwg);
+    product_prefetch(a.A, f);
+#if PDHG_STEPS_PREFETCH
+    if (threadIdx.x == 0) { s_pow[0] = pw_r; s_pow[1] = pw_g; }
+#endif
+    PDHG_STAMP(1);
+    grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt, err_pref);
+    PDHG_STAMP(2);
+    // ---- phase 1: y' and sum dy^2 (+ the deferred sum_y update)
+#if PDHG_STEPS_PREFETCH
+    if (threadIdx.x == 0) err_pref = __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    {
+      EpiArgs e{};
+      e.y = y; e.b = a.b; e.y_next = yn; e.sigma = sigma; e.num_eq = a.num_eq;
+      e.partials = a.pA; e.stride = a.pA_slots; e.lo_offset = a.pA_slots;
+      if (pend) { e.sum_y = a.sum_y; e.avg_w = pend_w; }
+      product_phase<MODE_DUAL, true>(a.A, a.xbar, e, a.uses_a + (unsigned long long)trials, a.relaxed, f, prod, red);
+    }
+    pend = 0;
+    product_prefetch(a.T, f);
+    PDHG_STAMP(3);
+    grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt, err_pref);
+    PDHG_STAMP(4);
+    // ---- phase 2: A'y' and the interaction sums
+#if PDHG_STEPS_PREFETCH
+    if (threadIdx.x == 0) err_pref = __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    {
+      EpiArgs e{};
+      e.x = x; e.x_next = xn; e.aty = aty; e.aty_next = atyn;
+      e.partials = a.pAt; e.stride = a.pAt_stride; e.lo_offset = 3 * a.pAt_stride;
+      product_phase<MODE_ATY, true>(a.T, yn, e, a.uses_t + (unsigned long long)trials, a.relaxed, f, prod, red);
+    }
+    PDHG_STAMP(5);
+    // ---- third barrier; its XCD leaders reduce and decide, and the decision IS the release: three words in the
+    // XCD's control line -- {epoch, accept, numerical_error}, the next step size, a check word -- that the waiting
+    // workgroups poll (one trip instead of release word, then decision, then error word)
+    ++epoch;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s_leader = 0;
+#if !PDHG_STEPS_PREFETCH
+      err_pref = __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+      s_dec[3] = (double)err_pref;
+      if (err_pref == 0) {
+        const unsigned xcd = xcc_id();
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(a.ctl->slot[xcd]);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long cnt = a.xcd_cnt[xcd];
+        const unsigned long long prev = __hip_atomic_fetch_add(&a.sync->xcd_arrive[xcd][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        if (prev + 1 == cnt * epoch) {
+          asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_fetch_add(&a.sync->global[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while (__hip_atomic_load(&a.sync->global[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)a.nxcd * epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > GRID_SPIN_LIMIT) { __hip_atomic_store(&a.sync->error[0], 4ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dec[3] = 4.0; break; }
+          }
+          asm volatile("buffer_inv sc1" ::: "memory");
+          s_leader = 1;
+          PDHG_STAMP(7);
+        } else {
+          for (;;) {
+            const unsigned long long w0 = __hip_atomic_load(slot + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long w1 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long w2 = __hip_atomic_load(slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w0 >> 2) == epoch && (w0 ^ w1 ^ RESULT_CHECK_SALT) == w2) {
+              s_dec[0] = (double)(w0 & 1ull); s_dec[1] = (double)((w0 >> 1) & 1ull);
+              s_dec[2] = __longlong_as_double((long long)w1);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > GRID_SPIN_LIMIT) { __hip_atomic_store(&a.sync->error[0], 5ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dec[3] = 5.0; break; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (s_leader) {                                          // workgroup-uniform
+      steps_second_stage(&a.ctl->sp, s_res);
+      if (threadIdx.x == 0) {
+        double res[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) res[k] = s_res[k];
+        res[4] *= 0.5;
+#if PDHG_STEPS_PREFETCH
+        const StepRule rule = adaptive_step_rule(res, a.primal_weight, s_st[0], s_pow[0], s_pow[1]);
+#else
+        const StepRule rule = adaptive_step_rule(res, a.primal_weight, s_st[0], a.pow_red[trials], a.pow_growth[trials]);
+#endif
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(a.ctl->slot[xcc_id()]);
+        const unsigned long long w0 = (epoch << 2) | (rule.accept ? 1ull : 0ull) | (rule.numerical_error ? 2ull : 0ull);
+        const unsigned long long w1 = (unsigned long long)__double_as_longlong(rule.next_step);
+        __hip_atomic_store(slot + 0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 2, w0 ^ w1 ^ RESULT_CHECK_SALT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_dec[0] = (double)rule.accept; s_dec[1] = (double)rule.numerical_error; s_dec[2] = rule.next_step;
+      }
+    }
+    if (threadIdx.x == 0) asm volatile("s_dcache_inv" ::: "memory");
+    __syncthreads();
+    PDHG_STAMP(6);
+#undef PDHG_STAMP
+    const int bad = __builtin_amdgcn_readfirstlane((int)(s_dec[3] != 0.0));
+    const int nerr = __builtin_amdgcn_readfirstlane((int)(s_dec[1] != 0.0));
+    const int acc = __builtin_amdgcn_readfirstlane((int)(s_dec[0] != 0.0));
+    if (bad) { hw_err = 1; break; }                          // a barrier timed out: this trial does not count (the host repeats it)
+    trials += 1;
+    if (nerr) { num_err = 1; mid = 0; break; }               // movement == 0: no accept, the step size stays (pdhg.jl:692-697)
+    if (acc) { flip ^= 1; pend = 1; steps += 1; }
+    mid = !acc;
+    if (threadIdx.x == 0) {
+      const double next = s_dec[2];
+      if (acc) {
+        const double entry = s_st[1];
+        s_st[2] = entry;                                     // update_solution_in_solver_state: weight = step size on entry (pdhg.jl:512)
+        s_st[3] = s_st[3] + entry; s_st[4] = s_st[4] + entry;
+        s_st[1] = next;
+      }
+      s_st[0] = next;
+    }
+    __syncthreads();                                         // the state is read, s_dec / s_leader rewritten, in the next trial
+  }
+  if (w == 0 && threadIdx.x == 0) {
+    // results, checksum, sequence number: the host accepts a read when both match (as for the single-trial kernel)
+    unsigned long long ck = RESULT_CHECK_SALT;
+    int k = 0;
+#define PDHG_PUB(v) do { const double pv = (v); a.res_host[k] = pv; ck ^= (unsigned long long)__double_as_longlong(pv) * (2ull * k + 1ull); ++k; } while (0)
+    PDHG_PUB(s_st[0]); PDHG_PUB((double)steps); PDHG_PUB((double)trials); PDHG_PUB((double)flip); PDHG_PUB((double)pend);
+    PDHG_PUB(s_st[2]); PDHG_PUB(s_st[3]); PDHG_PUB(s_st[4]); PDHG_PUB((double)num_err); PDHG_PUB((double)hw_err);
+    PDHG_PUB((double)epoch);
+    PDHG_PUB((double)__hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    PDHG_PUB((double)a.seq);
+#undef PDHG_PUB
+    a.res_host[14] = (double)mid;
+    a.res_host[13] = __longlong_as_double((long long)ck);
+    a.res_host[15] = (double)a.seq;
+  }
 }
 
 }  // namespace
