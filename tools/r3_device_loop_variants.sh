@@ -1,4 +1,5 @@
 #!/bin/bash
+# variants: libpdhg_{A,B,C,D}.so built with -DPDHG_STEPS_NOINLINE={0,0,1,1} -DPDHG_STEPS_PREFETCH={1,0,1,0} into firstorderlp.jl_amd/csrc/variants/ (git-ignored)
 cd "$GRAFT_REPO_ROOT"
 run() { python bench.py "${@:2}" --steps 4000 --warmup 300 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
 for v in A B C D; do
