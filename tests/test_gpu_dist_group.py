@@ -366,3 +366,26 @@ def test_rccl_binding_is_reported_and_version_checked(gpu_required):
     assert info["path"].endswith(".so") or ".so." in info["path"], info
     assert info["runtime_version"] // 10000 == info["compiled_version"] // 10000 == 2, info
     print("RCCL bound at run time:", info)
+
+
+def test_batched_take_steps_on_a_shard_group(gpu_required):
+    """pdhg_take_steps_adaptive on a 2-shard group (peer back end on one GPU): n steps in one call == n single calls."""
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (AdaptiveStepsizeParams, PdhgSolverState, take_step,
+                                                                 take_steps)
+    p = random_lp(3000, 2500, 6, seed=13)
+    policy = AdaptiveStepsizeParams(0.3, 0.6)
+    step, pw = H.initial_step_and_weight(p)
+    outs = []
+    for batched in (False, True):
+        eng = HipPdhgEngine.from_problem(p, device_ids=[0, 0])
+        st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+        if batched:
+            assert take_steps(policy, st, 40) == 40
+        else:
+            for _ in range(40):
+                take_step(policy, st)
+        outs.append((np.concatenate(eng.get_current()), np.concatenate(eng.get_average()), st.step_size,
+                     st.total_number_iterations, st.cumulative_kkt_passes))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2:] == outs[1][2:]
