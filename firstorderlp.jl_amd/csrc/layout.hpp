@@ -506,6 +506,17 @@ void make_row_blocks(int rows, const std::vector<int> &slab_rowptr, const std::v
   }
 }
 
+// First column of slab p of P (p = P: one past the last column).  Equal widths; PDHG_SLAB_SPLIT=f (dev knob, P = 2):
+// the first slab takes the fraction f of the columns.
+inline int slab_first_col(int cols, int P, int p) {
+  if (p >= P) return cols;
+  const int width = (cols + P - 1) / P;
+  if (P == 2 && p == 1) {
+    if (const char *f = getenv("PDHG_SLAB_SPLIT")) return std::max(16, std::min(cols - 16, (int)(atof(f) * cols) / 16 * 16));
+  }
+  return std::min(cols, p * width);
+}
+
 // Column-slab copies for the stream layout (see spmv_stream_kernel).  Used when the
 // gathered vector is 1.25 .. 4 slabs long (slab = PDHG_SLAB_MB MiB, default 4 = one XCD's
 // L2); beyond that the tiled sweep is the tool.  PDHG_SLABS=0 disables.
@@ -522,7 +533,7 @@ int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, c
   const int width = (cols + P - 1) / P;
   int rc;
   for (int p = 0; p < P; ++p) {
-    const int c0 = p * width, c1 = std::min(cols, (p + 1) * width);
+    const int c0 = slab_first_col(cols, P, p), c1 = slab_first_col(cols, P, p + 1);
     std::vector<int> rp((size_t)rows + 1, 0);
     for (int r = 0; r < rows; ++r) {
       int cnt = 0;
@@ -565,7 +576,7 @@ int build_slabs_device(CsrDev &D, int rows, int cols, const std::vector<int> &ro
   const int grid = (int)std::min<int64_t>(((int64_t)rows + 1 + TPB - 1) / TPB, 1 << 16);
   int rc;
   for (int p = 0; p < P; ++p) {
-    const int c0 = p * width, c1 = std::min(cols, (p + 1) * width);
+    const int c0 = slab_first_col(cols, P, p), c1 = slab_first_col(cols, P, p + 1);
     SlabDev S;
     HIP_TRY(hipMalloc((void **)&S.rowptr, sizeof(int) * ((size_t)rows + 1)));
     hipLaunchKernelGGL(slab_count_kernel, dim3(grid), dim3(TPB), 0, nullptr, rows, D.rowptr, D.col, c0, c1, BLOCK_NNZ, S.rowptr);
