@@ -163,3 +163,38 @@ def test_cached_point_products_match_recomputation(gpu_required):
         if phase == 2:
             a.restart_to_average(); b.restart_to_average()
             a.reset_average(); b.reset_average()
+
+
+def test_trust_region_search_branches_match_host(gpu_required):
+    """Every exit of the breakpoint search -- no finite breakpoint at all, every finite breakpoint inside the ball
+    (0 probe passes: the set-up pass's own sums), the bracket collapsing at t = 0, and the ordinary closed form --
+    against the host implementation (the reference's median elimination restated in numpy), over six decades of radius.
+    The value sums ride on the probes (sum g d min(t, thr)), the host clamps: same numbers to rounding."""
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd import linear_programming_problem
+    rng = np.random.default_rng(5)
+    base = random_lp(600, 800, 6, 4)
+    n, m = base.num_variables, base.num_constraints
+    free = linear_programming_problem(np.full(n, -np.inf), np.full(n, np.inf), base.objective_vector, 0.0,
+                                      base.constraint_matrix, base.right_hand_side, m)       # all equalities, free variables
+    boxed = linear_programming_problem(np.zeros(n), np.full(n, 0.5), base.objective_vector, 0.0,
+                                       base.constraint_matrix, base.right_hand_side, 0)       # every direction meets a bound
+    seen = set()
+    for p in (free, boxed, base):
+        eng, ev_h, ev_d, st = _setup(p, ruiz=0, alpha=None, steps=25)
+        wp = st.primal_weight / st.step_size
+        wd = 1.0 / st.step_size / st.primal_weight
+        for point in (POINT_CURRENT, POINT_AVERAGE):
+            for rad in (1e-9, 1e-4, 1e-2, 1.0, 1e2, 1e5):
+                for rng_ in (0, 1, 2):
+                    raw = eng.trust_region_bound(point, wp, wd, rad, rng_, False)
+                    seen.add((p is free, int(raw[6]) == 0, raw[5] > 0.0))
+                for norm in (EUCLIDEAN_NORM, MAX_NORM):
+                    gh = ev_h.bound(point, wp, wd, rad, norm, False)
+                    gd = ev_d.bound(point, wp, wd, rad, norm, False)
+                    sc = abs(gh.lagrangian_value) + abs(gh.upper_bound_value - gh.lower_bound_value) + 1e-9
+                    _close(gh.lower_bound_value, gd.lower_bound_value, rel=1e-9, scale=sc)
+                    _close(gh.upper_bound_value, gd.upper_bound_value, rel=1e-9, scale=sc)
+        eng.close()
+    # both kinds of exit were taken: with and without probe passes
+    assert any(zero_passes for _, zero_passes, _ in seen) and any(not zero_passes for _, zero_passes, _ in seen)
