@@ -382,8 +382,10 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         "kernels": kernels,
         "layout": {k: v for k, v in eng.layout_info().items() if "tiled" in k or "tile_cols" in k or "slab" in k or "graph" in k},
         "layout_products": [eng.kernel_name(_lib.K_SPMV_DUAL), eng.kernel_name(_lib.K_SPMV_ATY)],
-        "launch_path": {2: "one persistent kernel per trial (trial_kernel)", 1: "one HIP-graph launch per trial",
-                        0: "separate launches"}.get(eng.layout_info().get("trial_graph"), "?"),
+        "launch_path": ("one workgroup for the whole batch of steps, vectors in LDS (small_lp_steps_kernel)"
+                        if eng.layout_info().get("small_lp") and not args.per_step_calls else
+                        {2: "one persistent kernel per trial (trial_kernel)", 1: "one HIP-graph launch per trial",
+                         0: "separate launches"}.get(eng.layout_info().get("trial_graph"), "?")),
         "host_calls": "one per take_step (pdhg_take_step_adaptive)" if args.per_step_calls
                       else "one for the K steps (pdhg_take_steps_adaptive, as optimize() issues them between evaluations)",
         "setup_sec": {"generate": round(t_gen, 1), "create_upload": round(t_create, 1)},

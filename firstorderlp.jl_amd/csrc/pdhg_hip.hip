@@ -45,6 +45,7 @@
 #include "device_layout.hpp"
 #include "layout.hpp"
 #include "trial_kernel.hpp"
+#include "small_lp_kernel.hpp"
 
 namespace { struct DistGroup; }
 
@@ -168,6 +169,8 @@ struct pdhg_handle {
   int steps_pow_cap = 0;
   unsigned long long steps_seq = 0;
   int64_t steps_launches = 0, steps_trials = 0;
+  int small_lp_mode = -1;                   // -1 undecided, 0 off, 1: small_lp_steps_kernel takes the batches of steps
+  int64_t small_lp_launches = 0;
   double res_error = 0.0;                   // error word of the last checked result read
   // host-side breakdown of graph trials (PDHG_VERBOSE): seconds in node updates, in hipGraphLaunch, waiting
   double t_set = 0.0, t_launch = 0.0, t_wait = 0.0;
@@ -815,6 +818,118 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
                     "persistent kernel?) -- this handle uses the %s path from here on\n", r[11],
             graph_eligible(h) ? "graph" : "separate-launch");
   }
+  return 0;
+}
+
+// ---- small LPs: a batch of take_steps in one workgroup, vectors in LDS (small_lp_kernel.hpp) ---------------------
+int flush_pending(const Shards &L);
+bool small_lp_eligible(pdhg_handle *h) {
+  if (h->small_lp_mode < 0) {
+    const char *ev = getenv("PDHG_SMALL_LP");
+    const size_t lds = sizeof(double) * (9 * (size_t)h->n + 4 * (size_t)h->m);
+    bool on = !h->grp && !h->has_q && h->n > 0 && h->m > 0 && !h->A.tiled && !h->At.tiled && h->A.slabs.empty() &&
+              h->At.slabs.empty() && h->A.max_row_nnz <= SMALL_MAX_ROW && h->At.max_row_nnz <= SMALL_MAX_ROW &&
+              lds <= (size_t)144 * 1024;
+    if (ev) on = on && ev[0] != '0';
+    h->small_lp_mode = on ? 1 : 0;
+  }
+  return h->small_lp_mode == 1 && !h->profile;
+}
+
+// returns 1 when not eligible (nothing launched)
+int small_lp_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, double growth_exponent, double *step_size_io,
+                   double primal_weight, int64_t *total_number_iterations_io, double *cumulative_kkt_passes_io,
+                   int *numerical_error_out, int64_t *steps_done) {
+  *steps_done = 0;
+  if (!small_lp_eligible(h)) return 1;
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if (h->pend_x != h->pend_y) { Shards L = shards_of(h); if ((rc = flush_pending(L))) return rc; }
+  const int n = (int)std::min<int64_t>(n_steps, 1 << 20);
+  const int max_trials = 2 * n + 64, table_len = max_trials + 256;
+  if (!h->steps_res) {
+    HIP_TRY(hipHostMalloc((void **)&h->steps_res, STEPS_RES_WORDS * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(h->steps_res, 0, STEPS_RES_WORDS * sizeof(double));
+  }
+  if (h->steps_pow_cap < table_len) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->steps_pow_dev) (void)hipFree(h->steps_pow_dev);
+    if (h->steps_pow_host) (void)hipHostFree(h->steps_pow_host);
+    h->steps_pow_dev = h->steps_pow_host = nullptr;
+    h->steps_pow_cap = std::max(table_len, 512);
+    HIP_TRY(hipMalloc((void **)&h->steps_pow_dev, sizeof(double) * 2 * (size_t)h->steps_pow_cap));
+    HIP_TRY(hipHostMalloc((void **)&h->steps_pow_host, sizeof(double) * 2 * (size_t)h->steps_pow_cap + sizeof(FinalSpec) + 64, hipHostMallocDefault));
+  }
+  const size_t lds = sizeof(double) * (9 * (size_t)h->n + 4 * (size_t)h->m);
+  {
+    static size_t limit[64] = {};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &cur = limit[h->device & 63];
+    if (cur < lds) {
+      HIP_TRY(hipFuncSetAttribute((const void *)small_lp_steps_kernel<SMALL_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute((const void *)small_lp_steps_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      cur = lds;
+    }
+  }
+  for (int t = 0; t < table_len; ++t) {
+    const double k1 = (double)(*total_number_iterations_io + t + 2);
+    h->steps_pow_host[t] = pow(k1, -reduction_exponent);
+    h->steps_pow_host[table_len + t] = pow(k1, -growth_exponent);
+  }
+  HIP_TRY(hipMemcpyAsync(h->steps_pow_dev, h->steps_pow_host, sizeof(double) * 2 * (size_t)table_len, hipMemcpyHostToDevice, h->stream));
+  SmallLpArgs a{};
+  a.n = (int)h->n; a.m = (int)h->m; a.num_eq = (int)h->num_eq;
+  a.A = h->A.view(); a.T = h->At.view();
+  a.x = h->x; a.y = h->y; a.aty = h->aty; a.sum_x = h->sum_x; a.sum_y = h->sum_y;
+  a.c = h->c; a.lb = h->lb; a.ub = h->ub; a.b = h->b;
+  a.primal_weight = primal_weight; a.step_size = *step_size_io;
+  a.n_steps = n; a.max_trials = max_trials; a.table_len = table_len;
+  a.pend = h->pend_x ? 1 : 0; a.pend_w = h->pend_w;
+  a.wsum_x = h->sum_x_weights; a.wsum_y = h->sum_y_weights;
+  a.pow_red = h->steps_pow_dev; a.pow_growth = h->steps_pow_dev + table_len;
+  a.res_host = h->steps_res;
+  a.seq = ++h->steps_seq;
+  h->pend_x = h->pend_y = false;             // the launch applies it
+  const auto c1 = std::chrono::steady_clock::now();
+  static const int few_env = getenv("PDHG_SMALL_FEW_ROWS") ? atoi(getenv("PDHG_SMALL_FEW_ROWS")) : SMALL_FEW_ROWS;   // dev knob
+  if (std::max(h->n, h->m) <= few_env) hipLaunchKernelGGL(small_lp_steps_kernel<256>, dim3(1), dim3(256), lds, h->stream, a);
+  else hipLaunchKernelGGL(small_lp_steps_kernel<SMALL_TPB>, dim3(1), dim3(SMALL_TPB), lds, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  const auto c2 = std::chrono::steady_clock::now();
+  h->t_launch += std::chrono::duration<double>(c2 - c1).count();
+  const volatile unsigned long long *bits = reinterpret_cast<const volatile unsigned long long *>(h->steps_res);
+  double r[13];
+  auto ready = [&]() -> bool {
+    if (h->steps_res[15] != (double)a.seq) return false;
+    unsigned long long w[13], ck = RESULT_CHECK_SALT;
+    for (int k = 0; k < 13; ++k) { w[k] = bits[k]; ck ^= w[k] * (2ull * (unsigned long long)k + 1ull); }
+    if (ck != bits[13]) return false;
+    for (int k = 0; k < 13; ++k) memcpy(&r[k], &w[k], 8);
+    return r[12] == (double)a.seq;
+  };
+  bool seen = false;
+  for (long spin = 0; spin < 400000000L; ++spin) {
+    if (ready()) { seen = true; break; }
+    if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+  }
+  if (!seen) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!ready()) return fail(998, "small-LP kernel finished without publishing its results");
+  }
+  h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
+  const int64_t steps = (int64_t)r[1], trials = (int64_t)r[2];
+  h->small_lp_launches += 1; h->n_graph_trials += trials;
+  h->sum_x_count += steps; h->sum_y_count += steps;
+  h->sum_x_weights = r[6]; h->sum_y_weights = r[7];
+  h->state_version += 1;
+  *step_size_io = r[0];
+  *total_number_iterations_io += trials;
+  *cumulative_kkt_passes_io += (double)trials;
+  *steps_done = steps;
+  if (h->steps_res[14] != 0.0)
+    return fail(995, "small-LP kernel: more than 256 consecutive rejected trials inside one take_step");
+  if (r[8] != 0.0) { *numerical_error_out = 1; *steps_done = steps + 1; }
   return 0;
 }
 
@@ -2046,6 +2161,7 @@ int pdhg_set_objective_matrix(pdhg_handle *h0, int64_t q_nnz, const int64_t *q_c
     if (h->coop_trace) { (void)hipFree(h->coop_trace); h->coop_trace = nullptr; }
     h->coop_mode = -1; h->coop_launches = 0; h->coop_epoch = 0;
     h->graph_mode = -1;
+    h->small_lp_mode = -1;
     graph_destroy(h->tgraph[0]); graph_destroy(h->tgraph[1]);
     if (h->has_q) { free_csr_dev(h->Q); free_csr_dev(h->Qt); h->has_q = false; }
     if (all_zero) continue;  // iszero(objective_matrix): LP path (pdhg.jl:536)
@@ -2379,6 +2495,19 @@ int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_e
   const bool device_loop = dl_env && dl_env[0] == '1';
   int64_t s = 0;
   while (s < n_steps) {
+    if (n_steps - s >= 2 && !h->grp && check_handle(h) == 0 && small_lp_eligible(h)) {
+      // a small LP: the batch in one workgroup with the vectors in LDS (small_lp_kernel.hpp)
+      int64_t k = 0;
+      const int rc = small_lp_steps(h, n_steps - s, reduction_exponent, growth_exponent, step_size_io, primal_weight,
+                                    total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out, &k);
+      if (rc != 0 && rc != 1) return rc;
+      if (rc == 0) {
+        s += k;
+        *steps_done_out = s;
+        if (*numerical_error_out) break;
+        if (k > 0) continue;
+      }
+    }
     if (device_loop && n_steps - s >= 2 && !h->grp && !h->profile && check_handle(h) == 0) {
       int64_t k = 0;
       const int rc = coop_steps(h, n_steps - s, reduction_exponent, growth_exponent, step_size_io, primal_weight,
@@ -3294,7 +3423,7 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   info[12] = (int64_t)h->A.slabs.size(); info[13] = (int64_t)h->At.slabs.size();
   // 2: one persistent kernel per trial (trial_kernel.hpp), 1: one graph launch, 0: separate launches
   info[14] = (coop_eligible(h) || h->coop_mode == 1) ? 2 : ((graph_eligible(h) || (h->graph_mode == 1 && !h->has_q)) ? 1 : 0);
-  info[15] = (h->A.tiled && h->A.var_tiles ? 1 : 0) + (h->At.tiled && h->At.var_tiles ? 2 : 0);
+  info[15] = (h->A.tiled && h->A.var_tiles ? 1 : 0) + (h->At.tiled && h->At.var_tiles ? 2 : 0) + (small_lp_eligible(h) ? 4 : 0);
   info[0] = h->A.nblk; info[1] = h->A.nlong; info[2] = h->A.nchunks; info[3] = h->A.max_row_nnz;
   info[4] = h->At.nblk; info[5] = h->At.nlong; info[6] = h->At.nchunks; info[7] = h->At.max_row_nnz;
   info[8] = h->A.tiled ? h->A.nwaves : 0; info[9] = h->At.tiled ? h->At.nwaves : 0;

@@ -365,7 +365,9 @@ const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id);
  * profiling), 0 separate launches.  A handle leaves 2 for good when a grid barrier of
  * the persistent kernel times out (device shared with another persistent kernel): that
  * trial is repeated on the other path, with a line on stderr, [15] bit 0 / bit 1: A / A' use
- * equal-nonzero tiles of different widths (skewed columns; [10],[11] are then nominal). */
+ * equal-nonzero tiles of different widths (skewed columns; [10],[11] are then nominal); bit 2:
+ * a small LP -- pdhg_take_steps_adaptive takes its batches in one workgroup with the vectors in
+ * LDS (csrc/small_lp_kernel.hpp; pdhg_trial_step itself is launched as [14] says). */
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]);
 /* Diagnostics: order-sensitive 64-bit checksums of every device array of the two layouts
  * (out[0..16) CSR(A): row pointers, columns, values, row blocks, the four long-row tables, the

@@ -17,6 +17,7 @@ POLICY = AdaptiveStepsizeParams(0.3, 0.6)
 
 def _run(p, batches, monkeypatch, device_loop, relaxed=False):
     monkeypatch.setenv("PDHG_DEVICE_LOOP", "1" if device_loop else "0")
+    monkeypatch.setenv("PDHG_SMALL_LP", "0")              # (small LPs would otherwise take their batches in the LDS kernel)
     monkeypatch.setenv("PDHG_ROW_ORDER", "relaxed" if relaxed else "strict")
     eng = HipPdhgEngine.from_problem(p)
     assert eng.layout_info()["trial_graph"] == 2          # the persistent-kernel path is the one in use
@@ -84,6 +85,7 @@ def test_device_loop_in_relaxed_order_and_through_optimize(gpu_required, monkeyp
                                       1000, 0.5, 0.1, 0.9, 0.5, False)
     params = PdhgParameters(10, False, 1.0, 1.0, True, 0, True, 40, tc, rp, AdaptiveStepsizeParams(0.3, 0.6))
     outs = []
+    monkeypatch.setenv("PDHG_SMALL_LP", "0")
     for loop in ("0", "1"):
         monkeypatch.setenv("PDHG_DEVICE_LOOP", loop)
         o = optimize(params, q)
