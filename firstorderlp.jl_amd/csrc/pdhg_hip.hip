@@ -701,14 +701,19 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
 // caller goes on from the state left).  Returns 1 when nothing could be launched (not eligible).
 int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, double growth_exponent, double *step_size_io,
                double primal_weight, int64_t *total_number_iterations_io, double *cumulative_kkt_passes_io,
-               int *numerical_error_out, int64_t *steps_done) {
+               int *numerical_error_out, int64_t *steps_done, double *unfinished_entry) {
   *steps_done = 0;
+  *unfinished_entry = 0.0;
   if (!coop_eligible(h) || h->has_q || !h->lazy_accept || h->pend_x != h->pend_y) return 1;
   int rc = coop_prepare(h);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(h->device));
   const int n = (int)std::min<int64_t>(n_steps, 1 << 20);
-  const int max_trials = 2 * n + 64, table_len = max_trials + 256;
+  // trial budget: the steps asked for plus room for rejections (a launch that runs out returns at a take_step boundary and
+  // the caller launches again); 64 more table entries for finishing the take_step the budget ends in.  The table costs
+  // two pow() per entry on the host: sized to the batch, not to the worst case
+  int max_trials = n + n / 8 + 16, table_len = max_trials + 64;
+  if (const char *tv = getenv("PDHG_STEPS_TEST_TABLE")) max_trials = table_len = std::max(1, atoi(tv));   // test knob: launches end inside take_steps
   if (!h->steps_ctl) {
     HIP_TRY(hipMalloc((void **)&h->steps_ctl, sizeof(StepsCtl)));
     HIP_TRY(hipMemsetAsync(h->steps_ctl, 0, sizeof(StepsCtl), h->stream));
@@ -808,8 +813,7 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   *total_number_iterations_io += trials;
   *cumulative_kkt_passes_io += (double)trials;
   *steps_done = steps;
-  if (h->steps_res[14] != 0.0 && !aborted)
-    return fail(995, "multi-step trial kernel: more than 256 consecutive rejected trials inside one take_step");
+  *unfinished_entry = (h->steps_res[14] != 0.0 && !aborted) ? h->steps_res[14] : 0.0;
   if (r[8] != 0.0) { *numerical_error_out = 1; *steps_done = steps + 1; }   // the failing take_step counts as taken (it is not repeated)
   if (aborted) {
     h->coop_mode = 0;
@@ -839,14 +843,19 @@ bool small_lp_eligible(pdhg_handle *h) {
 // returns 1 when not eligible (nothing launched)
 int small_lp_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, double growth_exponent, double *step_size_io,
                    double primal_weight, int64_t *total_number_iterations_io, double *cumulative_kkt_passes_io,
-                   int *numerical_error_out, int64_t *steps_done) {
+                   int *numerical_error_out, int64_t *steps_done, double *unfinished_entry) {
   *steps_done = 0;
+  *unfinished_entry = 0.0;
   if (!small_lp_eligible(h)) return 1;
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if (h->pend_x != h->pend_y) { Shards L = shards_of(h); if ((rc = flush_pending(L))) return rc; }
   const int n = (int)std::min<int64_t>(n_steps, 1 << 20);
-  const int max_trials = 2 * n + 64, table_len = max_trials + 256;
+  // trial budget: the steps asked for plus room for rejections (a launch that runs out returns at a take_step boundary and
+  // the caller launches again); 64 more table entries for finishing the take_step the budget ends in.  The table costs
+  // two pow() per entry on the host: sized to the batch, not to the worst case
+  int max_trials = n + n / 8 + 16, table_len = max_trials + 64;
+  if (const char *tv = getenv("PDHG_STEPS_TEST_TABLE")) max_trials = table_len = std::max(1, atoi(tv));   // test knob: launches end inside take_steps
   if (!h->steps_res) {
     HIP_TRY(hipHostMalloc((void **)&h->steps_res, STEPS_RES_WORDS * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     memset(h->steps_res, 0, STEPS_RES_WORDS * sizeof(double));
@@ -927,8 +936,7 @@ int small_lp_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, d
   *total_number_iterations_io += trials;
   *cumulative_kkt_passes_io += (double)trials;
   *steps_done = steps;
-  if (h->steps_res[14] != 0.0)
-    return fail(995, "small-LP kernel: more than 256 consecutive rejected trials inside one take_step");
+  *unfinished_entry = h->steps_res[14];
   if (r[8] != 0.0) { *numerical_error_out = 1; *steps_done = steps + 1; }
   return 0;
 }
@@ -2445,13 +2453,25 @@ int pdhg_accept(pdhg_handle *h0, double avg_weight) {
  * statements as primal_dual_hybrid_gradient.py::take_step_adaptive (bitwise equal
  * results; tests/test_gpu_native_take_step.py); what it removes is the host
  * language's per-call overhead between the trial and the accept. */
+// step_on_entry: the step size the take_step was entered with (the average's weight, pdhg.jl:512) -- equal to
+// *step_size_io except when a multi-step kernel handed back a take_step it had begun (some trials already rejected)
+static int take_step_adaptive_from(pdhg_handle *h, double reduction_exponent, double growth_exponent,
+                                   double *step_size_io, double step_on_entry, double primal_weight,
+                                   int64_t *total_number_iterations_io, double *cumulative_kkt_passes_io,
+                                   int *numerical_error_out);
 int pdhg_take_step_adaptive(pdhg_handle *h, double reduction_exponent, double growth_exponent,
                             double *step_size_io, double primal_weight, int64_t *total_number_iterations_io,
                             double *cumulative_kkt_passes_io, int *numerical_error_out) {
   if (!h || !step_size_io || !total_number_iterations_io || !cumulative_kkt_passes_io || !numerical_error_out)
     return fail(-1, "null argument");
-  const double step_on_entry = *step_size_io;
-  double step_size = step_on_entry;
+  return take_step_adaptive_from(h, reduction_exponent, growth_exponent, step_size_io, *step_size_io, primal_weight,
+                                 total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out);
+}
+static int take_step_adaptive_from(pdhg_handle *h, double reduction_exponent, double growth_exponent,
+                                   double *step_size_io, double step_on_entry, double primal_weight,
+                                   int64_t *total_number_iterations_io, double *cumulative_kkt_passes_io,
+                                   int *numerical_error_out) {
+  double step_size = *step_size_io;
   *numerical_error_out = 0;
   bool done = false;
   while (!done) {
@@ -2495,32 +2515,36 @@ int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_e
   const bool device_loop = dl_env && dl_env[0] == '1';
   int64_t s = 0;
   while (s < n_steps) {
+    double entry = 0.0;         // nonzero: a multi-step kernel ended inside a take_step (its table of powers ran out)
     if (n_steps - s >= 2 && !h->grp && check_handle(h) == 0 && small_lp_eligible(h)) {
       // a small LP: the batch in one workgroup with the vectors in LDS (small_lp_kernel.hpp)
       int64_t k = 0;
       const int rc = small_lp_steps(h, n_steps - s, reduction_exponent, growth_exponent, step_size_io, primal_weight,
-                                    total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out, &k);
+                                    total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out, &k, &entry);
       if (rc != 0 && rc != 1) return rc;
       if (rc == 0) {
         s += k;
         *steps_done_out = s;
         if (*numerical_error_out) break;
-        if (k > 0) continue;
+        if (k > 0 && entry == 0.0) continue;
       }
     }
     if (device_loop && n_steps - s >= 2 && !h->grp && !h->profile && check_handle(h) == 0) {
       int64_t k = 0;
       const int rc = coop_steps(h, n_steps - s, reduction_exponent, growth_exponent, step_size_io, primal_weight,
-                                total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out, &k);
+                                total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out, &k, &entry);
       if (rc != 0 && rc != 1) return rc;
       if (rc == 0) {
         s += k;
         *steps_done_out = s;
         if (*numerical_error_out) break;
-        if (k > 0) continue;           // (k == 0: trial budget spent on rejections, or a time-out: take the next step singly)
+        if (k > 0 && entry == 0.0) continue;   // (k == 0: trial budget spent on rejections, or a time-out: take the next step singly)
       }
     }
-    const int rc = pdhg_take_step_adaptive(h, reduction_exponent, growth_exponent, step_size_io, primal_weight,
+    if (s >= n_steps) break;
+    // one take_step, launch by launch -- or the rest of one that a multi-step kernel began (entry: its step size on entry)
+    const int rc = take_step_adaptive_from(h, reduction_exponent, growth_exponent, step_size_io,
+                                           entry != 0.0 ? entry : *step_size_io, primal_weight,
                                            total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out);
     if (rc) return rc;
     *steps_done_out = ++s;

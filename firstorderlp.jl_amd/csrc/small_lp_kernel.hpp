@@ -167,7 +167,7 @@ __global__ __launch_bounds__(THREADS) void small_lp_steps_kernel(SmallLpArgs a) 
     PDHG_PUB((double)a.seq);
 #undef PDHG_PUB
     a.res_host[13] = __longlong_as_double((long long)ck);
-    a.res_host[14] = (double)mid;
+    a.res_host[14] = mid ? s_st[1] : 0.0;     // ended inside a take_step (table exhausted): its step size on entry, for the host to finish it
     a.res_host[15] = (double)a.seq;
   }
 }

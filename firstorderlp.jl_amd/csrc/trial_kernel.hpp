@@ -392,7 +392,7 @@ struct StepsKernelArgs {
 
 // result words: [0] step size, [1] steps taken, [2] trials, [3] flip, [4] pending average update, [5] its weight,
 // [6] / [7] weight sums, [8] numerical_error, [9] aborted on a barrier time-out, [10] barrier epoch, [11] the barriers'
-// error word, [12] sequence number; [13] checksum over [0..12]; [14] ended inside a take_step (table exhausted);
+// error word, [12] sequence number; [13] checksum over [0..12]; [14] nonzero: ended inside a take_step (table exhausted) whose step size on entry this is;
 // [15] sequence number again (what the host polls)
 constexpr int STEPS_RES_WORDS = 16;
 
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
     PDHG_PUB((double)__hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     PDHG_PUB((double)a.seq);
 #undef PDHG_PUB
-    a.res_host[14] = (double)mid;
+    a.res_host[14] = mid ? s_st[1] : 0.0;     // ended inside a take_step (table exhausted): its step size on entry, for the host to finish it
     a.res_host[13] = __longlong_as_double((long long)ck);
     a.res_host[15] = (double)a.seq;
   }

@@ -15,14 +15,14 @@ pytestmark = pytest.mark.gpu
 POLICY = AdaptiveStepsizeParams(0.3, 0.6)
 
 
-def _run(p, batches, monkeypatch, device_loop, relaxed=False):
+def _run(p, batches, monkeypatch, device_loop, relaxed=False, step_scale=1.0):
     monkeypatch.setenv("PDHG_DEVICE_LOOP", "1" if device_loop else "0")
     monkeypatch.setenv("PDHG_SMALL_LP", "0")              # (small LPs would otherwise take their batches in the LDS kernel)
     monkeypatch.setenv("PDHG_ROW_ORDER", "relaxed" if relaxed else "strict")
     eng = HipPdhgEngine.from_problem(p)
     assert eng.layout_info()["trial_graph"] == 2          # the persistent-kernel path is the one in use
     step, pw = H.initial_step_and_weight(p)
-    st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    st = PdhgSolverState(eng, step_size=step * step_scale, primal_weight=pw)
     sizes = []
     for k in batches:
         done = take_steps(POLICY, st, k)
@@ -52,6 +52,17 @@ def test_device_loop_is_bitwise_the_per_trial_launches(gpu_required, monkeypatch
     got = _run(p, batches, monkeypatch, device_loop=True)
     for k, (a, b) in enumerate(zip(ref, got)):
         assert np.array_equal(a, b), k
+
+
+def test_device_loop_hands_an_unfinished_take_step_back(gpu_required, monkeypatch):
+    """A table of 3 powers per launch: launches end inside take_steps all the time; the host finishes them."""
+    p = random_lp(5000, 4000, 8, seed=7)
+    ref = _run(p, [40, 40], monkeypatch, device_loop=False, step_scale=300.0)    # far too long a first step: rejections
+    monkeypatch.setenv("PDHG_STEPS_TEST_TABLE", "3")
+    got = _run(p, [40, 40], monkeypatch, device_loop=True, step_scale=300.0)
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(a, b), k
+    assert got[6] > 80
 
 
 def test_device_loop_matches_the_oracle_in_exact_sums_mode(gpu_required, monkeypatch):

@@ -15,12 +15,12 @@ pytestmark = pytest.mark.gpu
 POLICY = AdaptiveStepsizeParams(0.3, 0.6)
 
 
-def _run(p, batches, monkeypatch, small, relaxed=False, mix=False):
+def _run(p, batches, monkeypatch, small, relaxed=False, mix=False, step_scale=1.0):
     monkeypatch.setenv("PDHG_SMALL_LP", "1" if small else "0")
     monkeypatch.setenv("PDHG_ROW_ORDER", "relaxed" if relaxed else "strict")
     eng = HipPdhgEngine.from_problem(p)
     step, pw = H.initial_step_and_weight(p)
-    st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    st = PdhgSolverState(eng, step_size=step * step_scale, primal_weight=pw)
     sizes = []
     for i, k in enumerate(batches):
         if mix and i % 2 == 1:
@@ -61,6 +61,19 @@ def test_small_lp_batches_are_bitwise_the_per_trial_launches(gpu_required, monke
     relaxed_got = _run(p, batches, monkeypatch, small=True, relaxed=True)
     for k, (a, b) in enumerate(zip(relaxed_ref, relaxed_got)):
         assert np.array_equal(a, b), ("relaxed", k)
+
+
+def test_a_launch_that_ends_inside_a_take_step_is_finished_by_the_host(gpu_required, monkeypatch):
+    """The table of powers bounds the trials of a launch; when it runs out after a rejected trial the kernel hands the
+    unfinished take_step back (its step size on entry rides in the result words) and the host finishes it launch by
+    launch.  With a table of 3 entries that happens all the time: same trajectory."""
+    p = random_lp(300, 250, 5, seed=2)
+    ref = _run(p, [40, 40, 40], monkeypatch, small=False, step_scale=300.0)     # far too long a first step: rejections
+    monkeypatch.setenv("PDHG_STEPS_TEST_TABLE", "3")
+    got = _run(p, [40, 40, 40], monkeypatch, small=True, step_scale=300.0)
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(a, b), k
+    assert got[6] > 120                      # there were rejected trials, i.e. launches that ended inside a take_step
 
 
 def test_small_lp_matches_the_oracle_in_exact_sums_mode(gpu_required, monkeypatch):
