@@ -278,4 +278,252 @@ __global__ __launch_bounds__(TPB) void tr_probe_kernel(int n, int total, const d
   block_reduce_store<TR_Q * TR_K, 0>(a, partials, stride);
 }
 
+
+// ---- the breakpoint search as a state machine, ONE definition for the host loop (pdhg_trust_region_bound: a probe
+// pass is a kernel + a reduction) and for the one-workgroup kernel of small problems (tr_small_kernel: a probe pass is
+// a loop between two __syncthreads).
+//   tr_search_begin(set-up sums)  ->  while (tr_search_next(probes)) { sums of the probes; tr_search_feed(sums); }
+//   then tstar and `at` (the sums t* is computed from) are final:  value(t*) = at.v[0] + t* at.v[1] (primal), v[2], v[3] (dual)
+struct TrEnd { double low, high, v[4]; };     // v: vlow primal, vhigh primal, vlow dual, vhigh dual
+struct TrSearch {
+  double r2, tstar;
+  unsigned long long lo, hi, pb[TR_K];
+  TrEnd lo_end, at;
+  int have_lo, q0, zero_probe, done, passes;
+};
+__host__ __device__ inline unsigned long long tr_d2bits(double v) { unsigned long long b; memcpy(&b, &v, 8); return b; }
+__host__ __device__ inline double tr_bits2d(unsigned long long b) { double v; memcpy(&v, &b, 8); return v; }
+__host__ __device__ inline TrEnd tr_end_of(const double *p6) { return TrEnd{p6[0], p6[1], {p6[2], p6[3], p6[4], p6[5]}}; }
+// floor(span * num / den) for 1 <= num < den <= 8 without 128-bit division (the device has none)
+__host__ __device__ inline unsigned long long tr_mul_div(unsigned long long span, unsigned num, unsigned den) {
+  const unsigned long long lo32 = span & 0xFFFFFFFFull, hi32 = span >> 32;
+  const unsigned long long p0 = lo32 * num, p1 = hi32 * num + (p0 >> 32);      // span * num = p1 * 2^32 + (p0 & mask): < 2^67
+  const unsigned long long q1 = p1 / den, r1 = p1 % den;
+  const unsigned long long t0 = (r1 << 32) | (p0 & 0xFFFFFFFFull);
+  return (q1 << 32) + t0 / den;                                                 // < span: fits
+}
+__host__ __device__ inline void tr_search_finish(TrSearch &S) {
+  S.tstar = S.lo_end.high > 0.0 ? sqrt(fmax(S.r2 - S.lo_end.low, 0.0) / S.lo_end.high) : tr_bits2d(S.lo);
+  S.at = S.lo_end;
+  S.done = 1;
+}
+// at_tmax: the sums of the probe at t = tmax (every finite breakpoint passed), which the set-up pass produces itself
+__host__ __device__ inline void tr_search_begin(TrSearch &S, double r2, double tmax, double hinf, const TrEnd &at_tmax) {
+  S.r2 = r2; S.passes = 0; S.done = 0; S.have_lo = 0; S.zero_probe = 0; S.q0 = 0; S.tstar = 0.0;
+  S.lo_end = TrEnd{0.0, 0.0, {0.0, 0.0, 0.0, 0.0}};
+  S.at = S.lo_end;
+  if (at_tmax.low + tmax * tmax * at_tmax.high <= r2) {
+    // every finite breakpoint is reached before the radius
+    if (hinf <= 0.0) S.tstar = tmax;                     // "all bounds hit" special case
+    else S.tstar = sqrt((r2 - at_tmax.low) / hinf);
+    S.at = at_tmax;
+    S.done = 1;
+    return;
+  }
+  S.lo = 0; S.hi = tr_d2bits(tmax);
+}
+// false: the search is over.  true: pr holds the next pass's probes.
+__host__ __device__ inline bool tr_search_next(TrSearch &S, TrProbes &pr) {
+  if (S.done) return false;
+  if (S.hi - S.lo > 1) {
+    const unsigned long long span = S.hi - S.lo;
+    S.q0 = 0;
+    // Probe 0: the closed-form candidate from the current lower end, t' = sqrt((r2 - low)/high).  If no breakpoint
+    // lies in (lo, t'] the probe returns the same (low, high) and t' is the exact answer -- this fixed-point step
+    // usually lands within a few passes; the remaining probes keep a guaranteed bracket in IEEE bit space.
+    if (S.have_lo && S.lo_end.high > 0.0) {
+      const double cand = sqrt(fmax(S.r2 - S.lo_end.low, 0.0) / S.lo_end.high);
+      const unsigned long long cb = tr_d2bits(cand);
+      if (cb > S.lo && cb < S.hi) { S.pb[0] = cb; pr.t[0] = cand; S.q0 = 1; }
+    }
+    for (int q = S.q0; q < TR_K; ++q) {
+      unsigned long long off = tr_mul_div(span, (unsigned)(q - S.q0 + 1), (unsigned)(TR_K - S.q0 + 1));
+      if (off == 0) off = 1;
+      if (off >= span) off = span - 1;
+      S.pb[q] = S.lo + off;
+      pr.t[q] = tr_bits2d(S.pb[q]);
+    }
+    S.zero_probe = 0;
+    return true;
+  }
+  if (!S.have_lo) {            // bracket collapsed at t = 0: evaluate the sums there
+    for (int q = 0; q < TR_K; ++q) pr.t[q] = 0.0;
+    S.zero_probe = 1;
+    return true;
+  }
+  tr_search_finish(S);
+  return false;
+}
+__host__ __device__ inline void tr_search_feed(TrSearch &S, const TrProbes &pr, const double *lh) {
+  S.passes += 1;
+  if (S.zero_probe) {
+    S.lo_end = tr_end_of(lh);
+    S.have_lo = 1;
+    tr_search_finish(S);
+    return;
+  }
+  if (S.q0 == 1 && lh[0] == S.lo_end.low && lh[1] == S.lo_end.high) {
+    S.tstar = pr.t[0];
+    S.at = S.lo_end;
+    S.done = 1;
+    return;
+  }
+  unsigned long long nlo = S.lo, nhi = S.hi;
+  for (int q = 0; q < TR_K; ++q) {
+    const double f = lh[TR_Q * q] + pr.t[q] * pr.t[q] * lh[TR_Q * q + 1];
+    if (f <= S.r2) { if (S.pb[q] > nlo) { nlo = S.pb[q]; S.lo_end = tr_end_of(lh + TR_Q * q); S.have_lo = 1; } }
+    else { if (S.pb[q] < nhi) nhi = S.pb[q]; }
+  }
+  S.lo = nlo; S.hi = nhi;
+}
+
+
+// ---- bound_optimal_objective for SMALL problems (n + m <= TRS_MAX) in ONE workgroup, one launch: the set-up pass,
+// the whole breakpoint search (tr_search_*: thread 0 decides, every thread sums its elements for the five probes of a
+// pass, a pass is a loop between two __syncthreads) and the eight results, published like an evaluation reduction.
+// The multi-launch form costs a kernel + a second-stage kernel + a trip to the host per pass: 50-70 us per call for an
+// LP whose vectors fit a few KB, five calls per termination / restart check.
+constexpr int TRS_TPB = 1024, TRS_MAX = 4096;
+struct TrSmallArgs {
+  int n, m, ne, range, approximate;
+  const double *px, *py, *aty, *qx, *ax, *c, *b, *lb, *ub;
+  double wp, wd, radius;
+  double *host_out;
+  unsigned long long seq;
+};
+// sums (then maxes) of a per-thread accumulator over the workgroup, into res[] (LDS); every thread calls it
+template <int NS, int NM>
+__device__ __forceinline__ void block_reduce_lds(const RedAcc<NS, NM> &a, double (*red)[TRS_TPB / WAVE], double *res) {
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) { const double w = wave_sum_dpp(a.s[q]); if (lane == WAVE - 1) red[q][wid] = w; }
+#pragma unroll
+  for (int q = 0; q < NM; ++q) { const double w = wave_max_nonneg_dpp(a.m[q]); if (lane == WAVE - 1) red[NS + q][wid] = w; }
+  __syncthreads();
+  if (threadIdx.x < NS + NM) {
+    const int q = threadIdx.x;
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < TRS_TPB / WAVE; ++w) t = (q >= NS) ? fmax(t, red[q][w]) : t + red[q][w];
+    res[q] = t;
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(TRS_TPB) void tr_small_kernel(TrSmallArgs a) {
+  extern __shared__ double trs_dyn[];          // thr, w d^2, g d: n + m each
+  double *s_thr = trs_dyn, *s_wd2 = trs_dyn + (a.n + a.m), *s_gd = trs_dyn + 2 * (a.n + a.m);
+  __shared__ double red[TR_Q * TR_K + 2][TRS_TPB / WAVE];
+  __shared__ double res[TR_Q * TR_K + 2];
+  __shared__ TrProbes s_pr;
+  __shared__ int s_go;
+  __shared__ double s_out[8];
+  const int n = a.n, total = a.n + a.m, tid = threadIdx.x;
+  {
+    // the set-up pass: tr_setup_kernel's arithmetic, element by element (see there for the sums' meaning)
+    RedAcc<TR_SETUP_NS, 1> acc;
+    for (int k = tid; k < total; k += TRS_TPB) {
+      const bool primal = k < n;
+      const int i = primal ? k : k - n;
+      double z, g, lo, hi, w;
+      if (primal) {
+        z = a.px[i]; lo = a.lb[i]; hi = a.ub[i]; w = a.wp;
+        if (a.qx) { g = (a.qx[i] + a.c[i]) - a.aty[i]; acc.s[10] += z * a.qx[i]; }
+        else g = a.c[i] - a.aty[i];
+        acc.s[0] += a.c[i] * z; acc.s[1] += z * a.aty[i]; acc.s[8] += z * z;
+      } else {
+        z = a.py[i]; g = -(a.b[i] - a.ax[i]); lo = (i < a.ne) ? -INFINITY : 0.0; hi = INFINITY; w = a.wd;
+        acc.s[2] += z * a.b[i]; acc.s[9] += z * z;
+      }
+      const bool in_range = (a.range == 0) || (a.range == 1 && primal) || (a.range == 2 && !primal);
+      double d = 0.0, t = 0.0;
+      if (in_range && !((z >= hi && g <= 0.0) || (z <= lo && g >= 0.0))) {
+        d = -g / w;
+        if (d > 0.0) t = (hi - z) / d;
+        else if (d < 0.0) t = (lo - z) / d;
+        else t = 0.0;
+      }
+      const double wd2 = w * d * d, gd = g * d;
+      s_gd[k] = gd; s_wd2[k] = wd2; s_thr[k] = t;
+      if (in_range) {
+        acc.s[4] += g * g;
+        acc.s[5] += wd2;
+        if (primal) acc.s[6] += gd; else acc.s[7] += gd;
+        if (isinf(t)) {
+          acc.s[3] += wd2;
+          if (primal) acc.s[14] += gd; else acc.s[15] += gd;
+        } else {
+          acc.m[0] = fmax(acc.m[0], t);
+          if (wd2 != 0.0) {
+            acc.s[11] += wd2 * t * t;
+            if (primal) acc.s[12] += gd * t; else acc.s[13] += gd * t;
+          }
+        }
+      }
+    }
+    block_reduce_lds<TR_SETUP_NS, 1>(acc, red, res);
+  }
+  // thread 0: the host function's statements (pdhg_trust_region_bound) on the set-up sums
+  __shared__ TrSearch S;
+  if (tid == 0) {
+    const double *r = res;
+    s_out[0] = 0.5 * r[10] + r[0] - r[1] + r[2];
+    s_out[1] = s_out[2] = 0.0;
+    s_out[3] = r[8]; s_out[4] = r[9];
+    s_out[5] = 0.0; s_out[6] = 0.0; s_out[7] = 0.0;
+    const double hinf = r[3], g2 = r[4], wd2_all = r[5], tmax = r[TR_SETUP_NS];
+    const double r2 = a.radius * a.radius;
+    s_go = 0;
+    if (a.approximate) {
+      const double dn = sqrt(wd2_all);
+      const double sc = dn > 0.0 ? a.radius / dn : 1.0;
+      s_out[1] = sc * r[6]; s_out[2] = sc * r[7];
+    } else if (!(a.radius == 0.0 || g2 == 0.0)) {
+      tr_search_begin(S, r2, tmax, hinf, TrEnd{r[11], hinf, {r[12], r[14], r[13], r[15]}});
+      s_go = tr_search_next(S, s_pr) ? 1 : 2;      // 1: a pass to run, 2: the search is over already
+    }
+  }
+  __syncthreads();
+  while (s_go == 1) {
+    RedAcc<TR_Q * TR_K, 0> acc;
+    const TrProbes pr = s_pr;
+    for (int k = tid; k < total; k += TRS_TPB) {
+      const double wd2 = s_wd2[k];
+      if (wd2 == 0.0) continue;
+      const double t = s_thr[k], gd = s_gd[k];
+      const double lowc = wd2 * t * t, vlow = gd * t;
+      const int base = (k < n) ? 2 : 4;
+#pragma unroll
+      for (int q = 0; q < TR_K; ++q) {
+        if (t <= pr.t[q]) {
+          acc.s[TR_Q * q] += lowc;
+          if (base == 2) acc.s[TR_Q * q + 2] += vlow; else acc.s[TR_Q * q + 4] += vlow;
+        } else {
+          acc.s[TR_Q * q + 1] += wd2;
+          if (base == 2) acc.s[TR_Q * q + 3] += gd; else acc.s[TR_Q * q + 5] += gd;
+        }
+      }
+    }
+    block_reduce_lds<TR_Q * TR_K, 0>(acc, red, res);
+    if (tid == 0) {
+      tr_search_feed(S, s_pr, res);
+      s_go = tr_search_next(S, s_pr) ? 1 : 2;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (s_go == 2) {
+      s_out[1] = S.at.v[0] + S.tstar * S.at.v[1];
+      s_out[2] = S.at.v[2] + S.tstar * S.at.v[3];
+      s_out[5] = S.tstar; s_out[6] = (double)S.passes;
+    }
+    unsigned long long ck = EV_CHECK_SALT ^ a.seq ^ (8ull << 56);
+    for (int q = 0; q < 8; ++q) {
+      a.host_out[q] = s_out[q];
+      ck ^= (unsigned long long)__double_as_longlong(s_out[q]) * (2ull * (unsigned long long)q + 1ull);
+    }
+    a.host_out[EV_HOST_CK] = __longlong_as_double((long long)ck);
+    a.host_out[EV_HOST_SEQ] = __longlong_as_double((long long)a.seq);
+  }
+}
+
 }  // namespace

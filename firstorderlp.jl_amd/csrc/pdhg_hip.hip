@@ -2727,6 +2727,34 @@ static int ev_alloc(pdhg_handle *h) {
 
 // second stage of every shard's block partials (ns sums then nm maxes), then the
 // combination over ranks in rank order
+// the pinned result words of the evaluation reductions (multi_final_kernel, tr_small_kernel): k values, checksum, sequence number
+static int ev_ensure_host(pdhg_handle *h) {
+  if (!h->ev_host) {
+    HIP_TRY(hipHostMalloc((void **)&h->ev_host, (EV_HOST_SLOTS + 2) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(h->ev_host, 0, (EV_HOST_SLOTS + 2) * sizeof(double));
+  }
+  return 0;
+}
+static int ev_wait_host(pdhg_handle *h, int k, unsigned long long seq, double *out) {
+  const volatile unsigned long long *bits = reinterpret_cast<const volatile unsigned long long *>(h->ev_host);
+  auto ready = [&]() -> bool {
+    if (bits[EV_HOST_SEQ] != seq) return false;
+    unsigned long long w[EV_HOST_SLOTS];
+    unsigned long long ck = EV_CHECK_SALT ^ seq ^ ((unsigned long long)k << 56);
+    for (int q = 0; q < k; ++q) { w[q] = bits[q]; ck ^= w[q] * (2ull * (unsigned long long)q + 1ull); }
+    if (ck != bits[EV_HOST_CK]) return false;
+    for (int q = 0; q < k; ++q) memcpy(&out[q], &w[q], 8);
+    return true;
+  };
+  for (long spin = 0; spin < 40000000L; ++spin) {
+    if (ready()) return 0;
+    if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (ready()) return 0;
+  return fail(998, "evaluation reduction finished without publishing its results");
+}
+
 static int ev_finish(const Shards &L, int ns, int nm, double *out) {
   if (ns + nm > EV_MAXQ) return fail(-1, "too many scalars in one reduction");
   static const bool host_word = !(getenv("PDHG_EVAL_HOST_WORD") && getenv("PDHG_EVAL_HOST_WORD")[0] == '0');
@@ -2736,31 +2764,13 @@ static int ev_finish(const Shards &L, int ns, int nm, double *out) {
     const int k = ns + nm;
     if (k > EV_HOST_SLOTS) return fail(-1, "too many scalars in one reduction");
     HIP_TRY(hipSetDevice(h->device));
-    if (!h->ev_host) {
-      HIP_TRY(hipHostMalloc((void **)&h->ev_host, (EV_HOST_SLOTS + 2) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
-      memset(h->ev_host, 0, (EV_HOST_SLOTS + 2) * sizeof(double));
-    }
+    int rc0 = ev_ensure_host(h);
+    if (rc0) return rc0;
     const unsigned long long seq = ++h->ev_seq;
     hipLaunchKernelGGL(multi_final_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->ev_partials, h->ev_grid,
                        h->ev_grid, ns, nm, h->scal_dev, h->ev_host, seq);
     HIP_TRY(hipGetLastError());
-    const volatile unsigned long long *bits = reinterpret_cast<const volatile unsigned long long *>(h->ev_host);
-    auto ready = [&]() -> bool {
-      if (bits[EV_HOST_SEQ] != seq) return false;
-      unsigned long long w[EV_HOST_SLOTS];
-      unsigned long long ck = EV_CHECK_SALT ^ seq ^ ((unsigned long long)k << 56);
-      for (int q = 0; q < k; ++q) { w[q] = bits[q]; ck ^= w[q] * (2ull * (unsigned long long)q + 1ull); }
-      if (ck != bits[EV_HOST_CK]) return false;
-      for (int q = 0; q < k; ++q) memcpy(&out[q], &w[q], 8);
-      return true;
-    };
-    for (long spin = 0; spin < 40000000L; ++spin) {
-      if (ready()) return 0;
-      if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
-    }
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (ready()) return 0;
-    return fail(998, "evaluation reduction finished without publishing its results");
+    return ev_wait_host(h, k, seq, out);
   }
   FOR_SHARDS(L, h) {
     hipLaunchKernelGGL(multi_final_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->ev_partials, h->ev_grid,
@@ -2955,6 +2965,36 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
   if ((rc = flush_pending(L))) return rc;
   const double wp = primal_weight_norm, wd = dual_weight_norm;
   if ((rc = point_products(L, point))) return rc;
+  {
+    // small problems on one handle: set-up, search and results in ONE workgroup and one launch (tr_small_kernel)
+    const char *se = getenv("PDHG_SMALL_EVAL");
+    pdhg_handle *h = L.p[0];
+    if (!L.g && h->n + h->m <= TRS_MAX && !(se && se[0] == '0') && !h->profile) {
+      HIP_TRY(hipSetDevice(h->device));
+      if ((rc = ev_ensure_host(h))) return rc;
+      const size_t lds = sizeof(double) * 3 * (size_t)(h->n + h->m);
+      {
+        static size_t limit[64] = {};
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        size_t &cur = limit[h->device & 63];
+        if (cur < lds) {
+          HIP_TRY(hipFuncSetAttribute((const void *)tr_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          cur = lds;
+        }
+      }
+      TrSmallArgs a{};
+      a.n = (int)h->n; a.m = (int)h->m; a.ne = (int)h->num_eq; a.range = range; a.approximate = approximate ? 1 : 0;
+      a.px = h->pt_x; a.py = h->pt_y; a.aty = h->pt_aty; a.qx = h->pt_qx; a.ax = h->pt_ax;
+      a.c = h->c; a.b = h->b; a.lb = h->lb; a.ub = h->ub;
+      a.wp = wp; a.wd = wd; a.radius = radius;
+      a.host_out = h->ev_host;
+      a.seq = ++h->ev_seq;
+      hipLaunchKernelGGL(tr_small_kernel, dim3(1), dim3(TRS_TPB), lds, h->stream, a);
+      HIP_TRY(hipGetLastError());
+      return ev_wait_host(h, 8, a.seq, out);
+    }
+  }
   // every shard works on the concatenation [its column slice ; its rows]
   FOR_SHARDS(L, h) {
     if (!h->tr_g) {
@@ -2994,8 +3034,6 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
   // same closed form (trust_region_utils.jl:167-175).  Every probe carries the value sums of its t
   // (tr_probe_kernel), and the set-up pass those of t = tmax, so t* needs no pass of its own:
   //   value(t*) = vlow + t* vhigh  at the bracket's lower end (no breakpoint lies in between).
-  struct End { double low, high, v[4]; };     // v: vlow primal, vhigh primal, vlow dual, vhigh dual
-  auto end_of = [](const double *p6) { return End{p6[0], p6[1], {p6[2], p6[3], p6[4], p6[5]}}; };
   auto probe = [&](const TrProbes &pr, double *sums) -> int {
     FOR_SHARDS(L, h) {
       hipLaunchKernelGGL(tr_probe_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)(h->cn + h->m),
@@ -3006,67 +3044,15 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
   };
   double lh[TR_Q * TR_K];
   TrProbes pr;
-  int passes = 0;                            // probe passes (the set-up pass evaluates t = tmax itself)
-  double tstar;
-  End at{0.0, 0.0, {0.0, 0.0, 0.0, 0.0}};    // the sums that t* is computed from
-  const End at_tmax{r[11], hinf, {r[12], r[14], r[13], r[15]}};
-  if (at_tmax.low + tmax * tmax * at_tmax.high <= r2) {
-    // every finite breakpoint is reached before the radius
-    if (hinf <= 0.0) tstar = tmax;                       // "all bounds hit" special case
-    else tstar = sqrt((r2 - at_tmax.low) / hinf);
-    at = at_tmax;
-  } else {
-    uint64_t lo = 0, hi = d2bits(tmax);
-    End lo_end = at;
-    bool have_lo = false;
-    bool exact = false;
-    tstar = 0.0;
-    while (hi - lo > 1) {
-      uint64_t pb[TR_K];
-      const uint64_t span = hi - lo;
-      int q0 = 0;
-      // Probe 0: the closed-form candidate from the current lower end,
-      // t' = sqrt((r2 - low)/high).  If no breakpoint lies in (lo, t'] the
-      // probe returns the same (low, high) and t' is the exact answer -- this
-      // fixed-point step usually lands within a few passes; the remaining
-      // probes keep a guaranteed bracket in IEEE bit space.
-      if (have_lo && lo_end.high > 0.0) {
-        const double cand = sqrt(fmax(r2 - lo_end.low, 0.0) / lo_end.high);
-        const uint64_t cb = d2bits(cand);
-        if (cb > lo && cb < hi) { pb[0] = cb; pr.t[0] = cand; q0 = 1; }
-      }
-      for (int q = q0; q < TR_K; ++q) {
-        uint64_t off = (uint64_t)(((__uint128_t)span * (uint64_t)(q - q0 + 1)) / (uint64_t)(TR_K - q0 + 1));
-        if (off == 0) off = 1;
-        if (off >= span) off = span - 1;
-        pb[q] = lo + off;
-        pr.t[q] = bits2d(pb[q]);
-      }
-      if ((rc = probe(pr, lh))) return rc;
-      ++passes;
-      if (q0 == 1 && lh[0] == lo_end.low && lh[1] == lo_end.high) { tstar = pr.t[0]; exact = true; break; }
-      uint64_t nlo = lo, nhi = hi;
-      for (int q = 0; q < TR_K; ++q) {
-        const double f = lh[TR_Q * q] + pr.t[q] * pr.t[q] * lh[TR_Q * q + 1];
-        if (f <= r2) { if (pb[q] > nlo) { nlo = pb[q]; lo_end = end_of(lh + TR_Q * q); have_lo = true; } }
-        else { if (pb[q] < nhi) nhi = pb[q]; }
-      }
-      lo = nlo; hi = nhi;
-    }
-    if (!exact) {
-      if (!have_lo) {  // bracket collapsed at t = 0: evaluate the sums there
-        for (int q = 0; q < TR_K; ++q) pr.t[q] = 0.0;
-        if ((rc = probe(pr, lh))) return rc;
-        ++passes;
-        lo_end = end_of(lh);
-      }
-      tstar = lo_end.high > 0.0 ? sqrt(fmax(r2 - lo_end.low, 0.0) / lo_end.high) : bits2d(lo);
-    }
-    at = lo_end;
+  TrSearch S;                                // the search itself: eval_kernels.hpp (shared with the one-workgroup kernel)
+  tr_search_begin(S, r2, tmax, hinf, TrEnd{r[11], hinf, {r[12], r[14], r[13], r[15]}});
+  while (tr_search_next(S, pr)) {
+    if ((rc = probe(pr, lh))) return rc;
+    tr_search_feed(S, pr, lh);
   }
-  out[1] = at.v[0] + tstar * at.v[1];
-  out[2] = at.v[2] + tstar * at.v[3];
-  out[5] = tstar; out[6] = (double)passes;
+  out[1] = S.at.v[0] + S.tstar * S.at.v[1];
+  out[2] = S.at.v[2] + S.tstar * S.at.v[3];
+  out[5] = S.tstar; out[6] = (double)S.passes;     // probe passes (the set-up pass evaluates t = tmax itself)
   return 0;
 }
 

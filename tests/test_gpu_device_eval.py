@@ -165,13 +165,15 @@ def test_cached_point_products_match_recomputation(gpu_required):
             a.reset_average(); b.reset_average()
 
 
-def test_trust_region_search_branches_match_host(gpu_required):
+@pytest.mark.parametrize("small_eval", ["1", "0"], ids=["one_workgroup_kernel", "pass_by_pass"])
+def test_trust_region_search_branches_match_host(gpu_required, monkeypatch, small_eval):
     """Every exit of the breakpoint search -- no finite breakpoint at all, every finite breakpoint inside the ball
     (0 probe passes: the set-up pass's own sums), the bracket collapsing at t = 0, and the ordinary closed form --
     against the host implementation (the reference's median elimination restated in numpy), over six decades of radius.
     The value sums ride on the probes (sum g d min(t, thr)), the host clamps: same numbers to rounding."""
     import scipy.sparse as sp
     from firstorderlp_jl_amd import linear_programming_problem
+    monkeypatch.setenv("PDHG_SMALL_EVAL", small_eval)     # n + m <= 4096: the whole search in one launch, or pass by pass
     rng = np.random.default_rng(5)
     base = random_lp(600, 800, 6, 4)
     n, m = base.num_variables, base.num_constraints

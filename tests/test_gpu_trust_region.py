@@ -13,8 +13,10 @@ from tests import trust_region_cases as C
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("small_eval", ["1", "0"], ids=["one_workgroup_kernel", "pass_by_pass"])
 @pytest.mark.parametrize("case", C.CASES, ids=lambda c: c[0])
-def test_bound_optimal_objective_device(gpu_required, case):
+def test_bound_optimal_objective_device(gpu_required, monkeypatch, case, small_eval):
+    monkeypatch.setenv("PDHG_SMALL_EVAL", small_eval)
     name, maker, x, y, radius, norm, expected = case
     p = maker()
     eng = HipPdhgEngine.from_problem(p)
