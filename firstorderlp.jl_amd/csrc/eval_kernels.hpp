@@ -383,7 +383,7 @@ __host__ __device__ inline void tr_search_feed(TrSearch &S, const TrProbes &pr, 
 // pass, a pass is a loop between two __syncthreads) and the eight results, published like an evaluation reduction.
 // The multi-launch form costs a kernel + a second-stage kernel + a trip to the host per pass: 50-70 us per call for an
 // LP whose vectors fit a few KB, five calls per termination / restart check.
-constexpr int TRS_TPB = 1024, TRS_MAX = 4096;
+constexpr int TRS_TPB = 256, TRS_MAX = 4096;      // 4 waves, one per SIMD: the 30 DPP trees of a pass run once per SIMD (1024 threads: 4 waves per SIMD, 68 us per call against 4x fewer trees here)
 struct TrSmallArgs {
   int n, m, ne, range, approximate;
   const double *px, *py, *aty, *qx, *ax, *c, *b, *lb, *ub;
