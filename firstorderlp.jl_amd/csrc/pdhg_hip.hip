@@ -696,6 +696,60 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
   return 0;
 }
 
+// ---- what the two multi-step launchers (coop_steps, small_lp_steps) share ---------------------------------------
+// Trial budget of a launch of n steps, the tables of (total_number_iterations + 1)^-exponent for its trials (host pow,
+// uploaded), the pinned result words.  Budget: the steps asked for plus room for rejections (a launch that runs out
+// returns at a take_step boundary and the caller launches again); 64 more table entries for finishing the take_step
+// the budget ends in.  The tables cost two pow() per entry on the host: sized to the batch, not to the worst case.
+static int steps_prepare(pdhg_handle *h, int n, int64_t total_number_iterations, double reduction_exponent,
+                         double growth_exponent, int *max_trials_out, int *table_len_out) {
+  int max_trials = n + n / 8 + 16, table_len = max_trials + 64;
+  if (const char *tv = getenv("PDHG_STEPS_TEST_TABLE")) max_trials = table_len = std::max(1, atoi(tv));   // test knob: launches end inside take_steps
+  if (!h->steps_res) {
+    HIP_TRY(hipHostMalloc((void **)&h->steps_res, STEPS_RES_WORDS * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(h->steps_res, 0, STEPS_RES_WORDS * sizeof(double));
+  }
+  if (h->steps_pow_cap < table_len) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->steps_pow_dev) (void)hipFree(h->steps_pow_dev);
+    if (h->steps_pow_host) (void)hipHostFree(h->steps_pow_host);
+    h->steps_pow_dev = h->steps_pow_host = nullptr;
+    h->steps_pow_cap = std::max(table_len, 512);
+    HIP_TRY(hipMalloc((void **)&h->steps_pow_dev, sizeof(double) * 2 * (size_t)h->steps_pow_cap));
+    // (room behind the tables: coop_steps stages its FinalSpec there)
+    HIP_TRY(hipHostMalloc((void **)&h->steps_pow_host, sizeof(double) * 2 * (size_t)h->steps_pow_cap + sizeof(FinalSpec) + 64, hipHostMallocDefault));
+  }
+  // the t-th trial of the launch runs with total_number_iterations = total + t + 1 and uses k1 = that + 1 (pdhg.jl:713-714)
+  for (int t = 0; t < table_len; ++t) {
+    const double k1 = (double)(total_number_iterations + t + 2);
+    h->steps_pow_host[t] = pow(k1, -reduction_exponent);
+    h->steps_pow_host[table_len + t] = pow(k1, -growth_exponent);
+  }
+  HIP_TRY(hipMemcpyAsync(h->steps_pow_dev, h->steps_pow_host, sizeof(double) * 2 * (size_t)table_len, hipMemcpyHostToDevice, h->stream));
+  *max_trials_out = max_trials;
+  *table_len_out = table_len;
+  return 0;
+}
+// wait for a multi-step launch's result words: r[0..12] once sequence number and checksum match (bounded spin, then the stream)
+static int steps_wait(pdhg_handle *h, unsigned long long seq, double r[13]) {
+  const volatile unsigned long long *bits = reinterpret_cast<const volatile unsigned long long *>(h->steps_res);
+  auto ready = [&]() -> bool {
+    if (h->steps_res[15] != (double)seq) return false;
+    unsigned long long w[13], ck = RESULT_CHECK_SALT;
+    for (int k = 0; k < 13; ++k) { w[k] = bits[k]; ck ^= w[k] * (2ull * (unsigned long long)k + 1ull); }
+    if (ck != bits[13]) return false;
+    for (int k = 0; k < 13; ++k) memcpy(&r[k], &w[k], 8);
+    return r[12] == (double)seq;
+  };
+  for (long spin = 0; spin < 400000000L; ++spin) {
+    if (ready()) return 0;
+    if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (ready()) return 0;
+  return fail(998, "multi-step kernel finished without publishing its results");
+}
+
 // Up to n_steps adaptive take_steps in ONE launch (steps_kernel, trial_kernel.hpp).  On return *steps_done take_steps
 // have been taken (fewer when the launch ran out of its trial budget, met numerical_error, or a barrier timed out: the
 // caller goes on from the state left).  Returns 1 when nothing could be launched (not eligible).
@@ -709,34 +763,13 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   if (rc) return rc;
   HIP_TRY(hipSetDevice(h->device));
   const int n = (int)std::min<int64_t>(n_steps, 1 << 20);
-  // trial budget: the steps asked for plus room for rejections (a launch that runs out returns at a take_step boundary and
-  // the caller launches again); 64 more table entries for finishing the take_step the budget ends in.  The table costs
-  // two pow() per entry on the host: sized to the batch, not to the worst case
-  int max_trials = n + n / 8 + 16, table_len = max_trials + 64;
-  if (const char *tv = getenv("PDHG_STEPS_TEST_TABLE")) max_trials = table_len = std::max(1, atoi(tv));   // test knob: launches end inside take_steps
+  int max_trials = 0, table_len = 0;
   if (!h->steps_ctl) {
     HIP_TRY(hipMalloc((void **)&h->steps_ctl, sizeof(StepsCtl)));
     HIP_TRY(hipMemsetAsync(h->steps_ctl, 0, sizeof(StepsCtl), h->stream));
-    HIP_TRY(hipHostMalloc((void **)&h->steps_res, STEPS_RES_WORDS * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
-    memset(h->steps_res, 0, STEPS_RES_WORDS * sizeof(double));
-  }
-  if (h->steps_pow_cap < table_len) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->steps_pow_dev) (void)hipFree(h->steps_pow_dev);
-    if (h->steps_pow_host) (void)hipHostFree(h->steps_pow_host);
-    h->steps_pow_dev = h->steps_pow_host = nullptr;
-    h->steps_pow_cap = std::max(table_len, 512);
-    HIP_TRY(hipMalloc((void **)&h->steps_pow_dev, sizeof(double) * 2 * (size_t)h->steps_pow_cap));
-    HIP_TRY(hipHostMalloc((void **)&h->steps_pow_host, sizeof(double) * 2 * (size_t)h->steps_pow_cap + sizeof(FinalSpec) + 64, hipHostMallocDefault));
   }
   std::lock_guard<std::mutex> one_at_a_time(coop_device_mutex(h->device));
-  // the t-th trial of the launch runs with total_number_iterations = total + t + 1 and uses k1 = that + 1 (pdhg.jl:713-714)
-  for (int t = 0; t < table_len; ++t) {
-    const double k1 = (double)(*total_number_iterations_io + t + 2);
-    h->steps_pow_host[t] = pow(k1, -reduction_exponent);
-    h->steps_pow_host[table_len + t] = pow(k1, -growth_exponent);
-  }
-  HIP_TRY(hipMemcpyAsync(h->steps_pow_dev, h->steps_pow_host, sizeof(double) * 2 * (size_t)table_len, hipMemcpyHostToDevice, h->stream));
+  if ((rc = steps_prepare(h, n, *total_number_iterations_io, reduction_exponent, growth_exponent, &max_trials, &table_len))) return rc;
   StepsKernelArgs a{};
   a.n = (int)h->n; a.num_eq = (int)h->num_eq;
   a.xa = h->x; a.xb = h->x_next; a.ya = h->y; a.yb = h->y_next; a.atya = h->aty; a.atyb = h->aty_next;
@@ -776,26 +809,8 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   HIP_TRY(hipGetLastError());
   const auto c2 = std::chrono::steady_clock::now();
   h->t_launch += std::chrono::duration<double>(c2 - c1).count();
-  // wait for the result words (sequence number + checksum), then for the kernel itself: its counters go on from here
-  const volatile unsigned long long *bits = reinterpret_cast<const volatile unsigned long long *>(h->steps_res);
   double r[13];
-  auto ready = [&]() -> bool {
-    if (h->steps_res[15] != (double)a.seq) return false;
-    unsigned long long w[13], ck = RESULT_CHECK_SALT;
-    for (int k = 0; k < 13; ++k) { w[k] = bits[k]; ck ^= w[k] * (2ull * (unsigned long long)k + 1ull); }
-    if (ck != bits[13]) return false;
-    for (int k = 0; k < 13; ++k) memcpy(&r[k], &w[k], 8);
-    return r[12] == (double)a.seq;
-  };
-  bool seen = false;
-  for (long spin = 0; spin < 400000000L; ++spin) {
-    if (ready()) { seen = true; break; }
-    if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
-  }
-  if (!seen) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (!ready()) return fail(998, "multi-step trial kernel finished without publishing its results");
-  }
+  if ((rc = steps_wait(h, a.seq, r))) return rc;
   h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
   const int64_t steps = (int64_t)r[1], trials = (int64_t)r[2];
   const bool flip = r[3] != 0.0, aborted = r[9] != 0.0 || r[11] != 0.0;
@@ -851,24 +866,8 @@ int small_lp_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, d
   int rc;
   if (h->pend_x != h->pend_y) { Shards L = shards_of(h); if ((rc = flush_pending(L))) return rc; }
   const int n = (int)std::min<int64_t>(n_steps, 1 << 20);
-  // trial budget: the steps asked for plus room for rejections (a launch that runs out returns at a take_step boundary and
-  // the caller launches again); 64 more table entries for finishing the take_step the budget ends in.  The table costs
-  // two pow() per entry on the host: sized to the batch, not to the worst case
-  int max_trials = n + n / 8 + 16, table_len = max_trials + 64;
-  if (const char *tv = getenv("PDHG_STEPS_TEST_TABLE")) max_trials = table_len = std::max(1, atoi(tv));   // test knob: launches end inside take_steps
-  if (!h->steps_res) {
-    HIP_TRY(hipHostMalloc((void **)&h->steps_res, STEPS_RES_WORDS * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
-    memset(h->steps_res, 0, STEPS_RES_WORDS * sizeof(double));
-  }
-  if (h->steps_pow_cap < table_len) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->steps_pow_dev) (void)hipFree(h->steps_pow_dev);
-    if (h->steps_pow_host) (void)hipHostFree(h->steps_pow_host);
-    h->steps_pow_dev = h->steps_pow_host = nullptr;
-    h->steps_pow_cap = std::max(table_len, 512);
-    HIP_TRY(hipMalloc((void **)&h->steps_pow_dev, sizeof(double) * 2 * (size_t)h->steps_pow_cap));
-    HIP_TRY(hipHostMalloc((void **)&h->steps_pow_host, sizeof(double) * 2 * (size_t)h->steps_pow_cap + sizeof(FinalSpec) + 64, hipHostMallocDefault));
-  }
+  int max_trials = 0, table_len = 0;
+  if ((rc = steps_prepare(h, n, *total_number_iterations_io, reduction_exponent, growth_exponent, &max_trials, &table_len))) return rc;
   const size_t lds = sizeof(double) * (9 * (size_t)h->n + 4 * (size_t)h->m);
   {
     static size_t limit[64] = {};
@@ -881,12 +880,7 @@ int small_lp_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, d
       cur = lds;
     }
   }
-  for (int t = 0; t < table_len; ++t) {
-    const double k1 = (double)(*total_number_iterations_io + t + 2);
-    h->steps_pow_host[t] = pow(k1, -reduction_exponent);
-    h->steps_pow_host[table_len + t] = pow(k1, -growth_exponent);
-  }
-  HIP_TRY(hipMemcpyAsync(h->steps_pow_dev, h->steps_pow_host, sizeof(double) * 2 * (size_t)table_len, hipMemcpyHostToDevice, h->stream));
+
   SmallLpArgs a{};
   a.n = (int)h->n; a.m = (int)h->m; a.num_eq = (int)h->num_eq;
   a.A = h->A.view(); a.T = h->At.view();
@@ -907,25 +901,8 @@ int small_lp_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, d
   HIP_TRY(hipGetLastError());
   const auto c2 = std::chrono::steady_clock::now();
   h->t_launch += std::chrono::duration<double>(c2 - c1).count();
-  const volatile unsigned long long *bits = reinterpret_cast<const volatile unsigned long long *>(h->steps_res);
   double r[13];
-  auto ready = [&]() -> bool {
-    if (h->steps_res[15] != (double)a.seq) return false;
-    unsigned long long w[13], ck = RESULT_CHECK_SALT;
-    for (int k = 0; k < 13; ++k) { w[k] = bits[k]; ck ^= w[k] * (2ull * (unsigned long long)k + 1ull); }
-    if (ck != bits[13]) return false;
-    for (int k = 0; k < 13; ++k) memcpy(&r[k], &w[k], 8);
-    return r[12] == (double)a.seq;
-  };
-  bool seen = false;
-  for (long spin = 0; spin < 400000000L; ++spin) {
-    if (ready()) { seen = true; break; }
-    if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(h->stream) != hipErrorNotReady) break;
-  }
-  if (!seen) {
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (!ready()) return fail(998, "small-LP kernel finished without publishing its results");
-  }
+  if ((rc = steps_wait(h, a.seq, r))) return rc;
   h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
   const int64_t steps = (int64_t)r[1], trials = (int64_t)r[2];
   h->small_lp_launches += 1; h->n_graph_trials += trials;
