@@ -2485,11 +2485,19 @@ int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_e
   if (!h || !step_size_io || !total_number_iterations_io || !cumulative_kkt_passes_io || !numerical_error_out)
     return fail(-1, "null argument");
   *numerical_error_out = 0;
-  // PDHG_DEVICE_LOOP=1 (stream-layout LPs on one handle): several take_steps per launch (steps_kernel), the rule on
-  // the device.  Bitwise the per-trial launches (tests/test_gpu_device_loop.py) and NOT the default: measured slower --
-  // L1-SVM 58.5 us per step against 50.3, random 100K 50.8 against 44.7 (trial_kernel.hpp says where the time goes).
+  // Several take_steps per launch (steps_kernel: the rule on the device; stream-layout LPs on one handle).  Bitwise the
+  // per-trial launches (tests/test_gpu_device_loop.py).  Worth it on SMALL grids only: the third barrier and the
+  // leaders' second stage grow with the number of workgroups -- 24 workgroups (24K nonzeros) 37.2k it/s against
+  // 32.7k, 120 workgroups 33.0k against 28.8k, 168 workgroups 30.8k against 27.6k, 200 a tie, 240 workgroups 25.7k
+  // against 27.9k, L1-SVM's 856 17.1k against 19.9k (profiles/r03_trial_kernel.txt).  Default: grids of at most
+  // PDHG_DEVICE_LOOP_MAX_WGS (192) workgroups;
+  // PDHG_DEVICE_LOOP=0 / 1: never / whenever eligible.
   const char *dl_env = getenv("PDHG_DEVICE_LOOP");
-  const bool device_loop = dl_env && dl_env[0] == '1';
+  bool device_loop = dl_env && dl_env[0] == '1';
+  if (!dl_env && !h->grp && !h->profile && !h->has_q && check_handle(h) == 0 && coop_eligible(h)) {
+    static const int max_wgs = getenv("PDHG_DEVICE_LOOP_MAX_WGS") ? atoi(getenv("PDHG_DEVICE_LOOP_MAX_WGS")) : 192;
+    device_loop = h->coop_grid <= max_wgs;
+  }
   int64_t s = 0;
   while (s < n_steps) {
     double entry = 0.0;         // nonzero: a multi-step kernel ended inside a take_step (its table of powers ran out)

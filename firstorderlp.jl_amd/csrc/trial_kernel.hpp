@@ -339,18 +339,20 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(Tri
 // and leaves the decision in its XCD's control line for the workgroups it releases.  All eight leaders compute
 // the same bits from the same partials.
 //
-// MEASURED, AND NOT THE DEFAULT (PDHG_DEVICE_LOOP=1 turns it on; profiles/r03_trial_kernel.txt).  Bitwise the
-// per-trial launches over thousands of steps, but slower: L1-SVM 58.5 us per step against 50.3 (17.1k against 19.9k
-// it/s), random 100K x 100K 50.8 against 44.7.  The launch it saves is worth ~5 us + ~3 us of result round trip per
+// MEASURED: THE DEFAULT FOR SMALL GRIDS ONLY (at most 192 workgroups; PDHG_DEVICE_LOOP=0 / 1 forces;
+// profiles/r03_trial_kernel.txt).  Bitwise the per-trial launches over thousands of steps.  24 workgroups 37.2k it/s
+// against 32.7k, 120 workgroups 33.0k against 28.8k, 168 workgroups 30.8k against 27.6k -- but on large grids slower:
+// L1-SVM (856 workgroups) 58.5 us per step against 50.3 (17.1k against 19.9k it/s), random 100K x 100K 50.8 against 44.7.
+// On the large grids:  The launch it saves is worth ~5 us + ~3 us of result round trip per
 // trial; what it costs is more: (i) the phases up to the end of phase 2 take 41.8 us inside the loop against 35.0 after
 // a launch -- a launch starts every workgroup together, the loop starts each where the previous decision reached
 // it (~4 us of skew that barrier 1 then absorbs), and the coherent loads below add ~2 us; (ii) the third barrier
 // (~2 us to its global phase) and the leaders' second stage, which spills at this kernel's register limit once
 // its address arithmetic is hoisted out of the trial loop: 22 us from "global phase complete" to "every workgroup
 // knows the decision" (9 us with the second stage out of line, but then the call makes the phases' code worse by
-// more than that: PDHG_STEPS_NOINLINE).  Even a free second stage would only tie (41.8 + ~4 us per trial against
-// 46.5).  Kept as a tested, opt-in path: the pieces (one host/device step rule, coherent-load phase bodies, the
-// decision-as-release barrier) are what a future attempt with cheaper barriers would start from.
+// more than that: PDHG_STEPS_NOINLINE).  Even a free second stage would only tie there (41.8 + ~4 us per trial
+// against 46.5).  With a few dozen workgroups the barriers cost ~2.5 us, the second stage reads a few dozen slots, and
+// the launch + result round trip the loop saves (~8 us of a ~30 us trial) is what is left.
 //
 // What a multi-trial kernel must add to the single-trial one is L1 coherence ACROSS trials: x', xbar, y', A'y' are
 // rewritten every trial by other compute units than those that read them, and a compute unit's L1 may still hold

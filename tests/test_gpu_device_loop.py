@@ -65,6 +65,36 @@ def test_device_loop_hands_an_unfinished_take_step_back(gpu_required, monkeypatc
     assert got[6] > 80
 
 
+def test_device_loop_barrier_timeout_hands_over_to_the_graph_path(gpu_required, monkeypatch, capfd):
+    """A multi-step launch whose workgroups are not all co-resident (a grid four times what the device holds) cannot pass
+    its first barrier: every spin is bounded, the launch reports zero trials, the host repeats them on the graph path
+    and the handle stays there -- same trajectory as a handle that never used a persistent kernel."""
+    p = random_lp(3000, 2500, 6, seed=11)
+    monkeypatch.setenv("PDHG_COOP", "0")
+    ref = None
+    monkeypatch.setenv("PDHG_SMALL_LP", "0")
+    monkeypatch.setenv("PDHG_ROW_ORDER", "strict")
+    outs = []
+    for pretend in (None, "8192"):
+        monkeypatch.setenv("PDHG_COOP", "0" if pretend is None else "1")
+        monkeypatch.setenv("PDHG_DEVICE_LOOP", "0" if pretend is None else "1")
+        if pretend:
+            monkeypatch.setenv("PDHG_COOP_TEST_PRETEND_WGS", pretend)
+        eng = HipPdhgEngine.from_problem(p)
+        step, pw = H.initial_step_and_weight(p)
+        st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+        if pretend:
+            assert eng.layout_info()["trial_graph"] == 2
+        assert take_steps(POLICY, st, 30) == 30
+        if pretend:
+            assert eng.layout_info()["trial_graph"] == 1
+            assert "timed out" in capfd.readouterr().err
+        outs.append(eng.get_current() + eng.get_average() + (np.array([st.step_size, st.total_number_iterations]),))
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+
+
 def test_device_loop_matches_the_oracle_in_exact_sums_mode(gpu_required, monkeypatch):
     """600 free-running steps in batches of 64 against the CPU restatement with exactly rounded sums: bitwise."""
     p = random_lp(4000, 3000, 7, seed=5)

@@ -17,6 +17,7 @@ POLICY = AdaptiveStepsizeParams(0.3, 0.6)
 
 def _run(p, batches, monkeypatch, small, relaxed=False, mix=False, step_scale=1.0):
     monkeypatch.setenv("PDHG_SMALL_LP", "1" if small else "0")
+    monkeypatch.setenv("PDHG_DEVICE_LOOP", "0")          # the reference runs: one launch per trial (small grids would default to the multi-step kernel)
     monkeypatch.setenv("PDHG_ROW_ORDER", "relaxed" if relaxed else "strict")
     eng = HipPdhgEngine.from_problem(p)
     step, pw = H.initial_step_and_weight(p)
@@ -101,6 +102,7 @@ def test_small_lp_through_optimize(gpu_required, monkeypatch):
                                       1000, 0.5, 0.1, 0.9, 0.5, False)
     params = PdhgParameters(10, False, 1.0, 1.0, True, 0, True, 40, tc, rp, AdaptiveStepsizeParams(0.3, 0.6))
     outs = []
+    monkeypatch.setenv("PDHG_DEVICE_LOOP", "0")
     for small in ("0", "1"):
         monkeypatch.setenv("PDHG_SMALL_LP", small)
         o = optimize(params, q)
