@@ -384,6 +384,8 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         "layout_products": [eng.kernel_name(_lib.K_SPMV_DUAL), eng.kernel_name(_lib.K_SPMV_ATY)],
         "launch_path": ("one workgroup for the whole batch of steps, vectors in LDS (small_lp_steps_kernel)"
                         if eng.layout_info().get("small_lp") and not args.per_step_calls else
+                        "several take_steps per launch of one persistent kernel (steps_kernel)"
+                        if eng.layout_info().get("device_loop") and not args.per_step_calls else
                         {2: "one persistent kernel per trial (trial_kernel)", 1: "one HIP-graph launch per trial",
                          0: "separate launches"}.get(eng.layout_info().get("trial_graph"), "?")),
         "host_calls": "one per take_step (pdhg_take_step_adaptive)" if args.per_step_calls

@@ -2473,18 +2473,8 @@ static int take_step_adaptive_from(pdhg_handle *h, double reduction_exponent, do
   return 0;
 }
 
-/* `n_steps` consecutive take_steps (the iterations optimize() runs between two termination
- * evaluations, pdhg.jl:862-1046: nothing but take_step happens there).  Stops after the step that
- * raised numerical_error, like the reference's loop does at the top of the next iteration. */
-int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_exponent, double growth_exponent,
-                             double *step_size_io, double primal_weight, int64_t *total_number_iterations_io,
-                             double *cumulative_kkt_passes_io, int *numerical_error_out, int64_t *steps_done_out) {
-  if (!steps_done_out) return fail(-1, "null argument");
-  if (n_steps < 0) return fail(-2, "pdhg_take_steps_adaptive: n_steps < 0");
-  *steps_done_out = 0;
-  if (!h || !step_size_io || !total_number_iterations_io || !cumulative_kkt_passes_io || !numerical_error_out)
-    return fail(-1, "null argument");
-  *numerical_error_out = 0;
+// Does pdhg_take_steps_adaptive take this handle's batches with the multi-step kernel (steps_kernel)?
+static bool device_loop_for(pdhg_handle *h) {
   // Several take_steps per launch (steps_kernel: the rule on the device; stream-layout LPs on one handle).  Bitwise the
   // per-trial launches (tests/test_gpu_device_loop.py).  Worth it on SMALL grids only: the third barrier and the
   // leaders' second stage grow with the number of workgroups -- 24 workgroups (24K nonzeros) 37.2k it/s against
@@ -2498,6 +2488,22 @@ int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_e
     static const int max_wgs = getenv("PDHG_DEVICE_LOOP_MAX_WGS") ? atoi(getenv("PDHG_DEVICE_LOOP_MAX_WGS")) : 192;
     device_loop = h->coop_grid <= max_wgs;
   }
+  return device_loop;
+}
+
+/* `n_steps` consecutive take_steps (the iterations optimize() runs between two termination
+ * evaluations, pdhg.jl:862-1046: nothing but take_step happens there).  Stops after the step that
+ * raised numerical_error, like the reference's loop does at the top of the next iteration. */
+int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_exponent, double growth_exponent,
+                             double *step_size_io, double primal_weight, int64_t *total_number_iterations_io,
+                             double *cumulative_kkt_passes_io, int *numerical_error_out, int64_t *steps_done_out) {
+  if (!steps_done_out) return fail(-1, "null argument");
+  if (n_steps < 0) return fail(-2, "pdhg_take_steps_adaptive: n_steps < 0");
+  *steps_done_out = 0;
+  if (!h || !step_size_io || !total_number_iterations_io || !cumulative_kkt_passes_io || !numerical_error_out)
+    return fail(-1, "null argument");
+  *numerical_error_out = 0;
+  const bool device_loop = device_loop_for(h);
   int64_t s = 0;
   while (s < n_steps) {
     double entry = 0.0;         // nonzero: a multi-step kernel ended inside a take_step (its table of powers ran out)
@@ -3418,7 +3424,8 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   info[12] = (int64_t)h->A.slabs.size(); info[13] = (int64_t)h->At.slabs.size();
   // 2: one persistent kernel per trial (trial_kernel.hpp), 1: one graph launch, 0: separate launches
   info[14] = (coop_eligible(h) || h->coop_mode == 1) ? 2 : ((graph_eligible(h) || (h->graph_mode == 1 && !h->has_q)) ? 1 : 0);
-  info[15] = (h->A.tiled && h->A.var_tiles ? 1 : 0) + (h->At.tiled && h->At.var_tiles ? 2 : 0) + (small_lp_eligible(h) ? 4 : 0);
+  info[15] = (h->A.tiled && h->A.var_tiles ? 1 : 0) + (h->At.tiled && h->At.var_tiles ? 2 : 0) + (small_lp_eligible(h) ? 4 : 0) +
+             (!h->grp && !h->has_q && !small_lp_eligible(h) && device_loop_for(h) && coop_eligible(h) ? 8 : 0);
   info[0] = h->A.nblk; info[1] = h->A.nlong; info[2] = h->A.nchunks; info[3] = h->A.max_row_nnz;
   info[4] = h->At.nblk; info[5] = h->At.nlong; info[6] = h->At.nchunks; info[7] = h->At.max_row_nnz;
   info[8] = h->A.tiled ? h->A.nwaves : 0; info[9] = h->At.tiled ? h->At.nwaves : 0;

@@ -386,6 +386,7 @@ class HipPdhgEngine:
                 "A_slabs", "At_slabs", "trial_graph", "var_tiles"]   # var_tiles: bit 0 = A, bit 1 = A'
         out = dict(zip(keys, info.tolist()))
         out["small_lp"] = (out["var_tiles"] >> 2) & 1      # batches of take_steps run in the one-workgroup LDS kernel
+        out["device_loop"] = (out["var_tiles"] >> 3) & 1   # ... in the multi-step persistent kernel (small grids)
         out["var_tiles"] &= 3
         for k in ("A", "At"):    # width in bits of an entry's column field
             out[k + "_tile_shift"] = max(1, (out[k + "_tile_cols"] - 1).bit_length()) if out[k + "_tile_cols"] else 0

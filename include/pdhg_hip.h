@@ -367,7 +367,8 @@ const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id);
  * trial is repeated on the other path, with a line on stderr, [15] bit 0 / bit 1: A / A' use
  * equal-nonzero tiles of different widths (skewed columns; [10],[11] are then nominal); bit 2:
  * a small LP -- pdhg_take_steps_adaptive takes its batches in one workgroup with the vectors in
- * LDS (csrc/small_lp_kernel.hpp; pdhg_trial_step itself is launched as [14] says). */
+ * LDS (csrc/small_lp_kernel.hpp; pdhg_trial_step itself is launched as [14] says); bit 3: it takes
+ * them with the multi-step persistent kernel (several take_steps per launch: small grids). */
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]);
 /* Diagnostics: order-sensitive 64-bit checksums of every device array of the two layouts
  * (out[0..16) CSR(A): row pointers, columns, values, row blocks, the four long-row tables, the
