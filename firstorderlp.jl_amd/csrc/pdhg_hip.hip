@@ -803,6 +803,7 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   a.seq = ++h->steps_seq;
   a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
   a.trace = h->coop_trace;
+  a.small_second_stage = getenv("PDHG_STEPS_GENERAL_SECOND_STAGE") ? 0 : 1;
   for (int x = 0; x < 8; ++x) a.xcd_cnt[x] = h->coop_xcd_cnt[x];
   const auto c1 = std::chrono::steady_clock::now();
   hipLaunchKernelGGL(steps_kernel, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
@@ -2476,16 +2477,13 @@ static int take_step_adaptive_from(pdhg_handle *h, double reduction_exponent, do
 // Does pdhg_take_steps_adaptive take this handle's batches with the multi-step kernel (steps_kernel)?
 static bool device_loop_for(pdhg_handle *h) {
   // Several take_steps per launch (steps_kernel: the rule on the device; stream-layout LPs on one handle).  Bitwise the
-  // per-trial launches (tests/test_gpu_device_loop.py).  Worth it on SMALL grids only: the third barrier and the
-  // leaders' second stage grow with the number of workgroups -- 24 workgroups (24K nonzeros) 37.2k it/s against
-  // 32.7k, 120 workgroups 33.0k against 28.8k, 168 workgroups 30.8k against 27.6k, 200 a tie, 240 workgroups 25.7k
-  // against 27.9k, L1-SVM's 856 17.1k against 19.9k (profiles/r03_trial_kernel.txt).  Default: grids of at most
-  // PDHG_DEVICE_LOOP_MAX_WGS (192) workgroups;
-  // PDHG_DEVICE_LOOP=0 / 1: never / whenever eligible.
+  // per-trial launches (tests/test_gpu_device_loop.py) and faster on every grid measured but one tie: L1-SVM 19.7k ->
+  // 23.4k it/s, random 100K 22.5k -> 28.6k, 3000 x 2500 32.7k -> 52.7k (trial_kernel.hpp, profiles/r03_trial_kernel.txt).
+  // PDHG_DEVICE_LOOP=0 / 1: never / whenever eligible; PDHG_DEVICE_LOOP_MAX_WGS: largest grid it is the default for.
   const char *dl_env = getenv("PDHG_DEVICE_LOOP");
   bool device_loop = dl_env && dl_env[0] == '1';
   if (!dl_env && !h->grp && !h->profile && !h->has_q && check_handle(h) == 0 && coop_eligible(h)) {
-    static const int max_wgs = getenv("PDHG_DEVICE_LOOP_MAX_WGS") ? atoi(getenv("PDHG_DEVICE_LOOP_MAX_WGS")) : 192;
+    static const int max_wgs = getenv("PDHG_DEVICE_LOOP_MAX_WGS") ? atoi(getenv("PDHG_DEVICE_LOOP_MAX_WGS")) : (1 << 30);
     device_loop = h->coop_grid <= max_wgs;
   }
   return device_loop;

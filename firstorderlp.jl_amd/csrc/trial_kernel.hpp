@@ -64,6 +64,13 @@ __global__ __launch_bounds__(TPB) void xcd_register_kernel(GridSync *s) {
 #ifndef PDHG_TRIAL_PIPE
 #define PDHG_TRIAL_PIPE true
 #endif
+// the one-wave-per-quantity second stage of LPs (final_reduce_lp): load pairs in flight per lane; used by the single-trial kernel too
+#ifndef PDHG_STEPS_LP_BATCH
+#define PDHG_STEPS_LP_BATCH 8      // (L1-SVM, 856 slots per quantity: 22.8-23.2k it/s with 4, 23.1-23.4k with 6, 23.4-23.5k with 8)
+#endif
+#ifndef PDHG_TRIAL_LP_SECOND_STAGE
+#define PDHG_TRIAL_LP_SECOND_STAGE 0   // (the single-trial kernel does not spill in the general form: no difference measured there)
+#endif
 constexpr unsigned long long RESULT_CHECK_SALT = 0x9E3779B97F4A7C15ull;
 constexpr long GRID_SPIN_LIMIT = 4000000L;   // x s_sleep(1): ~0.1 s
 
@@ -305,6 +312,10 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(Tri
     double res[5];
     // (requested before the partials so that its trip to memory overlaps theirs)
     const unsigned long long errw = threadIdx.x == 0 ? __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#if PDHG_TRIAL_LP_SECOND_STAGE
+    if (!a.has_q) final_reduce_lp<PDHG_STEPS_LP_BATCH>(a.sp, res, &red[0][0]);      // (uniform; `red` is free: 6 x 4 doubles)
+    else
+#endif
     final_reduce_body<TPB / WAVE>(a.sp, res);
     if (threadIdx.x == 0) {
       // Publish WITHOUT a system-scope fence (an L2 write-back, microseconds): the eight words
@@ -339,20 +350,19 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void trial_kernel(Tri
 // and leaves the decision in its XCD's control line for the workgroups it releases.  All eight leaders compute
 // the same bits from the same partials.
 //
-// MEASURED: THE DEFAULT FOR SMALL GRIDS ONLY (at most 192 workgroups; PDHG_DEVICE_LOOP=0 / 1 forces;
-// profiles/r03_trial_kernel.txt).  Bitwise the per-trial launches over thousands of steps.  24 workgroups 37.2k it/s
-// against 32.7k, 120 workgroups 33.0k against 28.8k, 168 workgroups 30.8k against 27.6k -- but on large grids slower:
-// L1-SVM (856 workgroups) 58.5 us per step against 50.3 (17.1k against 19.9k it/s), random 100K x 100K 50.8 against 44.7.
-// On the large grids:  The launch it saves is worth ~5 us + ~3 us of result round trip per
-// trial; what it costs is more: (i) the phases up to the end of phase 2 take 41.8 us inside the loop against 35.0 after
-// a launch -- a launch starts every workgroup together, the loop starts each where the previous decision reached
-// it (~4 us of skew that barrier 1 then absorbs), and the coherent loads below add ~2 us; (ii) the third barrier
-// (~2 us to its global phase) and the leaders' second stage, which spills at this kernel's register limit once
-// its address arithmetic is hoisted out of the trial loop: 22 us from "global phase complete" to "every workgroup
-// knows the decision" (9 us with the second stage out of line, but then the call makes the phases' code worse by
-// more than that: PDHG_STEPS_NOINLINE).  Even a free second stage would only tie there (41.8 + ~4 us per trial
-// against 46.5).  With a few dozen workgroups the barriers cost ~2.5 us, the second stage reads a few dozen slots, and
-// the launch + result round trip the loop saves (~8 us of a ~30 us trial) is what is left.
+// THE DEFAULT for stream-layout LPs on one handle (PDHG_DEVICE_LOOP=0: one launch per trial).  Bitwise the per-trial
+// launches over thousands of steps (tests/test_gpu_device_loop.py).  Measured (profiles/r03_trial_kernel.txt):
+// L1-SVM (856 workgroups) 19.7k -> 23.4k it/s, random 100K x 100K 22.5k -> 28.6k, 60000 x 50000 27.2k -> 40.7k,
+// 3000 x 2500 32.7k -> 52.7k; random 250K x 250K (1232 workgroups) a tie.
+// What decided it was the SECOND STAGE.  With the general form (final_reduce_body: 2 x 4 x 5 doubles in flight per
+// lane) the kernel, at its register limit, spills there once the trial loop lets the compiler hoist that code's
+// address arithmetic: 11-22 us from "barrier 3's global phase complete" to "every workgroup knows the decision", and
+// the whole loop was SLOWER than a launch per trial on large grids (L1-SVM 17.1k against 19.9k).  With one wave per
+// quantity and eight load pairs in flight (final_reduce_lp) that takes 2.9 us on 40 workgroups and 6.9 us on 856.
+// What the loop still pays: the phases up to the end of phase 2 take ~2 us longer than after a launch (a launch
+// starts every workgroup together, the loop starts each where the previous decision reached it; coherent loads), and a
+// third barrier (~2 us to its global phase); what it saves: the launch (~5 us), the completion ticket and the result's
+// trip to the host and back (~6 us), the host's own ~3 us.
 //
 // What a multi-trial kernel must add to the single-trial one is L1 coherence ACROSS trials: x', xbar, y', A'y' are
 // rewritten every trial by other compute units than those that read them, and a compute unit's L1 may still hold
@@ -389,6 +399,7 @@ struct StepsKernelArgs {
   unsigned nxcd;
   unsigned xcd_cnt[8];
   int relaxed;
+  int small_second_stage;                         // the one-wave-per-quantity second stage (final_reduce_lp; dev: 0 = the general form)
   unsigned long long *trace;                      // PDHG_COOP_TRACE: stamps of the launch's last trial, as for trial_kernel ([7]: leaders, global phase done)
 };
 
@@ -432,6 +443,7 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
   __shared__ double s_st[5];
   __shared__ double s_pow[2];
   __shared__ double s_res[5];
+  __shared__ double s_res8[8];
   const int w = blockIdx.x, nwg = gridDim.x;
   int flip = 0, pend = a.pend, steps = 0, trials = 0, num_err = 0, hw_err = 0, mid = 0;
   if (threadIdx.x == 0) { s_st[0] = a.step_size; s_st[1] = a.step_size; s_st[2] = a.pend_w; s_st[3] = a.wsum_x; s_st[4] = a.wsum_y; }
@@ -544,11 +556,17 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
     }
     __syncthreads();
     if (s_leader) {                                          // workgroup-uniform
-      steps_second_stage(&a.ctl->sp, s_res);
-      if (threadIdx.x == 0) {
-        double res[5];
+      double res[5];
+      if (a.small_second_stage) {                            // (uniform: a launch argument)
+        final_reduce_lp<PDHG_STEPS_LP_BATCH>(a.ctl->sp, res, s_res8);
+      } else {
+        steps_second_stage(&a.ctl->sp, s_res);
+        if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) res[k] = s_res[k];
+          for (int k = 0; k < 5; ++k) res[k] = s_res[k];
+        }
+      }
+      if (threadIdx.x == 0) {
         res[4] *= 0.5;
 #if PDHG_STEPS_PREFETCH
         const StepRule rule = adaptive_step_rule(res, a.primal_weight, s_st[0], s_pow[0], s_pow[1]);

@@ -283,6 +283,40 @@ __device__ __forceinline__ void final_reduce_body(const FinalSpec &sp, double (&
   }
 }
 
+// The same second stage for an LP (quantity 4, dx'Q dx, is absent) with ONE WAVE PER QUANTITY: wave q adds quantity q,
+// B load pairs per lane in flight at a time -- a handful of registers (the general form above keeps 2 * 4 * 5 doubles
+// in flight per lane and spills inside the multi-step kernel: 11.4 us from "barrier complete" to "decision known" on a
+// 40-workgroup grid, 2.9 us with this one).  Exactly rounded double-double sums: the same bits whatever the grouping.
+// Called by a 4-wave workgroup; lds8: 8 doubles of LDS.
+__device__ __forceinline__ bool final_reduce_lp_ok(const FinalSpec &sp) { return sp.count[4] == 0; }
+template <int B>
+__device__ __forceinline__ void final_reduce_lp(const FinalSpec &sp, double (&res)[5], double *lds8) {
+  const int wid = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  const double *p = sp.ptr[wid], *pl = sp.ptr_lo[wid];
+  const int cnt = sp.count[wid];
+  double hi = 0.0, lo = 0.0;
+  for (int base = 0; base < cnt; base += B * WAVE) {         // wave-uniform trip count
+    double h[B], l[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const int i = base + lane + u * WAVE;
+      h[u] = i < cnt ? p[i] : 0.0;
+      l[u] = i < cnt ? pl[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < B; ++u)
+      if (base + lane + u * WAVE < cnt) dd_add_dd(hi, lo, h[u], l[u]);
+  }
+  wave_sum_dd(hi, lo);
+  if (lane == WAVE - 1) { lds8[wid] = hi; lds8[4 + wid] = lo; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) res[k] = lds8[k] + lds8[4 + k];
+    res[4] = 0.0;
+  }
+}
+
 __global__ __launch_bounds__(FINAL_TPB) void final_reduce_kernel(FinalSpec sp) {
   double res[5];
   final_reduce_body<FINAL_TPB / WAVE>(sp, res);
