@@ -552,13 +552,15 @@ int combine_scalars(const Shards &L, int k, int nsum, double *out) {
 // Contiguous row ranges balanced by nonzeros; equalities-first order is kept
 // because the ranges are contiguous.  bounds[world+1].
 // prefix[r] = nonzeros in rows [0, r)
-void row_nnz_prefix(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int base,
-                    std::vector<int64_t> &prefix) {
+// Returns the number of entries whose row index lies outside [base, m + base) (they are not counted).
+int64_t row_nnz_prefix(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int base,
+                       std::vector<int64_t> &prefix) {
   const int64_t nnz = colptr[n] - base;
   prefix.assign((size_t)m + 1, 0);
   // integer counts: host threads over entry ranges with relaxed atomic increments give the same
   // numbers as the serial loop (2.2 G entries: ~5 s serial)
   int64_t *cnt = prefix.data();
+  int64_t bad = 0;
   const int64_t grain = 1 << 22;
   const int parts = (int)std::min<int64_t>(1 << 20, std::max<int64_t>(1, (nnz + grain - 1) / grain));
   parallel_ranges(parts, 1, [&](int pb, int pe) {
@@ -566,9 +568,11 @@ void row_nnz_prefix(int64_t m, int64_t n, const int64_t *colptr, const int64_t *
     for (int64_t k = kb; k < ke; ++k) {
       const int64_t r = rowval[k] - base;
       if (r >= 0 && r < m) __atomic_fetch_add(&cnt[r + 1], (int64_t)1, __ATOMIC_RELAXED);
+      else __atomic_fetch_add(&bad, (int64_t)1, __ATOMIC_RELAXED);
     }
   });
   for (int64_t i = 0; i < m; ++i) prefix[(size_t)i + 1] += prefix[(size_t)i];
+  return bad;
 }
 
 void partition_rows_from_prefix(const std::vector<int64_t> &prefix, int world, std::vector<int64_t> &bounds) {

@@ -731,15 +731,23 @@ static int steps_prepare(pdhg_handle *h, int n, int64_t total_number_iterations,
   return 0;
 }
 // wait for a multi-step launch's result words: r[0..12] once sequence number and checksum match (bounded spin, then the stream)
-static int steps_wait(pdhg_handle *h, unsigned long long seq, double r[13]) {
+// Every word is read through the volatile pointer (a plain read in the spin loop may be hoisted).  r14: the step size
+// on entry of a take_step the launch ended inside (0: none); it is under the checksum like the other words.
+static int steps_wait(pdhg_handle *h, unsigned long long seq, double r[13], double *r14) {
   const volatile unsigned long long *bits = reinterpret_cast<const volatile unsigned long long *>(h->steps_res);
+  const double seq_d = (double)seq;
+  unsigned long long seq_bits;
+  memcpy(&seq_bits, &seq_d, 8);
   auto ready = [&]() -> bool {
-    if (h->steps_res[15] != (double)seq) return false;
+    if (bits[15] != seq_bits) return false;
     unsigned long long w[13], ck = RESULT_CHECK_SALT;
     for (int k = 0; k < 13; ++k) { w[k] = bits[k]; ck ^= w[k] * (2ull * (unsigned long long)k + 1ull); }
+    const unsigned long long w14 = bits[14];
+    ck ^= w14 * 29ull;
     if (ck != bits[13]) return false;
     for (int k = 0; k < 13; ++k) memcpy(&r[k], &w[k], 8);
-    return r[12] == (double)seq;
+    memcpy(r14, &w14, 8);
+    return r[12] == seq_d;
   };
   for (long spin = 0; spin < 400000000L; ++spin) {
     if (ready()) return 0;
@@ -810,8 +818,8 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   HIP_TRY(hipGetLastError());
   const auto c2 = std::chrono::steady_clock::now();
   h->t_launch += std::chrono::duration<double>(c2 - c1).count();
-  double r[13];
-  if ((rc = steps_wait(h, a.seq, r))) return rc;
+  double r[13], r14 = 0.0;
+  if ((rc = steps_wait(h, a.seq, r, &r14))) return rc;
   h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
   const int64_t steps = (int64_t)r[1], trials = (int64_t)r[2];
   const bool flip = r[3] != 0.0, aborted = r[9] != 0.0 || r[11] != 0.0;
@@ -829,7 +837,9 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   *total_number_iterations_io += trials;
   *cumulative_kkt_passes_io += (double)trials;
   *steps_done = steps;
-  *unfinished_entry = (h->steps_res[14] != 0.0 && !aborted) ? h->steps_res[14] : 0.0;
+  // (also after a barrier time-out: the launch may have aborted inside a take_step whose earlier trials were rejected,
+  //  and the word is written by the same thread as the other result words)
+  *unfinished_entry = r14;
   if (r[8] != 0.0) { *numerical_error_out = 1; *steps_done = steps + 1; }   // the failing take_step counts as taken (it is not repeated)
   if (aborted) {
     h->coop_mode = 0;
@@ -902,8 +912,8 @@ int small_lp_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, d
   HIP_TRY(hipGetLastError());
   const auto c2 = std::chrono::steady_clock::now();
   h->t_launch += std::chrono::duration<double>(c2 - c1).count();
-  double r[13];
-  if ((rc = steps_wait(h, a.seq, r))) return rc;
+  double r[13], r14 = 0.0;
+  if ((rc = steps_wait(h, a.seq, r, &r14))) return rc;
   h->t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - c2).count();
   const int64_t steps = (int64_t)r[1], trials = (int64_t)r[2];
   h->small_lp_launches += 1; h->n_graph_trials += trials;
@@ -914,7 +924,7 @@ int small_lp_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, d
   *total_number_iterations_io += trials;
   *cumulative_kkt_passes_io += (double)trials;
   *steps_done = steps;
-  *unfinished_entry = h->steps_res[14];
+  *unfinished_entry = r14;
   if (r[8] != 0.0) { *numerical_error_out = 1; *steps_done = steps + 1; }
   return 0;
 }
@@ -1885,7 +1895,7 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     if (stream) return fail(-1, "a matrix beyond the 32-bit nonzero limit is sharded on the device and cannot run on a "
                                 "caller-supplied stream: pass stream = NULL");
     if (index_base != 0 && index_base != 1) return fail(-1, "index_base must be 0 or 1");
-    if (!colptr || !rowval) return fail(-1, "null input array");
+    if (!colptr || !rowval || !nzval || !c || !b || !lb || !ub) return fail(-1, "null input array");
     if (colptr[0] != index_base || colptr[n] - index_base != nnz) return fail(-1, "colptr does not match nnz / index_base");
     int dev = device_id;
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
@@ -1894,7 +1904,9 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     const int64_t target = std::max<int64_t>(1, (cap / 10) * 8);
     int64_t shards = std::min<int64_t>(m, (nnz + target - 1) / target);
     std::vector<int64_t> prefix, bounds;
-    row_nnz_prefix(m, n, colptr, rowval, index_base, prefix);
+    // (every row index is range-checked here, before anything is indexed with it: create_shard's own validation
+    //  only runs after the partition has walked rowval)
+    if (row_nnz_prefix(m, n, colptr, rowval, index_base, prefix) != 0) return fail(-1, "row index out of range");
     for (int64_t r = 0; r < m; ++r)
       if (prefix[(size_t)r + 1] - prefix[(size_t)r] > cap)
         return fail(-2, "row " + std::to_string(r) + " alone holds " + std::to_string(prefix[(size_t)r + 1] - prefix[(size_t)r]) +
@@ -2518,7 +2530,9 @@ int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_e
         if (k > 0 && entry == 0.0) continue;
       }
     }
-    if (device_loop && n_steps - s >= 2 && !h->grp && !h->profile && check_handle(h) == 0) {
+    // (entry != 0: the small-LP launch above ended inside a take_step -- its step size on entry must reach the accept
+    //  of THAT take_step, so it is finished launch by launch below, never handed to a fresh multi-step launch)
+    if (entry == 0.0 && device_loop && n_steps - s >= 2 && !h->grp && !h->profile && check_handle(h) == 0) {
       int64_t k = 0;
       const int rc = coop_steps(h, n_steps - s, reduction_exponent, growth_exponent, step_size_io, primal_weight,
                                 total_number_iterations_io, cumulative_kkt_passes_io, numerical_error_out, &k, &entry);

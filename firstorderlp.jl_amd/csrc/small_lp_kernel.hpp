@@ -166,8 +166,10 @@ __global__ __launch_bounds__(THREADS) void small_lp_steps_kernel(SmallLpArgs a) 
     PDHG_PUB(0.0); PDHG_PUB(0.0);
     PDHG_PUB((double)a.seq);
 #undef PDHG_PUB
+    const double e14 = mid ? s_st[1] : 0.0;   // ended inside a take_step (table exhausted): its step size on entry, for the host to finish it
+    ck ^= (unsigned long long)__double_as_longlong(e14) * 29ull;     // (word 14 is under the checksum too: steps_wait)
+    a.res_host[14] = e14;
     a.res_host[13] = __longlong_as_double((long long)ck);
-    a.res_host[14] = mid ? s_st[1] : 0.0;     // ended inside a take_step (table exhausted): its step size on entry, for the host to finish it
     a.res_host[15] = (double)a.seq;
   }
 }

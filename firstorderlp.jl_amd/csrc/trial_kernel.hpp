@@ -536,7 +536,9 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
             if (++spins > GRID_SPIN_LIMIT) { __hip_atomic_store(&a.sync->error[0], 4ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dec[3] = 4.0; break; }
           }
           asm volatile("buffer_inv sc1" ::: "memory");
-          s_leader = 1;
+          // a leader whose global wait timed out must not reduce (the partials are incomplete) nor publish a decision
+          // with the current epoch: its XCD's slot stays stale and the waiters below leave through the error word
+          s_leader = (s_dec[3] == 0.0) ? 1 : 0;
           PDHG_STAMP(7);
         } else {
           for (;;) {
@@ -550,6 +552,10 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
             }
             __builtin_amdgcn_s_sleep(1);
             if (++spins > GRID_SPIN_LIMIT) { __hip_atomic_store(&a.sync->error[0], 5ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dec[3] = 5.0; break; }
+            if ((spins & 0xFFF) == 0) {                      // a leader that gave up publishes nothing: leave with its error
+              const unsigned long long ew = __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (ew != 0) { s_dec[3] = (double)ew; break; }
+            }
           }
         }
       }
@@ -617,7 +623,9 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
     PDHG_PUB((double)__hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     PDHG_PUB((double)a.seq);
 #undef PDHG_PUB
-    a.res_host[14] = mid ? s_st[1] : 0.0;     // ended inside a take_step (table exhausted): its step size on entry, for the host to finish it
+    const double e14 = mid ? s_st[1] : 0.0;   // ended inside a take_step (table exhausted): its step size on entry, for the host to finish it
+    ck ^= (unsigned long long)__double_as_longlong(e14) * 29ull;     // (word 14 is under the checksum too: steps_wait)
+    a.res_host[14] = e14;
     a.res_host[13] = __longlong_as_double((long long)ck);
     a.res_host[15] = (double)a.seq;
   }

@@ -15,9 +15,13 @@ pytestmark = pytest.mark.gpu
 POLICY = AdaptiveStepsizeParams(0.3, 0.6)
 
 
-def _run(p, batches, monkeypatch, small, relaxed=False, mix=False, step_scale=1.0):
+def _run(p, batches, monkeypatch, small, relaxed=False, mix=False, step_scale=1.0, device_loop="0"):
     monkeypatch.setenv("PDHG_SMALL_LP", "1" if small else "0")
-    monkeypatch.setenv("PDHG_DEVICE_LOOP", "0")          # the reference runs: one launch per trial (small grids would default to the multi-step kernel)
+    # the reference runs: one launch per trial (small grids would default to the multi-step kernel)
+    if device_loop is None:
+        monkeypatch.delenv("PDHG_DEVICE_LOOP", raising=False)
+    else:
+        monkeypatch.setenv("PDHG_DEVICE_LOOP", device_loop)
     monkeypatch.setenv("PDHG_ROW_ORDER", "relaxed" if relaxed else "strict")
     eng = HipPdhgEngine.from_problem(p)
     step, pw = H.initial_step_and_weight(p)
@@ -75,6 +79,21 @@ def test_a_launch_that_ends_inside_a_take_step_is_finished_by_the_host(gpu_requi
     for k, (a, b) in enumerate(zip(ref, got)):
         assert np.array_equal(a, b), k
     assert got[6] > 120                      # there were rejected trials, i.e. launches that ended inside a take_step
+
+
+@pytest.mark.parametrize("device_loop", [None, "1"], ids=["default", "forced"])
+def test_an_unfinished_take_step_never_reaches_the_multi_step_kernel(gpu_required, monkeypatch, device_loop):
+    """The shipped configuration has BOTH batch kernels on (small-LP kernel first, multi-step kernel as the next
+    choice).  A small-LP launch that ends inside a take_step must be finished launch by launch with its step size on
+    entry as the average's weight (pdhg.jl:512) -- a fresh multi-step launch would start a new take_step and weigh the
+    accept with the already reduced step size: the averages would silently drift from the reference."""
+    p = random_lp(300, 250, 5, seed=2)
+    ref = _run(p, [40, 40, 40], monkeypatch, small=False, step_scale=300.0)
+    monkeypatch.setenv("PDHG_STEPS_TEST_TABLE", "3")
+    got = _run(p, [40, 40, 40], monkeypatch, small=True, step_scale=300.0, device_loop=device_loop)
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(a, b), k
+    assert got[6] > 120
 
 
 def test_small_lp_matches_the_oracle_in_exact_sums_mode(gpu_required, monkeypatch):
