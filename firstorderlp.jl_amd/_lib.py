@@ -31,7 +31,7 @@ EXPORTS = [
     "pdhg_get_current", "pdhg_set_current", "pdhg_get_trial", "pdhg_spmv",
     "pdhg_spmv_t", "pdhg_dist_get_unique_id", "pdhg_create_dist", "pdhg_create_multi",
     "pdhg_dist_info", "pdhg_profile_enable", "pdhg_profile_read",
-    "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info", "pdhg_measure_triad",
+    "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info", "pdhg_measure_triad", "pdhg_measure_sweep_ceiling",
     "pdhg_set_original_problem", "pdhg_eval_point", "pdhg_save_restart_point",
     "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound",
     "pdhg_point_sumsq", "pdhg_rescale", "pdhg_get_problem_vectors", "pdhg_matrix_max_abs",
@@ -39,7 +39,7 @@ EXPORTS = [
     "pdhg_measure_launch_overhead", "pdhg_layout_checksums",
 ]
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 UNIQUE_ID_BYTES = 128
 (K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_ALLGATHER, K_REDUCE_SCATTER,
  K_INTERACTION, K_COUNT) = range(9)
@@ -59,6 +59,39 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB_PATH
+
+
+# ---- sanitizer builds of the HOST side (the kernels are compiled as usual: -fno-gpu-sanitize) ----------------------
+# libpdhg_hip_asan.so: AddressSanitizer + UndefinedBehaviorSanitizer.  tests/test_sanitizer_host.py drives the
+# host-only entry points (row partition, argument validation) through it in a child process that preloads the ASan
+# runtime; libpdhg_hip_tsan.so: ThreadSanitizer, for the shard pool's issuing threads (tools/r4_tsan_shards.sh, GPU box).
+SANITIZED = {"asan": (os.path.join(CSRC, "libpdhg_hip_asan.so"),
+                      ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]),
+             "tsan": (os.path.join(CSRC, "libpdhg_hip_tsan.so"), ["-fsanitize=thread"])}
+
+
+def sanitizer_runtime(kind="asan"):
+    """Path of the clang runtime a process must LD_PRELOAD before it loads the sanitized library."""
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    name = {"asan": "libclang_rt.asan-x86_64.so", "tsan": "libclang_rt.tsan-x86_64.so"}[kind]
+    clang = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang")
+    out = subprocess.check_output([clang if os.path.exists(clang) else hipcc, f"-print-file-name={name}"]).decode().strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
+
+
+def build_sanitized(kind="asan", force=False, verbose=False):
+    """hipcc -O1 -g -fsanitize=... -fno-gpu-sanitize: the same translation unit, host code instrumented."""
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    path, flags = SANITIZED[kind]
+    sources = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))] + \
+              [os.path.join(INCLUDE, "pdhg_hip.h")]
+    if not force and os.path.exists(path) and os.path.getmtime(path) >= max(os.path.getmtime(f) for f in sources):
+        return path
+    cmd = [hipcc, "-O1", "-g"] + HIPCC_FLAGS[1:] + flags + ["-fno-gpu-sanitize", "-I", INCLUDE, "-o", path, SRC_PATH] + LINK_FLAGS
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return path
 
 
 class PdhgHipError(RuntimeError):
@@ -137,6 +170,8 @@ def lib():
     L.pdhg_spmv_t.argtypes = [_vp, _dp, _dp]
     L.pdhg_measure_triad.restype = i32
     L.pdhg_measure_triad.argtypes = [_vp, i64, i32, _dp]
+    L.pdhg_measure_sweep_ceiling.restype = i32
+    L.pdhg_measure_sweep_ceiling.argtypes = [_vp, i64, i64, i64, i32, _dp]
     L.pdhg_layout_checksums.restype = i32
     L.pdhg_layout_checksums.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64)]
     L.pdhg_measure_launch_overhead.restype = i32

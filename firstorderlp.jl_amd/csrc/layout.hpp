@@ -606,6 +606,38 @@ int build_slabs_device(CsrDev &D, int rows, int cols, const std::vector<int> &ro
 
 // Everything of a CsrDev that follows from the row pointers alone: row blocks, the long-row
 // tables and their buffers.  (Host loops over the rows; the per-nonzero arrays are not touched.)
+// Row blocks of (about) EQUAL COST for matrices whose whole product is a few workgroups per compute unit -- an
+// OPT-IN (PDHG_BALANCED_BLOCKS=1), kept for the measurement it settled.  The greedy blocks above are filled to
+// BLOCK_NNZ; when they number between one and four per compute unit the persistent trial kernels
+// (trial_kernel.hpp: one item per workgroup and phase, four workgroups per CU) run with three full blocks on some CUs
+// and four on others, and round 3's timeline of the L1-SVM LP (856 items on 256 CUs) showed every phase ending
+// 3-4 us after its mean workgroup (profiles/r03_trial_kernel.txt).  The cut below makes the item count a multiple
+// of the CU count and gives every block the same cost (entries + a little per row).  MEASURED (round 4,
+// profiles/r04_steps_kernel.txt): the spread does not come from the block sizes -- with 1024 equal blocks the
+// slowest workgroup of a phase is still 3.1-4.9 us behind the mean (12.9 against 9.8 us, 12.8 against 7.9) and the
+// two extra barrier arrivals per XCD cost more than the shorter blocks save: L1-SVM 23.9k -> 23.1k it/s, random
+// 100K x 100K 30.2k -> 30.6k, 250K x 250K 15.1k -> 15.5k.  Same rows, same order inside a row: the row sums keep
+// their bits, and the block partials are exactly rounded double-double sums (common.hpp), which do not depend on
+// the grouping.  PDHG_BALANCED_CUS overrides the CU count (tests).
+inline int balanced_block_target(int greedy_blocks, int nchunks) {
+  const char *ev = getenv("PDHG_BALANCED_BLOCKS");
+  if (!ev || ev[0] != '1') return 0;
+  int cus = 256;
+  if (const char *cv = getenv("PDHG_BALANCED_CUS")) cus = std::max(1, atoi(cv));
+  else {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  const int items = greedy_blocks + nchunks;
+  if (items <= cus || items > 4 * cus) return 0;            // at most one per CU, or more than the persistent grid holds
+  // blocks are launched in eights (one XCD each: the grid is per_xcd * 8), the long-row chunks ride behind them
+  const int per_cu = (items + cus - 1) / cus;
+  const int target = (per_cu * cus - nchunks) / NUM_XCD * NUM_XCD;
+  return target > greedy_blocks ? target : 0;
+}
+
 int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, bool remap) {
   D.rows = rows;
   D.cols = cols;
@@ -638,6 +670,50 @@ int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &r
       ++r;
     }
     blks.push_back(make_int2(r0, r));
+  }
+  if (const int target0 = balanced_block_target((int)blks.size(), (int)chunk_row.size())) {
+    // cost of a row: its entries (gathers, products) + ROW_COST for its extent, epilogue operands and stores
+    constexpr int64_t ROW_COST = 2;
+    auto cost_of = [&](int row) -> int64_t {
+      const int len = rowptr[row + 1] - rowptr[row];
+      return len > BLOCK_NNZ ? 0 : (int64_t)len + ROW_COST;
+    };
+    int64_t total = 0;
+    for (int row = 0; row < rows; ++row) total += cost_of(row);
+    std::vector<int2> cut;
+    int target = target0;
+    for (int attempt = 0; attempt < 4 && target > (int)blks.size(); ++attempt) {
+      cut.clear();
+      int64_t have = 0;               // cost of the rows placed so far
+      int row = 0;
+      while (row < rows) {
+        if (rowptr[row + 1] - rowptr[row] > BLOCK_NNZ) { ++row; continue; }
+        // this block ends where the running cost passes the next multiple of total / target (never empty; hard caps as above)
+        const int64_t goal = (total * ((int64_t)cut.size() + 1) + target - 1) / target;
+        const int r0 = row;
+        int nn = 0;
+        while (row < rows && (row - r0) < MAX_ROWS_PER_BLOCK) {
+          const int len = rowptr[row + 1] - rowptr[row];
+          if (len > BLOCK_NNZ - nn) break;
+          const int64_t cst = cost_of(row);
+          if (row > r0 && have + cst > goal && goal - have <= cst / 2) break;    // closer to the goal without this row
+          nn += len;
+          have += cst;
+          ++row;
+          if (have >= goal) break;
+        }
+        cut.push_back(make_int2(r0, row));
+      }
+      // the hard caps can add a few blocks: the cut must stay within the multiple of the CU count it was made for
+      const int excess = (int)cut.size() - target0;
+      if (excess <= 0) break;
+      target -= (excess + NUM_XCD - 1) / NUM_XCD * NUM_XCD;
+      cut.clear();
+    }
+    if (getenv("PDHG_VERBOSE"))
+      fprintf(stderr, "[pdhg_hip] stream layout %d x %d: %zu row blocks filled to %d entries -> %zu of equal cost (target %d)\n", rows, cols,
+              blks.size(), BLOCK_NNZ, cut.size(), target0);
+    if (!cut.empty()) blks.swap(cut);
   }
   D.nblk = (int)blks.size();
   D.per_xcd = (D.nblk + NUM_XCD - 1) / NUM_XCD;

@@ -1822,7 +1822,7 @@ int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colpt
 extern "C" {
 
 const char *pdhg_last_error(void) { return g_last_error.c_str(); }
-int pdhg_abi_version(void) { return 7; }
+int pdhg_abi_version(void) { return 8; }
 
 // The kernels behind one fused product, as rocprofv3 prints them (template arguments <MODE,
 // INIT, TAG> / <MODE, CH> / <TAG>; MODE 0 plain, 1 dual epilogue, 2 A'y epilogue; TAG 0 = A,
@@ -3369,6 +3369,142 @@ int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps) {
 namespace {
 __global__ void noop_kernel(int *sink) { if (sink && threadIdx.x == 1024) *sink = 0; }
 }  // namespace
+
+extern "C++" {
+namespace {
+// ---- what the tiled sweep's ACCESS PATTERN can reach on this chip, with nothing else in the kernel ------------------
+// The geometry of spmv_tiled_kernel -- 8-wave workgroups, two per CU (the dynamic LDS of the product is reserved, unused),
+// every wave walking the same column tiles in lock step with one pacing barrier per tile, the entries of a (wave, tile)
+// cell streamed as 4-byte packed offsets + 8-byte values with non-temporal loads one tile ahead, one 8-byte gather per
+// entry from the tile's window of the vector -- but no accumulators, no row logic, no epilogue: the products are added
+// into a register.  Its time for the same number of gathers is the floor of this design on this matrix shape; bench.py
+// reports the product kernel's time against it (roofline.ceiling_frac) next to the 8 TB/s figure.  FLAT: no tiles, no
+// barrier, every gather of every wave falls into ONE window of tile_cols columns -- the same wave geometry with a perfect
+// cache (what tile switches and pacing cost), not the chip's all-hit rate at full occupancy.
+template <bool FLAT>
+__global__ __launch_bounds__(TW_WPB * WAVE) void sweep_ceiling_kernel(const unsigned *__restrict__ pk, const double *__restrict__ tv,
+                                                                      const double *__restrict__ x, double *__restrict__ out,
+                                                                      int nwaves, int ntiles, int tile_cols, int cnt) {
+  extern __shared__ double ceiling_lds[];
+  constexpr int C = 3;                                   // 64-entry chunks per cell held in registers (TW_U)
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  const int w = blockIdx.x * TW_WPB + wid;
+  const bool live = w < nwaves;
+  const size_t cell = (size_t)C * WAVE;
+  const unsigned *my = pk + (size_t)(live ? w : 0) * ntiles * cell;
+  const double *myv = tv + (size_t)(live ? w : 0) * ntiles * cell;
+  double s = 0.0;
+  unsigned p[2][C];
+  double v[2][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const bool ok = live && c * WAVE + lane < cnt;
+    p[0][c] = ok ? __builtin_nontemporal_load(my + c * WAVE + lane) : 0u;
+    v[0][c] = ok ? __builtin_nontemporal_load(myv + c * WAVE + lane) : 0.0;
+  }
+  for (int t0 = 0; t0 < ntiles; t0 += 2) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int t = t0 + b;
+      if (t < ntiles) {                                  // workgroup-uniform
+        const double *xt = FLAT ? x : x + (size_t)t * tile_cols;
+        double g[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c] = (live && c * WAVE + lane < cnt) ? xt[p[b][c]] : 0.0;
+        if (t + 1 < ntiles) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const bool ok = live && c * WAVE + lane < cnt;
+            p[b ^ 1][c] = ok ? __builtin_nontemporal_load(my + (size_t)(t + 1) * cell + c * WAVE + lane) : 0u;
+            v[b ^ 1][c] = ok ? __builtin_nontemporal_load(myv + (size_t)(t + 1) * cell + c * WAVE + lane) : 0.0;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) s = s + v[b][c] * g[c];
+        if (!FLAT) __syncthreads();                      // the sweep's pacing barrier
+      }
+    }
+  }
+  if (s == 0.123456789) out[0] = s + ceiling_lds[0];     // keeps the sum (and the LDS reservation) alive
+}
+__global__ __launch_bounds__(TPB) void ceiling_fill_kernel(unsigned *pk, double *tv, size_t len, unsigned tile_cols) {
+  const size_t stride = (size_t)gridDim.x * TPB;
+  for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < len; i += stride) {
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    pk[i] = (unsigned)(z % tile_cols);
+    tv[i] = 1.0 + (double)(z >> 40) * 1e-9;
+  }
+}
+}  // namespace
+}  // extern "C++"
+
+/* out[0]: G gathers/s of the sweep's pattern (tiles + pacing barriers + entry streams, no accumulation) for `rows` rows,
+ * `cols` columns and `nnz` entries in this handle's geometry (its constraint matrix's sweep layout when it has one:
+ * waves, tiles, tile width; otherwise 1221 rows per wave and the tile width the library would choose);
+ * out[1]: milliseconds of one such pass; out[2]: G gathers/s when every gather falls into ONE window of the tile's width
+ * and nothing synchronises (the chip's all-hit rate for 8-byte gathers beside the entry streams); out[3]: entries per
+ * (wave, tile) cell; out[4] / out[5]: waves and tiles of the probe. */
+int pdhg_measure_sweep_ceiling(pdhg_handle *h, int64_t rows, int64_t cols, int64_t nnz, int reps, double out[6]) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (rows <= 0 || cols <= 0 || nnz <= 0 || reps <= 0 || !out) return fail(-1, "bad ceiling-probe arguments");
+  HIP_TRY(hipSetDevice(h->device));
+  auto fits = [&](const CsrDev &M) { return M.tiled && M.nwaves > 0 && M.ntiles > 0 && M.rows == rows && M.cols == cols; };
+  const CsrDev &D = (!fits(h->A) && fits(h->At)) ? h->At : h->A;      // the sweep layout of the product with these extents
+  const bool have = fits(D);
+  const int tile_cols = have ? D.tile_cols : std::max(4096, choose_tile_cols(cols, nnz, rows) > 0 ? choose_tile_cols(cols, nnz, rows) : 65536);
+  const int ntiles = have ? D.ntiles : (int)((cols + tile_cols - 1) / tile_cols);
+  const int tw_rows = have ? D.tw_rows : 1221;
+  const int nwaves = have ? D.nwaves : (int)((rows + tw_rows - 1) / tw_rows);
+  const int cnt = (int)std::min<int64_t>(3 * WAVE, std::max<int64_t>(1, (nnz + (int64_t)nwaves * ntiles / 2) / ((int64_t)nwaves * ntiles)));
+  const size_t len = (size_t)nwaves * ntiles * 3 * WAVE;
+  if (len > ((size_t)1 << 32)) return fail(-2, "ceiling probe: geometry too large");
+  unsigned *pk = nullptr;
+  double *tv = nullptr, *x = nullptr, *o = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t err = hipMalloc((void **)&pk, sizeof(unsigned) * len);
+  if (err == hipSuccess) err = hipMalloc((void **)&tv, sizeof(double) * len);
+  if (err == hipSuccess) err = hipMalloc((void **)&x, sizeof(double) * ((size_t)ntiles * tile_cols + 16));
+  if (err == hipSuccess) err = hipMalloc((void **)&o, 64);
+  if (err == hipSuccess) err = hipMemsetAsync(x, 0, sizeof(double) * ((size_t)ntiles * tile_cols + 16), h->stream);
+  if (err == hipSuccess) err = hipEventCreate(&e0);
+  if (err == hipSuccess) err = hipEventCreate(&e1);
+  double best[2] = {1e30, 1e30};
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(ceiling_fill_kernel, dim3(4096), dim3(TPB), 0, h->stream, pk, tv, len, (unsigned)tile_cols);
+    const size_t lds = have ? tiled_lds_bytes(D) : (size_t)78 * 1024;     // two workgroups per CU, as the product runs
+    err = hipFuncSetAttribute((const void *)sweep_ceiling_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void *)sweep_ceiling_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int grid = (nwaves + TW_WPB - 1) / TW_WPB;
+    for (int flat = 0; flat < 2 && err == hipSuccess; ++flat) {
+      for (int r = 0; r <= reps && err == hipSuccess; ++r) {               // pass 0 warms up
+        (void)hipEventRecord(e0, h->stream);
+        if (flat) hipLaunchKernelGGL(sweep_ceiling_kernel<true>, dim3(grid), dim3(TW_WPB * WAVE), lds, h->stream, pk, tv, x, o, nwaves, ntiles, tile_cols, cnt);
+        else hipLaunchKernelGGL(sweep_ceiling_kernel<false>, dim3(grid), dim3(TW_WPB * WAVE), lds, h->stream, pk, tv, x, o, nwaves, ntiles, tile_cols, cnt);
+        (void)hipEventRecord(e1, h->stream);
+        err = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && ms < best[flat]) best[flat] = ms;
+      }
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  for (void *q : {(void *)pk, (void *)tv, (void *)x, (void *)o}) if (q) (void)hipFree(q);
+  HIP_TRY(err);
+  const double gathers = (double)nwaves * ntiles * cnt;
+  out[0] = gathers / (best[0] * 1e-3) / 1e9;
+  out[1] = best[0];
+  out[2] = gathers / (best[1] * 1e-3) / 1e9;
+  out[3] = (double)cnt;
+  out[4] = (double)nwaves;
+  out[5] = (double)ntiles;
+  return 0;
+}
 
 int pdhg_measure_launch_overhead(pdhg_handle *h, int reps, double out[2]) {
   int rc = check_handle(h);

@@ -563,15 +563,10 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
     __syncthreads();
     if (s_leader) {                                          // workgroup-uniform
       double res[5];
-      if (a.small_second_stage) {                            // (uniform: a launch argument)
-        final_reduce_lp<PDHG_STEPS_LP_BATCH>(a.ctl->sp, res, s_res8);
-      } else {
-        steps_second_stage(&a.ctl->sp, s_res);
-        if (threadIdx.x == 0) {
-#pragma unroll
-          for (int k = 0; k < 5; ++k) res[k] = s_res[k];
-        }
-      }
+      // one wave per quantity (an LP has four).  The general form (final_reduce_body) was kept beside it as a dev
+      // option through round 3: its per-thread index arithmetic is loop-invariant, was hoisted in front of the trial loop
+      // and cost 60 of the kernel's spilled registers although it never ran.
+      final_reduce_lp<PDHG_STEPS_LP_BATCH>(a.ctl->sp, res, s_res8);
       if (threadIdx.x == 0) {
         res[4] *= 0.5;
 #if PDHG_STEPS_PREFETCH

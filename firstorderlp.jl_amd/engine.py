@@ -348,6 +348,15 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_measure_triad(self._h, int(length), int(reps), ctypes.byref(out)))
         return out.value
 
+    def measure_sweep_ceiling(self, rows, cols, nnz, reps=3):
+        """What the tiled sweep's access pattern reaches on this device with nothing else in the kernel
+        (pdhg_measure_sweep_ceiling; measurement only): dict with G gathers/s of the pattern, of the all-hit window,
+        the pass time and the probe's geometry."""
+        out = np.zeros(6)
+        _lib.check(self._L.pdhg_measure_sweep_ceiling(self._h, int(rows), int(cols), int(nnz), int(reps), _pd(out)))
+        return {"pattern_Ggathers_per_s": float(out[0]), "pattern_ms": float(out[1]), "all_hit_window_Ggathers_per_s": float(out[2]),
+                "entries_per_cell": int(out[3]), "waves": int(out[4]), "tiles": int(out[5])}
+
     def layout_checksums(self):
         """32 order-sensitive checksums of the device arrays of both layouts (pdhg_layout_checksums)."""
         out = np.zeros(32, dtype=np.uint64)

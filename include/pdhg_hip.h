@@ -381,6 +381,14 @@ int pdhg_layout_checksums(pdhg_handle *h, uint64_t out[32]);
  * doubles (len % 4 == 0) on this handle's device and stream (24*len bytes per pass), in GB/s --
  * the box's own streaming ceiling to put beside the 8 TB/s spec figure. */
 int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps);
+
+/* Measurement aid for the benchmark line's `roofline.ceiling_frac`: the gather rate the tiled sweep's ACCESS PATTERN
+ * reaches on this device with nothing else in the kernel (same workgroup geometry, tiles, pacing barriers and entry
+ * streams as the product of this handle's constraint matrix; no accumulators, no epilogue).  out[0] G gathers/s of the
+ * pattern, out[1] ms per pass, out[2] G gathers/s with every gather inside one resident window and no barriers,
+ * out[3] entries per (wave, tile) cell, out[4] waves, out[5] tiles.  No reference counterpart (the reference has no
+ * device code); stands beside pdhg_measure_triad. */
+int pdhg_measure_sweep_ceiling(pdhg_handle *h, int64_t rows, int64_t cols, int64_t nnz, int reps, double out[6]);
 /* Measurement only: what a HIP-event bracket reports for EMPTY launches on this handle's
  * stream -- out[0] ms for one empty kernel between the two events, out[1] ms for every further
  * launch inside the same bracket (best of `reps`).  pdhg_profile_read's brackets contain this

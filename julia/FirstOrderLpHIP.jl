@@ -1,4 +1,4 @@
-# FirstOrderLpHIP.jl -- `ccall` shim over libpdhg_hip.so (include/pdhg_hip.h, abi 7).
+# FirstOrderLpHIP.jl -- `ccall` shim over libpdhg_hip.so (include/pdhg_hip.h, abi 8).
 #
 # Drop-in for FirstOrderLp.jl's PDHG path on MI355X:
 #
@@ -26,7 +26,7 @@ using SparseArrays
 import Random
 
 const LIB = get(ENV, "PDHG_HIP_LIB", "libpdhg_hip.so")
-const ABI_VERSION = 7
+const ABI_VERSION = 8
 const POINT_CURRENT = Cint(0)
 const POINT_AVERAGE = Cint(1)
 const POINT_RESTART = Cint(2)
@@ -889,6 +889,13 @@ function measure_triad(s::HipSolverState, len::Int64 = 1 << 26, reps::Int = 5)
   gbps = Ref{Float64}(0.0)
   check(ccall((:pdhg_measure_triad, LIB), Cint, (Ptr{Cvoid}, Int64, Cint, Ref{Float64}), s.handle, len, reps, gbps))
   return gbps[]
+end
+
+# the gather rate the tiled sweep's access pattern reaches with nothing else in the kernel (benchmark aid)
+function measure_sweep_ceiling(s::HipSolverState, rows::Int64, cols::Int64, nnz::Int64, reps::Int = 3)
+  out = zeros(Float64, 6)
+  check(ccall((:pdhg_measure_sweep_ceiling, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ptr{Float64}), s.handle, rows, cols, nnz, reps, out))
+  return out
 end
 
 end # module

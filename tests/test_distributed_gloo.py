@@ -3,7 +3,7 @@ the CPU oracle injected as each rank's local engine.  Checks that the sharded
 run reproduces the unsharded oracle: same accept/reject decisions, iterates
 equal to 1e-12 (the only differences are the 2-term rank-ordered sums of the
 reduce-scatter and the per-slice numpy dots).  The engine under test is the
-numpy mirror of csrc/dist.hpp (distributed.RowPartitionedEngine): row shards,
+numpy mirror of csrc/dist.hpp (tests/dist_mirror.py: RowPartitionedEngine): row shards,
 owned column slices, reduce-scatter -> slice -> all-gather, scalars combined in
 rank order."""
 import os
@@ -21,8 +21,8 @@ def _worker(rank, world, port, q):
     import folp_loader
     folp_loader.load()
     import torch.distributed as dist
-    from firstorderlp_jl_amd.distributed import (RowPartitionedEngine, TorchComm,
-                                                 partition_rows, shard_rows)
+    from firstorderlp_jl_amd.distributed import partition_rows, shard_rows
+    from tests.dist_mirror import RowPartitionedEngine, TorchComm
     from firstorderlp_jl_amd.generators import random_lp
     from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
         AdaptiveStepsizeParams, PdhgSolverState, take_step)
@@ -33,7 +33,12 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = random_lp(600, 500, 6, seed=5)
-        ranges = partition_rows(p.constraint_matrix, world)
+        # the row partition comes from the PRODUCT library (pdhg_partition_rows: host-only C code of csrc/dist.hpp, no GPU
+        # needed), evaluated independently on every rank; the package's numpy statement of the same rule must agree
+        from firstorderlp_jl_amd import HipPdhgEngine
+        bounds = HipPdhgEngine.partition_rows(p.constraint_matrix, world)
+        ranges = [(int(bounds[k]), int(bounds[k + 1])) for k in range(world)]
+        assert ranges == partition_rows(p.constraint_matrix, world)
         lo, hi = ranges[rank]
         local = OracleEngine(**shard_rows(p, lo, hi))
         eng = RowPartitionedEngine(local, TorchComm(), ranges)
@@ -123,8 +128,8 @@ def _kat_worker(rank, world, port, q):
     import folp_loader
     folp_loader.load()
     import torch.distributed as dist
-    from firstorderlp_jl_amd.distributed import (RowPartitionedEngine, TorchComm,
-                                                 partition_rows, shard_rows)
+    from firstorderlp_jl_amd.distributed import partition_rows, shard_rows
+    from tests.dist_mirror import RowPartitionedEngine, TorchComm
     from firstorderlp_jl_amd.primal_dual_hybrid_gradient import optimize
     from firstorderlp_jl_amd.saddle_point import RestartScheme
     from tests import kat_common
@@ -204,8 +209,8 @@ def _mp_worker(rank, world, port, q):
     import folp_loader
     folp_loader.load()
     import torch.distributed as dist
-    from firstorderlp_jl_amd.distributed import (RowPartitionedEngine, TorchComm,
-                                                 partition_rows, shard_rows)
+    from firstorderlp_jl_amd.distributed import partition_rows, shard_rows
+    from tests.dist_mirror import RowPartitionedEngine, TorchComm
     from firstorderlp_jl_amd.generators import random_lp
     from firstorderlp_jl_amd.primal_dual_hybrid_gradient import PdhgSolverState, take_step
     from tests.oracle_engine import OracleEngine
@@ -282,8 +287,8 @@ def _qp_worker(rank, world, port, q):
     import folp_loader
     folp_loader.load()
     import torch.distributed as dist
-    from firstorderlp_jl_amd.distributed import (RowPartitionedEngine, TorchComm,
-                                                 partition_rows, shard_rows)
+    from firstorderlp_jl_amd.distributed import partition_rows, shard_rows
+    from tests.dist_mirror import RowPartitionedEngine, TorchComm
     from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (
         AdaptiveStepsizeParams, PdhgSolverState, take_step)
     from tests.oracle_engine import OracleEngine

@@ -63,7 +63,7 @@ int main(int argc, char **argv) {
   long nblocks = (count + (long)TPB * U - 1) / ((long)TPB * U);
   double *out; CK(hipMalloc(&out, nblocks * TPB * 8));
   const char *names[8] = {"plain", "sc0", "sc1", "sc0 sc1", "nt", "sc0 nt", "sc1 nt", "sc0 sc1 nt"};
-  for (long N : {1000000L, 10000000L}) {
+  for (long N : {4096L, 16384L, 65536L, 262144L, 1000000L, 10000000L}) {   // 32 KB (L1), 128 KB, 512 KB, 2 MB (L2), 8 MB, 80 MB
     std::mt19937_64 rng(1);
     for (long i = 0; i < count; ++i) h[i] = (int)(rng() % N);
     CK(hipMemcpy(idx, h.data(), count * 4, hipMemcpyHostToDevice));
