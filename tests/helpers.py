@@ -105,3 +105,42 @@ def skewed_lp(m, n, seed, dense_rows=1, dense_cols=1, base_nnz=4):
     lb = np.where(rng.random(n) < 0.2, -INF, 0.0)
     ub = np.where(rng.random(n) < 0.5, INF, 2.0)
     return linear_programming_problem(lb, ub, c, 0.0, A, b, num_eq)
+
+
+def bitexact_row_limit():
+    """Rows of at most this many entries are bit-identical to the oracle's sequential sums in the row order the test runs
+    in (conftest.row_order_mode sets PDHG_ROW_ORDER): 2048 (BLOCK_NNZ) in strict order, 256 (RELAXED_MIN_ROW) in the
+    shipped relaxed order; longer rows are within 1e-13 * sum |a x| of them (spmv_kernels.hpp)."""
+    import os
+    return 256 if os.environ.get("PDHG_ROW_ORDER", "relaxed") == "relaxed" else 2048
+
+
+def assert_rows_match_oracle(got, want, row_nnz, abs_scale, label=""):
+    """got / want: a product's rows on the device / from the oracle; row_nnz: entries per row; abs_scale: sum |a x| per
+    row (or any bound of it).  Short rows bitwise, long rows within 1e-13 of the scale."""
+    short = row_nnz <= bitexact_row_limit()
+    assert np.array_equal(got[short], want[short]), label + ": short rows differ"
+    if np.any(~short):
+        assert np.all(np.abs(got[~short] - want[~short]) <= 1e-13 * abs_scale[~short] + 1e-300), label + ": long rows beyond 1e-13 * sum|a x|"
+
+
+def assert_products_match_oracle(eng, A, x, y, forced_sweep=False, label=""):
+    """A x and A'y of `eng` against the oracle's sequential loops in the row order the test runs in: rows up to the
+    bit-exact limit bitwise, longer rows within 1e-13 * sum |a x| (and never worse than that anywhere).
+    forced_sweep: PDHG_SPMV=tiled put the sweep on a matrix whose rows have long runs inside one tile (the builder itself
+    would stream it).  In relaxed order a CHUNK holding a same-row run of more than 8 entries is tree-reduced as a whole
+    (tiled_chunk_relaxed), so only rows of at most 8 entries are then guaranteed bitwise; strict order is unaffected."""
+    import os
+    from oracle import oracle as orc
+    import scipy.sparse as sp
+    A = sp.csc_matrix(A)
+    m, n = A.shape
+    relaxed = os.environ.get("PDHG_ROW_ORDER", "relaxed") == "relaxed"
+    limit = (8 if forced_sweep else 256) if relaxed else 2048
+    absA = abs(A).tocsr()
+    for got, want, nnz_per, scale, name in (
+            (eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x), np.diff(A.tocsr().indptr), absA @ np.abs(x), "A x"),
+            (eng.spmv_t(y), orc.spmv_t(m, n, A.indptr, A.indices, A.data, y), np.diff(A.indptr), absA.T @ np.abs(y), "A'y")):
+        short = nnz_per <= limit
+        assert np.array_equal(got[short], want[short]), f"{label} {name}: rows of <= {limit} entries differ from the oracle"
+        assert np.all(np.abs(got - want) <= 1e-13 * scale + 1e-300), f"{label} {name}: beyond 1e-13 * sum |a x|"

@@ -57,7 +57,7 @@ def test_slab_passes_are_bit_identical(gpu_required, monkeypatch, maker, slab_mb
     x, y = rng.standard_normal(n), rng.standard_normal(m)
     ref, ref_t = orc.spmv(m, n, A.indptr, A.indices, A.data, x), orc.spmv_t(m, n, A.indptr, A.indices, A.data, y)
     got, got_t = eng.spmv(x), eng.spmv_t(y)
-    short, short_t = np.diff(A.tocsr().indptr) <= 2048, np.diff(A.indptr) <= 2048
+    short, short_t = np.diff(A.tocsr().indptr) <= H.bitexact_row_limit(), np.diff(A.indptr) <= H.bitexact_row_limit()
     assert np.array_equal(got[short], ref[short]) and np.array_equal(got_t[short_t], ref_t[short_t])
     assert np.all(np.abs(got - ref) <= 1e-13 * (abs(A) @ np.abs(x)) + 1e-300)
     # trajectories: slabs (graph and plain launches) and the single-pass layout
