@@ -43,6 +43,42 @@ int fail_hip(hipError_t e, const char *what) {
     }                                                                        \
   } while (0)
 
+// ---------------------------------------------------------------- roctx ranges (tracing)
+// PDHG_ROCTX=1: the C-ABI entry points and every fused product push / pop a named roctx range, so that a
+// `rocprofv3 --marker-trace --kernel-trace` timeline shows which take_step / product / evaluation a kernel belongs to
+// (SURVEY section 5 lists tracing among the auxiliary subsystems; the reference itself has Julia's @info logging only).
+// The marker library is bound at run time -- librocprofiler-sdk-roctx (what rocprofv3 listens to), else libroctx64 --
+// and the ranges are no-ops when the variable is unset or neither library is there: no link-time dependency.
+struct RoctxApi {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  bool on = false;
+};
+inline RoctxApi &roctx_api() {
+  static RoctxApi api = [] {
+    RoctxApi a;
+    const char *ev = getenv("PDHG_ROCTX");
+    if (!ev || ev[0] == '0') return a;
+    for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      a.push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+      a.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (a.push && a.pop) { a.on = true; break; }
+    }
+    if (!a.on) fprintf(stderr, "[pdhg_hip] PDHG_ROCTX is set but no roctx library could be bound: ranges are off\n");
+    return a;
+  }();
+  return api;
+}
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char *name) : on(roctx_api().on) { if (on) roctx_api().push(name); }
+  ~RoctxRange() { if (on) roctx_api().pop(); }
+  RoctxRange(const RoctxRange &) = delete;
+  RoctxRange &operator=(const RoctxRange &) = delete;
+};
+
 // ---------------------------------------------------------------- device utils
 
 // Julia's max/min on Float64 for non-NaN inputs, including signed zeros

@@ -51,7 +51,21 @@ struct CsrDev {
   // stream-kernel launch per slab and `grid` is the LAST slab's grid (its blocks write the partials)
   std::vector<SlabDev> slabs;
   double *slab_partial = nullptr;   // [rows] row sums between the passes
-  int slots() const { return grid + nlong; }      // block partials: one per row block, one per long row
+  // ---- 64-bit extents (quadratic_programming.jl:64: the reference's indices are Int64).  The kernels index entries with
+  // 32 bits; a matrix with more entries than that is held as SEGMENTS of whole consecutive rows, each a complete CsrDev
+  // of its own (own arrays and tables, offsets local to the segment: the 64-bit part of an entry's address is the
+  // segment's base pointer).  This head then owns no arrays: rows / cols / nnz are the whole matrix's, `segs` the
+  // parts in row order.  Rows are never cut, so every row sum keeps its order and its bits, and the two products need no
+  // exchange (unlike the row SHARDS of dist.hpp, whose A_p' products are partial sums).
+  std::vector<CsrDev> segs;
+  int row0 = 0;                    // a segment's first row in the whole matrix
+  int slot0 = 0;                   // ... and its first block-partial slot
+  int slots() const {              // block partials: one per row block, one per long row
+    if (segs.empty()) return grid + nlong;
+    int total = 0;
+    for (const CsrDev &S : segs) total += S.slots();
+    return total;
+  }
   CsrView view() const { return CsrView{rows, rowptr, col, val}; }
 };
 
@@ -800,6 +814,7 @@ int build_csr_dev_resident(CsrDev &D, int rows, int cols, const std::vector<int>
 }
 
 void free_csr_dev(CsrDev &D) {
+  for (CsrDev &S : D.segs) free_csr_dev(S);
   void *ptrs[] = {D.rowptr, D.col, D.val, D.blks, D.long_row, D.long_chunk_ptr,
                   D.chunk_row, D.chunk_off, D.chunk_lidx, D.long_ticket, D.chunk_partial, D.wave_rows, D.wave_ent, D.pk, D.tv,
                   D.wave_step_off, D.step_tile, D.wg_step_off};

@@ -16,6 +16,7 @@
 // (-ffp-contract=off: elementwise updates must round like Julia's unfused
 //  broadcasts; the product a*x and the sum are separate roundings).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -188,10 +189,17 @@ int ew_grid(int64_t len) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(g, EW_MAX_BLOCKS));
 }
 
+inline const char *prof_scope_name(int kid) {
+  static const char *names[PDHG_K_COUNT] = {"pdhg:primal (K1+K2)", "pdhg:A*xbar + dual step (K3+K4)", "pdhg:A'*y' + interaction sums (K5+K6)",
+                                           "pdhg:second-stage reduction (K6b)", "pdhg:accept (K7)", "pdhg:all-gather xbar",
+                                           "pdhg:reduce-scatter A'y'", "pdhg:interaction on the slice"};
+  return (kid >= 0 && kid < PDHG_K_COUNT && names[kid]) ? names[kid] : "pdhg:kernel";
+}
 struct ProfScope {
   pdhg_handle *h;
   int kid;
-  ProfScope(pdhg_handle *h_, int kid_) : h(h_), kid(kid_) {
+  RoctxRange range;
+  ProfScope(pdhg_handle *h_, int kid_) : h(h_), kid(kid_), range(prof_scope_name(kid_)) {
     if (h->profile) (void)hipEventRecord(h->ev0, h->stream);
   }
   ~ProfScope() {
@@ -255,6 +263,25 @@ int launch_tiled(pdhg_handle *h, const CsrDev &D, const double *xin, const EpiAr
 // TAG: 0 the constraint matrix, 1 its transpose, 2 the objective matrix (profiler names)
 template <int MODE, int TAG>
 int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
+  if (!D.segs.empty()) {
+    // segments of whole rows (layout.hpp): the same product segment by segment, every row-indexed operand moved to the
+    // segment's first row, its block partials behind those of the segments before it
+    for (const CsrDev &S : D.segs) {
+      EpiArgs se = e;
+      const int r0 = S.row0;
+      if (MODE == MODE_PLAIN) se.out = e.out + r0;
+      if (MODE == MODE_DUAL) {
+        se.y = e.y + r0; se.b = e.b + r0; se.y_next = e.y_next + r0;
+        se.num_eq = std::max(0, std::min(S.rows, e.num_eq - r0));
+        if (e.sum_y) se.sum_y = e.sum_y + r0;
+      }
+      if (MODE == MODE_ATY) { se.x = e.x + r0; se.x_next = e.x_next + r0; se.aty = e.aty + r0; se.aty_next = e.aty_next + r0; }
+      if (e.partials) se.partials = e.partials + S.slot0;
+      const int rc = launch_spmv<MODE, TAG>(h, S, xin, se);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   const int rx = h->relaxed ? 1 : 0;
   if (D.tiled) {
     if (D.grid > 0) {
@@ -524,7 +551,7 @@ bool coop_eligible(pdhg_handle *h) {
   if (h->coop_mode < 0) {
     const char *ev = getenv("PDHG_COOP");
     bool on = !h->grp && !h->A.tiled && !h->At.tiled && h->A.slabs.empty() && h->At.slabs.empty() &&
-              h->n > 0 && h->m > 0;
+              h->A.segs.empty() && h->At.segs.empty() && h->n > 0 && h->m > 0;
     if (h->has_q) on = on && !h->Q.tiled && !h->Qt.tiled && h->Q.slabs.empty() && h->Qt.slabs.empty();
     if (ev) on = on && ev[0] != '0';
     const char *gv = getenv("PDHG_GRAPH");             // PDHG_GRAPH=0: separate launches, no one-launch path of either kind
@@ -857,7 +884,7 @@ bool small_lp_eligible(pdhg_handle *h) {
   if (h->small_lp_mode < 0) {
     const char *ev = getenv("PDHG_SMALL_LP");
     const size_t lds = sizeof(double) * (9 * (size_t)h->n + 4 * (size_t)h->m);
-    bool on = !h->grp && !h->has_q && h->n > 0 && h->m > 0 && !h->A.tiled && !h->At.tiled && h->A.slabs.empty() &&
+    bool on = !h->grp && !h->has_q && h->n > 0 && h->m > 0 && h->A.segs.empty() && h->At.segs.empty() && !h->A.tiled && !h->At.tiled && h->A.slabs.empty() &&
               h->At.slabs.empty() && h->A.max_row_nnz <= SMALL_MAX_ROW && h->At.max_row_nnz <= SMALL_MAX_ROW &&
               lds <= (size_t)144 * 1024;
     if (ev) on = on && ev[0] != '0';
@@ -936,7 +963,7 @@ bool graph_eligible(pdhg_handle *h) {
     // take_step loop in C the separate launches already overlap the kernels -- random 1M x 1M 5 709 it/s as a graph
     // against 5 637, 4M x 4M 1 667 / 1 672, config S 611 / 613 (profiles/r03_trial_kernel.txt).
     const bool tiled_ok = getenv("PDHG_GRAPH_TILED") != nullptr;
-    bool on = !h->grp && !h->has_q && h->n > 0 && (tiled_ok || (!h->A.tiled && !h->At.tiled));
+    bool on = !h->grp && !h->has_q && h->n > 0 && h->A.segs.empty() && h->At.segs.empty() && (tiled_ok || (!h->A.tiled && !h->At.tiled));
     if (ev) on = on && ev[0] != '0';
     h->graph_mode = on ? 1 : 0;
   }
@@ -1515,26 +1542,11 @@ int ingest_on_device(CsrDev &A, CsrDev &At, int64_t rows, int64_t cols, int64_t 
   return 0;
 }
 
-// One shard: device layouts + vectors for the rows it is given.  n_alloc >= n is the
-// allocation length of the n-vectors that take part in collectives.
-int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
-                 const int64_t *colptr, const int64_t *rowval, const double *nzval,
-                 int index_base, const double *c, const double *b, const double *lb,
-                 const double *ub, int64_t num_equalities, int device_id, void *stream, int64_t n_alloc) {
-  *out = nullptr;
-  if (index_base != 0 && index_base != 1) return fail(-1, "index_base must be 0 or 1");
-  if (num_equalities < 0 || num_equalities > m) return fail(-1, "num_equalities out of range");
-  if (!colptr || !c || !lb || !ub || (m > 0 && !b) || (nnz > 0 && (!rowval || !nzval)))
-    return fail(-1, "null input array");
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) return fail(-3, "no HIP device visible");
-  int dev = device_id;
-  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
-  if (dev >= ndev) return fail(-1, "device_id out of range");
-  HIP_TRY(hipSetDevice(dev));
-  n_alloc = std::max(n_alloc, n);
-
+// Both device layouts of one CSC matrix (either may be skipped: a row segment of a matrix beyond the 32-bit entry limit
+// needs only one of them, create_segmented below): ingest -- on the device from 8M nonzeros, host threads below --
+// then the row blocks, long-row tables and, where chosen, the sweep's tile-major copy or the column slabs.
+int build_layout_pair(int dev, bool remap, bool relaxed, int64_t m, int64_t n, int64_t nnz, const int64_t *colptr,
+                      const int64_t *rowval, const double *nzval, int index_base, CsrDev *A_out, CsrDev *At_out) {
   const bool verbose = getenv("PDHG_VERBOSE") != nullptr;   // phase timings of the set-up on stderr
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
@@ -1558,6 +1570,140 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     if (rc) return rc;
   }
   const auto t_conv = now();
+  // the two layouts are independent: CSR(A) is built on a second host thread while this one builds CSR(A')
+  // (each fans out over host_threads() workers for the per-nonzero passes; uploads are synchronous copies)
+  int rc_a = 0;
+  std::string err_a;
+  double t_a = 0.0, t_at = 0.0;
+  const int tile_a = choose_tile_cols(n, nnz, m), tile_at = choose_tile_cols(m, nnz, n);
+  // Off by default: measured on the 2 x 64-core host of the GPU box at config S, the two builds side by side took
+  // 0.92 s against 0.83 s one after the other (0.78 || 0.60 s against 0.47 + 0.36 s) -- the per-nonzero passes are bound
+  // by host memory bandwidth, not by threads (32 threads per pass instead of 16 changed nothing either).
+  const bool two = A_out && At_out && nnz >= (1 << 22) && getenv("PDHG_PARALLEL_LAYOUTS") != nullptr;
+  if (device_layout) {
+    if (A_out) *A_out = dev_A; else free_csr_dev(dev_A);
+    if (At_out) *At_out = dev_At; else free_csr_dev(dev_At);
+    dev_A = CsrDev(); dev_At = CsrDev();
+  }
+  auto build_a = [&]() {
+    if (!A_out) return;
+    const auto t0 = now();
+    if (hipSetDevice(dev) != hipSuccess) { rc_a = 999; err_a = "hipSetDevice failed on the layout thread"; return; }
+    rc_a = device_layout ? build_csr_dev_resident(*A_out, (int)m, (int)n, rowptr, remap, tile_a, relaxed)
+                         : build_csr_dev(*A_out, (int)m, (int)n, rowptr, col, val, remap, tile_a, relaxed);
+    if (rc_a) err_a = g_last_error;
+    t_a = secs(t0, now());
+  };
+  std::thread worker;
+  if (two) worker = std::thread(build_a); else build_a();
+  const auto t0 = now();
+  int rc_t = 0;
+  if (At_out)
+    rc_t = device_layout ? build_csr_dev_resident(*At_out, (int)n, (int)m, t_rowptr, remap, tile_at, relaxed)
+                         : build_csr_dev(*At_out, (int)n, (int)m, t_rowptr, t_col, t_val, remap, tile_at, relaxed);
+  t_at = secs(t0, now());
+  if (two) worker.join();
+  if (rc_a) { g_last_error = err_a; return rc_a; }
+  if (rc_t) return rc_t;
+  if (verbose)
+    fprintf(stderr, "pdhg_create (%s): CSC -> CSR(A), CSR(A') %.2fs; layouts%s A %.2fs %s A' %.2fs (%.2fs elapsed)\n",
+            device_layout ? "device layout construction" : "host layout construction", secs(t_start, t_conv),
+            device_layout ? "" : " + upload", t_a, two ? "beside" : "then", t_at, secs(t_conv, now()));
+  return 0;
+}
+
+// A matrix with more entries than the layouts' 32-bit offsets index (quadratic_programming.jl:64: Int64 in the reference):
+// both copies are built as SEGMENTS of whole rows (layout.hpp, CsrDev::segs) -- CSR(A) from row ranges of the matrix,
+// CSR(A') from column ranges (= row ranges of A'), every range below `cap` entries -- inside ONE ordinary handle: no
+// shards, no exchange, every row sum in its reference order.  Each range is ingested like a matrix of its own; the
+// side of the pair that the range does not need is not built.
+int build_segments(int dev, pdhg_handle *h, int64_t m, int64_t n, int64_t nnz, const int64_t *colptr, const int64_t *rowval,
+                   const double *nzval, int base, int64_t cap) {
+  if (!colptr || !rowval || !nzval) return fail(-1, "null input array");
+  if (colptr[0] != base || colptr[n] - base != nnz) return fail(-1, "colptr does not match nnz / index_base");
+  for (int64_t j = 0; j < n; ++j)
+    if (colptr[j + 1] < colptr[j]) return fail(-1, "colptr not monotone");
+  std::vector<int64_t> prefix;
+  // (every row index is range-checked here, before anything is indexed with it)
+  if (row_nnz_prefix(m, n, colptr, rowval, base, prefix) != 0) return fail(-1, "row index out of range");
+  const int64_t target = std::max<int64_t>(1, (cap / 10) * 8);         // aim at 80 % of the limit
+  auto cut = [&](int64_t count, auto extent, const char *what, std::vector<int64_t> &bounds) -> int {
+    bounds.assign(1, 0);
+    int64_t i = 0;
+    while (i < count) {
+      const int64_t i0 = i;
+      if (extent(i0, i0 + 1) > cap)
+        return fail(-2, std::string(what) + " " + std::to_string(i0) + " alone holds " + std::to_string(extent(i0, i0 + 1)) +
+                            " nonzeros, more than 32-bit offsets can index (" + std::to_string(cap) + ")");
+      ++i;
+      while (i < count && extent(i0, i + 1) <= target) ++i;
+      bounds.push_back(i);
+    }
+    return 0;
+  };
+  std::vector<int64_t> rb, cb;
+  int rc;
+  if ((rc = cut(m, [&](int64_t a, int64_t b) { return prefix[(size_t)b] - prefix[(size_t)a]; }, "row", rb))) return rc;
+  if ((rc = cut(n, [&](int64_t a, int64_t b) { return colptr[b] - colptr[a]; }, "column", cb))) return rc;
+  const bool verbose = getenv("PDHG_VERBOSE") != nullptr;
+  if (verbose)
+    fprintf(stderr, "[pdhg_hip] %lld nonzeros exceed the 32-bit entry limit (%lld): CSR(A) in %zu row segments, CSR(A') in %zu\n",
+            (long long)nnz, (long long)cap, rb.size() - 1, cb.size() - 1);
+  h->A.rows = (int)m; h->A.cols = (int)n; h->A.nnz = nnz;
+  h->At.rows = (int)n; h->At.cols = (int)m; h->At.nnz = nnz;
+  int slot = 0;
+  for (size_t k = 0; k + 1 < rb.size(); ++k) {
+    std::vector<int64_t> cp;
+    uvec<int64_t> rv;
+    dvec nv;
+    slice_csc_rows(n, colptr, rowval, nzval, base, rb[k], rb[k + 1], cp, rv, nv);        // 0-based CSC of the row range
+    CsrDev S;
+    static const int64_t none_i = 0;
+    static const double none_d = 0.0;
+    if ((rc = build_layout_pair(dev, h->remap, h->relaxed, rb[k + 1] - rb[k], n, cp[(size_t)n], cp.data(), rv.empty() ? &none_i : rv.data(),
+                                nv.empty() ? &none_d : nv.data(), 0, &S, nullptr))) { free_csr_dev(S); return rc; }
+    S.row0 = (int)rb[k];
+    S.slot0 = slot;
+    slot += S.slots();
+    h->A.max_row_nnz = std::max(h->A.max_row_nnz, S.max_row_nnz);
+    h->A.segs.push_back(S);
+  }
+  slot = 0;
+  for (size_t k = 0; k + 1 < cb.size(); ++k) {
+    const int64_t c0 = cb[k], c1 = cb[k + 1], k0 = colptr[c0] - base;
+    std::vector<int64_t> cp((size_t)(c1 - c0) + 1);
+    for (int64_t j = c0; j <= c1; ++j) cp[(size_t)(j - c0)] = colptr[j] - colptr[c0] + base;
+    CsrDev S;
+    if ((rc = build_layout_pair(dev, h->remap, h->relaxed, m, c1 - c0, colptr[c1] - colptr[c0], cp.data(), rowval + k0, nzval + k0, base,
+                                nullptr, &S))) { free_csr_dev(S); return rc; }
+    S.row0 = (int)c0;
+    S.slot0 = slot;
+    slot += S.slots();
+    h->At.max_row_nnz = std::max(h->At.max_row_nnz, S.max_row_nnz);
+    h->At.segs.push_back(S);
+  }
+  return 0;
+}
+
+// One shard: device layouts + vectors for the rows it is given.  n_alloc >= n is the
+// allocation length of the n-vectors that take part in collectives.
+int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
+                 const int64_t *colptr, const int64_t *rowval, const double *nzval,
+                 int index_base, const double *c, const double *b, const double *lb,
+                 const double *ub, int64_t num_equalities, int device_id, void *stream, int64_t n_alloc, int64_t seg_cap) {
+  *out = nullptr;
+  if (index_base != 0 && index_base != 1) return fail(-1, "index_base must be 0 or 1");
+  if (num_equalities < 0 || num_equalities > m) return fail(-1, "num_equalities out of range");
+  if (!colptr || !c || !lb || !ub || (m > 0 && !b) || (nnz > 0 && (!rowval || !nzval)))
+    return fail(-1, "null input array");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(-3, "no HIP device visible");
+  int dev = device_id;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= ndev) return fail(-1, "device_id out of range");
+  HIP_TRY(hipSetDevice(dev));
+  n_alloc = std::max(n_alloc, n);
 
   pdhg_handle *h = new pdhg_handle();
   h->self = h;
@@ -1577,40 +1723,8 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     h->own_stream = true;
   }
 #define CK(expr) do { int _rc = (expr); if (_rc) { destroy_shard(h); return _rc; } } while (0)
-  // the two layouts are independent: CSR(A) is built on a second host thread while this one builds CSR(A')
-  // (each fans out over host_threads() workers for the per-nonzero passes; uploads are synchronous copies)
-  {
-    int rc_a = 0;
-    std::string err_a;
-    double t_a = 0.0, t_at = 0.0;
-    const int tile_a = choose_tile_cols(n, nnz, m), tile_at = choose_tile_cols(m, nnz, n);
-    // Off by default: measured on the 2 x 64-core host of the GPU box at config S, the two builds side by side took
-    // 0.92 s against 0.83 s one after the other (0.78 ‖ 0.60 s against 0.47 + 0.36 s) -- the per-nonzero passes are bound
-    // by host memory bandwidth, not by threads (32 threads per pass instead of 16 changed nothing either).
-    const bool two = nnz >= (1 << 22) && getenv("PDHG_PARALLEL_LAYOUTS") != nullptr;
-    if (device_layout) { h->A = dev_A; h->At = dev_At; dev_A = CsrDev(); dev_At = CsrDev(); }
-    auto build_a = [&]() {
-      const auto t0 = now();
-      if (hipSetDevice(dev) != hipSuccess) { rc_a = 999; err_a = "hipSetDevice failed on the layout thread"; return; }
-      rc_a = device_layout ? build_csr_dev_resident(h->A, (int)m, (int)n, rowptr, h->remap, tile_a, h->relaxed)
-                           : build_csr_dev(h->A, (int)m, (int)n, rowptr, col, val, h->remap, tile_a, h->relaxed);
-      if (rc_a) err_a = g_last_error;
-      t_a = secs(t0, now());
-    };
-    std::thread worker;
-    if (two) worker = std::thread(build_a); else build_a();
-    const auto t0 = now();
-    const int rc_t = device_layout ? build_csr_dev_resident(h->At, (int)n, (int)m, t_rowptr, h->remap, tile_at, h->relaxed)
-                                   : build_csr_dev(h->At, (int)n, (int)m, t_rowptr, t_col, t_val, h->remap, tile_at, h->relaxed);
-    t_at = secs(t0, now());
-    if (two) worker.join();
-    if (rc_a) { g_last_error = err_a; destroy_shard(h); return rc_a; }
-    CK(rc_t);
-    if (verbose)
-      fprintf(stderr, "pdhg_create (%s): CSC -> CSR(A), CSR(A') %.2fs; layouts%s A %.2fs %s A' %.2fs (%.2fs elapsed)\n",
-              device_layout ? "device layout construction" : "host layout construction", secs(t_start, t_conv),
-              device_layout ? "" : " + upload", t_a, two ? "beside" : "then", t_at, secs(t_conv, now()));
-  }
+  if (seg_cap > 0 && nnz > seg_cap) CK(build_segments(dev, h, m, n, nnz, colptr, rowval, nzval, index_base, seg_cap));   // 64-bit extents
+  else CK(build_layout_pair(dev, h->remap, h->relaxed, m, n, nnz, colptr, rowval, nzval, index_base, &h->A, &h->At));
   auto up = [&](double **dst, const double *src, int64_t len) -> int {
     int r2 = alloc_zero(dst, len);
     if (r2) return r2;
@@ -1752,7 +1866,7 @@ int create_rank_shard_local(DistGroup *g, int rank, int64_t n, const int64_t *co
   const int64_t ne = std::min<int64_t>(std::max<int64_t>(g->num_eq_global - lo, 0), hi - lo);
   pdhg_handle *s = nullptr;
   int rc = create_shard(&s, hi - lo, n, colptr[n] - base, colptr, rowval, nzval, base, c, b_local,
-                        lb, ub, ne, device_id, stream, g->world * g->S);
+                        lb, ub, ne, device_id, stream, g->world * g->S, 0);
   if (rc) return rc;
   if (hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming) != hipSuccess) {
@@ -1829,6 +1943,8 @@ int pdhg_abi_version(void) { return 8; }
 // 1 = A'), joined by " + ": a profile of the separate launches adds up to the product by
 // summing these names (tools/rocprof_summary.py does).
 static std::string product_kernels(const CsrDev &D, int mode, int tag) {
+  if (!D.segs.empty())
+    return product_kernels(D.segs.front(), mode, tag) + " (x " + std::to_string(D.segs.size()) + " row segments)";
   std::string out;
   auto add = [&](const std::string &k) { out += (out.empty() ? "" : " + ") + k; };
   const std::string m = std::to_string(mode), t = std::to_string(tag);
@@ -1883,11 +1999,17 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   if (!out) return fail(-1, "out == NULL");
   // The device layouts index nonzeros with 32 bits.  The reference's matrices are
   // SparseMatrixCSC{Float64,Int64} (quadratic_programming.jl:64): a matrix with more
-  // nonzeros than that is cut into row shards on this ONE device (the row-partitioned
-  // form with the peer-kernel exchange, dist.hpp), each below the limit.  m and n stay
-  // below 2^31.  PDHG_MAX_SHARD_NNZ lowers the limit (tests).
+  // nonzeros than that is held as SEGMENTS of whole rows inside this one handle (64-bit
+  // extents = segment base pointer + 32-bit local offsets; build_segments) -- the default
+  // since round 4: no exchange, every row sum in its reference order.  PDHG_HUGE=shards keeps
+  // rounds 2-3's form: row shards on this ONE device behind a group handle (the row-partitioned
+  // form with the peer-kernel exchange, dist.hpp).  m and n stay below 2^31.
+  // PDHG_MAX_SHARD_NNZ lowers the limit (tests).
   int64_t cap = (int64_t)INT32_MAX - 1;
   if (const char *ev = getenv("PDHG_MAX_SHARD_NNZ")) cap = std::max<int64_t>(1, atoll(ev));
+  const char *huge = getenv("PDHG_HUGE");
+  if (nnz > cap && !(huge && !strcmp(huge, "shards")))
+    return create_shard(out, m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities, device_id, stream, n, cap);
   if (nnz > cap && m > 1) {
     *out = nullptr;
     // The shards run on private streams and synchronise among themselves: work the caller
@@ -1924,7 +2046,7 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
                              (int)shards, ids.data(), bounds.data());
   }
   return create_shard(out, m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities,
-                      device_id, stream, n);
+                      device_id, stream, n, 0);
 }
 
 // ---- row-partitioned multi-GPU handles -------------------------------------------
@@ -2397,6 +2519,7 @@ int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight, doub
 }
 
 int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, double theta, double out[5]) {
+  RoctxRange roctx_range("pdhg_trial_step");
   int rc = check_handle(h);
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
@@ -2412,6 +2535,7 @@ int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, doub
 }
 
 int pdhg_accept(pdhg_handle *h0, double avg_weight) {
+  RoctxRange roctx_range("pdhg_accept");
   int rc = check_handle(h0);
   if (rc) return rc;
   const Shards L = shards_of(h0);
@@ -2507,6 +2631,7 @@ static bool device_loop_for(pdhg_handle *h) {
 int pdhg_take_steps_adaptive(pdhg_handle *h, int64_t n_steps, double reduction_exponent, double growth_exponent,
                              double *step_size_io, double primal_weight, int64_t *total_number_iterations_io,
                              double *cumulative_kkt_passes_io, int *numerical_error_out, int64_t *steps_done_out) {
+  RoctxRange roctx_range("pdhg_take_steps_adaptive");
   if (!steps_done_out) return fail(-1, "null argument");
   if (n_steps < 0) return fail(-2, "pdhg_take_steps_adaptive: n_steps < 0");
   *steps_done_out = 0;
@@ -2626,6 +2751,7 @@ static int refresh_full_x(const Shards &L) {
 }
 
 int pdhg_restart_to_average(pdhg_handle *h0) {
+  RoctxRange roctx_range("pdhg_restart_to_average");
   int rc = check_handle(h0);
   if (rc) return rc;
   const Shards L = shards_of(h0);
@@ -2883,6 +3009,7 @@ int pdhg_set_original_problem(pdhg_handle *h0, const double *constraint_rescalin
 }
 
 int pdhg_eval_point(pdhg_handle *h0, int point, double out[24]) {
+  RoctxRange roctx_range("pdhg_eval_point");
   int rc = check_handle(h0);
   if (rc) return rc;
   if (!h0->has_original) return fail(-1, "pdhg_set_original_problem has not been called");
@@ -3074,6 +3201,10 @@ struct RescaleTmp {
 extern "C++" {
 template <int OP>
 static void launch_row_op(pdhg_handle *h, const CsrDev &D, int cols, double pexp, const double *inv_scale, double *out) {
+  if (!D.segs.empty()) {        // row segments (layout.hpp): the statistic is per row, segment by segment
+    for (const CsrDev &S : D.segs) launch_row_op<OP>(h, S, cols, pexp, inv_scale ? inv_scale + S.row0 : inv_scale, out + S.row0);
+    return;
+  }
   hipLaunchKernelGGL(row_op_kernel<OP>, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.view(), cols, pexp, inv_scale, out);
   if (D.nlong > 0) {
     hipLaunchKernelGGL(row_op_long_partial_kernel<OP>, dim3(D.nchunks), dim3(TPB), 0, h->stream, D.view(),
@@ -3090,25 +3221,29 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
   const int n = (int)h->n, m = (int)h->m;
   hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_m), dim3(TPB), 0, h->stream, m, t.ev, t.inv_e, 0);
   hipLaunchKernelGGL(resc_zero_to_one_inv_kernel, dim3(h->ew_grid_n), dim3(TPB), 0, h->stream, n, t.dv, t.inv_d, 0);
-  CsrDev *Ls[2] = {&h->A, &h->At};
-  for (int k = 0; k < 2; ++k) {
-    CsrDev &D = *Ls[k];
-    if (D.nnz == 0) continue;
+  // every resident copy of one matrix (k = 0: CSR(A), rows -> E; k = 1: CSR(A'), rows -> D); a row segment takes the
+  // row-indexed factor from its first row on
+  std::function<void(CsrDev &, const double *, const double *, int)> scale_one =
+      [&](CsrDev &D, const double *inv_e, const double *inv_d, int k) {
+    for (CsrDev &S : D.segs) scale_one(S, k == 0 ? inv_e + S.row0 : inv_e, k == 1 ? inv_d + S.row0 : inv_d, k);
+    if (!D.segs.empty() || D.nnz == 0) return;
     hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, D.rowptr,
-                       D.col, D.val, t.inv_e, t.inv_d, k, 1);
+                       D.col, D.val, inv_e, inv_d, k, 1);
     if (D.nlong > 0)
       hipLaunchKernelGGL(scale_long_kernel, dim3(D.nchunks), dim3(TPB), 0, h->stream, (const int *)D.rowptr,
                          (const int *)D.col, D.val, (const int *)D.chunk_row, (const int *)D.chunk_off,
-                         (const double *)t.inv_e, (const double *)t.inv_d, k);
+                         inv_e, inv_d, k);
     if (D.tiled && D.nwaves > 0)
       hipLaunchKernelGGL(scale_tiled_kernel, dim3(row_grid(D.nwaves)), dim3(TPB), 0, h->stream, D.wave_rows,
                          D.wave_ent, D.wave_step_off, D.step_tile, D.wg_step_off, D.nwaves, D.tile_shift,
-                         D.pk, D.tv, t.inv_e, t.inv_d, k);
+                         D.pk, D.tv, inv_e, inv_d, k);
     for (const SlabDev &S : D.slabs)
       if (S.nnz > 0)
         hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, S.rowptr,
-                           S.col, S.val, t.inv_e, t.inv_d, k, 0);
-  }
+                           S.col, S.val, inv_e, inv_d, k, 0);
+  };
+  scale_one(h->A, t.inv_e, t.inv_d, 0);
+  scale_one(h->At, t.inv_e, t.inv_d, 1);
   if (h->has_q) {
     // objective_matrix = (D^-1 Q) D^-1 (preprocess.jl:562-564); Qt holds Q' entry by entry, so the
     // "transposed" order reproduces the same two roundings on it
@@ -3267,6 +3402,18 @@ int pdhg_matrix_max_abs(pdhg_handle *h0, double *out) {
   const Shards L = shards_of(h0);
   FOR_SHARDS(L, h) {
     if ((rc = ev_alloc(h))) return rc;
+    if (!h->At.segs.empty()) {            // row segments: the max over the segments' maxima (single handle: L is this one)
+      double best = 0.0;
+      for (const CsrDev &S : h->At.segs) {
+        hipLaunchKernelGGL(maxabs_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int64_t)S.nnz, S.val, h->ev_partials, h->ev_grid);
+        HIP_TRY(hipGetLastError());
+        double part = 0.0;
+        if ((rc = ev_finish(L, 0, 1, &part))) return rc;
+        best = std::max(best, part);
+      }
+      *out = best;
+      return 0;
+    }
     hipLaunchKernelGGL(maxabs_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int64_t)h->At.nnz, h->At.val,
                        h->ev_partials, h->ev_grid);
     HIP_TRY(hipGetLastError());
@@ -3531,6 +3678,7 @@ int pdhg_layout_checksums(pdhg_handle *h, uint64_t out[32]) {
   int rc = check_handle(h);
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
+  if (!h->A.segs.empty() || !h->At.segs.empty()) return fail(-2, "layout checksums are per piece: not defined for a matrix held as row segments");
   HIP_TRY(hipStreamSynchronize(h->stream));
   const CsrDev *Ls[2] = {&h->A, &h->At};
   for (int k = 0; k < 2; ++k) {
@@ -3572,12 +3720,27 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   info[12] = (int64_t)h->A.slabs.size(); info[13] = (int64_t)h->At.slabs.size();
   // 2: one persistent kernel per trial (trial_kernel.hpp), 1: one graph launch, 0: separate launches
   info[14] = (coop_eligible(h) || h->coop_mode == 1) ? 2 : ((graph_eligible(h) || (h->graph_mode == 1 && !h->has_q)) ? 1 : 0);
-  info[15] = (h->A.tiled && h->A.var_tiles ? 1 : 0) + (h->At.tiled && h->At.var_tiles ? 2 : 0) + (small_lp_eligible(h) ? 4 : 0) +
+  info[15] = ((h->A.tiled && h->A.var_tiles) || (!h->A.segs.empty() && h->A.segs.front().tiled && h->A.segs.front().var_tiles) ? 1 : 0) +
+             ((h->At.tiled && h->At.var_tiles) || (!h->At.segs.empty() && h->At.segs.front().tiled && h->At.segs.front().var_tiles) ? 2 : 0) +
+             (small_lp_eligible(h) ? 4 : 0) +
              (!h->grp && !h->has_q && !small_lp_eligible(h) && device_loop_for(h) && coop_eligible(h) ? 8 : 0);
-  info[0] = h->A.nblk; info[1] = h->A.nlong; info[2] = h->A.nchunks; info[3] = h->A.max_row_nnz;
-  info[4] = h->At.nblk; info[5] = h->At.nlong; info[6] = h->At.nchunks; info[7] = h->At.max_row_nnz;
-  info[8] = h->A.tiled ? h->A.nwaves : 0; info[9] = h->At.tiled ? h->At.nwaves : 0;
-  info[10] = h->A.tiled ? h->A.tile_cols : 0; info[11] = h->At.tiled ? h->At.tile_cols : 0;
+  // a matrix held as row segments (64-bit extents, layout.hpp) reports the sums over its segments, the first segment's
+  // tile width, and the segment counts in bits 8-15 (A) and 16-23 (A') of info[15]
+  auto total = [](const CsrDev &D, auto f) { int64_t t = 0; if (D.segs.empty()) return (int64_t)f(D); for (const CsrDev &S : D.segs) t += f(S); return t; };
+  auto first = [](const CsrDev &D) -> const CsrDev & { return D.segs.empty() ? D : D.segs.front(); };
+  const CsrDev *Ms[2] = {&h->A, &h->At};
+  for (int k = 0; k < 2; ++k) {
+    const CsrDev &D = *Ms[k];
+    info[4 * k + 0] = total(D, [](const CsrDev &S) { return S.nblk; });
+    info[4 * k + 1] = total(D, [](const CsrDev &S) { return S.nlong; });
+    info[4 * k + 2] = total(D, [](const CsrDev &S) { return S.nchunks; });
+    info[4 * k + 3] = D.max_row_nnz;
+    info[8 + k] = total(D, [](const CsrDev &S) { return S.tiled ? S.nwaves : 0; });
+    info[10 + k] = first(D).tiled ? first(D).tile_cols : 0;
+    info[15] += (int64_t)std::min<size_t>(D.segs.size(), 255) << (8 + 8 * k);
+  }
+  if (!h->A.segs.empty()) info[12] = (int64_t)first(h->A).slabs.size();
+  if (!h->At.segs.empty()) info[13] = (int64_t)first(h->At).slabs.size();
   return 0;
 }
 

@@ -457,8 +457,16 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
     for (int i = 0; i < U; ++i) {
       const int k = kbeg + i * WAVE + lane;
       const bool ok = k < kend;
+#ifdef TWD_UNCOND   // dev variant: every lane loads (lanes without an entry re-read the cell's first one), so that the loads are straight-line code and the compiler counts them (exact vmcnt)
+      const int kk = ok ? k : kbeg;
+      const unsigned pl = __builtin_nontemporal_load(pk + kk);
+      const double vl = __builtin_nontemporal_load(tv + kk);
+      pp[i] = ok ? pl : TW_PAD;
+      vv[i] = ok ? vl : 0.0;
+#else
       pp[i] = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
       vv[i] = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
+#endif
     }
   };
 
@@ -501,11 +509,13 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
         for (int i = 0; i < U; ++i) xv[i] = (p[s][i] != TW_PAD) ? xt[p[s][i] & cmask] : 0.0;
 #endif
         // 2. entry loads for tile t+D
+#ifndef TWD_PREFETCH_LATE
         ks[f] = ke[(s + D - 1) % R];
         ke[f] = ke_ahead;
         tl[f] = (t + D < ntiles) ? stile[t + D] : 0;
         load_set(p[f], v[f], ks[f], ke[f]);
         ke_ahead = (live && t + D + 1 < ntiles) ? tp[t + D + 2] : ke_ahead;  // end of tile t+D+1
+#endif
         // 3. accumulate tile t
 #pragma unroll
         for (int i = 0; i < U; ++i) {
@@ -525,6 +535,13 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
           else if (CH == 2) tiled_chunk_relaxed(acc, pp, vv, xx, tile_shift, lane);
           else tiled_chunk(acc, pp, vv, xx, tile_shift, lane);
         }
+#ifdef TWD_PREFETCH_LATE   // dev variant: the entry loads for tile t+D behind the accumulate instead of between the gathers and their wait
+        ks[f] = ke[(s + D - 1) % R];
+        ke[f] = ke_ahead;
+        tl[f] = (t + D < ntiles) ? stile[t + D] : 0;
+        load_set(p[f], v[f], ks[f], ke[f]);
+        ke_ahead = (live && t + D + 1 < ntiles) ? tp[t + D + 2] : ke_ahead;  // end of tile t+D+1
+#endif
         // 4. pacing barrier: keep the workgroup inside one column tile
         //    (without it the kernel is 1.7x slower: waves drift apart and the
         //    gathers stop hitting L2)

@@ -396,6 +396,9 @@ class HipPdhgEngine:
         out = dict(zip(keys, info.tolist()))
         out["small_lp"] = (out["var_tiles"] >> 2) & 1      # batches of take_steps run in the one-workgroup LDS kernel
         out["device_loop"] = (out["var_tiles"] >> 3) & 1   # ... in the multi-step persistent kernel (small grids)
+        # nnz beyond the 32-bit entry limit: the matrix is held as this many segments of whole rows (0: one piece)
+        out["A_segments"] = (out["var_tiles"] >> 8) & 255
+        out["At_segments"] = (out["var_tiles"] >> 16) & 255
         out["var_tiles"] &= 3
         for k in ("A", "At"):    # width in bits of an entry's column field
             out[k + "_tile_shift"] = max(1, (out[k + "_tile_cols"] - 1).bit_length()) if out[k + "_tile_cols"] else 0

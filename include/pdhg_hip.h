@@ -51,11 +51,13 @@ int pdhg_abi_version(void);
  * `stream`: a hipStream_t to run on (e.g. the caller's torch stream), or NULL
  * for a private stream.  `device_id` < 0 keeps the current device.
  * Sizes: m, n and m + n below 2^31.  nnz may exceed 2^31 - 1 (the reference's
- * index type is Int64): the matrix is then cut into row shards of fewer nonzeros
- * on the same device (the row-partitioned form below with its peer-kernel
- * exchange; up to 16 shards, every shard checked against the limit), behind the same
- * handle; `stream` must be NULL then (the shards run on private streams: -1 otherwise),
- * and a single row beyond the limit is refused with -2, naming the row.
+ * index type is Int64): both device copies are then held as SEGMENTS of whole rows
+ * inside this one handle (CSR(A) cut by rows, CSR(A') by columns; an entry's address
+ * is the segment's base pointer + a 32-bit local offset).  No exchange, every row sum
+ * in its reference order: products and trajectories are those of the matrix in one
+ * piece.  A single row or column beyond the limit is refused with -2, naming it.
+ * (PDHG_HUGE=shards keeps the earlier form: row shards on the same device behind a
+ * group handle, peer-kernel exchange, `stream` must be NULL.)
  */
 int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
                 const int64_t *colptr, const int64_t *rowval,

@@ -66,3 +66,41 @@ def test_unsupported_and_misordered_calls(gpu_required):
     # the engine is still usable after errors
     raw = eng.trial_step(0.1, 1.0, 1.0)
     assert np.all(np.isfinite(raw))
+
+
+def test_roctx_ranges_bind_at_run_time(gpu_required, tmp_path):
+    """PDHG_ROCTX=1: the entry points and the fused products push / pop named roctx ranges through a marker library
+    bound with dlopen (no link-time dependency).  A child process takes a few steps with the ranges on; under rocprofv3's
+    marker trace (when the tool is on the box) the range names must show up in its output."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, folp_loader\n"
+            "pkg = folp_loader.load()\n"
+            "from firstorderlp_jl_amd.generators import random_lp\n"
+            "p = random_lp(3000, 2500, 6, seed=1)\n"
+            "e = pkg.HipPdhgEngine.from_problem(p)\n"
+            "for _ in range(3):\n"
+            "    raw = e.trial_step(0.1, 1.0, 1.0); e.accept(0.1)\n"
+            "print('ROCTX_CHILD_OK', float(raw[1]))\n" % root)
+    script = tmp_path / "child.py"
+    script.write_text(code)
+    env = dict(os.environ, PDHG_ROCTX="1", PDHG_GRAPH="0", TMPDIR="/tmp")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ROCTX_CHILD_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    assert "no roctx library could be bound" not in r.stderr, r.stderr[-500:]
+    rp = shutil.which("rocprofv3")
+    if rp:
+        out = tmp_path / "trace"
+        r = subprocess.run([rp, "--marker-trace", "--kernel-trace", "--output-format", "csv", "-d", str(out), "--", sys.executable, str(script)],
+                           env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        text = ""
+        for dirpath, _, files in os.walk(out):
+            for f in files:
+                if "marker" in f and f.endswith(".csv"):
+                    text += open(os.path.join(dirpath, f), errors="replace").read()
+        assert "pdhg_trial_step" in text and "pdhg:A*xbar + dual step (K3+K4)" in text, text[:800]

@@ -1,7 +1,10 @@
-"""nnz beyond the 32-bit layout limit: pdhg_create cuts the matrix into row shards on the
-one device (each below the limit) behind an ordinary handle.  The limit is lowered through
-PDHG_MAX_SHARD_NNZ so that the path runs on a small problem; RUN_HUGE_NNZ=1 additionally
-builds a real 2.2 G-nonzero matrix (tens of GB of host memory, minutes)."""
+"""nnz beyond the 32-bit layout limit (the reference's indices are Int64, quadratic_programming.jl:64).  Since round 4
+pdhg_create holds such a matrix as SEGMENTS of whole rows inside one ordinary handle -- CSR(A) cut by rows, CSR(A') by
+columns, 32-bit offsets local to a segment: no exchange, every row sum in its reference order, so both products stay
+bit-exact with the oracle and whole trajectories bitwise those of the matrix in one piece.  PDHG_HUGE=shards keeps the
+earlier form (row shards on the one device behind a group handle).  The limit is lowered through PDHG_MAX_SHARD_NNZ so
+that both paths run on a small problem; RUN_HUGE_NNZ=1 additionally builds a real 2.2 G-nonzero matrix (tens of GB of
+host memory, minutes)."""
 import os
 
 import numpy as np
@@ -17,11 +20,49 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("maker", [lambda: random_lp(60_000, 50_000, 10, seed=12),                      # stream layouts
+                                   lambda: H.skewed_lp(30_000, 40_000, seed=3, dense_rows=2, dense_cols=2, base_nnz=8),   # + long rows
+                                   lambda: random_lp(700_000, 650_000, 4, seed=101)],                # swept segments
+                         ids=["stream", "long_rows", "tiled"])
+def test_matrix_above_the_entry_limit_is_held_as_row_segments(gpu_required, monkeypatch, maker):
+    p = maker()
+    A = p.constraint_matrix
+    m, n = A.shape
+    monkeypatch.setenv("PDHG_MAX_SHARD_NNZ", str(A.nnz // 4))
+    eng = HipPdhgEngine.from_problem(p)
+    info = eng.layout_info()
+    assert eng.dist_info()["world"] == 1 and info["A_segments"] >= 4 and info["At_segments"] >= 4, info
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    H.assert_products_match_oracle(eng, A, x, y, label="segmented")          # BOTH products: rows are whole in a segment
+    monkeypatch.delenv("PDHG_MAX_SHARD_NNZ")
+    one = HipPdhgEngine.from_problem(p)
+    assert one.layout_info()["A_segments"] == 0
+    assert np.array_equal(eng.spmv(x), one.spmv(x)) and np.array_equal(eng.spmv_t(y), one.spmv_t(y))
+    outs = []
+    for e in (eng, one):
+        step, pw = H.initial_step_and_weight(p)
+        st = PdhgSolverState(e, step_size=step, primal_weight=pw)
+        for _ in range(50):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+        outs.append((*e.get_current(), *e.get_average(), np.array([st.step_size]), st.total_number_iterations))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)               # exactly rounded sums: the block grouping of the segments does not show
+    # device rescaling walks every segment (Ruiz: exact maxima, so the same factors and the same scaled entries)
+    for e in (eng, one):
+        e.rescale(10, False, 1.0)
+    assert np.array_equal(eng.spmv(x), one.spmv(x)) and np.array_equal(eng.spmv_t(y), one.spmv_t(y))
+    assert eng.matrix_max_abs() == one.matrix_max_abs()
+    eng.close()
+    one.close()
+
+
 def test_matrix_above_the_shard_limit_is_cut_on_one_device(gpu_required, monkeypatch):
     p = random_lp(60_000, 50_000, 10, seed=12)           # 600k nonzeros
     A = p.constraint_matrix
     m, n = A.shape
     monkeypatch.setenv("PDHG_MAX_SHARD_NNZ", "150000")
+    monkeypatch.setenv("PDHG_HUGE", "shards")            # rounds 2-3's form
     eng = HipPdhgEngine.from_problem(p)
     info = eng.dist_info()
     assert info["world"] == info["local_ranks"] == 5 and info["backend"] == 1     # 600k / (0.8 * 150k)
@@ -75,7 +116,7 @@ def test_2p2_billion_nonzeros(gpu_required):
     t0 = time.time()
     eng = HipPdhgEngine(Csc, np.ones(n), np.ones(m), np.zeros(n), np.full(n, np.inf), 0)
     print(f"pdhg_create: {time.time() - t0:.0f} s, {eng.dist_info()}, {eng.layout_info()}", flush=True)
-    assert eng.dist_info()["world"] >= 2
+    assert eng.dist_info()["world"] == 1 and eng.layout_info()["A_segments"] >= 2 and eng.layout_info()["At_segments"] >= 2
     want = float(np.sum(1.0 / (kk + 1.0)))
     np.testing.assert_allclose(eng.spmv(np.ones(n)), np.full(m, want), rtol=1e-12)
     np.testing.assert_allclose(eng.spmv_t(np.ones(m)), np.full(n, want), rtol=1e-12)
@@ -103,6 +144,7 @@ def test_sharded_create_checks_every_shard_and_refuses_a_caller_stream(gpu_requi
         objective_matrix=sp.csc_matrix((n, n)), objective_vector=rng.standard_normal(n), objective_constant=0.0,
         constraint_matrix=A, right_hand_side=rng.standard_normal(m), num_equalities=100)
     monkeypatch.setenv("PDHG_MAX_SHARD_NNZ", "30000")
+    monkeypatch.setenv("PDHG_HUGE", "shards")
     eng = HipPdhgEngine.from_problem(p)
     info = eng.dist_info()
     assert info["world"] >= 4 and info["backend"] == 1
@@ -113,6 +155,10 @@ def test_sharded_create_checks_every_shard_and_refuses_a_caller_stream(gpu_requi
     monkeypatch.setenv("PDHG_MAX_SHARD_NNZ", "1000")            # a 1500-entry row cannot be indexed
     with pytest.raises(Exception, match="row 0 alone holds 1500"):
         HipPdhgEngine.from_problem(p)
+    monkeypatch.delenv("PDHG_HUGE")                              # ... by a segment either
+    with pytest.raises(Exception, match="row 0 alone holds 1500"):
+        HipPdhgEngine.from_problem(p)
+    monkeypatch.setenv("PDHG_HUGE", "shards")
     monkeypatch.setenv("PDHG_MAX_SHARD_NNZ", "30000")
     import torch
     with pytest.raises(Exception, match="caller-supplied stream"):
