@@ -243,7 +243,7 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
     # the contract times EXACTLY the K steps asked for; when K is small (the driver's 20: 32 ms on config S) the line
     # also carries the rate over 200 further steps, timed the same way
     steady = None
-    if steps < 100 and dist is None:
+    if steps < 100 and dist is None and not args.no_self_profile:      # (not in the short child runs of tools/selfprof.py)
         barrier()
         t0 = time.perf_counter()
         run_steps(200)
@@ -439,6 +439,26 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
     }
     if issue_stats is not None:
         out["host_us_per_trial"] = issue_stats
+    # where a trial's time goes INSIDE the persistent kernel (stream-layout LPs on the one-launch paths): a second, traced
+    # engine on the same LP (PDHG_COOP_TRACE=1: phase-boundary stamps of the 100 MHz wall clock per workgroup), 300 steps
+    if dist is None and args.shards == 0 and out["layout"].get("trial_graph") == 2 and problem is not None and not args.per_step_calls:
+        try:
+            os.environ["PDHG_COOP_TRACE"] = "1"
+            eng2 = pkg.HipPdhgEngine.from_problem(problem, device_id=local_rank)
+            st2 = PdhgSolverState(eng2, step_size=step0, primal_weight=pw0)
+            done = 0
+            while done < 300:
+                done += take_steps(policy, st2, 300 - done)
+            tl = eng2.trial_timeline()
+            eng2.close()
+            if tl:
+                tl["note"] = ("last trial of a traced run of 300 steps (pdhg_trial_timeline): per-workgroup durations of the phases "
+                              "between the grid barriers; the stamps themselves cost ~1 us per trial")
+                out["trial_timeline"] = tl
+        except Exception as exc:      # measurement extra
+            out["trial_timeline"] = {"error": repr(exc)}
+        finally:
+            os.environ.pop("PDHG_COOP_TRACE", None)
     if out["layout"].get("trial_graph") == 2:
         out["kernels_note"] = ("the timed region runs one trial as ONE persistent kernel (trial_kernel: the same device "
                                "functions as the separate kernels between two grid barriers); the per-kernel figures are "
@@ -523,12 +543,12 @@ def main():
             rf["traffic_source"] = "committed: " + str(rf.get("traffic_source"))
         if rf.get("kernel_ms_rocprof") is not None:
             rf["rocprof_source"] = "committed: " + str(rf.get("rocprof_source"))
-        if dist is not None or args.no_self_profile or args.shards or time.time() - t_prof0 > 300:
+        if dist is not None or args.no_self_profile or args.shards or time.time() - t_prof0 > 240:
             continue
         from tools import selfprof
         extra = ["--m", str(args.m), "--n", str(args.n), "--nnz-per-row", str(args.nnz_per_row), "--seed", str(args.seed),
                  "--pagerank-nodes", str(args.pagerank_nodes)]
-        res = selfprof.run(sp["workload"], sp["product"], extra)
+        res = selfprof.run(sp["workload"], sp["product"], extra, deadline=t_prof0 + 300)
         rf["self_profile"] = {k: res[k] for k in ("command", "seconds", "error", "failed_passes", "kernels") if k in res}
         if "kernel_ms" in res:
             rf["kernel_ms_rocprof"] = res["kernel_ms"]

@@ -31,7 +31,7 @@ EXPORTS = [
     "pdhg_get_current", "pdhg_set_current", "pdhg_get_trial", "pdhg_spmv",
     "pdhg_spmv_t", "pdhg_dist_get_unique_id", "pdhg_create_dist", "pdhg_create_multi",
     "pdhg_dist_info", "pdhg_profile_enable", "pdhg_profile_read",
-    "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info", "pdhg_measure_triad", "pdhg_measure_sweep_ceiling",
+    "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info", "pdhg_measure_triad", "pdhg_measure_sweep_ceiling", "pdhg_trial_timeline",
     "pdhg_set_original_problem", "pdhg_eval_point", "pdhg_save_restart_point",
     "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound",
     "pdhg_point_sumsq", "pdhg_rescale", "pdhg_get_problem_vectors", "pdhg_matrix_max_abs",
@@ -39,7 +39,7 @@ EXPORTS = [
     "pdhg_measure_launch_overhead", "pdhg_layout_checksums",
 ]
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 UNIQUE_ID_BYTES = 128
 (K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_ALLGATHER, K_REDUCE_SCATTER,
  K_INTERACTION, K_COUNT) = range(9)
@@ -172,6 +172,8 @@ def lib():
     L.pdhg_measure_triad.argtypes = [_vp, i64, i32, _dp]
     L.pdhg_measure_sweep_ceiling.restype = i32
     L.pdhg_measure_sweep_ceiling.argtypes = [_vp, i64, i64, i64, i32, _dp]
+    L.pdhg_trial_timeline.restype = i32
+    L.pdhg_trial_timeline.argtypes = [_vp, _dp]
     L.pdhg_layout_checksums.restype = i32
     L.pdhg_layout_checksums.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64)]
     L.pdhg_measure_launch_overhead.restype = i32

@@ -164,6 +164,7 @@ struct pdhg_handle {
   volatile double *res_host = nullptr;     // pinned, coherent: 5 results + [7] = sequence number
   unsigned long long seq_expected = 0;
   int coop_fallbacks = 0;                   // trials repeated on the other paths after a barrier time-out
+  double timeline_last_out[5] = {0, 0, 0, 0, 0};   // trial_timeline: when the last workgroup left each phase
   // several take_steps per launch (steps_kernel): control lines, pow tables (device + pinned staging), result words
   StepsCtl *steps_ctl = nullptr;
   double *steps_pow_dev = nullptr, *steps_pow_host = nullptr, *steps_res = nullptr;
@@ -1756,6 +1757,37 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   return 0;
 }
 
+// Phase timeline of the LAST one-launch trial (PDHG_COOP_TRACE=1: the persistent kernels stamp the 100 MHz wall clock at
+// every phase boundary, per workgroup).  out[0..4]: mean duration (us) over the workgroups of phase 0, barrier 1, phase 1,
+// barrier 2, phase 2; out[5..9]: the slowest workgroup's; out[10]: when the last workgroup left phase 2 (us after the
+// trial's first stamp); out[11]: barrier 3's global phase complete (multi-step kernel; 0: single-trial kernel);
+// out[12]: decision known to the last workgroup / results published; out[13]: workgroups.
+int trial_timeline(pdhg_handle *h, double out[14]) {
+  if (!h->coop_trace || h->coop_grid <= 0) return 1;
+  std::vector<unsigned long long> t((size_t)8 * h->coop_grid);
+  if (hipMemcpy(t.data(), h->coop_trace, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  unsigned long long t0 = ~0ull;
+  for (int w = 0; w < h->coop_grid; ++w) t0 = std::min(t0, t[(size_t)w * 8]);
+  for (int k = 0; k < 5; ++k) {
+    double sum = 0, mx = 0, last_end = 0;
+    for (int w = 0; w < h->coop_grid; ++w) {
+      const double d = 0.01 * (double)(t[(size_t)w * 8 + k + 1] - t[(size_t)w * 8 + k]);
+      sum += d; mx = std::max(mx, d);
+      last_end = std::max(last_end, 0.01 * (double)(t[(size_t)w * 8 + k + 1] - t0));
+    }
+    out[k] = sum / h->coop_grid;
+    out[5 + k] = mx;
+    h->timeline_last_out[k] = last_end;
+  }
+  out[10] = h->timeline_last_out[4];
+  unsigned long long fin = 0, lead = 0;
+  for (int w = 0; w < h->coop_grid; ++w) { fin = std::max(fin, t[(size_t)w * 8 + 6]); lead = std::max(lead, t[(size_t)w * 8 + 7]); }
+  out[11] = lead ? 0.01 * (double)(lead - t0) : 0.0;
+  out[12] = fin ? 0.01 * (double)(fin - t0) : 0.0;
+  out[13] = (double)h->coop_grid;
+  return 0;
+}
+
 void destroy_shard(pdhg_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
@@ -1766,26 +1798,15 @@ void destroy_shard(pdhg_handle *h) {
             1e6 * h->t_wait / h->n_graph_trials);
   if (h->coop_trace && (h->coop_launches > 0 || h->steps_launches > 0)) {
     // phase timeline of the LAST one-launch trial: per phase, mean and max over the workgroups of its duration (us)
-    std::vector<unsigned long long> t((size_t)8 * h->coop_grid);
-    if (hipMemcpy(t.data(), h->coop_trace, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost) == hipSuccess) {
-      unsigned long long t0 = ~0ull, tend = 0;
-      for (int w = 0; w < h->coop_grid; ++w) { t0 = std::min(t0, t[(size_t)w * 8]); tend = std::max(tend, t[(size_t)w * 8 + 5]); }
+    double t[14];
+    if (trial_timeline(h, t) == 0) {
       const char *names[5] = {"phase 0 (x', xbar) + entry prefetch", "barrier 1", "phase 1 (A xbar, y')", "barrier 2", "phase 2 (A'y', sums)"};
       fprintf(stderr, "[pdhg_hip] one-launch trial timeline (last launch, %d workgroups, 100 MHz clock):\n", h->coop_grid);
-      for (int k = 0; k < 5; ++k) {
-        double sum = 0, mx = 0, last_end = 0;
-        for (int w = 0; w < h->coop_grid; ++w) {
-          const double d = 0.01 * (double)(t[(size_t)w * 8 + k + 1] - t[(size_t)w * 8 + k]);
-          sum += d; mx = std::max(mx, d);
-          last_end = std::max(last_end, 0.01 * (double)(t[(size_t)w * 8 + k + 1] - t0));
-        }
-        fprintf(stderr, "    %-38s mean %6.2f us, max %6.2f us; last workgroup out at %6.2f us\n", names[k], sum / h->coop_grid, mx, last_end);
-      }
-      unsigned long long fin = 0, lead = 0;
-      for (int w = 0; w < h->coop_grid; ++w) { fin = std::max(fin, t[(size_t)w * 8 + 6]); lead = std::max(lead, t[(size_t)w * 8 + 7]); }
-      if (lead) fprintf(stderr, "    barrier 3: global phase complete at %6.2f us; decision known to the last workgroup at %6.2f us (multi-step kernel, last trial)\n",
-                        0.01 * (double)(lead - t0), 0.01 * (double)(fin - t0));
-      else fprintf(stderr, "    second-stage reduction published at %6.2f us\n", 0.01 * (double)(fin - t0));
+      for (int k = 0; k < 5; ++k)
+        fprintf(stderr, "    %-38s mean %6.2f us, max %6.2f us; last workgroup out at %6.2f us\n", names[k], t[k], t[5 + k], h->timeline_last_out[k]);
+      if (t[11] > 0) fprintf(stderr, "    barrier 3: global phase complete at %6.2f us; decision known to the last workgroup at %6.2f us (multi-step kernel, last trial)\n",
+                             t[11], t[12]);
+      else fprintf(stderr, "    second-stage reduction published at %6.2f us\n", t[12]);
     }
   }
   free_csr_dev(h->A); free_csr_dev(h->At); free_csr_dev(h->Q); free_csr_dev(h->Qt);
@@ -1936,7 +1957,7 @@ int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colpt
 extern "C" {
 
 const char *pdhg_last_error(void) { return g_last_error.c_str(); }
-int pdhg_abi_version(void) { return 8; }
+int pdhg_abi_version(void) { return 9; }
 
 // The kernels behind one fused product, as rocprofv3 prints them (template arguments <MODE,
 // INIT, TAG> / <MODE, CH> / <TAG>; MODE 0 plain, 1 dual epilogue, 2 A'y epilogue; TAG 0 = A,
@@ -3651,6 +3672,17 @@ int pdhg_measure_sweep_ceiling(pdhg_handle *h, int64_t rows, int64_t cols, int64
   out[4] = (double)nwaves;
   out[5] = (double)ntiles;
   return 0;
+}
+
+/* Phase timeline of the last one-launch trial (needs PDHG_COOP_TRACE=1 in the environment when the handle takes its
+ * first one-launch trial): see trial_timeline.  Returns 1 when no trace was recorded.  Measurement only. */
+int pdhg_trial_timeline(pdhg_handle *h, double out[14]) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!out) return fail(-1, "out == NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return trial_timeline(h, out) ? fail(1, "no one-launch trial has been traced (PDHG_COOP_TRACE=1, stream-layout LP on one handle)") : 0;
 }
 
 int pdhg_measure_launch_overhead(pdhg_handle *h, int reps, double out[2]) {

@@ -357,6 +357,22 @@ class HipPdhgEngine:
         return {"pattern_Ggathers_per_s": float(out[0]), "pattern_ms": float(out[1]), "all_hit_window_Ggathers_per_s": float(out[2]),
                 "entries_per_cell": int(out[3]), "waves": int(out[4]), "tiles": int(out[5])}
 
+    def trial_timeline(self):
+        """Phase timeline (us) of the last one-launch trial, or None when nothing was traced (PDHG_COOP_TRACE=1)."""
+        out = np.zeros(14)
+        if self._L.pdhg_trial_timeline(self._h, _pd(out)) != 0:
+            return None
+        names = ["phase0_primal", "barrier1", "phase1_A_xbar", "barrier2", "phase2_At_y"]
+        d = {"mean_us": {n: round(float(out[k]), 2) for k, n in enumerate(names)},
+             "max_us": {n: round(float(out[5 + k]), 2) for k, n in enumerate(names)},
+             "last_workgroup_out_of_phase2_us": round(float(out[10]), 2), "workgroups": int(out[13])}
+        if out[11] > 0:
+            d["barrier3_global_phase_complete_us"] = round(float(out[11]), 2)
+            d["decision_known_to_last_workgroup_us"] = round(float(out[12]), 2)
+        else:
+            d["results_published_us"] = round(float(out[12]), 2)
+        return d
+
     def layout_checksums(self):
         """32 order-sensitive checksums of the device arrays of both layouts (pdhg_layout_checksums)."""
         out = np.zeros(32, dtype=np.uint64)

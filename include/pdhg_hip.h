@@ -391,6 +391,14 @@ int pdhg_measure_triad(pdhg_handle *h, int64_t len, int reps, double *gbps);
  * out[3] entries per (wave, tile) cell, out[4] waves, out[5] tiles.  No reference counterpart (the reference has no
  * device code); stands beside pdhg_measure_triad. */
 int pdhg_measure_sweep_ceiling(pdhg_handle *h, int64_t rows, int64_t cols, int64_t nnz, int reps, double out[6]);
+
+/* Measurement aid for the benchmark line's `trial_timeline`: where the time of one trial goes INSIDE the persistent
+ * trial kernels (PDHG_COOP_TRACE=1 makes them stamp the 100 MHz wall clock at every phase boundary, per workgroup).
+ * out[0..4] mean duration in us over the workgroups of phase 0 (x', xbar), barrier 1, phase 1 (A xbar, y'), barrier 2,
+ * phase 2 (A'y', sums); out[5..9] the slowest workgroup's; out[10] last workgroup out of phase 2; out[11] barrier 3's
+ * global phase complete (multi-step kernel, else 0); out[12] decision known / results published; out[13] workgroups.
+ * Returns 1 when nothing was traced.  No reference counterpart. */
+int pdhg_trial_timeline(pdhg_handle *h, double out[14]);
 /* Measurement only: what a HIP-event bracket reports for EMPTY launches on this handle's
  * stream -- out[0] ms for one empty kernel between the two events, out[1] ms for every further
  * launch inside the same bracket (best of `reps`).  pdhg_profile_read's brackets contain this

@@ -1,4 +1,4 @@
-# FirstOrderLpHIP.jl -- `ccall` shim over libpdhg_hip.so (include/pdhg_hip.h, abi 8).
+# FirstOrderLpHIP.jl -- `ccall` shim over libpdhg_hip.so (include/pdhg_hip.h, abi 9).
 #
 # Drop-in for FirstOrderLp.jl's PDHG path on MI355X:
 #
@@ -26,7 +26,7 @@ using SparseArrays
 import Random
 
 const LIB = get(ENV, "PDHG_HIP_LIB", "libpdhg_hip.so")
-const ABI_VERSION = 8
+const ABI_VERSION = 9
 const POINT_CURRENT = Cint(0)
 const POINT_AVERAGE = Cint(1)
 const POINT_RESTART = Cint(2)
@@ -896,6 +896,13 @@ function measure_sweep_ceiling(s::HipSolverState, rows::Int64, cols::Int64, nnz:
   out = zeros(Float64, 6)
   check(ccall((:pdhg_measure_sweep_ceiling, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ptr{Float64}), s.handle, rows, cols, nnz, reps, out))
   return out
+end
+
+# phase timeline of the last one-launch trial (PDHG_COOP_TRACE=1); `nothing` when nothing was traced
+function trial_timeline(s::HipSolverState)
+  out = zeros(Float64, 14)
+  rc = ccall((:pdhg_trial_timeline, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), s.handle, out)
+  return rc == 0 ? out : nothing
 end
 
 end # module

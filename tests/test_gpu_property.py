@@ -77,6 +77,12 @@ def _engine(p, layout):
 @given(case=small_lps(), layout=st.sampled_from(LAYOUTS))
 def test_products_and_one_trial_are_bit_identical_to_the_oracle(gpu_required, case, layout):
     p, seed, step, pw, theta = case
+    # A sweep FORCED onto a small dense-ish matrix with 64-column tiles has same-row runs of dozens of entries inside a
+    # tile; in the shipped relaxed order such chunks are tree-reduced (tiled_chunk_relaxed), so bit-identity with the
+    # sequential sums is a strict-order property there (the builder itself would stream these matrices).  The relaxed
+    # bound for forced sweeps is checked in test_gpu_tiled.py / test_gpu_row_order.py.
+    from hypothesis import assume
+    assume(not (os.environ.get("PDHG_ROW_ORDER") == "relaxed" and "tiled" in layout))
     A = p.constraint_matrix
     m, n = A.shape
     eng = _engine(p, layout)

@@ -106,7 +106,7 @@ def child_command(workload, extra):
             "--no-cpu-baseline", "--no-other-configs", "--profile-steps", "0", "--no-self-profile"] + list(extra)
 
 
-def run(workload, product, extra=(), timeout=420, keep=None):
+def run(workload, product, extra=(), timeout=180, keep=None, deadline=None):
     """Profile a short child run of bench.py for `workload`; `product` is the dominant product's kernel list
     (pdhg_kernel_name).  Returns a dict (kernel_ms, traffic, detail, seconds) or {"error": ...}; never raises."""
     rp = shutil.which("rocprofv3")
@@ -119,9 +119,16 @@ def run(workload, product, extra=(), timeout=420, keep=None):
     try:
         passes = [("kt", ["--kernel-trace", "--stats"])] + [(f"p{i + 1}", ["--kernel-trace", "--pmc"] + list(c)) for i, c in enumerate(PMC_PASSES)]
         for tag, flags in passes:
+            if deadline is not None and time.time() > deadline:      # the bench line must not wait on its evidence
+                out.setdefault("failed_passes", []).append({"pass": tag, "rc": None, "stderr_tail": "skipped: time budget spent"})
+                continue
             d = os.path.join(work, tag)
             cmd = [rp] + flags + ["-d", d, "--"] + child_command(workload, extra)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            except subprocess.TimeoutExpired:
+                out.setdefault("failed_passes", []).append({"pass": tag, "rc": None, "stderr_tail": f"timed out after {timeout} s"})
+                continue
             if r.returncode != 0:
                 out.setdefault("failed_passes", []).append({"pass": tag, "rc": r.returncode, "stderr_tail": r.stderr.decode(errors="replace")[-400:]})
         times = kernel_times(os.path.join(work, "kt"))
