@@ -2029,8 +2029,18 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   int64_t cap = (int64_t)INT32_MAX - 1;
   if (const char *ev = getenv("PDHG_MAX_SHARD_NNZ")) cap = std::max<int64_t>(1, atoll(ev));
   const char *huge = getenv("PDHG_HUGE");
-  if (nnz > cap && !(huge && !strcmp(huge, "shards")))
+  if (nnz > cap && !(huge && !strcmp(huge, "shards"))) {
+    // host-side validation first (no device needed, nothing indexed with an unchecked row index later on)
+    *out = nullptr;
+    if (index_base != 0 && index_base != 1) return fail(-1, "index_base must be 0 or 1");
+    if (!colptr || !rowval || !nzval || !c || !b || !lb || !ub) return fail(-1, "null input array");
+    if (colptr[0] != index_base || colptr[n] - index_base != nnz) return fail(-1, "colptr does not match nnz / index_base");
+    {
+      std::vector<int64_t> prefix;
+      if (row_nnz_prefix(m, n, colptr, rowval, index_base, prefix) != 0) return fail(-1, "row index out of range");
+    }
     return create_shard(out, m, n, nnz, colptr, rowval, nzval, index_base, c, b, lb, ub, num_equalities, device_id, stream, n, cap);
+  }
   if (nnz > cap && m > 1) {
     *out = nullptr;
     // The shards run on private streams and synchronise among themselves: work the caller
