@@ -163,3 +163,27 @@ def test_sharded_create_checks_every_shard_and_refuses_a_caller_stream(gpu_requi
     import torch
     with pytest.raises(Exception, match="caller-supplied stream"):
         HipPdhgEngine.from_problem(p, stream=torch.cuda.Stream().cuda_stream)
+
+
+def test_segmented_matrix_through_a_whole_optimize(gpu_required, monkeypatch):
+    """optimize() -- device rescaling, the evaluation branch (unscaled statistics, trust-region bounds), restarts to the
+    average, termination -- on a matrix held as row segments: the same iteration count, termination reason and solution as
+    the matrix in one piece (every kernel of the evaluation branch and of the rescaling walks the segments)."""
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import PdhgParameters, optimize
+    from firstorderlp_jl_amd.saddle_point import RestartScheme, RestartToCurrentMetric, construct_restart_parameters
+    from firstorderlp_jl_amd.termination import construct_termination_criteria
+    q = random_lp(4000, 3000, 7, seed=23)
+    tc = construct_termination_criteria(eps_optimal_absolute=1e-6, eps_optimal_relative=1e-6, iteration_limit=3000)
+    rp = construct_restart_parameters(RestartScheme.ADAPTIVE_NORMALIZED, RestartToCurrentMetric.GAP_OVER_DISTANCE_SQUARED,
+                                      1000, 0.5, 0.1, 0.9, 0.5, False)
+    params = PdhgParameters(10, False, 1.0, 1.0, True, 0, True, 40, tc, rp, AdaptiveStepsizeParams(0.3, 0.6))
+    outs = []
+    for cap in (None, str(q.constraint_matrix.nnz // 5)):
+        if cap is None:
+            monkeypatch.delenv("PDHG_MAX_SHARD_NNZ", raising=False)
+        else:
+            monkeypatch.setenv("PDHG_MAX_SHARD_NNZ", cap)
+        o = optimize(params, q)
+        outs.append((o.iteration_count, o.termination_reason, o.primal_solution, o.dual_solution))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1], (outs[0][:2], outs[1][:2])
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
