@@ -839,7 +839,6 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   a.seq = ++h->steps_seq;
   a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
   a.trace = h->coop_trace;
-  a.small_second_stage = getenv("PDHG_STEPS_GENERAL_SECOND_STAGE") ? 0 : 1;
   for (int x = 0; x < 8; ++x) a.xcd_cnt[x] = h->coop_xcd_cnt[x];
   const auto c1 = std::chrono::steady_clock::now();
   hipLaunchKernelGGL(steps_kernel, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);

@@ -399,7 +399,6 @@ struct StepsKernelArgs {
   unsigned nxcd;
   unsigned xcd_cnt[8];
   int relaxed;
-  int small_second_stage;                         // the one-wave-per-quantity second stage (final_reduce_lp; dev: 0 = the general form)
   unsigned long long *trace;                      // PDHG_COOP_TRACE: stamps of the launch's last trial, as for trial_kernel ([7]: leaders, global phase done)
 };
 
@@ -409,29 +408,9 @@ struct StepsKernelArgs {
 // [15] sequence number again (what the host polls)
 constexpr int STEPS_RES_WORDS = 16;
 
-// The leaders' second stage, out of line: inlined into the trial loop its loop-invariant address arithmetic is
-// hoisted in front of the loop and kept alive through every phase -- in a kernel at its register limit that is
-// 436 bytes of scratch per lane.
-#ifndef PDHG_STEPS_NOINLINE
-#define PDHG_STEPS_NOINLINE 0
-#endif
 #ifndef PDHG_STEPS_PREFETCH
 #define PDHG_STEPS_PREFETCH 1
 #endif
-#if PDHG_STEPS_NOINLINE
-__device__ __attribute__((noinline)) void steps_second_stage(
-#else
-__device__ __forceinline__ void steps_second_stage(
-#endif
-    const FinalSpec *sp, double *res5_lds) {
-  double res[5];
-  final_reduce_body<TPB / WAVE>(*sp, res);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) res5_lds[k] = res[k];
-  }
-}
-
 __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(StepsKernelArgs a) {
   __shared__ double prod[BLOCK_NNZ];
   __shared__ double red[6][TPB / WAVE];
@@ -442,7 +421,6 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
   // the pending average update, [3] / [4] the averages' weight sums
   __shared__ double s_st[5];
   __shared__ double s_pow[2];
-  __shared__ double s_res[5];
   __shared__ double s_res8[8];
   const int w = blockIdx.x, nwg = gridDim.x;
   int flip = 0, pend = a.pend, steps = 0, trials = 0, num_err = 0, hw_err = 0, mid = 0;
