@@ -128,6 +128,21 @@ struct ShardPool {
   }
 };
 
+struct GroupTrialArgs;
+struct GridSync;
+// one device's share of a group trial taken as persistent kernels (group_kernel.hpp)
+struct GroupDevLaunch {
+  int device = 0;
+  std::vector<int> members;             // indices into DistGroup::sh, ascending rank
+  std::vector<int> base;                // first workgroup of every member (+ the total)
+  int grid = 0;
+  hipStream_t stream = nullptr;         // the first member's stream: the launch runs here
+  GroupTrialArgs *args_dev = nullptr, *args_host = nullptr;
+  GridSync **sync_dev = nullptr;
+  std::vector<hipEvent_t> ev;           // "the member's own stream is drained"
+  hipEvent_t ev_done = nullptr;         // "the launch is queued" (the members' streams wait for it)
+};
+
 struct DistGroup {
   ShardPool *pool = nullptr;            // several local shards: one issuing thread each (trial steps)
   // host-side cost of the trials issued so far: seconds until the last launch call returned
@@ -155,8 +170,33 @@ struct DistGroup {
   bool force_remote = false;
   // (force_remote is honoured for a single local shard only: with several local RCCL shards the
   // one-rank-per-process route would issue a collective on one of N communicators and hang)
+  // one persistent kernel per device and trial with cross-shard barriers inside (group_kernel.hpp)
+  int coop_mode = -1;                   // -1 undecided, 0 off, 1 on
+  struct GroupSync *gsync = nullptr;    // shared by the shards' kernels
+  std::vector<GroupDevLaunch> coop_dev; // one launch per device: its shards, their places in the grid, staging for the arguments
+  // The launches run on the first member's stream.  Ordering against the members' own streams is settled lazily: trials and
+  // (lazy) accepts queue nothing there, so only the first trial after any OTHER entry point waits for the members' streams
+  // (members_dirty), and only the first other entry point after a trial makes them wait for the launch (join_pending).
+  bool members_dirty = true, join_pending = false;
+  unsigned long long xepoch = 0;        // cross-shard barriers passed so far
+  int coop_fallbacks = 0;
+  int64_t coop_trials = 0;              // trials taken that way
   bool all_local() const { return (int)sh.size() == world && !(force_remote && backend == COMM_RCCL && sh.size() == 1); }
 };
+
+// frees what group_coop_prepare (pdhg_hip.hip) set up for the persistent group launches
+inline void group_coop_release(DistGroup &g) {
+  for (GroupDevLaunch &D : g.coop_dev) {
+    (void)hipSetDevice(D.device);
+    if (D.args_dev) (void)hipFree(D.args_dev);
+    if (D.args_host) (void)hipHostFree(D.args_host);
+    if (D.sync_dev) (void)hipFree(D.sync_dev);
+    for (hipEvent_t e : D.ev) if (e) (void)hipEventDestroy(e);
+    if (D.ev_done) (void)hipEventDestroy(D.ev_done);
+  }
+  g.coop_dev.clear();
+}
+
 
 // ---- the shard list every entry point walks: the group's local shards, or the handle itself
 struct Shards {

@@ -180,6 +180,7 @@ struct pdhg_handle {
 };
 
 #include "dist.hpp"
+#include "group_kernel.hpp"
 
 namespace {
 
@@ -545,7 +546,7 @@ int wait_result_word(pdhg_handle *h, double out[5], bool checked = false) {
 
 // ---- the trial step as ONE persistent kernel (trial_kernel.hpp) -----------------------------
 
-int coop_prepare(pdhg_handle *h);
+int coop_prepare(pdhg_handle *h, int cap_limit = 0, bool several_items = false);
 bool graph_eligible(pdhg_handle *h);
 
 bool coop_eligible(pdhg_handle *h) {
@@ -564,7 +565,9 @@ bool coop_eligible(pdhg_handle *h) {
 }
 
 // grid of the persistent launch + the census of workgroups per XCD (once per handle)
-int coop_prepare(pdhg_handle *h) {
+// cap_limit: at most this many workgroups (several shards share a device); several_items: accept more items than
+// workgroups (the phases then walk several row blocks per workgroup)
+int coop_prepare(pdhg_handle *h, int cap_limit, bool several_items) {
   if (h->gsync) return 0;
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_result_word(h);
@@ -575,6 +578,7 @@ int coop_prepare(pdhg_handle *h) {
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));
   int cap = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
   if (const char *ev = getenv("PDHG_COOP_WGS")) cap = std::max(8, std::min(cap, atoi(ev) / 8 * 8));
+  if (cap_limit > 0) cap = std::max(8, std::min(cap, cap_limit / 8 * 8));
   // test knob: pretend the device holds this many workgroups (more than it does: the barriers cannot complete)
   const char *pretend = getenv("PDHG_COOP_TEST_PRETEND_WGS");
   if (pretend) cap = std::max(8, atoi(pretend) / 8 * 8);
@@ -585,7 +589,7 @@ int coop_prepare(pdhg_handle *h) {
   // More items than co-resident workgroups: the persistent kernel would walk several row blocks per workgroup at
   // 5 workgroups per CU, where the separate stream kernels keep 8 per CU in flight -- measured slower (PageRank-1M,
   // 4 552 items on 1 280 workgroups: 4 380 it/s against 4 620 as a graph of slab passes).  Leave those to the graph.
-  if (items > cap && !getenv("PDHG_COOP_FORCE")) {
+  if (items > cap && !several_items && !getenv("PDHG_COOP_FORCE")) {
     h->coop_mode = 0;
     return 1;       // not an error: the caller falls through to the graph / plain path
   }
@@ -1190,8 +1194,21 @@ int graph_trial(pdhg_handle *h, double step_size, double primal_weight, double t
   return rcw;
 }
 
-int check_handle(pdhg_handle *h) {
+// queues_work: the entry point may put work on the shards' own streams (everything but a trial step and a lazy accept)
+int check_handle(pdhg_handle *h, bool queues_work = true) {
   if (!h) return fail(-1, "null handle");
+  if (queues_work && h->grp && !h->grp->coop_dev.empty()) {
+    DistGroup &g = *h->grp;
+    if (g.join_pending) {          // the members' streams wait for the last persistent group launch (group_kernel.hpp)
+      for (GroupDevLaunch &D : g.coop_dev) {
+        HIP_TRY(hipSetDevice(D.device));
+        for (int i : D.members)
+          if (g.sh[(size_t)i]->stream != D.stream) HIP_TRY(hipStreamWaitEvent(g.sh[(size_t)i]->stream, D.ev_done, 0));
+      }
+      g.join_pending = false;
+    }
+    g.members_dirty = true;
+  }
   HIP_TRY(hipSetDevice(h->device));
   return 0;
 }
@@ -1856,6 +1873,8 @@ void destroy_group(DistGroup *g) {
       (void)hipSetDevice(g->sh[i]->device);
       if (g->ev[f][i]) (void)hipEventDestroy(g->ev[f][i]);
     }
+  group_coop_release(*g);
+  if (g->gsync) { (void)hipSetDevice(g->sh.empty() ? 0 : g->sh[0]->device); (void)hipFree(g->gsync); }
   for (pdhg_handle *s : g->sh) destroy_shard(s);
   delete g;
 }
@@ -2439,6 +2458,247 @@ static int trial_group_mt(const Shards &L, const TrialArgs &a, double out[5]) {
   return 0;
 }
 
+// ---- a group's trial as ONE persistent kernel per device (group_kernel.hpp) -----------------------------------------
+// Eligible: every shard of the group lives in this process on the peer back end, LP, stream layouts without slabs, and
+// the shards' grids fit their device side by side.  Default: on when all shards share ONE device (the configuration this
+// environment can test -- bitwise the ordinary group path); for shards on distinct devices the protocol has never run,
+// so it waits for PDHG_GROUP_COOP=1.  PDHG_GROUP_COOP=0: off.
+static int group_coop_prepare(const Shards &L) {
+  DistGroup &g = *L.g;
+  std::vector<int> devs;
+  for (int i = 0; i < L.count; ++i) devs.push_back(L.p[i]->device);
+  std::sort(devs.begin(), devs.end());
+  devs.erase(std::unique(devs.begin(), devs.end()), devs.end());
+  const char *pretend = getenv("PDHG_COOP_TEST_PRETEND_WGS");       // test knob: a grid the device cannot hold
+  for (int dev : devs) {
+    HIP_TRY(hipSetDevice(dev));
+    GroupDevLaunch D;
+    D.device = dev;
+    for (int i = 0; i < L.count; ++i) if (L.p[i]->device == dev) D.members.push_back(i);
+    D.stream = L.p[D.members[0]]->stream;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, group_trial_kernel, TPB, 0));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    const int cap = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
+    // every shard one workgroup per item where the device holds that many side by side, else in proportion
+    std::vector<int> items, grid;
+    int64_t total_items = 0;
+    for (int i : D.members) {
+      const pdhg_handle *s = L.p[i];
+      items.push_back(std::max(8, (std::max(s->A.grid + s->A.nchunks, s->At.grid + s->At.nchunks) + 7) / 8 * 8));
+      total_items += items.back();
+    }
+    int total = 0;
+    for (size_t k = 0; k < items.size(); ++k) {
+      int gk = total_items <= cap ? items[k] : std::max(8, (int)((int64_t)cap * items[k] / total_items) / 8 * 8);
+      if (pretend) gk = std::max(8, atoi(pretend) / 8 * 8);
+      if (items[k] > 2 * gk) { g_last_error = "too many row blocks for one persistent launch per device"; return 1; }
+      grid.push_back(gk);
+      total += gk;
+    }
+    if (total > cap && !pretend) return 1;
+    D.base.assign(1, 0);
+    for (int gk : grid) D.base.push_back(D.base.back() + gk);
+    D.grid = total;
+    const size_t k_n = D.members.size();
+    HIP_TRY(hipMalloc((void **)&D.args_dev, sizeof(GroupTrialArgs) * k_n));
+    HIP_TRY(hipHostMalloc((void **)&D.args_host, sizeof(GroupTrialArgs) * k_n, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&D.sync_dev, sizeof(GridSync *) * k_n));
+    HIP_TRY(hipEventCreateWithFlags(&D.ev_done, hipEventDisableTiming));
+    D.ev.assign(k_n, nullptr);
+    std::vector<GridSync *> syncs;
+    for (size_t k = 0; k < k_n; ++k) {
+      pdhg_handle *s = L.p[D.members[k]];
+      HIP_TRY(hipEventCreateWithFlags(&D.ev[k], hipEventDisableTiming));
+      int rc = ensure_result_word(s);
+      if (rc) return rc;
+      if (!s->gsync) HIP_TRY(hipMalloc((void **)&s->gsync, sizeof(GridSync)));
+      HIP_TRY(hipMemset(s->gsync, 0, sizeof(GridSync)));
+      s->coop_grid = grid[k];
+      s->coop_epoch = 0; s->coop_launches = 0;
+      if (s->coop_grid > s->pAt_stride) {          // the interaction partials take one slot per workgroup
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (s->pAt) (void)hipFree(s->pAt);
+        s->pAt = nullptr;
+        s->pAt_stride = s->coop_grid;
+        if ((rc = alloc_zero(&s->pAt, 6 * (int64_t)s->pAt_stride))) return rc;
+      }
+      syncs.push_back(s->gsync);
+    }
+    HIP_TRY(hipMemcpy(D.sync_dev, syncs.data(), sizeof(GridSync *) * k_n, hipMemcpyHostToDevice));
+    // census of the merged launch shape: workgroups of every shard per XCD
+    GroupDeviceArgs da{};
+    da.shard = D.args_dev; da.nshards = (int)k_n;
+    for (size_t k = 0; k <= k_n; ++k) da.base[k] = D.base[k];
+    HIP_TRY(hipDeviceSynchronize());
+    hipLaunchKernelGGL(group_register_kernel, dim3(D.grid), dim3(TPB), 0, D.stream, da, (GridSync *const *)D.sync_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(D.stream));
+    for (size_t k = 0; k < k_n; ++k) {
+      pdhg_handle *s = L.p[D.members[k]];
+      GridSync host;
+      HIP_TRY(hipMemcpy(&host, s->gsync, sizeof(GridSync), hipMemcpyDeviceToHost));
+      unsigned long long seen = 0;
+      s->coop_nxcd = 0;
+      for (int x = 0; x < 8; ++x) { seen += host.xcd_count[x][0]; s->coop_nxcd += host.xcd_count[x][0] > 0; s->coop_xcd_cnt[x] = (unsigned)host.xcd_count[x][0]; }
+      if (seen != (unsigned long long)grid[k] || s->coop_nxcd == 0) return fail(996, "group trial kernel: workgroup census does not add up");
+    }
+    g.coop_dev.push_back(D);
+  }
+  if (!g.gsync) {
+    HIP_TRY(hipSetDevice(L.p[0]->device));
+    void *p = nullptr;
+    // fine-grained device memory when the runtime offers it: the devices poll these words with system-scope atomics
+    if (hipExtMallocWithFlags(&p, sizeof(GroupSync), hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_TRY(hipMalloc(&p, sizeof(GroupSync)));
+    }
+    HIP_TRY(hipMemset(p, 0, sizeof(GroupSync)));
+    HIP_TRY(hipDeviceSynchronize());
+    g.gsync = reinterpret_cast<GroupSync *>(p);
+  }
+  return 0;
+}
+
+static bool group_coop_eligible(const Shards &L) {
+  DistGroup &g = *L.g;
+  if (g.coop_mode < 0) {
+    const char *ev = getenv("PDHG_GROUP_COOP");
+    bool on = g.all_local() && g.backend == COMM_P2P && L.count == g.world && g.world >= 2 && g.world <= P2P_MAX_WORLD &&
+              !(ev && ev[0] == '0') && !(getenv("PDHG_GRAPH") && getenv("PDHG_GRAPH")[0] == '0');
+    bool one_device = true;
+    for (int i = 0; i < L.count && on; ++i) {
+      const pdhg_handle *s = L.p[i];
+      one_device = one_device && s->device == L.p[0]->device;
+      on = !s->has_q && s->lazy_accept && s->n > 0 && s->cn > 0 && !s->A.tiled && !s->At.tiled && s->A.slabs.empty() &&
+           s->At.slabs.empty() && s->A.segs.empty() && s->At.segs.empty() && s->coop_mode != 1 && !s->gsync;
+    }
+    if (on && !one_device && !(ev && ev[0] == '1')) on = false;
+    g.coop_mode = 0;
+    if (on) {
+      const int rc = group_coop_prepare(L);
+      if (rc == 0) g.coop_mode = 1;
+      else { (void)hipGetLastError(); group_coop_release(g); }
+      if (getenv("PDHG_VERBOSE")) {
+        fprintf(stderr, "[pdhg_hip] group of %d shards: one persistent kernel per device and trial %s", g.world, rc == 0 ? "ON" : "not possible");
+        for (const GroupDevLaunch &D : g.coop_dev) fprintf(stderr, " [device %d: %zu shards, %d workgroups]", D.device, D.members.size(), D.grid);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+  return g.coop_mode == 1 && !L.p[0]->profile;
+}
+
+// returns 1 when the trial was not taken here (the caller runs the ordinary group path)
+static int group_coop_trial(const Shards &L, const TrialArgs &ta, double out[5]) {
+  DistGroup &g = *L.g;
+  // one persistent launch set at a time per device (two half-resident sets would wait for each other)
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (GroupDevLaunch &D : g.coop_dev) locks.emplace_back(coop_device_mutex(D.device));      // (ascending device ids)
+  const auto t_begin = std::chrono::steady_clock::now();
+  const double sigma = ta.primal_weight * ta.step_size;
+  for (GroupDevLaunch &D : g.coop_dev) {
+    HIP_TRY(hipSetDevice(D.device));
+    for (size_t k = 0; k < D.members.size(); ++k) {
+      pdhg_handle *s = L.p[D.members[k]];
+      GroupTrialArgs a{};
+      a.rank = s->rank; a.world = g.world;
+      const int64_t o = s->clo;
+      a.cn = (int)s->cn; a.clo = o; a.xbar_only = ta.primal ? 0 : 1;
+      a.x = s->x + o; a.c = s->c + o; a.aty = s->aty + o; a.lb = s->lb + o; a.ub = s->ub + o;
+      a.tau = ta.step_size / ta.primal_weight; a.theta = ta.theta;
+      a.x_next = s->x_next + o;
+      a.avg_w = s->pend_w; a.sum_x = (s->pend_x && ta.primal) ? s->sum_x + o : nullptr;
+      for (int q = 0; q < L.count; ++q) {
+        a.xbar_peer[L.p[q]->rank] = L.p[q]->xbar;
+        a.part_peer[L.p[q]->rank] = L.p[q]->aty_next;
+      }
+      EpiArgs de{};
+      de.y = s->y; de.b = s->b; de.y_next = s->y_next; de.sigma = sigma; de.num_eq = (int)s->num_eq;
+      de.partials = s->pA; de.stride = s->A.slots(); de.lo_offset = s->A.slots();
+      if (s->pend_y) { de.sum_y = s->sum_y; de.avg_w = s->pend_w; }
+      a.A = trial_product(s, s->A, s->xbar, de);
+      EpiArgs te{};
+      te.out = s->aty_next;
+      a.T = trial_product(s, s->At, s->y_next, te);
+      a.off = o; a.aty_next = s->aty_next;
+      a.pAt = s->pAt; a.pAt_stride = s->pAt_stride;
+      a.sp.ptr[0] = s->pAt;                         a.sp.count[0] = s->coop_grid;
+      a.sp.ptr[1] = s->pAt + s->pAt_stride;         a.sp.count[1] = s->coop_grid;
+      a.sp.ptr[2] = s->pA;                          a.sp.count[2] = s->A.slots();
+      a.sp.ptr[3] = s->pAt + 2 * s->pAt_stride;     a.sp.count[3] = s->coop_grid;
+      a.sp.ptr[4] = s->pQ;                          a.sp.count[4] = 0;
+      for (int q : {0, 1, 3}) a.sp.ptr_lo[q] = a.sp.ptr[q] + 3 * s->pAt_stride;
+      a.sp.ptr_lo[2] = s->pA + s->A.slots();
+      a.sp.ptr_lo[4] = s->pQ + s->ew_grid_n;
+      a.sp.out = nullptr;
+      a.sync = s->gsync; a.gsync = g.gsync;
+      a.epoch = s->coop_epoch; s->coop_epoch += 3;
+      a.xepoch = g.xepoch;
+      a.launch = s->coop_launches; s->coop_launches += 1;
+      s->seq_expected += 1;
+      a.seq = s->seq_expected;
+      a.nxcd = s->coop_nxcd;
+      for (int x = 0; x < 8; ++x) a.xcd_cnt[x] = s->coop_xcd_cnt[x];
+      a.seq_dev = s->seq_dev; a.res_host = s->res_host; a.relaxed = s->relaxed ? 1 : 0;
+      D.args_host[k] = a;                       // (the previous launch has returned its results: the staging copy is free)
+      if (ta.primal) s->pend_x = false;
+      s->pend_y = false;                        // the launch carries the deferred average update
+      // whatever the shard's own stream has queued since the last trial (a flush, a set_current, an evaluation) comes first
+      if (g.members_dirty && s->stream != D.stream) {
+        HIP_TRY(hipEventRecord(D.ev[k], s->stream));
+        HIP_TRY(hipStreamWaitEvent(D.stream, D.ev[k], 0));
+      }
+    }
+    if ((int)D.members.size() <= GROUP_INLINE_SHARDS) {            // the argument blocks by value: nothing to upload
+      const int k_n = (int)D.members.size();
+      hipLaunchKernelGGL(group_trial_inline_kernel, dim3(D.grid), dim3(TPB), 0, D.stream, D.args_host[0], D.args_host[k_n > 1 ? 1 : 0],
+                         k_n, k_n > 1 ? D.base[1] : D.grid, D.grid);
+    } else {
+      HIP_TRY(hipMemcpyAsync(D.args_dev, D.args_host, sizeof(GroupTrialArgs) * D.members.size(), hipMemcpyHostToDevice, D.stream));
+      GroupDeviceArgs da{};
+      da.shard = D.args_dev; da.nshards = (int)D.members.size();
+      for (size_t k = 0; k <= D.members.size(); ++k) da.base[k] = D.base[k];
+      hipLaunchKernelGGL(group_trial_kernel, dim3(D.grid), dim3(TPB), 0, D.stream, da);
+    }
+    HIP_TRY(hipGetLastError());
+    // ... and whatever is queued on the members' streams next comes after this launch (check_handle: lazily)
+    HIP_TRY(hipEventRecord(D.ev_done, D.stream));
+  }
+  g.members_dirty = false;
+  g.join_pending = true;
+  g.xepoch += 2;
+  const auto t_issued = std::chrono::steady_clock::now();
+  bool failed = false;
+  double sums[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < L.count; ++i) {
+    pdhg_handle *s = L.p[i];
+    HIP_TRY(hipSetDevice(s->device));
+    double r[5];
+    const int rc = wait_result_word(s, r, true);
+    if (rc) return rc;
+    failed = failed || s->res_error != 0.0;
+    for (int q = 0; q < 4; ++q) sums[q] = (i == 0) ? r[q] : sums[q] + r[q];      // rank order (L.p is ascending in rank)
+  }
+  g.t_issue += std::chrono::duration<double>(t_issued - t_begin).count();
+  g.t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_issued).count();
+  g.n_trials += 1;
+  if (failed) {
+    // a barrier ran into its spin limit (the launches were not all co-resident): every workgroup still ran every phase, so
+    // the deferred average updates are applied exactly once; x', y', A'y' and the sums are not trustworthy -- the caller
+    // repeats the trial on the ordinary group path (its inputs are untouched) and the group stays there
+    g.coop_mode = 0;
+    g.coop_fallbacks += 1;
+    fprintf(stderr, "[pdhg_hip] group trial kernel: a barrier timed out -- this group uses the per-launch path from here on\n");
+    return check_handle(L.p[0]) ? -1 : 1;        // (the members' streams wait for the failed launches before the repeat)
+  }
+  for (int q = 0; q < 4; ++q) out[q] = sums[q];
+  out[4] = 0.0;
+  g.coop_trials += 1;
+  return 0;
+}
+
 // Row-partitioned group: the dual half of a trial.  xbar's owned slices are ready.
 static int trial_dual_group(const Shards &L, double step_size, double primal_weight, double out[5]) {
   DistGroup &g = *L.g;
@@ -2535,12 +2795,15 @@ int pdhg_trial_primal(pdhg_handle *h, double step_size, double primal_weight) {
 }
 
 int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight, double theta, double out[5]) {
-  int rc = check_handle(h);
+  int rc = check_handle(h, !(h && h->grp && h->grp->coop_mode == 1));
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
   if (!L.g && coop_eligible(h)) {         // Malitsky-Pock retries: xbar + the dual half
     if ((rc = coop_trial(h, step_size, primal_weight, theta, true, out)) != 1) return rc;    // 1: not run / timed out, repeat below
+  }
+  if (L.g && group_coop_eligible(L)) {
+    if ((rc = group_coop_trial(L, TrialArgs{step_size, primal_weight, theta, false}, out)) != 1) return rc;
   }
   if (L.g && L.g->pool && !L.p[0]->profile) return trial_group_mt(L, TrialArgs{step_size, primal_weight, theta, false}, out);
   FOR_SHARDS(L, s) { if ((rc = launch_xbar(s, theta))) return rc; }
@@ -2550,7 +2813,7 @@ int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight, doub
 
 int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, double theta, double out[5]) {
   RoctxRange roctx_range("pdhg_trial_step");
-  int rc = check_handle(h);
+  int rc = check_handle(h, !(h && h->grp && h->grp->coop_mode == 1));
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
@@ -2558,6 +2821,9 @@ int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, doub
     if ((rc = coop_trial(h, step_size, primal_weight, theta, false, out)) != 1) return rc;   // 1: not run / timed out, repeat below
   }
   if (!L.g && graph_eligible(h)) return graph_trial(h, step_size, primal_weight, theta, out);
+  if (L.g && group_coop_eligible(L)) {
+    if ((rc = group_coop_trial(L, TrialArgs{step_size, primal_weight, theta, true}, out)) != 1) return rc;
+  }
   if (L.g && L.g->pool && !L.p[0]->profile) return trial_group_mt(L, TrialArgs{step_size, primal_weight, theta, true}, out);
   FOR_SHARDS(L, s) { if ((rc = launch_primal(s, step_size / primal_weight, theta, true))) return rc; }
   if (L.g) return trial_dual_group(L, step_size, primal_weight, out);
@@ -2566,7 +2832,8 @@ int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, doub
 
 int pdhg_accept(pdhg_handle *h0, double avg_weight) {
   RoctxRange roctx_range("pdhg_accept");
-  int rc = check_handle(h0);
+  // (a lazy accept with nothing pending queues no work: the iterates are swapped on the host)
+  int rc = check_handle(h0, !(h0 && h0->grp && h0->grp->coop_mode == 1 && h0->lazy_accept && !h0->pend_x && !h0->pend_y));
   if (rc) return rc;
   const Shards L = shards_of(h0);
   if ((rc = flush_pending(L))) return rc;   // two accepts without a trial in between
@@ -3780,6 +4047,8 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
     info[10 + k] = first(D).tiled ? first(D).tile_cols : 0;
     info[15] += (int64_t)std::min<size_t>(D.segs.size(), 255) << (8 + 8 * k);
   }
+  if (h->grp)     // bits 24-39: trials this group took as one persistent kernel per shard (group_kernel.hpp); 40-47: its fallbacks
+    info[15] += (std::min<int64_t>(h->grp->coop_trials, 65535) << 24) + ((int64_t)std::min(h->grp->coop_fallbacks, 255) << 40);
   if (!h->A.segs.empty()) info[12] = (int64_t)first(h->A).slabs.size();
   if (!h->At.segs.empty()) info[13] = (int64_t)first(h->At).slabs.size();
   return 0;

@@ -48,6 +48,7 @@ struct GridSync {                           // device memory, one per handle; on
   unsigned long long xcd_done[8][16];       // workgroups of the XCD that have finished their last phase
   unsigned long long ticket[3][16];         // [2]: XCDs done (the last workgroup of the last XCD runs the second-stage reduction)
   unsigned long long error[16];
+  unsigned long long xrelease[16];          // group_kernel.hpp: last cross-shard barrier the shard's last XCD leader has passed
 };
 
 __device__ __forceinline__ unsigned xcc_id() {
@@ -175,8 +176,9 @@ struct Prefetched {
   int kind;            // 0 nothing, 1 row block, 2 long-row chunk
   StreamRegs g;
 };
-__device__ __forceinline__ void product_prefetch(const TrialProduct &P, Prefetched &f) {
-  const int w = blockIdx.x, nwg = gridDim.x;
+// (w, nwg: this workgroup's index and the number of workgroups that share the product -- the launch's own by default;
+//  the group kernel, one launch for several shards, passes the workgroup's place inside its shard)
+__device__ __forceinline__ void product_prefetch(const TrialProduct &P, Prefetched &f, int w, int nwg) {
   int blk;
   f.kind = 0;
   const int c = nwg - 1 - w;
@@ -188,14 +190,14 @@ __device__ __forceinline__ void product_prefetch(const TrialProduct &P, Prefetch
     f.kind = 1;
   }
 }
+__device__ __forceinline__ void product_prefetch(const TrialProduct &P, Prefetched &f) { product_prefetch(P, f, (int)blockIdx.x, (int)gridDim.x); }
 
 // xin, e, uses: the operands that change from trial to trial (the single-trial kernel passes P's own)
 template <int MODE, bool COH = false>
 __device__ __forceinline__ void product_phase(const TrialProduct &P, const double *xin, const EpiArgs &e,
                                               unsigned long long uses, int relaxed,
-                                              Prefetched &f, double *prod, double (*red)[TPB / WAVE]) {
+                                              Prefetched &f, double *prod, double (*red)[TPB / WAVE], int w, int nwg) {
   const unsigned long long launch = uses;
-  const int w = blockIdx.x, nwg = gridDim.x;
   __shared__ int finish_row;
   StreamRegs &g = f.g;
   const bool pre = f.kind == 1;
@@ -237,6 +239,13 @@ __device__ __forceinline__ void product_phase(const TrialProduct &P, const doubl
       }
     }
   }
+}
+
+template <int MODE, bool COH = false>
+__device__ __forceinline__ void product_phase(const TrialProduct &P, const double *xin, const EpiArgs &e,
+                                              unsigned long long uses, int relaxed,
+                                              Prefetched &f, double *prod, double (*red)[TPB / WAVE]) {
+  product_phase<MODE, COH>(P, xin, e, uses, relaxed, f, prod, red, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // waves per SIMD: the kernel needs 96 VGPRs (5 waves per SIMD, 5 workgroups per CU).  Forcing the 8 of the separate

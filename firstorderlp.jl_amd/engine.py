@@ -415,6 +415,9 @@ class HipPdhgEngine:
         # nnz beyond the 32-bit entry limit: the matrix is held as this many segments of whole rows (0: one piece)
         out["A_segments"] = (out["var_tiles"] >> 8) & 255
         out["At_segments"] = (out["var_tiles"] >> 16) & 255
+        # shard groups: trials taken as one persistent kernel per shard (group_kernel.hpp), and its fall-backs
+        out["group_coop_trials"] = (out["var_tiles"] >> 24) & 65535
+        out["group_coop_fallbacks"] = (out["var_tiles"] >> 40) & 255
         out["var_tiles"] &= 3
         for k in ("A", "At"):    # width in bits of an entry's column field
             out[k + "_tile_shift"] = max(1, (out[k + "_tile_cols"] - 1).bit_length()) if out[k + "_tile_cols"] else 0

@@ -389,3 +389,45 @@ def test_batched_take_steps_on_a_shard_group(gpu_required):
         eng.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert outs[0][2:] == outs[1][2:]
+
+
+# ---- round 4: a group's trial as one persistent kernel per shard with cross-shard barriers (group_kernel.hpp) ---------
+
+@pytest.mark.parametrize("maker", [lambda: random_lp(30000, 20000, 6, seed=21),
+                                   lambda: H.skewed_lp(9000, 12000, seed=5, dense_rows=2, dense_cols=2, base_nnz=6)],
+                         ids=["random", "long_rows"])
+@pytest.mark.parametrize("device_ids", [[0, 0], [0, 0, 0], [0] * 4], ids=["2", "3", "4"])
+def test_group_trial_kernels_are_bitwise_the_per_launch_group_path(gpu_required, monkeypatch, device_ids, maker):
+    """Shards on one device: the trial as ONE persistent kernel per shard -- xbar stored into every shard's buffer, the
+    partial A_p'y_p added by the slice's owner in rank order, two cross-shard barriers inside the kernels -- against the
+    ordinary group path (launch by launch, exchange kernels between cross-stream events).  Same element arithmetic, the
+    same rank order in the reduce, exactly rounded acceptance sums: not a bit may differ -- adaptive steps, the
+    Malitsky-Pock split (xbar-only retries), the lazy average update, restart to the average."""
+    p = maker()
+    runs = {}
+    for coop in ("1", "0"):
+        monkeypatch.setenv("PDHG_GROUP_COOP", coop)
+        eng = HipPdhgEngine.from_problem(p, device_ids=device_ids)
+        runs[coop] = _run(eng, p, 60, 25)
+        runs[coop]["launches"] = eng.layout_info()["group_coop_trials"]
+        eng.close()
+    assert runs["1"].pop("launches") >= 60 and runs["0"].pop("launches") == 0          # the new path really ran
+    for key, val in runs["1"].items():
+        assert np.array_equal(np.asarray(val), np.asarray(runs["0"][key])), key
+    s = _run(HipPdhgEngine.from_problem(p), p, 60, 25)
+    _compare(runs["1"], s, p)
+
+
+def test_group_trial_kernels_fall_back_when_a_barrier_cannot_complete(gpu_required, monkeypatch):
+    """More workgroups than the device holds side by side (test knob): the first cross-shard barrier times out, the
+    kernels raise their error words, the host repeats the trial launch by launch and keeps the group there -- same bits."""
+    p = random_lp(30000, 20000, 6, seed=22)
+    monkeypatch.setenv("PDHG_GROUP_COOP", "0")
+    ref = _run(HipPdhgEngine.from_problem(p, device_ids=[0, 0]), p, 12)
+    monkeypatch.setenv("PDHG_GROUP_COOP", "1")
+    monkeypatch.setenv("PDHG_COOP_TEST_PRETEND_WGS", "4096")
+    eng = HipPdhgEngine.from_problem(p, device_ids=[0, 0])
+    got = _run(eng, p, 12)
+    assert eng.layout_info()["group_coop_fallbacks"] == 1
+    for key, val in got.items():
+        assert np.array_equal(np.asarray(val), np.asarray(ref[key])), key

@@ -111,3 +111,37 @@ def test_l1svm_full_size(gpu_required):
     p = l1_svm_rcv1_like_lp(seed=0)
     info = _full_size_trial_check(p, "l1svm")
     assert info["At_long_chunks"] > 0                                    # dense feature columns: long rows of A'
+
+
+@pytest.mark.own_row_order          # rows of config S have ~10 entries: both row orders take the same code path
+@pytest.mark.timeout(1200)
+def test_config_s_free_running_trajectory_is_bitwise_the_exact_sums_oracle(gpu_required):
+    """BASELINE configs[4] at FULL size, free-running: 12 adaptive take_steps from the zero start (step-size rule, accepts,
+    rejects and the weighted average included), the library through its batched call, the CPU oracle in exact-sums mode.
+    Step sizes, iteration counts, iterates and averages must be the same BITS -- the north star's "same iterates within a
+    stated tolerance" at tolerance zero on the headline LP (the oracle's default sequential sums differ from BLAS-order
+    sums by construction; see DESIGN.md section 2 for what that comparison can and cannot show)."""
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import AdaptiveStepsizeParams, PdhgSolverState, take_steps
+    m = n = 10_000_000
+    p = random_lp(m, n, 10, 12345)
+    eng = HipPdhgEngine.from_problem(p)
+    step, pw = H.initial_step_and_weight(p)
+    st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    o = H.oracle_from_problem(p)
+    o.exact_sums = True
+    o.step_size, o.primal_weight = step, pw
+    K = 12
+    done = 0
+    while done < K:
+        done += take_steps(AdaptiveStepsizeParams(0.3, 0.6), st, K - done)
+    for _ in range(K):
+        o.take_step_adaptive(0.3, 0.6)
+    assert st.total_number_iterations == o.total_number_iterations
+    assert st.step_size == o.step_size
+    x, y = eng.get_current()
+    assert np.array_equal(x, o.x) and np.array_equal(y, o.y)
+    xa, ya = eng.get_average()
+    xo, yo = o.compute_average()
+    assert np.array_equal(xa, xo) and np.array_equal(ya, yo)
+    eng.close()
+    o.close()
