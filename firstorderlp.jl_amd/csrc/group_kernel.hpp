@@ -9,8 +9,8 @@
 //
 // Why.  The group's trial is ~8 launches per shard with cross-stream event barriers around two exchange kernels (peer
 // back end) or two RCCL collectives: measured on the L1-SVM LP, two shards on one device, 146 us per trial (90 us of
-// host issue, 54 us waiting) against 42-50 us for the plain handle (profiles/r04_l1svm_shards.txt).  Here a shard's
-// trial is one launch; the shards meet at CROSS-SHARD barriers inside their kernels:
+// host issue, 54 us waiting) against 42-50 us for the plain handle (profiles/r04_l1svm_shards.txt).  Here a device's
+// shards share one launch per trial; the shards meet at CROSS-SHARD barriers inside it:
 //
 //   phase 0   x', xbar on the OWNED column slice (K1+K2, + the deferred sum_x update); xbar is stored into EVERY
 //             shard's xbar buffer (the all-gather as P stores per element: peer-mapped memory)

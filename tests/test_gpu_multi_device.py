@@ -133,3 +133,27 @@ def test_optimize_with_device_evaluation_and_rescaling_on_two_gpus(gpu_required)
     assert abs(c2.primal_objective - c1.primal_objective) <= 50 * tol * scale
     assert abs(c2.dual_objective - c1.dual_objective) <= 50 * tol * scale
     assert 0.5 <= grp.iteration_count / one.iteration_count <= 2.0
+
+
+# ---- round 4: the persistent group trial kernels (csrc/group_kernel.hpp) ACROSS devices ---------------------------------
+# On one device they are the default and bitwise the per-launch path (tests/test_gpu_dist_group.py).  Across devices the
+# protocol -- peer stores of xbar, system-scope write-back / invalidate around cross-device flag barriers, the owner's
+# rank-ordered reduce of the peers' partials -- has never executed, so it is opt-in (PDHG_GROUP_COOP=1) and this is the
+# test that decides whether it may become the default: not a bit may differ from the per-launch path.
+
+@needs2
+@pytest.mark.parametrize("device_ids", [[0, 1], [0, 1, 0, 1]], ids=["one_shard_per_gpu", "two_shards_per_gpu"])
+def test_group_trial_kernels_across_two_gpus_are_bitwise_the_per_launch_path(gpu_required, monkeypatch, device_ids):
+    monkeypatch.setenv("PDHG_COMM", "p2p")             # the peer back end (the kernels exchange through peer-mapped memory)
+    p = random_lp(30000, 20000, 6, seed=21)
+    runs = {}
+    for coop in ("1", "0"):
+        monkeypatch.setenv("PDHG_GROUP_COOP", coop)
+        eng = HipPdhgEngine.from_problem(p, device_ids=device_ids)
+        assert eng.dist_info()["backend"] == 1
+        runs[coop] = _run(eng, p, 60, 25)
+        runs[coop]["trials"] = eng.layout_info()["group_coop_trials"]
+        eng.close()
+    assert runs["1"].pop("trials") >= 60 and runs["0"].pop("trials") == 0
+    for key, val in runs["1"].items():
+        assert np.array_equal(np.asarray(val), np.asarray(runs["0"][key])), key
