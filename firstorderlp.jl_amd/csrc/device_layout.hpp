@@ -318,12 +318,12 @@ __global__ __launch_bounds__(TPB) void tw_count_kernel(const int2 *__restrict__ 
 
 // entries per group of 16 columns over the rows that are not long (the skew test of build_tiled)
 __global__ __launch_bounds__(TPB) void cnt16_kernel(int rows, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                    int *__restrict__ cnt16) {
+                                                    int *__restrict__ cnt16, int long_thr) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) / WAVE, nw = (int64_t)gridDim.x * TPB / WAVE;
   for (int64_t r = wave; r < rows; r += nw) {
     const int k0 = rowptr[r], k1 = rowptr[r + 1];
-    if (k1 - k0 > BLOCK_NNZ) continue;
+    if (k1 - k0 > long_thr) continue;
     for (int k = k0 + lane; k < k1; k += WAVE) atomicAdd(&cnt16[col[k] >> 4], 1);
   }
 }

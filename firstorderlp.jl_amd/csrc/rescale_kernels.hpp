@@ -14,12 +14,12 @@ enum { ROP_MAXABS = 0, ROP_SUMPOW = 1, ROP_SUMSQ_SCALED = 2 };
 template <int OP>
 __global__ __launch_bounds__(TPB) void row_op_kernel(CsrView A, int cols, double pexp,
                                                      const double *__restrict__ inv_scale,
-                                                     double *__restrict__ out) {
+                                                     double *__restrict__ out, int long_thr) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int r = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
   if (r >= A.rows) return;
   const int k0 = A.rowptr[r], k1 = A.rowptr[r + 1];
-  if (k1 - k0 > BLOCK_NNZ) return;        // long rows: row_op_long_* below (one workgroup per 8192-entry chunk)
+  if (k1 - k0 > long_thr) return;        // long rows: row_op_long_* below (one workgroup per 8192-entry chunk)
   const double sc = (OP == ROP_SUMSQ_SCALED) ? inv_scale[r] : 1.0;
   double acc = 0.0;
   for (int k = k0 + lane; k < k1; k += WAVE) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(TPB) void scale_csr_kernel(int rows, const int *__r
   const int r = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
   if (r >= rows) return;
   const int k0 = rowptr[r], k1 = rowptr[r + 1];
-  if (skip_long && k1 - k0 > BLOCK_NNZ) return;      // scale_long_kernel does them chunk by chunk
+  if (skip_long && k1 - k0 > skip_long) return;      // skip_long = the long-row threshold: scale_long_kernel does those rows chunk by chunk
   for (int k = k0 + lane; k < k1; k += WAVE) {
     const int c = col[k];
     const double ie = transposed ? inv_e[c] : inv_e[r];

@@ -18,7 +18,33 @@ ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--tol", type=float, default=1e-4)
 ap.add_argument("--iteration_limit", type=int, default=20000)
 ap.add_argument("--verbosity", type=int, default=2)
+ap.add_argument("--breakdown", action="store_true", help="time the stages of the evaluation branch (wall clock around the host calls)")
 a = ap.parse_args()
+stage_time, stage_calls = {}, {}
+if a.breakdown:
+    import firstorderlp_jl_amd.primal_dual_hybrid_gradient as _pd
+    def _timed(mod, name):
+        f = getattr(mod, name)
+        def g(*args, **kw):
+            t = time.perf_counter()
+            try:
+                return f(*args, **kw)
+            finally:
+                stage_time[name] = stage_time.get(name, 0.0) + time.perf_counter() - t
+                stage_calls[name] = stage_calls.get(name, 0) + 1
+        setattr(mod, name, g)
+    for nm in ("update_objective_bound_estimates", "check_termination_criteria", "run_restart_scheme",
+               "compute_new_primal_weight", "take_steps"):
+        _timed(_pd, nm)
+    _it = _pd.DeviceEvaluator.iteration_stats
+    def _its(self, *args, **kw):
+        t = time.perf_counter()
+        try:
+            return _it(self, *args, **kw)
+        finally:
+            stage_time["iteration_stats"] = stage_time.get("iteration_stats", 0.0) + time.perf_counter() - t
+            stage_calls["iteration_stats"] = stage_calls.get("iteration_stats", 0) + 1
+    _pd.DeviceEvaluator.iteration_stats = _its
 t0 = time.time()
 if a.workload == "pagerank":
     p = pagerank_lp(a.n)
@@ -42,3 +68,7 @@ print(f"{out.termination_string} after {out.iteration_count} iterations in {dt:.
       f"kkt passes {last.cumulative_kkt_matrix_passes:.0f}) "
       f"pobj={ci.primal_objective:.8g} dobj={ci.dual_objective:.8g} "
       f"rel_res=({ci.relative_l2_primal_residual:.2e},{ci.relative_l2_dual_residual:.2e}) gap={ci.relative_optimality_gap:.2e}")
+if a.breakdown:
+    for k in sorted(stage_time, key=stage_time.get, reverse=True):
+        print(f"  {k:36s} {stage_time[k]*1e3:9.2f} ms in {stage_calls[k]:6d} calls = {stage_time[k]/stage_calls[k]*1e6:8.1f} us each")
+    print(f"  {'everything else (setup, rescaling, first launches)':36s} {(dt - sum(stage_time.values()))*1e3:9.2f} ms")
