@@ -10,16 +10,14 @@ constexpr int BLOCK_NNZ = 2048;      // products staged in LDS per workgroup (16
 constexpr int UNROLL = BLOCK_NNZ / TPB;
 constexpr int MAX_ROWS_PER_BLOCK = 4 * TPB;
 constexpr int LONG_CHUNK = BLOCK_NNZ;   // nnz per workgroup for rows longer than BLOCK_NNZ: read like a row block (spmv_kernels.hpp)
-// Rows with more entries than this go to the long-row kernels (chunks of LONG_CHUNK entries + ordered combine) instead of
-// a row block / the tiled sweep.  BLOCK_NNZ is the capacity limit; PDHG_LONG_THR (dev knob) lowers it: hub rows of a
-// power-law graph then leave the sweep, whose lanes sum a row's entries inside a tile one after the other.
-inline int long_row_threshold() {
-  static const int thr = [] {
-    const char *e = getenv("PDHG_LONG_THR");
-    const int v = e ? atoi(e) : BLOCK_NNZ;
-    return v < 16 ? 16 : (v > BLOCK_NNZ ? BLOCK_NNZ : v);
-  }();
-  return thr;
+// Rows with more entries than CsrDev::long_thr go to the long-row kernels (chunks of LONG_CHUNK entries + ordered combine)
+// instead of a row block / the tiled sweep.  BLOCK_NNZ is the capacity limit and the default; PDHG_LONG_THR (dev knob,
+// read when a layout is built and kept with it) lowers it: hub rows of a power-law graph then leave the sweep, whose
+// lanes sum a row's entries inside a tile one after the other.
+inline int long_row_threshold_from_env() {
+  const char *e = getenv("PDHG_LONG_THR");
+  const int v = e ? atoi(e) : BLOCK_NNZ;
+  return v < 16 ? 16 : (v > BLOCK_NNZ ? BLOCK_NNZ : v);
 }
 constexpr int NUM_XCD = 8;
 constexpr int EW_MAX_BLOCKS = 256 * 8;  // elementwise kernels: grid-stride above this

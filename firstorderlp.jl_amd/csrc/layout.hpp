@@ -31,6 +31,7 @@ struct CsrDev {
   unsigned long long coop_uses = 0;          // one-launch trials that have run this layout's product (the tickets' base)
   double *chunk_partial = nullptr;
   int64_t max_row_nnz = 0;
+  int long_thr = BLOCK_NNZ;          // rows beyond this many entries: long-row kernels (common.hpp)
   // tiled-sweep layout (optional)
   bool tiled = false;
   int tile_shift = 0, tile_cols = 0, nwaves = 0, ntiles = 0, tw_rows = 0;   // tile widths <= 1 << tile_shift
@@ -166,7 +167,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
       int *d16 = nullptr;
       HIP_TRY(hipMalloc((void **)&d16, sizeof(int) * (size_t)std::max(groups, 1)));
       HIP_TRY(hipMemset(d16, 0, sizeof(int) * (size_t)std::max(groups, 1)));
-      hipLaunchKernelGGL(cnt16_kernel, dim3(2048), dim3(TPB), 0, nullptr, rows, (const int *)D.rowptr, (const int *)D.col, d16, long_row_threshold());
+      hipLaunchKernelGGL(cnt16_kernel, dim3(2048), dim3(TPB), 0, nullptr, rows, (const int *)D.rowptr, (const int *)D.col, d16, D.long_thr);
       hipError_t e = hipMemcpy(cnt16.data(), d16, sizeof(int) * (size_t)groups, hipMemcpyDeviceToHost);
       (void)hipFree(d16);
       HIP_TRY(e);
@@ -175,7 +176,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
       parallel_ranges(rows, 1 << 16, [&](int rb, int re) {
         std::vector<int> mine((size_t)groups, 0);
         for (int r = rb; r < re; ++r) {
-          if (rowptr[r + 1] - rowptr[r] > long_row_threshold()) continue;    // long rows are not in the sweep
+          if (rowptr[r + 1] - rowptr[r] > D.long_thr) continue;    // long rows are not in the sweep
           for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) mine[(size_t)(col[k] >> 4)] += 1;
         }
         std::lock_guard<std::mutex> lock(merge);
@@ -264,9 +265,9 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     wave_rows.clear();
     int r = 0;
     while (r < rows) {
-      if (rowptr[r + 1] - rowptr[r] > long_row_threshold()) { ++r; continue; }  // long row: separate path
+      if (rowptr[r + 1] - rowptr[r] > D.long_thr) { ++r; continue; }  // long row: separate path
       const int r0 = r;
-      while (r < rows && (r - r0) < TW_ROWS && rowptr[r + 1] - rowptr[r] <= long_row_threshold() &&
+      while (r < rows && (r - r0) < TW_ROWS && rowptr[r + 1] - rowptr[r] <= D.long_thr &&
              (r == r0 || (int64_t)rowptr[r + 1] - rowptr[r0] <= nnz_cap)) ++r;
       wave_rows.push_back(make_int2(r0, r));
     }
@@ -504,13 +505,13 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
 // <= MAX_ROWS_PER_BLOCK rows.  Rows that are LONG in the full matrix belong to the long-row
 // path: no block may contain them (their epilogue must run exactly once, there).
 void make_row_blocks(int rows, const std::vector<int> &slab_rowptr, const std::vector<int> &full_rowptr,
-                     std::vector<int2> &blks) {
+                     std::vector<int2> &blks, int long_thr) {
   int r = 0;
   while (r < rows) {
-    if (full_rowptr[r + 1] - full_rowptr[r] > long_row_threshold()) { ++r; continue; }
+    if (full_rowptr[r + 1] - full_rowptr[r] > long_thr) { ++r; continue; }
     const int r0 = r;
     int nn = 0;
-    while (r < rows && (r - r0) < MAX_ROWS_PER_BLOCK && full_rowptr[r + 1] - full_rowptr[r] <= long_row_threshold()) {
+    while (r < rows && (r - r0) < MAX_ROWS_PER_BLOCK && full_rowptr[r + 1] - full_rowptr[r] <= long_thr) {
       const int len = slab_rowptr[r + 1] - slab_rowptr[r];
       if (len > BLOCK_NNZ - nn) break;
       nn += len;
@@ -551,7 +552,7 @@ int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, c
     std::vector<int> rp((size_t)rows + 1, 0);
     for (int r = 0; r < rows; ++r) {
       int cnt = 0;
-      if (rowptr[r + 1] - rowptr[r] <= long_row_threshold())          // long rows stay with the long-row path
+      if (rowptr[r + 1] - rowptr[r] <= D.long_thr)          // long rows stay with the long-row path
         for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) cnt += (col[k] >= c0 && col[k] < c1);
       rp[(size_t)r + 1] = rp[(size_t)r] + cnt;
     }
@@ -559,14 +560,14 @@ int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, c
     dvec sv((size_t)rp[(size_t)rows]);
     parallel_ranges(rows, 1 << 14, [&](int rb, int re) {
       for (int r = rb; r < re; ++r) {
-        if (rowptr[r + 1] - rowptr[r] > long_row_threshold()) continue;
+        if (rowptr[r + 1] - rowptr[r] > D.long_thr) continue;
         int q = rp[(size_t)r];
         for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
           if (col[k] >= c0 && col[k] < c1) { sc[(size_t)q] = col[k]; sv[(size_t)q] = val[k]; ++q; }
       }
     });
     std::vector<int2> blks;
-    make_row_blocks(rows, rp, rowptr, blks);
+    make_row_blocks(rows, rp, rowptr, blks, D.long_thr);
     SlabDev S;
     S.nnz = rp[(size_t)rows];
     S.nblk = (int)blks.size();
@@ -593,7 +594,7 @@ int build_slabs_device(CsrDev &D, int rows, int cols, const std::vector<int> &ro
     const int c0 = slab_first_col(cols, P, p), c1 = slab_first_col(cols, P, p + 1);
     SlabDev S;
     HIP_TRY(hipMalloc((void **)&S.rowptr, sizeof(int) * ((size_t)rows + 1)));
-    hipLaunchKernelGGL(slab_count_kernel, dim3(grid), dim3(TPB), 0, nullptr, rows, D.rowptr, D.col, c0, c1, long_row_threshold(), S.rowptr);
+    hipLaunchKernelGGL(slab_count_kernel, dim3(grid), dim3(TPB), 0, nullptr, rows, D.rowptr, D.col, c0, c1, D.long_thr, S.rowptr);
     HIP_TRY(hipGetLastError());
     if ((rc = device_exclusive_scan(S.rowptr, S.rowptr, (int64_t)rows + 1, nullptr, nullptr))) return rc;
     std::vector<int> rp((size_t)rows + 1);
@@ -601,11 +602,11 @@ int build_slabs_device(CsrDev &D, int rows, int cols, const std::vector<int> &ro
     S.nnz = rp[(size_t)rows];
     HIP_TRY(hipMalloc((void **)&S.col, sizeof(int) * (size_t)std::max<int64_t>(S.nnz, 1)));
     HIP_TRY(hipMalloc((void **)&S.val, sizeof(double) * (size_t)std::max<int64_t>(S.nnz, 1)));
-    hipLaunchKernelGGL(slab_fill_kernel, dim3(grid), dim3(TPB), 0, nullptr, rows, D.rowptr, D.col, D.val, c0, c1, long_row_threshold(),
+    hipLaunchKernelGGL(slab_fill_kernel, dim3(grid), dim3(TPB), 0, nullptr, rows, D.rowptr, D.col, D.val, c0, c1, D.long_thr,
                        S.rowptr, S.col, S.val);
     HIP_TRY(hipGetLastError());
     std::vector<int2> blks;
-    make_row_blocks(rows, rp, rowptr, blks);
+    make_row_blocks(rows, rp, rowptr, blks, D.long_thr);
     S.nblk = (int)blks.size();
     S.per_xcd = (S.nblk + NUM_XCD - 1) / NUM_XCD;
     S.grid = remap ? S.per_xcd * NUM_XCD : S.nblk;
@@ -656,13 +657,14 @@ int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &r
   D.rows = rows;
   D.cols = cols;
   D.nnz = rowptr[rows];
+  D.long_thr = long_row_threshold_from_env();
   std::vector<int2> blks;
   std::vector<int> long_row, long_chunk_ptr(1, 0), chunk_row, chunk_off, chunk_lidx;
   int r = 0;
   while (r < rows) {
     int len = rowptr[r + 1] - rowptr[r];
     D.max_row_nnz = std::max<int64_t>(D.max_row_nnz, len);
-    if (len > long_row_threshold()) {
+    if (len > D.long_thr) {
       const int l = (int)long_row.size();
       long_row.push_back(r);
       for (int off = 0; off < len; off += LONG_CHUNK) {
@@ -678,7 +680,7 @@ int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &r
     int nn = 0;
     while (r < rows && (r - r0) < MAX_ROWS_PER_BLOCK) {
       len = rowptr[r + 1] - rowptr[r];
-      if (len > long_row_threshold() || len > BLOCK_NNZ - nn) break;
+      if (len > D.long_thr || len > BLOCK_NNZ - nn) break;
       D.max_row_nnz = std::max<int64_t>(D.max_row_nnz, len);
       nn += len;
       ++r;
@@ -690,7 +692,7 @@ int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &r
     constexpr int64_t ROW_COST = 2;
     auto cost_of = [&](int row) -> int64_t {
       const int len = rowptr[row + 1] - rowptr[row];
-      return len > long_row_threshold() ? 0 : (int64_t)len + ROW_COST;
+      return len > D.long_thr ? 0 : (int64_t)len + ROW_COST;
     };
     int64_t total = 0;
     for (int row = 0; row < rows; ++row) total += cost_of(row);
@@ -701,14 +703,14 @@ int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &r
       int64_t have = 0;               // cost of the rows placed so far
       int row = 0;
       while (row < rows) {
-        if (rowptr[row + 1] - rowptr[row] > long_row_threshold()) { ++row; continue; }
+        if (rowptr[row + 1] - rowptr[row] > D.long_thr) { ++row; continue; }
         // this block ends where the running cost passes the next multiple of total / target (never empty; hard caps as above)
         const int64_t goal = (total * ((int64_t)cut.size() + 1) + target - 1) / target;
         const int r0 = row;
         int nn = 0;
         while (row < rows && (row - r0) < MAX_ROWS_PER_BLOCK) {
           const int len = rowptr[row + 1] - rowptr[row];
-          if (len > long_row_threshold() || len > BLOCK_NNZ - nn) break;
+          if (len > D.long_thr || len > BLOCK_NNZ - nn) break;
           const int64_t cst = cost_of(row);
           if (row > r0 && have + cst > goal && goal - have <= cst / 2) break;    // closer to the goal without this row
           nn += len;

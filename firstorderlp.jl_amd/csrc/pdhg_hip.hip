@@ -3503,7 +3503,7 @@ static void launch_row_op(pdhg_handle *h, const CsrDev &D, int cols, double pexp
     return;
   }
   hipLaunchKernelGGL(row_op_kernel<OP>, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.view(), cols, pexp, inv_scale, out,
-                     long_row_threshold());
+                     D.long_thr);
   if (D.nlong > 0) {
     hipLaunchKernelGGL(row_op_long_partial_kernel<OP>, dim3(D.nchunks), dim3(TPB), 0, h->stream, D.view(),
                        (const int *)D.chunk_row, (const int *)D.chunk_off, pexp, inv_scale, D.chunk_partial);
@@ -3526,7 +3526,7 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
     for (CsrDev &S : D.segs) scale_one(S, k == 0 ? inv_e + S.row0 : inv_e, k == 1 ? inv_d + S.row0 : inv_d, k);
     if (!D.segs.empty() || D.nnz == 0) return;
     hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, D.rowptr,
-                       D.col, D.val, inv_e, inv_d, k, long_row_threshold());
+                       D.col, D.val, inv_e, inv_d, k, D.long_thr);
     if (D.nlong > 0)
       hipLaunchKernelGGL(scale_long_kernel, dim3(D.nchunks), dim3(TPB), 0, h->stream, (const int *)D.rowptr,
                          (const int *)D.col, D.val, (const int *)D.chunk_row, (const int *)D.chunk_off,
