@@ -47,6 +47,7 @@
 #include "layout.hpp"
 #include "trial_kernel.hpp"
 #include "small_lp_kernel.hpp"
+#include "tr_coop_kernel.hpp"
 
 namespace { struct DistGroup; }
 
@@ -105,6 +106,14 @@ struct pdhg_handle {
   uint64_t state_version = 1;                      // bumped by everything that moves x, y, the sums or A
   uint64_t ev_cversion[2] = {0, 0}, avg_version = 0;
   double *tr_g = nullptr, *tr_dir = nullptr, *tr_thr = nullptr;  // n+m each: g d, w d^2, breakpoint (tr_setup_kernel)
+  // the trust-region search as one persistent launch (tr_coop_kernel.hpp): its own barrier words, census and partials
+  int tr_coop = -1;                         // -1 not decided yet, 0 off (not wanted / does not suit / a barrier failed), 1 on
+  int tr_grid = 0;
+  GridSync *tr_sync = nullptr;
+  unsigned long long tr_epoch = 0;
+  unsigned tr_nxcd = 0, tr_xcd_cnt[8] = {};
+  double *tr_partials = nullptr;
+  long tr_coop_calls = 0;
   double *ev_partials = nullptr;
   double *ev_xg = nullptr;                         // [n_alloc] full x at the evaluated point (group only)
   // the point being evaluated and its products (set by point_products)
@@ -1841,6 +1850,8 @@ void destroy_shard(pdhg_handle *h) {
   if (h->ev_comm) (void)hipEventDestroy(h->ev_comm);
   if (h->seq_dev) (void)hipFree(h->seq_dev);
   if (h->gsync) (void)hipFree(h->gsync);
+  if (h->tr_sync) (void)hipFree(h->tr_sync);
+  if (h->tr_partials) (void)hipFree(h->tr_partials);
   if (h->coop_trace) (void)hipFree(h->coop_trace);
   if (h->res_host) (void)hipHostFree((void *)h->res_host);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
@@ -3383,6 +3394,83 @@ int pdhg_get_point(pdhg_handle *h0, int point, double *x, double *y) {
 static inline uint64_t d2bits(double v) { uint64_t b; memcpy(&b, &v, 8); return b; }
 static inline double bits2d(uint64_t b) { double v; memcpy(&v, &b, 8); return v; }
 
+// ---- the trust-region problem as ONE persistent launch (tr_coop_kernel.hpp) ----
+// Decided once per handle: a single handle (no shard group) whose n + m elements fit PDHG_TR_COOP_MAX (default 1M;
+// measured per call, 5 passes: n + m = 40K 94 -> 73 us, 229K (L1-SVM) 104 -> 80, 500K 138 -> 90, 1M 143 -> 110, 2M 167 -> 160:
+// beyond that a pass is bandwidth, not latency, and the multi-launch kernels' 1 024 workgroups stream it as fast as 256 do).
+// PDHG_TR_COOP=0 turns it off.  Returns 0 (prepared), 1 (does not apply) or an error code.
+static int tr_coop_prepare(pdhg_handle *h) {
+  if (h->tr_coop >= 0) return h->tr_coop ? 0 : 1;
+  h->tr_coop = 0;
+  const char *ev = getenv("PDHG_TR_COOP");
+  if (ev && ev[0] == '0') return 1;
+  const int64_t total = h->n + h->m;
+  const int64_t cap = getenv("PDHG_TR_COOP_MAX") ? atoll(getenv("PDHG_TR_COOP_MAX")) : 1000000;
+  if (total > cap || total < 1) return 1;
+  HIP_TRY(hipSetDevice(h->device));
+  int grid = (int)std::min<int64_t>(TRC_MAX_WGS, (total + TPB * 4 - 1) / (TPB * 4));
+  grid = std::max(8, (grid + 7) / 8 * 8);
+  if (const char *g = getenv("PDHG_TR_COOP_WGS")) grid = std::max(8, std::min(TRC_MAX_WGS, atoi(g) / 8 * 8));
+  HIP_TRY(hipMalloc((void **)&h->tr_sync, sizeof(GridSync)));
+  HIP_TRY(hipMemsetAsync(h->tr_sync, 0, sizeof(GridSync), h->stream));
+  HIP_TRY(hipMalloc((void **)&h->tr_partials, sizeof(double) * 2 * EV_MAXQ * (size_t)grid));
+  HIP_TRY(hipMemsetAsync(h->tr_partials, 0, sizeof(double) * 2 * EV_MAXQ * (size_t)grid, h->stream));
+  hipLaunchKernelGGL(xcd_register_kernel, dim3(grid), dim3(TPB), 0, h->stream, h->tr_sync);
+  HIP_TRY(hipGetLastError());
+  GridSync host;
+  HIP_TRY(hipMemcpyAsync(&host, h->tr_sync, sizeof(GridSync), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  unsigned long long seen = 0;
+  h->tr_nxcd = 0;
+  for (int x = 0; x < 8; ++x) { seen += host.xcd_count[x][0]; h->tr_nxcd += host.xcd_count[x][0] > 0; h->tr_xcd_cnt[x] = (unsigned)host.xcd_count[x][0]; }
+  if (seen != (unsigned long long)grid || h->tr_nxcd == 0) return 1;     // no census: the multi-launch form
+  // test knob: a census that expects one workgroup too many -- the first barrier cannot complete (spin limit, error word)
+  if (getenv("PDHG_TR_COOP_TEST_BAD_CENSUS")) h->tr_xcd_cnt[0] += 1;
+  h->tr_grid = grid;
+  h->tr_epoch = 0;
+  h->tr_coop = 1;
+  if (getenv("PDHG_VERBOSE"))
+    fprintf(stderr, "[pdhg_hip] trust-region search: one persistent launch of %d workgroups on %u XCDs per call\n", grid, h->tr_nxcd);
+  return 0;
+}
+
+// one call; returns 0 with out[] filled, 1 when a barrier could not complete (the caller repeats the call launch by
+// launch, and this handle stays with that form), or an error code
+static int tr_coop_call(pdhg_handle *h, double wp, double wd, double radius, int range, int approximate, double out[8]) {
+  int rc = ev_ensure_host(h);
+  if (rc) return rc;
+  TrCoopArgs a{};
+  a.n = (int)h->n; a.m = (int)h->m; a.ne = (int)h->num_eq; a.range = range; a.approximate = approximate ? 1 : 0;
+  a.px = h->pt_x; a.py = h->pt_y; a.aty = h->pt_aty; a.qx = h->pt_qx; a.ax = h->pt_ax;
+  a.c = h->c; a.b = h->b; a.lb = h->lb; a.ub = h->ub;
+  a.wp = wp; a.wd = wd; a.radius = radius;
+  a.gdv = h->tr_g; a.wd2v = h->tr_dir; a.thr = h->tr_thr;
+  a.partials = h->tr_partials;
+  a.sync = h->tr_sync;
+  a.epoch = h->tr_epoch;
+  a.nxcd = h->tr_nxcd;
+  for (int x = 0; x < 8; ++x) a.xcd_cnt[x] = h->tr_xcd_cnt[x];
+  a.host_out = h->ev_host;
+  a.seq = ++h->ev_seq;
+  double r[10];
+  {
+    // one partly resident persistent kernel at a time per device (as the trial kernels): from launch to results
+    std::lock_guard<std::mutex> lock(coop_device_mutex(h->device));
+    hipLaunchKernelGGL(tr_coop_kernel, dim3(h->tr_grid), dim3(TPB), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    if ((rc = ev_wait_host(h, 10, a.seq, r))) return rc;
+  }
+  h->tr_epoch = (unsigned long long)r[9];
+  if (r[8] != 0.0) {
+    h->tr_coop = 0;
+    if (getenv("PDHG_VERBOSE")) fprintf(stderr, "[pdhg_hip] trust-region search: a grid barrier timed out (code %g); back to one launch per pass\n", r[8]);
+    return 1;
+  }
+  for (int q = 0; q < 8; ++q) out[q] = r[q];
+  h->tr_coop_calls += 1;
+  return 0;
+}
+
 int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_norm, double dual_weight_norm,
                             double radius, int range, int approximate, double out[8]) {
   int rc = check_handle(h0);
@@ -3430,6 +3518,18 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
       if ((rc = alloc_zero(&h->tr_dir, total))) return rc;
       if ((rc = alloc_zero(&h->tr_thr, total))) return rc;
     }
+  }
+  if (!L.g && !L.p[0]->profile) {
+    // medium problems on one handle: set-up, every probe pass and the results in ONE persistent launch (tr_coop_kernel.hpp)
+    pdhg_handle *h = L.p[0];
+    rc = tr_coop_prepare(h);
+    if (rc > 1 || rc < 0) return rc;
+    if (rc == 0) {
+      rc = tr_coop_call(h, wp, wd, radius, range, approximate, out);
+      if (rc != 1) return rc;
+    }
+  }
+  FOR_SHARDS(L, h) {
     const int64_t o = h->clo;
     hipLaunchKernelGGL(tr_setup_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)h->m,
                        (int)h->num_eq, h->pt_x + o, h->pt_y, h->pt_aty + o, h->pt_qx ? h->pt_qx + o : nullptr, h->pt_ax,
@@ -4050,6 +4150,7 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   }
   if (h->grp)     // bits 24-39: trials this group took as one persistent kernel per shard (group_kernel.hpp); 40-47: its fallbacks
     info[15] += (std::min<int64_t>(h->grp->coop_trials, 65535) << 24) + ((int64_t)std::min(h->grp->coop_fallbacks, 255) << 40);
+  info[15] += std::min<int64_t>(h->tr_coop_calls, 16383) << 48;      // trust-region calls taken as one persistent launch
   if (!h->A.segs.empty()) info[12] = (int64_t)first(h->A).slabs.size();
   if (!h->At.segs.empty()) info[13] = (int64_t)first(h->At).slabs.size();
   return 0;

@@ -1,0 +1,206 @@
+// tr_coop_kernel.hpp -- part of the single translation unit pdhg_hip.hip (included there, after trial_kernel.hpp).
+// bound_optimal_objective's trust-region problem (trust_region_utils.jl:57-224, 271-360) for MEDIUM problems as ONE
+// persistent launch: the set-up pass, every probe pass of the breakpoint search and the eight results, with a grid
+// barrier where the multi-launch form (pdhg_trust_region_bound: tr_setup_kernel / tr_probe_kernel + multi_final_kernel
+// + a trip to the host PER PASS) has a launch pair and a host round trip.
+//
+// Why.  A termination / restart check makes five such calls of four to six passes each; on the L1-SVM LP a pass is
+// 9 us of probe kernel + 4.4 us of second stage + 10-11 us of host round trip = 24 us, 30 passes = 0.72 of the check's
+// 1.07 ms under the profiler (tools/r4_eval_timeline.sh), and the checks are 30 % of a whole solve.  Here a pass is the
+// probe arithmetic on elements the thread already owns + one XCD-scoped grid barrier (trial_kernel.hpp: ~3.3 us) + a
+// reduction of <= 256 block partials per quantity that every workgroup repeats for itself (so the search state -- the
+// tr_search_* machine of eval_kernels.hpp, thread 0 of every workgroup -- needs no broadcast: same sums, same
+// decisions, everywhere).
+//
+// Arithmetic: tr_setup_kernel's and tr_probe_range's statements element by element; the sums are grouped by THIS
+// kernel's grid (<= 256 workgroups, a multiple of 8), so results agree with the multi-launch form to rounding, not to
+// the bit -- as the one-workgroup kernel of small problems (tr_small_kernel) already does.  Deterministic: fixed grid,
+// fixed order.
+//
+// The block partials alternate between two buffers: a workgroup can run at most one barrier ahead of the slowest, so
+// pass k + 1's partials never overwrite what somebody still reads from pass k.  Partials are read with agent-scope
+// loads (past the CU's L1, which may hold the lines of two passes ago); across XCDs the barrier's write-back /
+// invalidate makes them visible.
+#pragma once
+
+namespace {
+
+constexpr int TRC_MAX_WGS = 256;                   // <= 4 partials per lane and quantity in the repeated second stage
+constexpr int TRC_Q = TR_Q * TR_K;                 // 30 sums per probe pass
+static_assert(TRC_Q <= EV_MAXQ && TR_SETUP_NS + 1 <= EV_MAXQ, "partials are EV_MAXQ quantities wide");
+
+struct TrCoopArgs {
+  int n, m, ne, range, approximate;
+  const double *px, *py, *aty, *qx, *ax, *c, *b, *lb, *ub;
+  double wp, wd, radius;
+  double *gdv, *wd2v, *thr;                        // n + m each (the handle's tr_g / tr_dir / tr_thr)
+  double *partials;                                // 2 x EV_MAXQ x gridDim.x
+  GridSync *sync;
+  unsigned long long epoch;                        // barriers this GridSync has passed so far
+  unsigned nxcd;
+  unsigned xcd_cnt[8];
+  double *host_out;                                // pinned: out[0..7], error word, epoch after the launch
+  unsigned long long seq;
+};
+
+// every workgroup: quantity q (NS sums, then NM maxes) over the `count` block partials of one pass, into res[q] (LDS).
+// Wave w takes q = w, w + 4, ...; all its loads are issued before the first tree.
+template <int NS, int NM>
+__device__ __forceinline__ void trc_reduce(const double *partials, int stride, int count, double *res) {
+  constexpr int K = NS + NM, WAVES = TPB / WAVE, PER_WAVE = (K + WAVES - 1) / WAVES, PER_LANE = TRC_MAX_WGS / WAVE;
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  double t[PER_WAVE][PER_LANE];
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int q = wave + i * WAVES;
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j) {
+      const int b = lane + j * WAVE;
+      t[i][j] = (q < K && b < count) ? __hip_atomic_load(partials + (size_t)q * stride + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int q = wave + i * WAVES;
+    const bool is_max = q >= NS;
+    double v = 0.0;                                 // partials of maxes are >= 0
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j) v = is_max ? fmax(v, t[i][j]) : v + t[i][j];
+    v = is_max ? wave_max_nonneg_dpp(v) : wave_sum_dpp(v);
+    if (q < K && lane == WAVE - 1) res[q] = v;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(TPB) void tr_coop_kernel(TrCoopArgs a) {
+  __shared__ double res[EV_MAXQ];
+  __shared__ TrProbes s_pr;
+  __shared__ int s_go;
+  __shared__ double s_out[8];
+  __shared__ TrSearch S;
+  const int n = a.n, total = a.n + a.m;
+  const int gtid = blockIdx.x * TPB + threadIdx.x, gstride = gridDim.x * TPB, stride = gridDim.x;
+  unsigned long long epoch = a.epoch;
+  int buf = 0;
+  {
+    // the set-up pass: tr_setup_kernel's statements (see there for the meaning of the sums)
+    RedAcc<TR_SETUP_NS, 1> acc;
+    for (int k = gtid; k < total; k += gstride) {
+      const bool primal = k < n;
+      const int i = primal ? k : k - n;
+      double z, g, lo, hi, w;
+      if (primal) {
+        z = a.px[i]; lo = a.lb[i]; hi = a.ub[i]; w = a.wp;
+        if (a.qx) { g = (a.qx[i] + a.c[i]) - a.aty[i]; acc.s[10] += z * a.qx[i]; }
+        else g = a.c[i] - a.aty[i];
+        acc.s[0] += a.c[i] * z; acc.s[1] += z * a.aty[i]; acc.s[8] += z * z;
+      } else {
+        z = a.py[i]; g = -(a.b[i] - a.ax[i]); lo = (i < a.ne) ? -INFINITY : 0.0; hi = INFINITY; w = a.wd;
+        acc.s[2] += z * a.b[i]; acc.s[9] += z * z;
+      }
+      const bool in_range = (a.range == 0) || (a.range == 1 && primal) || (a.range == 2 && !primal);
+      double d = 0.0, t = 0.0;
+      if (in_range && !((z >= hi && g <= 0.0) || (z <= lo && g >= 0.0))) {
+        d = -g / w;
+        if (d > 0.0) t = (hi - z) / d;
+        else if (d < 0.0) t = (lo - z) / d;
+        else t = 0.0;
+      }
+      const double wd2 = w * d * d, gd = g * d;
+      a.gdv[k] = gd; a.wd2v[k] = wd2; a.thr[k] = t;           // read back by this very thread in the probe passes
+      if (in_range) {
+        acc.s[4] += g * g;
+        acc.s[5] += wd2;
+        if (primal) acc.s[6] += gd; else acc.s[7] += gd;
+        if (isinf(t)) {
+          acc.s[3] += wd2;
+          if (primal) acc.s[14] += gd; else acc.s[15] += gd;
+        } else {
+          acc.m[0] = fmax(acc.m[0], t);
+          if (wd2 != 0.0) {
+            acc.s[11] += wd2 * t * t;
+            if (primal) acc.s[12] += gd * t; else acc.s[13] += gd * t;
+          }
+        }
+      }
+    }
+    block_reduce_store<TR_SETUP_NS, 1>(acc, a.partials, stride);
+    grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
+    trc_reduce<TR_SETUP_NS, 1>(a.partials, stride, (int)gridDim.x, res);
+    buf ^= 1;
+  }
+  if (threadIdx.x == 0) {
+    // the host function's statements (pdhg_trust_region_bound) on the set-up sums, in every workgroup
+    const double *r = res;
+    s_out[0] = 0.5 * r[10] + r[0] - r[1] + r[2];
+    s_out[1] = s_out[2] = 0.0;
+    s_out[3] = r[8]; s_out[4] = r[9];
+    s_out[5] = 0.0; s_out[6] = 0.0; s_out[7] = 0.0;
+    const double hinf = r[3], g2 = r[4], wd2_all = r[5], tmax = r[TR_SETUP_NS];
+    const double r2 = a.radius * a.radius;
+    s_go = 0;
+    if (a.approximate) {
+      const double dn = sqrt(wd2_all);
+      const double sc = dn > 0.0 ? a.radius / dn : 1.0;
+      s_out[1] = sc * r[6]; s_out[2] = sc * r[7];
+    } else if (!(a.radius == 0.0 || g2 == 0.0)) {
+      tr_search_begin(S, r2, tmax, hinf, TrEnd{r[11], hinf, {r[12], r[14], r[13], r[15]}});
+      s_go = tr_search_next(S, s_pr) ? 1 : 2;
+    }
+  }
+  __syncthreads();
+  while (s_go == 1) {
+    RedAcc<TRC_Q, 0> acc;
+    const TrProbes pr = s_pr;
+    for (int k = gtid; k < total; k += gstride) {
+      const double wd2 = a.wd2v[k];
+      if (wd2 == 0.0) continue;                                // d == 0: blocked by its bound, or outside the range
+      const double t = a.thr[k], gd = a.gdv[k];
+      const double lowc = wd2 * t * t, vlow = gd * t;
+      const bool primal = k < n;
+#pragma unroll
+      for (int q = 0; q < TR_K; ++q) {
+        if (t <= pr.t[q]) {
+          acc.s[TR_Q * q] += lowc;
+          if (primal) acc.s[TR_Q * q + 2] += vlow; else acc.s[TR_Q * q + 4] += vlow;
+        } else {
+          acc.s[TR_Q * q + 1] += wd2;
+          if (primal) acc.s[TR_Q * q + 3] += gd; else acc.s[TR_Q * q + 5] += gd;
+        }
+      }
+    }
+    double *part = a.partials + (size_t)buf * EV_MAXQ * stride;
+    block_reduce_store<TRC_Q, 0>(acc, part, stride);
+    grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
+    trc_reduce<TRC_Q, 0>(part, stride, (int)gridDim.x, res);
+    buf ^= 1;
+    if (threadIdx.x == 0) {
+      tr_search_feed(S, s_pr, res);
+      s_go = tr_search_next(S, s_pr) ? 1 : 2;
+      // a barrier that timed out leaves the error word set and every later barrier falls through: stop searching on
+      // sums that may be incomplete (the host sees the error word and repeats the call launch by launch)
+      if (__hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_go = 3;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (s_go == 2) {
+      s_out[1] = S.at.v[0] + S.tstar * S.at.v[1];
+      s_out[2] = S.at.v[2] + S.tstar * S.at.v[3];
+      s_out[5] = S.tstar; s_out[6] = (double)S.passes;
+    }
+    double w[10];
+    for (int q = 0; q < 8; ++q) w[q] = s_out[q];
+    w[8] = (double)__hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w[9] = (double)epoch;
+    unsigned long long ck = EV_CHECK_SALT ^ a.seq ^ (10ull << 56);
+    for (int q = 0; q < 10; ++q) {
+      a.host_out[q] = w[q];
+      ck ^= (unsigned long long)__double_as_longlong(w[q]) * (2ull * (unsigned long long)q + 1ull);
+    }
+    a.host_out[EV_HOST_CK] = __longlong_as_double((long long)ck);
+    a.host_out[EV_HOST_SEQ] = __longlong_as_double((long long)a.seq);
+  }
+}
+
+}  // namespace

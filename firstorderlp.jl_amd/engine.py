@@ -418,6 +418,8 @@ class HipPdhgEngine:
         # shard groups: trials taken as one persistent kernel per shard (group_kernel.hpp), and its fall-backs
         out["group_coop_trials"] = (out["var_tiles"] >> 24) & 65535
         out["group_coop_fallbacks"] = (out["var_tiles"] >> 40) & 255
+        # trust-region calls taken as one persistent launch (tr_coop_kernel.hpp)
+        out["tr_coop_calls"] = (out["var_tiles"] >> 48) & 16383
         out["var_tiles"] &= 3
         for k in ("A", "At"):    # width in bits of an entry's column field
             out[k + "_tile_shift"] = max(1, (out[k + "_tile_cols"] - 1).bit_length()) if out[k + "_tile_cols"] else 0

@@ -13,10 +13,12 @@ from tests import trust_region_cases as C
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("small_eval", ["1", "0"], ids=["one_workgroup_kernel", "pass_by_pass"])
+@pytest.mark.parametrize("small_eval,coop", [("1", "1"), ("0", "1"), ("0", "0")],
+                         ids=["one_workgroup_kernel", "one_persistent_launch", "pass_by_pass"])
 @pytest.mark.parametrize("case", C.CASES, ids=lambda c: c[0])
-def test_bound_optimal_objective_device(gpu_required, monkeypatch, case, small_eval):
+def test_bound_optimal_objective_device(gpu_required, monkeypatch, case, small_eval, coop):
     monkeypatch.setenv("PDHG_SMALL_EVAL", small_eval)
+    monkeypatch.setenv("PDHG_TR_COOP", coop)
     name, maker, x, y, radius, norm, expected = case
     p = maker()
     eng = HipPdhgEngine.from_problem(p)
@@ -25,6 +27,7 @@ def test_bound_optimal_objective_device(gpu_required, monkeypatch, case, small_e
     eng.set_current(np.array(x), np.array(y))
     r = ev.bound(POINT_CURRENT, 1.0, 1.0, radius, norm, False)
     C.check(r, expected, 1e-12)
+    assert (eng.layout_info()["tr_coop_calls"] > 0) == (small_eval == "0" and coop == "1")
 
 
 @pytest.mark.parametrize("case", __import__("tests.stats_cases", fromlist=["CASES"]).CASES, ids=lambda c: c[0])
@@ -44,3 +47,61 @@ def test_convergence_information_device(gpu_required, case):
     st = ev.iteration_stats(POINT_CURRENT, tc, True, 6, 5.0, 1.5, 1.0, 1.0, PointType.POINT_TYPE_CURRENT_ITERATE)
     S.check_ci(st.convergence_information[0], want_ci, 1e-14)
     assert st.iteration_number == 5
+
+
+# ---- round 4: the search as ONE persistent launch (csrc/tr_coop_kernel.hpp) against the pass-by-pass form ------------
+def _bounds(p, monkeypatch, coop, steps=30, env=()):
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import AdaptiveStepsizeParams, PdhgSolverState, take_steps
+    from tests import helpers as H
+    monkeypatch.setenv("PDHG_TR_COOP", coop)
+    for k, v in env:
+        monkeypatch.setenv(k, v)
+    eng = HipPdhgEngine.from_problem(p)
+    step, pw = H.initial_step_and_weight(p)
+    st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    take_steps(AdaptiveStepsizeParams(0.3, 0.6), st, steps)
+    eng.save_restart_point()
+    take_steps(AdaptiveStepsizeParams(0.3, 0.6), st, steps)
+    out = []
+    for point in (0, 1):                    # current iterate, average
+        for rng in (0, 1, 2):
+            for radius in (0.0, 0.3, 5.0, 1e6):
+                for approx in (0, 1):
+                    out.append(np.array(eng.trust_region_bound(point, 1.7, 0.6, radius, rng, approx)))
+    info = eng.layout_info()
+    eng.close()
+    for k, _ in env:
+        monkeypatch.delenv(k)
+    return np.array(out), info
+
+
+@pytest.mark.parametrize("name", ["random", "pagerank", "qp"])
+def test_one_launch_search_matches_pass_by_pass(gpu_required, monkeypatch, name):
+    from firstorderlp_jl_amd.generators import pagerank_lp, random_lp
+    from tests import helpers as H
+    if name == "random":
+        p = random_lp(40000, 30000, 6, seed=5)
+    elif name == "pagerank":
+        p = pagerank_lp(50000, seed=3)
+    else:
+        import scipy.sparse as sp
+        from dataclasses import replace
+        p = random_lp(9000, 12000, 5, seed=8)
+        q = sp.random(12000, 12000, density=2e-4, random_state=1, format="csc")
+        p = replace(p, objective_matrix=(q @ q.T + sp.identity(12000) * 0.1).tocsc())
+    want, i0 = _bounds(p, monkeypatch, "0")
+    got, i1 = _bounds(p, monkeypatch, "1")
+    assert i0["tr_coop_calls"] == 0 and i1["tr_coop_calls"] == len(got)
+    # [0] Lagrangian value, [1] / [2] primal / dual value change, [3] / [4] norms, [5] t*: sums grouped by another grid
+    scale = np.maximum(np.abs(want).max(axis=0), 1e-300)
+    np.testing.assert_allclose(got[:, :6] / scale[:6], want[:, :6] / scale[:6], rtol=0, atol=2e-12)
+    assert np.array_equal(got[:, 6], want[:, 6])        # probe passes: the same search
+
+
+def test_one_launch_search_falls_back_when_a_barrier_cannot_complete(gpu_required, monkeypatch):
+    from firstorderlp_jl_amd.generators import random_lp
+    p = random_lp(20000, 15000, 6, seed=6)
+    want, _ = _bounds(p, monkeypatch, "0", steps=10)
+    got, info = _bounds(p, monkeypatch, "1", steps=10, env=(("PDHG_TR_COOP_TEST_BAD_CENSUS", "1"),))
+    assert info["tr_coop_calls"] == 0                    # the first call timed out (~0.1 s) and the handle left that form
+    assert np.array_equal(got, want)                     # ... for the pass-by-pass form: the same bits
