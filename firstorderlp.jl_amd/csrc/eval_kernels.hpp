@@ -62,13 +62,14 @@ constexpr int EV_HOST_CK = EV_HOST_SLOTS, EV_HOST_SEQ = EV_HOST_SLOTS + 1;
 constexpr unsigned long long EV_CHECK_SALT = 0xD1B54A32D192ED03ull;
 __global__ __launch_bounds__(FINAL_TPB) void multi_final_kernel(const double *__restrict__ partials, int stride,
                                                                 int count, int ns, int nm, double *__restrict__ out,
-                                                                double *host_out, unsigned long long seq) {
+                                                                double *host_out, unsigned long long seq,
+                                                                unsigned max_mask) {
   __shared__ double res[EV_HOST_SLOTS];
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
   const int k = ns + nm;
   for (int q = wave; q < k; q += FINAL_TPB / WAVE) {
     const double *p = partials + (size_t)q * stride;
-    const bool is_max = q >= ns;
+    const bool is_max = max_mask ? ((max_mask >> q) & 1u) != 0 : q >= ns;   // max_mask: several kernels' partials side by side (pdhg_eval_point)
     double v = 0.0;
     for (int base = lane; base < count; base += 8 * WAVE) {
       double t[8];

@@ -3192,7 +3192,7 @@ static int ev_wait_host(pdhg_handle *h, int k, unsigned long long seq, double *o
   return fail(998, "evaluation reduction finished without publishing its results");
 }
 
-static int ev_finish(const Shards &L, int ns, int nm, double *out) {
+static int ev_finish(const Shards &L, int ns, int nm, double *out, unsigned max_mask = 0) {
   if (ns + nm > EV_MAXQ) return fail(-1, "too many scalars in one reduction");
   static const bool host_word = !(getenv("PDHG_EVAL_HOST_WORD") && getenv("PDHG_EVAL_HOST_WORD")[0] == '0');
   if (!L.g && host_word) {
@@ -3205,13 +3205,13 @@ static int ev_finish(const Shards &L, int ns, int nm, double *out) {
     if (rc0) return rc0;
     const unsigned long long seq = ++h->ev_seq;
     hipLaunchKernelGGL(multi_final_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->ev_partials, h->ev_grid,
-                       h->ev_grid, ns, nm, h->scal_dev, h->ev_host, seq);
+                       h->ev_grid, ns, nm, h->scal_dev, h->ev_host, seq, max_mask);
     HIP_TRY(hipGetLastError());
     return ev_wait_host(h, k, seq, out);
   }
   FOR_SHARDS(L, h) {
     hipLaunchKernelGGL(multi_final_kernel, dim3(1), dim3(FINAL_TPB), 0, h->stream, h->ev_partials, h->ev_grid,
-                       h->ev_grid, ns, nm, h->scal_dev, (double *)nullptr, 0ull);
+                       h->ev_grid, ns, nm, h->scal_dev, (double *)nullptr, 0ull, 0u);
     HIP_TRY(hipGetLastError());
   }
   return combine_scalars(L, ns + nm, ns, out);
@@ -3324,6 +3324,25 @@ int pdhg_eval_point(pdhg_handle *h0, int point, double out[24]) {
   const Shards L = shards_of(h0);
   if ((rc = flush_pending(L))) return rc;
   if ((rc = point_products(L, point))) return rc;
+  const char *hw = getenv("PDHG_EVAL_HOST_WORD");          // (read per call: tests compare the two forms in one process)
+  if (!L.g && !(hw && hw[0] == '0')) {
+    // one handle: the row and the column kernels leave their block partials side by side (8 + 14 quantities), ONE second
+    // stage reduces all 22 and the host makes one round trip instead of two.  Same partials, same order per quantity:
+    // the same bits as the two-round form below.
+    pdhg_handle *h = L.p[0];
+    hipLaunchKernelGGL(eval_rows_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->m, (int)h->num_eq,
+                       h->pt_ax, h->pt_y, h->E, h->b_o, h->ev_partials, h->ev_grid);
+    hipLaunchKernelGGL(eval_cols_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, h->pt_aty,
+                       h->pt_qx, h->pt_x, h->Dv, h->c_o, h->lb_o, h->ub_o, h->ev_partials + (size_t)8 * h->ev_grid, h->ev_grid);
+    HIP_TRY(hipGetLastError());
+    double r[22];
+    // quantities 0-3 sums, 4-7 maxes (rows); 8-14 sums, 15-21 maxes (columns)
+    if ((rc = ev_finish(L, 22, 0, r, 0xF0u | (0x7Fu << 15)))) return rc;
+    for (int q = 0; q < 8; ++q) out[q] = r[q];
+    for (int q = 0; q < 6; ++q) { out[8 + q] = r[8 + q]; out[14 + q] = r[8 + 7 + q]; }
+    out[20] = r[8 + 6]; out[21] = r[8 + 13]; out[22] = out[23] = 0.0;
+    return 0;
+  }
   FOR_SHARDS(L, h) {
     hipLaunchKernelGGL(eval_rows_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->m, (int)h->num_eq,
                        h->pt_ax, h->pt_y, h->E, h->b_o, h->ev_partials, h->ev_grid);

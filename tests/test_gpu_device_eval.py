@@ -200,3 +200,18 @@ def test_trust_region_search_branches_match_host(gpu_required, monkeypatch, smal
         eng.close()
     # both kinds of exit were taken: with and without probe passes
     assert any(zero_passes for _, zero_passes, _ in seen) and any(not zero_passes for _, zero_passes, _ in seen)
+
+
+def test_eval_point_one_round_trip_is_bitwise_the_two_round_form(gpu_required, monkeypatch):
+    """pdhg_eval_point on one handle reduces the row and the column statistics in ONE second stage (22 quantities side by
+    side, one trip to the host); PDHG_EVAL_HOST_WORD=0 keeps the two rounds.  Same block partials, same order per
+    quantity: not a bit may differ."""
+    for p in (random_lp(30000, 20000, 6, seed=2), pagerank_lp(40000, seed=1)):
+        eng, _, ev_d, _ = _setup(p)
+        for point in (POINT_CURRENT, POINT_AVERAGE):
+            one = np.array(eng.eval_point(point))
+            monkeypatch.setenv("PDHG_EVAL_HOST_WORD", "0")
+            two = np.array(eng.eval_point(point))
+            monkeypatch.delenv("PDHG_EVAL_HOST_WORD")
+            assert np.array_equal(one, two)
+        eng.close()
