@@ -165,6 +165,11 @@ struct pdhg_handle {
   unsigned coop_nxcd = 0;               // XCDs that hold workgroups of such a launch
   unsigned coop_xcd_cnt[8] = {0};       // ... and how many each
   unsigned long long coop_launches = 0, coop_epoch = 0;   // launches / grid barriers of the one-launch kernel so far
+  // the multi-step kernel's XCD-local mode (small grids: every working workgroup on one XCD, trial_kernel.hpp)
+  int local_mode = -1;                  // -1 not decided, 0 off, 1 on
+  GridSync *lsync = nullptr;
+  unsigned long long local_epoch = 0;
+  long local_launches = 0;
   GridSync *gsync = nullptr;
   unsigned long long *coop_trace = nullptr;   // PDHG_COOP_TRACE=1: phase stamps of the last launch
   int graph_mode = -1;                  // -1 undecided, 0 off, 1 on
@@ -802,6 +807,32 @@ static int steps_wait(pdhg_handle *h, unsigned long long seq, double r[13], doub
 // Up to n_steps adaptive take_steps in ONE launch (steps_kernel, trial_kernel.hpp).  On return *steps_done take_steps
 // have been taken (fewer when the launch ran out of its trial budget, met numerical_error, or a barrier timed out: the
 // caller goes on from the state left).  Returns 1 when nothing could be launched (not eligible).
+// The multi-step kernel's XCD-local mode: LPs whose products are at most PDHG_COOP_LOCAL_MAX (default 32: one per compute
+// unit of an XCD) items.  8 x coop_grid workgroups are launched, the dispatcher deals them round the XCDs, those on XCD 0
+// work -- the census must find exactly coop_grid of them there.  Own barrier words and epoch (the single-trial kernel
+// keeps the handle's all-XCD census).  PDHG_COOP_LOCAL=0 turns it off.  Returns 0 when the mode is on.
+static int steps_local_prepare(pdhg_handle *h) {
+  if (h->local_mode >= 0) return h->local_mode ? 0 : 1;
+  h->local_mode = 0;
+  const char *ev = getenv("PDHG_COOP_LOCAL");
+  if (ev && ev[0] == '0') return 1;
+  const int cap = getenv("PDHG_COOP_LOCAL_MAX") ? atoi(getenv("PDHG_COOP_LOCAL_MAX")) : 32;
+  if (h->coop_grid <= 0 || h->coop_grid > cap || getenv("PDHG_COOP_TEST_PRETEND_WGS")) return 1;
+  HIP_TRY(hipMalloc((void **)&h->lsync, sizeof(GridSync)));
+  HIP_TRY(hipMemsetAsync(h->lsync, 0, sizeof(GridSync), h->stream));
+  hipLaunchKernelGGL(xcd_register_kernel, dim3(8 * h->coop_grid), dim3(TPB), 0, h->stream, h->lsync);
+  HIP_TRY(hipGetLastError());
+  GridSync host;
+  HIP_TRY(hipMemcpyAsync(&host, h->lsync, sizeof(GridSync), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (host.xcd_count[0][0] != (unsigned long long)h->coop_grid) return 1;      // the dispatcher dealt them otherwise: all-XCD mode
+  h->local_epoch = 0;
+  h->local_mode = 1;
+  if (getenv("PDHG_VERBOSE"))
+    fprintf(stderr, "[pdhg_hip] multi-step kernel: XCD-local mode, %d workgroups on XCD 0 (of %d launched)\n", h->coop_grid, 8 * h->coop_grid);
+  return 0;
+}
+
 int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, double growth_exponent, double *step_size_io,
                double primal_weight, int64_t *total_number_iterations_io, double *cumulative_kkt_passes_io,
                int *numerical_error_out, int64_t *steps_done, double *unfinished_entry) {
@@ -847,14 +878,19 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   a.pend = h->pend_x ? 1 : 0; a.pend_w = h->pend_w;
   a.wsum_x = h->sum_x_weights; a.wsum_y = h->sum_y_weights;
   a.pow_red = h->steps_pow_dev; a.pow_growth = h->steps_pow_dev + table_len;
-  a.epoch = h->coop_epoch;
-  a.sync = h->gsync; a.ctl = h->steps_ctl; a.res_host = h->steps_res;
+  const bool local = steps_local_prepare(h) == 0;
+  a.epoch = local ? h->local_epoch : h->coop_epoch;
+  a.sync = local ? h->lsync : h->gsync; a.ctl = h->steps_ctl; a.res_host = h->steps_res;
+  a.local_g = local ? h->coop_grid : 0; a.local_home = 0;
+  // test knob: the kernel expects eight workgroups more than are launched on the home XCD -- its first barrier times out
+  if (local && getenv("PDHG_COOP_LOCAL_TEST_BAD")) a.local_g += 8;
   a.seq = ++h->steps_seq;
   a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
   a.trace = h->coop_trace;
   for (int x = 0; x < 8; ++x) a.xcd_cnt[x] = h->coop_xcd_cnt[x];
   const auto c1 = std::chrono::steady_clock::now();
-  hipLaunchKernelGGL(steps_kernel, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
+  if (local) hipLaunchKernelGGL(steps_kernel<true>, dim3(8 * h->coop_grid), dim3(TPB), 0, h->stream, a);
+  else hipLaunchKernelGGL(steps_kernel<false>, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
   const auto c2 = std::chrono::steady_clock::now();
   h->t_launch += std::chrono::duration<double>(c2 - c1).count();
@@ -864,7 +900,8 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   const int64_t steps = (int64_t)r[1], trials = (int64_t)r[2];
   const bool flip = r[3] != 0.0, aborted = r[9] != 0.0 || r[11] != 0.0;
   h->steps_launches += 1; h->steps_trials += trials; h->n_graph_trials += trials;
-  h->coop_epoch = (unsigned long long)r[10];
+  if (local) { h->local_epoch = (unsigned long long)r[10]; h->local_launches += 1; }
+  else h->coop_epoch = (unsigned long long)r[10];
   h->A.coop_uses += (unsigned long long)trials + (aborted ? 1ull : 0ull);
   h->At.coop_uses += (unsigned long long)trials + (aborted ? 1ull : 0ull);
   if (flip) { std::swap(h->x, h->x_next); std::swap(h->y, h->y_next); std::swap(h->aty, h->aty_next); }
@@ -881,7 +918,11 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   //  and the word is written by the same thread as the other result words)
   *unfinished_entry = r14;
   if (r[8] != 0.0) { *numerical_error_out = 1; *steps_done = steps + 1; }   // the failing take_step counts as taken (it is not repeated)
-  if (aborted) {
+  if (aborted && local) {
+    // the XCD-local form failed (a workgroup of the launch was not where the census saw it): the all-XCD form from here on
+    h->local_mode = 0;
+    fprintf(stderr, "[pdhg_hip] multi-step trial kernel, XCD-local mode: a barrier timed out (code %g) -- all-XCD mode from here on\n", r[11]);
+  } else if (aborted) {
     h->coop_mode = 0;
     h->coop_fallbacks += 1;
     fprintf(stderr, "[pdhg_hip] multi-step trial kernel: a grid barrier timed out (code %g; is the device shared with another "
@@ -1851,6 +1892,7 @@ void destroy_shard(pdhg_handle *h) {
   if (h->seq_dev) (void)hipFree(h->seq_dev);
   if (h->gsync) (void)hipFree(h->gsync);
   if (h->tr_sync) (void)hipFree(h->tr_sync);
+  if (h->lsync) (void)hipFree(h->lsync);
   if (h->tr_partials) (void)hipFree(h->tr_partials);
   if (h->coop_trace) (void)hipFree(h->coop_trace);
   if (h->res_host) (void)hipHostFree((void *)h->res_host);
@@ -4151,7 +4193,8 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   info[15] = ((h->A.tiled && h->A.var_tiles) || (!h->A.segs.empty() && h->A.segs.front().tiled && h->A.segs.front().var_tiles) ? 1 : 0) +
              ((h->At.tiled && h->At.var_tiles) || (!h->At.segs.empty() && h->At.segs.front().tiled && h->At.segs.front().var_tiles) ? 2 : 0) +
              (small_lp_eligible(h) ? 4 : 0) +
-             (!h->grp && !h->has_q && !small_lp_eligible(h) && device_loop_for(h) && coop_eligible(h) ? 8 : 0);
+             (!h->grp && !h->has_q && !small_lp_eligible(h) && device_loop_for(h) && coop_eligible(h) ? 8 : 0) +
+             (h->local_mode == 1 && h->local_launches > 0 ? 16 : 0);      // the multi-step kernel runs in its XCD-local mode
   // a matrix held as row segments (64-bit extents, layout.hpp) reports the sums over its segments, the first segment's
   // tile width, and the segment counts in bits 8-15 (A) and 16-23 (A') of info[15]
   auto total = [](const CsrDev &D, auto f) { int64_t t = 0; if (D.segs.empty()) return (int64_t)f(D); for (const CsrDev &S : D.segs) t += f(S); return t; };

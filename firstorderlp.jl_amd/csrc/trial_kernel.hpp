@@ -109,6 +109,30 @@ __device__ __forceinline__ void grid_barrier(GridSync *s, unsigned long long epo
   __syncthreads();
 }
 
+// The barrier of a launch whose workgroups all sit on ONE XCD (steps_kernel's XCD-local mode): they share one L2, so
+// there is nothing to write back or invalidate and no second level -- an arrival counter and a release word in that L2.
+// (Loads of data another compute unit rewrote still have to pass the reader's L1: the agent-scope loads the multi-step
+// kernel uses anyway.)  cnt: workgroups of the launch; x: their XCD.
+__device__ __forceinline__ void grid_barrier_local(GridSync *s, unsigned long long epoch, unsigned x, unsigned long long cnt,
+                                                   unsigned long long err_known) {
+  __syncthreads();
+  if (threadIdx.x == 0 && err_known == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long prev = __hip_atomic_fetch_add(&s->xcd_arrive[x][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1 == cnt * epoch) {
+      __hip_atomic_store(&s->xcd_release[x][0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      long spins = 0;
+      while (__hip_atomic_load(&s->xcd_release[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > GRID_SPIN_LIMIT) { __hip_atomic_store(&s->error[0], 3ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    asm volatile("s_dcache_inv" ::: "memory");
+  }
+  __syncthreads();
+}
+
 // store that is visible device-wide once `s_waitcnt vmcnt(0)` has returned (write-through,
 // no L2 write-back needed): the few words a workgroup hands to a "last one finishes" ticket
 __device__ __forceinline__ void store_agent(double *p, double v) {
@@ -409,6 +433,8 @@ struct StepsKernelArgs {
   unsigned xcd_cnt[8];
   int relaxed;
   unsigned long long *trace;                      // PDHG_COOP_TRACE: stamps of the launch's last trial, as for trial_kernel ([7]: leaders, global phase done)
+  int local_g;                                    // > 0: XCD-local mode -- the launch is 8 x local_g workgroups, those on XCD local_home work
+  unsigned local_home;
 };
 
 // result words: [0] step size, [1] steps taken, [2] trials, [3] flip, [4] pending average update, [5] its weight,
@@ -420,6 +446,9 @@ constexpr int STEPS_RES_WORDS = 16;
 #ifndef PDHG_STEPS_PREFETCH
 #define PDHG_STEPS_PREFETCH 1
 #endif
+// LOCAL: the XCD-local mode as its own instantiation (the all-XCD kernel sits at its register limit: as a run-time flag
+// the mode cost it 92 more bytes of scratch per lane)
+template <bool LOCAL>
 __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(StepsKernelArgs a) {
   __shared__ double prod[BLOCK_NNZ];
   __shared__ double red[6][TPB / WAVE];
@@ -431,7 +460,20 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
   __shared__ double s_st[5];
   __shared__ double s_pow[2];
   __shared__ double s_res8[8];
-  const int w = blockIdx.x, nwg = gridDim.x;
+  int w = blockIdx.x, nwg = gridDim.x;
+  constexpr bool local = LOCAL;
+  if (local) {
+    // XCD-local mode (small grids): one XCD's workgroups do all the work -- one L2, barriers without write-back /
+    // invalidate (grid_barrier_local).  Eight times the workgroups are launched (the dispatcher deals them round the
+    // XCDs); the others leave at once.  The stayers number themselves as they arrive: any bijection serves (row blocks
+    // and partial slots are indexed by item, not by who worked on it).
+    if (xcc_id() != a.local_home) return;
+    __shared__ int s_w;
+    if (threadIdx.x == 0)
+      s_w = (int)(__hip_atomic_fetch_add(&a.sync->ticket[0][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % (unsigned long long)a.local_g);
+    __syncthreads();
+    w = s_w; nwg = a.local_g;
+  }
   int flip = 0, pend = a.pend, steps = 0, trials = 0, num_err = 0, hw_err = 0, mid = 0;
   if (threadIdx.x == 0) { s_st[0] = a.step_size; s_st[1] = a.step_size; s_st[2] = a.pend_w; s_st[3] = a.wsum_x; s_st[4] = a.wsum_y; }
   unsigned long long epoch = a.epoch;
@@ -463,12 +505,13 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
     // ---- phase 0: x' and xbar (+ the deferred sum_x update of the previous accept)
     primal_body<false, true, true>(a.n, x, a.c, aty, nullptr, a.lb, a.ub, tau, 1.0, xn, a.xbar, pend_w,
                                    pend ? a.sum_x : nullptr, w, nwg);
-    product_prefetch(a.A, f);
+    product_prefetch(a.A, f, w, nwg);
 #if PDHG_STEPS_PREFETCH
     if (threadIdx.x == 0) { s_pow[0] = pw_r; s_pow[1] = pw_g; }
 #endif
     PDHG_STAMP(1);
-    grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt, err_pref);
+    if (local) grid_barrier_local(a.sync, ++epoch, a.local_home, (unsigned long long)a.local_g, err_pref);
+    else grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt, err_pref);
     PDHG_STAMP(2);
     // ---- phase 1: y' and sum dy^2 (+ the deferred sum_y update)
 #if PDHG_STEPS_PREFETCH
@@ -479,12 +522,13 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
       e.y = y; e.b = a.b; e.y_next = yn; e.sigma = sigma; e.num_eq = a.num_eq;
       e.partials = a.pA; e.stride = a.pA_slots; e.lo_offset = a.pA_slots;
       if (pend) { e.sum_y = a.sum_y; e.avg_w = pend_w; }
-      product_phase<MODE_DUAL, true>(a.A, a.xbar, e, a.uses_a + (unsigned long long)trials, a.relaxed, f, prod, red);
+      product_phase<MODE_DUAL, true>(a.A, a.xbar, e, a.uses_a + (unsigned long long)trials, a.relaxed, f, prod, red, w, nwg);
     }
     pend = 0;
-    product_prefetch(a.T, f);
+    product_prefetch(a.T, f, w, nwg);
     PDHG_STAMP(3);
-    grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt, err_pref);
+    if (local) grid_barrier_local(a.sync, ++epoch, a.local_home, (unsigned long long)a.local_g, err_pref);
+    else grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt, err_pref);
     PDHG_STAMP(4);
     // ---- phase 2: A'y' and the interaction sums
 #if PDHG_STEPS_PREFETCH
@@ -494,7 +538,7 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
       EpiArgs e{};
       e.x = x; e.x_next = xn; e.aty = aty; e.aty_next = atyn;
       e.partials = a.pAt; e.stride = a.pAt_stride; e.lo_offset = 3 * a.pAt_stride;
-      product_phase<MODE_ATY, true>(a.T, yn, e, a.uses_t + (unsigned long long)trials, a.relaxed, f, prod, red);
+      product_phase<MODE_ATY, true>(a.T, yn, e, a.uses_t + (unsigned long long)trials, a.relaxed, f, prod, red, w, nwg);
     }
     PDHG_STAMP(5);
     // ---- third barrier; its XCD leaders reduce and decide, and the decision IS the release: three words in the
@@ -512,13 +556,17 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
         const unsigned xcd = xcc_id();
         unsigned long long *slot = reinterpret_cast<unsigned long long *>(a.ctl->slot[xcd]);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        const unsigned long long cnt = a.xcd_cnt[xcd];
+        const unsigned long long cnt = local ? (unsigned long long)a.local_g : (unsigned long long)a.xcd_cnt[xcd];
         const unsigned long long prev = __hip_atomic_fetch_add(&a.sync->xcd_arrive[xcd][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         long spins = 0;
         if (prev + 1 == cnt * epoch) {
-          asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_fetch_add(&a.sync->global[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          while (__hip_atomic_load(&a.sync->global[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)a.nxcd * epoch) {
+          // (XCD-local mode: the partials are in this XCD's L2 already -- no write-back, no global phase; the invalidate
+          //  below still clears this compute unit's L1, which may hold the partials of an earlier trial)
+          if (!local) {
+            asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&a.sync->global[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          while (!local && __hip_atomic_load(&a.sync->global[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)a.nxcd * epoch) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > GRID_SPIN_LIMIT) { __hip_atomic_store(&a.sync->error[0], 4ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dec[3] = 4.0; break; }
           }

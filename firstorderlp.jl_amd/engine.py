@@ -412,6 +412,7 @@ class HipPdhgEngine:
         out = dict(zip(keys, info.tolist()))
         out["small_lp"] = (out["var_tiles"] >> 2) & 1      # batches of take_steps run in the one-workgroup LDS kernel
         out["device_loop"] = (out["var_tiles"] >> 3) & 1   # ... in the multi-step persistent kernel (small grids)
+        out["steps_local"] = (out["var_tiles"] >> 4) & 1   # ... whose workgroups all sit on one XCD (<= 32 row blocks + chunks per product)
         # nnz beyond the 32-bit entry limit: the matrix is held as this many segments of whole rows (0: one piece)
         out["A_segments"] = (out["var_tiles"] >> 8) & 255
         out["At_segments"] = (out["var_tiles"] >> 16) & 255

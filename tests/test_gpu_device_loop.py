@@ -133,3 +133,43 @@ def test_device_loop_in_relaxed_order_and_through_optimize(gpu_required, monkeyp
         outs.append((o.iteration_count, o.termination_reason, o.primal_solution, o.dual_solution))
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
     assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
+
+
+# ---- round 4: the multi-step kernel's XCD-local mode (<= 32 items per product: every working workgroup on one XCD) ----
+def _local_run(p, monkeypatch, local, bad=False, steps=(9, 40, 40)):
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import take_steps
+    monkeypatch.setenv("PDHG_COOP_LOCAL", local)
+    if bad:
+        monkeypatch.setenv("PDHG_COOP_LOCAL_TEST_BAD", "1")
+    eng = HipPdhgEngine.from_problem(p)
+    step, pw = H.initial_step_and_weight(p)
+    st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    sizes = []
+    for k in steps:
+        assert take_steps(AdaptiveStepsizeParams(0.3, 0.6), st, k) == k
+        sizes.append(st.step_size)
+    out = (np.array(sizes), st.total_number_iterations) + tuple(eng.get_current()) + tuple(eng.get_average())
+    info = eng.layout_info()
+    eng.close()
+    if bad:
+        monkeypatch.delenv("PDHG_COOP_LOCAL_TEST_BAD")
+    return out, info
+
+
+@pytest.mark.parametrize("shape", [(3000, 2500, 6), (6000, 5000, 5), (1800, 4000, 12)])
+def test_xcd_local_mode_is_bitwise_the_all_xcd_kernel(gpu_required, monkeypatch, shape):
+    p = random_lp(*shape, seed=13)
+    ref, i0 = _local_run(p, monkeypatch, "0")
+    got, i1 = _local_run(p, monkeypatch, "1")
+    assert i0["device_loop"] == 1 and i0["steps_local"] == 0 and i1["steps_local"] == 1
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(a, b), k
+
+
+def test_xcd_local_mode_falls_back_when_its_barrier_cannot_complete(gpu_required, monkeypatch):
+    p = random_lp(3000, 2500, 6, seed=14)
+    ref, _ = _local_run(p, monkeypatch, "0")
+    got, info = _local_run(p, monkeypatch, "1", bad=True)       # first launch times out (~0.1 s), the trial is repeated
+    assert info["steps_local"] == 0 and info["device_loop"] == 1   # ... by the all-XCD kernel, which the handle keeps
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert np.array_equal(a, b), k
