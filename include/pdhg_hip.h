@@ -305,6 +305,9 @@ int pdhg_get_point(pdhg_handle *h, int point, double *x, double *y);
  * The two value sums are evaluated as sum g d min(t*, breakpoint) -- the same numbers as
  * the reference's sum g (clamp(z + t* d) - z) up to rounding -- so that they come out of
  * the search's own passes.
+ * How a call runs (same results to rounding, chosen per handle): n + m <= 4096 in one workgroup; single handles up to
+ * n + m = 1M as ONE persistent launch with a grid barrier per probe pass (csrc/tr_coop_kernel.hpp; PDHG_TR_COOP=0 off);
+ * otherwise, and on shard groups, a kernel pair and a host round trip per pass.
  */
 int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm,
                             double dual_weight_norm, double radius, int range,
