@@ -41,6 +41,15 @@ struct EpiArgs {
   double avg_w;
 };
 
+// (dev, -DPDHG_WT_STORES: the vectors of a multi-trial kernel are stored write-through, so that the grid barrier's L2
+//  write-back finds their lines clean)
+template <bool COH>
+__device__ __forceinline__ void stc(double *p, double v) {
+#ifdef PDHG_WT_STORES
+  if (COH) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+#endif
+  *p = v;
+}
 template <int MODE, bool COH = false>
 __device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
                                              Acc3 &acc) {
@@ -51,7 +60,7 @@ __device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
     const double yo = ldc<COH>(e.y + r);
     if (e.sum_y) {
       const double t = yo * e.avg_w;
-      e.sum_y[r] = ldc<COH>(e.sum_y + r) + t;
+      stc<COH>(e.sum_y + r, ldc<COH>(e.sum_y + r) + t);
     }
     const double dg = e.b[r] - s;
     // next_dual = y .+ (pw*step) .* dual_gradient   pdhg.jl:489-490
@@ -59,12 +68,12 @@ __device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
     double yn = yo + t;
     // project_dual!: only inequality rows           saddle_point.jl:110-117
     if (r >= e.num_eq) yn = jl_max(yn, 0.0);
-    e.y_next[r] = yn;
+    stc<COH>(e.y_next + r, yn);
     const double dy = yn - yo;                       // pdhg.jl:535
     dd_add(acc.hi[0], acc.lo[0], dy * dy);
   } else {
     // next_dual_product = A' * next_dual            pdhg.jl:492
-    e.aty_next[r] = s;
+    stc<COH>(e.aty_next + r, s);
     const double dx = ldc<COH>(e.x_next + r) - ldc<COH>(e.x + r);   // pdhg.jl:534
     const double dd = s - ldc<COH>(e.aty + r);                     // pdhg.jl:543
     dd_add(acc.hi[0], acc.lo[0], dx * dd);
