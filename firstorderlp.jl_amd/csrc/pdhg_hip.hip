@@ -168,7 +168,7 @@ struct pdhg_handle {
   // the multi-step kernel's XCD-local mode (small grids: every working workgroup on one XCD, trial_kernel.hpp)
   int local_mode = -1;                  // -1 not decided, 0 off, 1 on
   GridSync *lsync = nullptr;
-  unsigned long long local_epoch = 0;
+  unsigned long long local_epoch = 0, local_tickets = 0;
   long local_launches = 0;
   GridSync *gsync = nullptr;
   unsigned long long *coop_trace = nullptr;   // PDHG_COOP_TRACE=1: phase stamps of the last launch
@@ -884,6 +884,7 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   a.local_g = local ? h->coop_grid : 0; a.local_home = 0;
   // test knob: the kernel expects eight workgroups more than are launched on the home XCD -- its first barrier times out
   if (local && getenv("PDHG_COOP_LOCAL_TEST_BAD")) a.local_g += 8;
+  if (local) { a.local_ticket_base = h->local_tickets; h->local_tickets += (unsigned long long)h->coop_grid; }
   a.seq = ++h->steps_seq;
   a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
   a.trace = h->coop_trace;

@@ -435,6 +435,7 @@ struct StepsKernelArgs {
   unsigned long long *trace;                      // PDHG_COOP_TRACE: stamps of the launch's last trial, as for trial_kernel ([7]: leaders, global phase done)
   int local_g;                                    // > 0: XCD-local mode -- the launch is 8 x local_g workgroups, those on XCD local_home work
   unsigned local_home;
+  unsigned long long local_ticket_base;            // tickets drawn by earlier launches (local_g each)
 };
 
 // result words: [0] step size, [1] steps taken, [2] trials, [3] flip, [4] pending average update, [5] its weight,
@@ -470,9 +471,12 @@ __global__ __launch_bounds__(TPB, PDHG_TRIAL_WAVES_PER_EU) void steps_kernel(Ste
     if (xcc_id() != a.local_home) return;
     __shared__ int s_w;
     if (threadIdx.x == 0)
-      s_w = (int)(__hip_atomic_fetch_add(&a.sync->ticket[0][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % (unsigned long long)a.local_g);
+      s_w = (int)(__hip_atomic_fetch_add(&a.sync->ticket[0][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.local_ticket_base);
     __syncthreads();
     w = s_w; nwg = a.local_g;
+    // more workgroups on the home XCD than the census saw: the surplus leaves (exactly local_g work, the barriers' counts
+    // hold); fewer: a barrier times out and the host goes back to the all-XCD kernel
+    if (w >= nwg) return;
   }
   int flip = 0, pend = a.pend, steps = 0, trials = 0, num_err = 0, hw_err = 0, mid = 0;
   if (threadIdx.x == 0) { s_st[0] = a.step_size; s_st[1] = a.step_size; s_st[2] = a.pend_w; s_st[3] = a.wsum_x; s_st[4] = a.wsum_y; }
