@@ -478,6 +478,31 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
     return out
 
 
+def multi_gpu_failure(args, world, rank, exc, real_stdout):
+    """N > 1 has never run in the builder's environment (one GPU per box): whatever fails first -- a device that is not
+    there, RCCL initialisation, peer access, a barrier another rank never reaches -- must leave ONE parseable line that
+    says so, not a traceback alone or a hang.  The launcher stops every rank as soon as one exits, so the FIRST rank to
+    fail prints the line (a marker file per rendezvous port elects it)."""
+    import tempfile
+    import traceback
+    traceback.print_exc()
+    first = True
+    try:
+        os.close(os.open(os.path.join(tempfile.gettempdir(), f"pdhg_bench_failed_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"),
+                         os.O_CREAT | os.O_EXCL | os.O_WRONLY))
+    except OSError:
+        first = False
+    if first:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps({"metric": "pdhg_iterations_per_sec", "value": None, "unit": "iterations/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": args.workload},
+                          "error": f"rank {rank}: {exc!r} (the multi-GPU path failed; nothing was measured)"}), flush=True)
+    os._exit(1)
+
+
 def main():
     args = parse()
     if args.plain_launches:
@@ -502,7 +527,12 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    try:
+        torch.cuda.set_device(local_rank)
+    except Exception as exc:
+        if world == 1:
+            raise
+        multi_gpu_failure(args, world, rank, exc, real_stdout)
     dist = None
     # PDHG_FORCE_DIST=1: take the N > 1 route of this script with ONE rank (gloo group of 1, id
     # broadcast, pdhg_create_dist, 1-rank RCCL communicator) -- how that route is exercised on a
@@ -512,11 +542,18 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        # (a rank that fails leaves the others in a barrier: ten minutes, not gloo's default thirty, then the error line below)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
     ctx = {"pkg": pkg, "dist": dist, "rank": rank, "world": world, "local_rank": local_rank}
 
     cpu_s = 0.0 if args.no_cpu_baseline else args.cpu_baseline_seconds
-    head = measure(args, args.workload, ctx, args.steps, args.warmup, cpu_s)
+    try:
+        head = measure(args, args.workload, ctx, args.steps, args.warmup, cpu_s)
+    except Exception as exc:
+        if dist is None:
+            raise
+        multi_gpu_failure(args, world, rank, exc, real_stdout)
     others = []
     if dist is None and not args.no_other_configs and args.workload == "random" and args.shards == 0:
         for wl in ("pagerank", "l1svm"):
