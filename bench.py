@@ -592,6 +592,11 @@ def main():
             rf["frac_rocprof"] = round(sp["algorithmic_bytes"] / (res["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             rf["rocprof_source"] = "measured in this run: rocprofv3 --kernel-trace --stats around a child run of this script (tools/selfprof.py)"
             rf["rocprof_measured_in_this_run"] = True
+        if "l2_requests" in res and "kernel_ms" in res:
+            # every random gather is one L2 request whether it hits or not: the rate at which the product's kernels make
+            # them is what config S, PageRank and the L1-SVM LP have in common
+            rf["l2_requests_per_launch"] = res["l2_requests"]
+            rf["l2_request_rate_G_per_s"] = round(res["l2_requests"] / (res["kernel_ms"] * 1e-3) / 1e9, 1)
         if "traffic" in res:
             rf["traffic"] = res["traffic"]
             rf["traffic_over_algorithmic"] = round(res["traffic"] / sp["algorithmic_bytes"], 3)

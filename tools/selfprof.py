@@ -96,6 +96,8 @@ def product_traffic_bytes(ctr, product):
     carriers = [detail[m]["launches"] for m in members if "long" not in m] or [detail[members[0]]["launches"]]
     base = min(carriers)
     total = sum((d["read_bytes"] + d["write_bytes"]) * d["launches"] / base for d in detail.values())
+    for d in detail.values():      # L2 requests (hits + misses) of one product's launches of this kernel
+        d["l2_requests_per_product"] = int((d["l2_hits"] + d["l2_misses"]) * d["launches"] / base)
     return int(total), detail
 
 
@@ -144,6 +146,7 @@ def run(workload, product, extra=(), timeout=180, keep=None, deadline=None):
         if traffic is not None:
             out["traffic"] = traffic
             out["traffic_detail"] = detail
+            out["l2_requests"] = sum(d["l2_requests_per_product"] for d in detail.values())
     except Exception as exc:      # measurement extra: the bench line must not depend on it
         out["error"] = repr(exc)
     finally:
