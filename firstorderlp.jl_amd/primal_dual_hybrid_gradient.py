@@ -469,13 +469,19 @@ def _optimize(params, original_problem, engine_factory, created):
             with np.errstate(divide="ignore"):
                 primal_weight_norm = float(np.float64(1) / solver_state.step_size * solver_state.primal_weight)
                 dual_weight_norm = float(np.float64(1) / solver_state.step_size / solver_state.primal_weight)
-            update_objective_bound_estimates(
-                current_iteration_stats.method_specific_stats, ev, avg_point,
-                primal_weight_norm, dual_weight_norm)
             termination_reason = check_termination_criteria(
                 termination_criteria, qp_cache, current_iteration_stats)
             if solver_state.numerical_error and termination_reason is False:
                 termination_reason = TerminationReason.TERMINATION_REASON_NUMERICAL_ERROR
+            # update_objective_bound_estimates (pdhg.jl:938-945) fills three entries of method_specific_stats that are
+            # only ever read from KEPT stats (solve_log; the final log, saddle_point.jl:961-993) -- neither the
+            # termination test nor the restart scheme sees them.  A check whose stats are dropped skips the two
+            # trust-region problems behind them (a quarter of a check on medium LPs); the values of kept stats are
+            # the reference's (both functions only read the state, so their order does not matter).
+            if params.record_iteration_stats or termination_reason is not False:
+                update_objective_bound_estimates(
+                    current_iteration_stats.method_specific_stats, ev, avg_point,
+                    primal_weight_norm, dual_weight_norm)
 
             if params.record_iteration_stats or termination_reason is not False:
                 iteration_stats.append(current_iteration_stats)

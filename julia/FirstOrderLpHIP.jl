@@ -803,13 +803,16 @@ function FirstOrderLp.optimize(hp::HipPdhgParameters,
       # :932-937  define_norms: uniform weights, kept as two scalars
       primal_weight_norm = 1 / solver_state.step_size * solver_state.primal_weight
       dual_weight_norm = 1 / solver_state.step_size / solver_state.primal_weight
-      # :938-945  -> pdhg_point_sumsq + pdhg_trust_region_bound
-      update_objective_bound_estimates(method_specific_stats, solver_state, problem.objective_constant,
-                                       avg_point, primal_weight_norm, dual_weight_norm)
       termination_reason = FirstOrderLp.check_termination_criteria(
         termination_criteria, qp_cache, current_iteration_stats)
       if solver_state.numerical_error && termination_reason == false
         termination_reason = FirstOrderLp.TERMINATION_REASON_NUMERICAL_ERROR
+      end
+      # :938-945  -> pdhg_point_sumsq + pdhg_trust_region_bound.  The three entries it fills are only ever read from KEPT
+      # stats (the solve log; the final log, saddle_point.jl:961-993): a check whose stats are dropped skips them.
+      if params.record_iteration_stats || termination_reason != false
+        update_objective_bound_estimates(method_specific_stats, solver_state, problem.objective_constant,
+                                         avg_point, primal_weight_norm, dual_weight_norm)
       end
       if params.record_iteration_stats || termination_reason != false
         push!(iteration_stats_log, current_iteration_stats)

@@ -46,3 +46,22 @@ def test_device_solve_matches_host_solve(gpu_required, name, maker):
     # both are 1e-6-optimal points of the same LP (which need not have a unique solution)
     diff = np.linalg.norm(dev.primal_solution - host.primal_solution)
     assert diff <= 0.05 * (1.0 + np.linalg.norm(host.primal_solution))
+
+
+def test_dropped_checks_skip_the_bound_estimates_and_kept_stats_are_unchanged(gpu_required):
+    """update_objective_bound_estimates (pdhg.jl:938-945) only feeds stats that are KEPT (the log, the final report):
+    with record_iteration_stats = false the checks that do not terminate skip its two trust-region problems.  The solve
+    itself must not notice -- same iterations, same solution, bit for bit -- and the final (kept) stats carry the same
+    three entries as when every check records."""
+    import dataclasses
+    p = random_lp(12000, 10000, 8, seed=42)
+    keep = _params(1e-5, 20000)
+    drop = dataclasses.replace(keep, record_iteration_stats=False)
+    a, b = optimize(keep, p), optimize(drop, p)
+    assert a.termination_string == b.termination_string == "OPTIMAL"
+    assert a.iteration_count == b.iteration_count
+    assert np.array_equal(a.primal_solution, b.primal_solution) and np.array_equal(a.dual_solution, b.dual_solution)
+    assert len(a.iteration_stats) > 3 and len(b.iteration_stats) == 1
+    ma, mb = a.iteration_stats[-1].method_specific_stats, b.iteration_stats[-1].method_specific_stats
+    for key in ("lagrangian_value", "estimated_lower_bound", "estimated_upper_bound"):
+        assert ma[key] == mb[key], key

@@ -18,6 +18,7 @@ ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--tol", type=float, default=1e-4)
 ap.add_argument("--iteration_limit", type=int, default=20000)
 ap.add_argument("--verbosity", type=int, default=2)
+ap.add_argument("--no-record", action="store_true", help="record_iteration_stats = false: only the terminating check's stats are kept")
 ap.add_argument("--breakdown", action="store_true", help="time the stages of the evaluation branch (wall clock around the host calls)")
 a = ap.parse_args()
 stage_time, stage_calls = {}, {}
@@ -57,7 +58,7 @@ tc = construct_termination_criteria(eps_optimal_absolute=a.tol, eps_optimal_rela
                                     iteration_limit=a.iteration_limit)
 rp = construct_restart_parameters(RestartScheme.ADAPTIVE_NORMALIZED, RestartToCurrentMetric.GAP_OVER_DISTANCE_SQUARED,
                                   1000, 0.5, 0.1, 0.9, 0.5, False)
-params = PdhgParameters(10, False, 1.0, 1.0, True, a.verbosity, True, 40, tc, rp, AdaptiveStepsizeParams(0.3, 0.6))
+params = PdhgParameters(10, False, 1.0, 1.0, True, a.verbosity, not a.no_record, 40, tc, rp, AdaptiveStepsizeParams(0.3, 0.6))
 t0 = time.time()
 out = optimize(params, p)
 dt = time.time() - t0
