@@ -2848,8 +2848,14 @@ int pdhg_trial_primal(pdhg_handle *h, double step_size, double primal_weight) {
   return 0;
 }
 
+// true when the trial will be taken as persistent group launches (group_kernel.hpp), which queue nothing on the members' own
+// streams -- the same predicate group_coop_eligible() ends on (a profiled group takes the per-launch path, which DOES)
+static bool trial_stays_off_member_streams(const pdhg_handle *h) {
+  return h && h->grp && h->grp->coop_mode == 1 && !h->grp->sh.empty() && !h->grp->sh[0]->profile;
+}
+
 int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight, double theta, double out[5]) {
-  int rc = check_handle(h, !(h && h->grp && h->grp->coop_mode == 1));
+  int rc = check_handle(h, !trial_stays_off_member_streams(h));
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
@@ -2867,7 +2873,7 @@ int pdhg_trial_dual(pdhg_handle *h, double step_size, double primal_weight, doub
 
 int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, double theta, double out[5]) {
   RoctxRange roctx_range("pdhg_trial_step");
-  int rc = check_handle(h, !(h && h->grp && h->grp->coop_mode == 1));
+  int rc = check_handle(h, !trial_stays_off_member_streams(h));
   if (rc) return rc;
   if (!out) return fail(-1, "out == NULL");
   const Shards L = shards_of(h);
@@ -2887,7 +2893,7 @@ int pdhg_trial_step(pdhg_handle *h, double step_size, double primal_weight, doub
 int pdhg_accept(pdhg_handle *h0, double avg_weight) {
   RoctxRange roctx_range("pdhg_accept");
   // (a lazy accept with nothing pending queues no work: the iterates are swapped on the host)
-  int rc = check_handle(h0, !(h0 && h0->grp && h0->grp->coop_mode == 1 && h0->lazy_accept && !h0->pend_x && !h0->pend_y));
+  int rc = check_handle(h0, !(trial_stays_off_member_streams(h0) && h0->lazy_accept && !h0->pend_x && !h0->pend_y));
   if (rc) return rc;
   const Shards L = shards_of(h0);
   if ((rc = flush_pending(L))) return rc;   // two accepts without a trial in between
@@ -3884,7 +3890,10 @@ int pdhg_matrix_max_abs(pdhg_handle *h0, double *out) {
 // ---- measurement ------------------------------------------------------------
 
 int pdhg_profile_enable(pdhg_handle *h, int enable) {
-  if (!h) return fail(-1, "null handle");
+  // (through check_handle: switching the profile flag moves a group between the persistent launches and the per-launch path,
+  //  so the members' streams must first wait for the last persistent launch)
+  int rc0 = check_handle(h);
+  if (rc0) return rc0;
   h->profile = enable != 0;     // a group is profiled through its first local shard
   if (enable) for (int k = 0; k < PDHG_K_COUNT; ++k) { h->prof_count[k] = 0; h->prof_ms[k] = 0.0; }
   return 0;

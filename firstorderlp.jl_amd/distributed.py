@@ -145,9 +145,10 @@ def multi_device_factory(device_ids):
     return factory
 
 
-def row_partitioned_factory(group=None):
-    """The same for one process per GPU (torch.distributed group for the id hand-out)."""
+def row_partitioned_factory(group=None, device_id=None):
+    """The same for one process per GPU (torch.distributed group for the id hand-out).
+    ``device_id``: this rank's GPU (default: LOCAL_RANK)."""
     def factory(problem):
-        return make_row_partitioned_hip_engine(problem, group=group)
+        return make_row_partitioned_hip_engine(problem, device_id=device_id, group=group)
     factory.takes_original_problem = True
     return factory

@@ -1,0 +1,68 @@
+"""The one-process-per-GPU routes of csrc/dist.hpp EXECUTED with world 2 / 4 / 8 on a ONE-GPU box.
+
+Real RCCL refuses two ranks on one device, so until round 5 ``pdhg_create_dist`` / ``pdhg_create_dist_rows`` had only
+ever run with world = 1.  Here every rank is a real process (``python -m torch.distributed.run``), all on cuda:0, and the
+library's run-time RCCL binding (csrc/rccl_loader.hpp, ``PDHG_RCCL_LIB``) is pointed at the test-only stand-in
+``tests/fake_rccl`` (host-staged exchange through a shared mapping, rank-ordered sums).  What runs is the PRODUCT code:
+rank-local ingest, the all-gather of xbar, the reduce-scatter / per-slice reduce of A_p'y_p on the comm stream,
+``combine_scalars`` over ncclAllGather, the row-range broadcasts of the getters, device evaluation, rescaling, restarts.
+Checks: every rank holds the same bits; the multi-process result is BITWISE the in-process shard group's (same
+rank-ordered sums); decisions equal the single handle's and iterates agree to 1e-9; the reference's KATs pass; a whole
+``optimize`` terminates OPTIMAL like the single handle.  (Arithmetic being distributed:
+src/primal_dual_hybrid_gradient.jl:442-549, 653-731.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests import fake_rccl
+
+pytestmark = [pytest.mark.gpu, pytest.mark.own_row_order]     # rows of <= 256 entries: the row order changes nothing here
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_PORT = [29700]
+
+
+def _spawn(world, *argv, timeout=840, **env_extra):
+    _PORT[0] += 1
+    env = fake_rccl.env(FAKE_RCCL_TIMEOUT_S=240, **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_PORT[0]),
+           os.path.join(ROOT, "tests", "workers", "dist_fake_worker.py"), *argv]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "fake worker ok" in r.stdout and "FAILED" not in r.stdout, r.stdout[-2000:]
+    return r.stdout
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,ingest,overlap", [(w, i, o) for w in (2, 4) for i in ("global", "rows") for o in ("0", "1")] +
+                         [(8, "global", "0"), (8, "rows", "1")],       # (eight processes sharing one GPU take ~20 s per case)
+                         ids=lambda v: {"0": "reduce_scatter", "1": "per_slice_reduce"}.get(v, str(v)))
+def test_processes_on_one_gpu_match_the_in_process_group_bitwise(gpu_required, world, ingest, overlap):
+    _spawn(world, "traj", ingest, overlap, "small")
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("overlap", ["0", "1"], ids=["reduce_scatter", "per_slice_reduce"])
+def test_two_processes_tiled_shards_with_the_product_cut_into_rounds(gpu_required, overlap):
+    """A_p' tiled and launched a residency round at a time, slice k reduced (ncclReduce on the comm stream) while the
+    next round computes: the overlapped exchange between real processes."""
+    out = _spawn(2, "traj", "rows", overlap, "tiled")
+    assert "layout 0" not in out
+
+
+_KATS = ("low_precision,high_precision,adaptive_restart_heuristic,malitsky_pock_no_smoothing,quadratic_programming_1,"
+         "ruiz,l2_norm_rescaling,lp_without_bounds,correlation_clustering_triangle_plus")
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+def test_reference_kats_between_processes(gpu_required, world):
+    _spawn(world, "kat", _KATS)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_optimize_with_device_evaluation_and_rescaling_between_processes(gpu_required, world):
+    _spawn(world, "optimize")
