@@ -14,6 +14,7 @@ struct SlabDev {
   int2 *blks = nullptr;
   int nblk = 0, per_xcd = 0, grid = 0;
   int64_t nnz = 0;
+  SjDev sj;                        // the slab's entries in the sliced jagged layout (sj_kernels.hpp), when built
   CsrView view(int rows) const { return CsrView{rows, rowptr, col, val}; }
 };
 
@@ -52,6 +53,10 @@ struct CsrDev {
   // stream-kernel launch per slab and `grid` is the LAST slab's grid (its blocks write the partials)
   std::vector<SlabDev> slabs;
   double *slab_partial = nullptr;   // [rows] row sums between the passes
+  // sliced jagged copy of the stream layout (sj_kernels.hpp): the product kernel of stream-class matrices with more row
+  // blocks than the persistent trial kernels take (the CSR arrays and row blocks above stay: evaluation-time callers,
+  // the one-launch paths and the long-row kernels use them)
+  SjDev sj;
   // ---- 64-bit extents (quadratic_programming.jl:64: the reference's indices are Int64).  The kernels index entries with
   // 32 bits; a matrix with more entries than that is held as SEGMENTS of whole consecutive rows, each a complete CsrDev
   // of its own (own arrays and tables, offsets local to the segment: the 64-bit part of an entry's address is the
@@ -753,6 +758,8 @@ int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &r
   return 0;
 }
 
+int build_sj_copies(CsrDev &D, int rows, const std::vector<int> &rowptr, bool remap);
+
 int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
                   const ivec &col, const dvec &val,
                   bool remap, int tile_cols = 0, bool relaxed = false) {
@@ -767,7 +774,7 @@ int build_csr_dev(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr,
   if (!D.tiled) {
     if ((rc = build_slabs(D, rows, cols, rowptr, col, val, remap))) return rc;
   }
-  return 0;
+  return build_sj_copies(D, rows, rowptr, remap);
 }
 
 // The same with D.rowptr / D.col / D.val ALREADY in HBM (device_layout.hpp): tables from the row
@@ -812,7 +819,121 @@ int build_csr_dev_resident(CsrDev &D, int rows, int cols, const std::vector<int>
       if (rc) return rc;
     }
   }
+  return build_sj_copies(D, rows, rowptr, remap);
+}
+
+// ---- sliced jagged layout (sj_kernels.hpp) ------------------------------------------------------------------------
+// Host: the slot order (rows of a window by decreasing length, stable) and the slice offsets, from the row pointers
+// alone; device: the entries of (d_rowptr, d_col, d_val) copied into the level-major order.  `full_rowptr` decides
+// which rows are LONG (they belong to the long-row kernels: slot row -1); `rowptr` gives the lengths (a column slab's
+// row pointers, or the same array).
+void free_sj(SjDev &J) {
+  void *ptrs[] = {J.meta, J.slice_off, J.col, J.val};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  J = SjDev();
+}
+
+int build_sj(SjDev &J, int rows, const std::vector<int> &rowptr, const std::vector<int> &full_rowptr, int long_thr,
+             const int *d_rowptr, const int *d_col, const double *d_val, bool remap, int max_wgs) {
+  const int nslices = (rows + WAVE - 1) / WAVE;
+  if (nslices == 0) return 0;
+  const size_t nslots = (size_t)nslices * WAVE;
+  std::vector<int> slice_off((size_t)nslices + 1, 0);
+  std::vector<unsigned> meta(nslots, SJ_NONE << 16);
+  const int nwin = (rows + SJ_SIGMA - 1) / SJ_SIGMA;
+  parallel_ranges(nwin, 64, [&](int wb, int we) {
+    std::vector<int> start((size_t)BLOCK_NNZ + 2);
+    for (int w = wb; w < we; ++w) {
+      const int r0 = w * SJ_SIGMA, r1 = std::min(rows, r0 + SJ_SIGMA);
+      // stable counting sort by decreasing length; long rows sort as empty ones and keep no slot row
+      std::fill(start.begin(), start.end(), 0);
+      auto len_of = [&](int r) { return full_rowptr[r + 1] - full_rowptr[r] > long_thr ? 0 : rowptr[r + 1] - rowptr[r]; };
+      for (int r = r0; r < r1; ++r) start[(size_t)(BLOCK_NNZ - len_of(r)) + 1] += 1;       // bucket = BLOCK_NNZ - length: ascending bucket = descending length
+      for (int b = 0; b <= BLOCK_NNZ; ++b) start[(size_t)b + 1] += start[(size_t)b];
+      for (int r = r0; r < r1; ++r) {
+        const int l = len_of(r);
+        const size_t slot = (size_t)r0 + (size_t)start[(size_t)(BLOCK_NNZ - l)]++;
+        const bool is_long = full_rowptr[r + 1] - full_rowptr[r] > long_thr;
+        meta[slot] = ((is_long ? SJ_NONE : (unsigned)(r - r0)) << 16) | (unsigned)l;
+      }
+    }
+  });
+  int64_t total = 0;
+  for (int s = 0; s < nslices; ++s) {
+    slice_off[(size_t)s] = (int)total;
+    for (int q = 0; q < WAVE; ++q) total += meta[(size_t)s * WAVE + q] & 0xFFFFu;
+  }
+  slice_off[(size_t)nslices] = (int)total;
+  J.nslices = nslices;
+  J.rows = rows;
+  J.nnz = total;
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  const int ngroups = (nslices + TPB / WAVE - 1) / (TPB / WAVE);
+  // never more workgroups than the CSR kernel's grid: every workgroup owns a block-partial slot of that grid
+  J.grid = std::max(1, std::min(std::min(SJ_WGS_PER_CU * cus, ngroups), std::max(1, max_wgs)));
+  if (remap) J.grid = std::max(NUM_XCD, (J.grid + NUM_XCD - 1) / NUM_XCD * NUM_XCD > max_wgs ? J.grid / NUM_XCD * NUM_XCD : (J.grid + NUM_XCD - 1) / NUM_XCD * NUM_XCD);
+  int rc;
+  if ((rc = upload(&J.meta, meta))) return rc;
+  if ((rc = upload(&J.slice_off, slice_off))) return rc;
+  HIP_TRY(hipMalloc((void **)&J.col, sizeof(int) * (size_t)std::max<int64_t>(total, 1)));
+  HIP_TRY(hipMalloc((void **)&J.val, sizeof(double) * (size_t)std::max<int64_t>(total, 1)));
+  hipLaunchKernelGGL(sj_fill_kernel, dim3((nslices + TPB / WAVE - 1) / (TPB / WAVE)), dim3(TPB), 0, nullptr, nslices, J.meta,
+                     J.slice_off, d_rowptr, d_col, d_val, J.col, J.val);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(nullptr));
   return 0;
+}
+
+// Which stream layouts get the sliced jagged copy: those with more row blocks than the persistent trial kernels take
+// (trial_kernel.hpp: <= 1 024 items; such LPs are latency-bound and stay on the CSR row blocks) -- i.e. products that are
+// bandwidth work -- whose rows (the long ones apart) have at most SJ_MAX_LEN entries (sj_kernels.hpp: a lane walks its
+// row).  PDHG_SJ=0 / 1 forces it off / on whatever the shape (tests compare the two layouts bitwise).
+// ... and whose 256-row groups are nearly uniform inside: a workgroup trip lasts as long as its longest row, so the
+// layout pays when entries / (256 x longest row of the group), summed over the groups, is >= 0.8.  Measured (round 5,
+// profiles/r05_sj_layout.txt, banded 10M +-50000): rows of exactly 10 entries 0.80 -> 0.62 ms (rocSPARSE 0.70); its
+// transpose, column counts Poisson(10), fill 0.5: 0.79 ms on either layout -> stays on the CSR row blocks.
+inline bool sj_wanted(int nblk, int rows, const std::vector<int> &rowptr, const std::vector<int> &full_rowptr, int long_thr) {
+  if (const char *ev = getenv("PDHG_SJ")) return ev[0] != '0';
+  if (nblk <= 1024) return false;
+  int64_t entries = 0, capacity = 0;
+  for (int r0 = 0; r0 < rows; r0 += SJ_SIGMA) {
+    int longest = 0;
+    for (int r = r0; r < std::min(rows, r0 + SJ_SIGMA); ++r) {
+      if (full_rowptr[r + 1] - full_rowptr[r] > long_thr) continue;
+      const int l = rowptr[r + 1] - rowptr[r];
+      if (l > SJ_MAX_LEN) return false;
+      longest = std::max(longest, l);
+      entries += l;
+    }
+    capacity += (int64_t)SJ_SIGMA * longest;
+  }
+  return capacity > 0 && 10 * entries >= 8 * capacity;
+}
+
+// after the stream tables / slabs exist and D.rowptr / D.col / D.val are in HBM
+int build_sj_copies(CsrDev &D, int rows, const std::vector<int> &rowptr, bool remap) {
+  if (D.tiled || !D.segs.empty()) return 0;
+  int rc;
+  if (!D.slabs.empty()) {
+    // all slabs or none (the passes hand the row sums on in one format either way; one rule keeps the kernel names simple)
+    int nblk_max = 0;
+    for (const SlabDev &S : D.slabs) nblk_max = std::max(nblk_max, S.nblk);
+    if (!sj_wanted(nblk_max, rows, rowptr, rowptr, D.long_thr)) return 0;
+    for (SlabDev &S : D.slabs) {
+      std::vector<int> rp((size_t)rows + 1);
+      HIP_TRY(hipMemcpy(rp.data(), S.rowptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost));
+      if ((rc = build_sj(S.sj, rows, rp, rowptr, D.long_thr, S.rowptr, S.col, S.val, remap, S.grid))) return rc;
+    }
+    return 0;
+  }
+  if (D.grid <= 0 || !sj_wanted(D.nblk, rows, rowptr, rowptr, D.long_thr)) return 0;
+  return build_sj(D.sj, rows, rowptr, rowptr, D.long_thr, D.rowptr, D.col, D.val, remap, D.grid);
 }
 
 void free_csr_dev(CsrDev &D) {
@@ -824,7 +945,9 @@ void free_csr_dev(CsrDev &D) {
   for (SlabDev &S : D.slabs) {
     void *sp[] = {S.rowptr, S.col, S.val, S.blks};
     for (void *p : sp) if (p) (void)hipFree(p);
+    free_sj(S.sj);
   }
+  free_sj(D.sj);
   if (D.slab_partial) (void)hipFree(D.slab_partial);
   D = CsrDev();
 }

@@ -40,6 +40,7 @@
 // placement, and one TU keeps every launch a direct call).
 #include "common.hpp"
 #include "spmv_kernels.hpp"
+#include "sj_kernels.hpp"
 #include "vector_kernels.hpp"
 #include "eval_kernels.hpp"
 #include "rescale_kernels.hpp"
@@ -309,6 +310,20 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
     const int P = (int)D.slabs.size(), rm = h->remap ? 1 : 0;
     for (int p = 0; p < P; ++p) {
       const SlabDev &S = D.slabs[(size_t)p];
+      if (S.sj.on()) {        // the slab in the sliced jagged layout (sj_kernels.hpp)
+        EpiArgs pe{};
+        pe.out = D.slab_partial;
+        pe.init = D.slab_partial;
+        EpiArgs le = e;
+        le.init = D.slab_partial;
+        if (p + 1 < P && p == 0)
+          hipLaunchKernelGGL((spmv_sj_kernel<MODE_PLAIN, false, TAG>), dim3(S.sj.grid), dim3(TPB), 0, h->stream, sj_view(S.sj), xin, rm, 0, pe);
+        else if (p + 1 < P)
+          hipLaunchKernelGGL((spmv_sj_kernel<MODE_PLAIN, true, TAG>), dim3(S.sj.grid), dim3(TPB), 0, h->stream, sj_view(S.sj), xin, rm, 0, pe);
+        else
+          hipLaunchKernelGGL((spmv_sj_kernel<MODE, true, TAG>), dim3(S.sj.grid), dim3(TPB), 0, h->stream, sj_view(S.sj), xin, rm, S.grid, le);
+        continue;
+      }
       if (p + 1 < P) {
         EpiArgs pe{};
         pe.out = D.slab_partial;
@@ -326,6 +341,9 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
                            S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx, le);
       }
     }
+  } else if (D.sj.on()) {
+    hipLaunchKernelGGL((spmv_sj_kernel<MODE, false, TAG>), dim3(D.sj.grid), dim3(TPB), 0, h->stream, sj_view(D.sj), xin,
+                       h->remap ? 1 : 0, D.grid, e);
   } else if (D.grid > 0) {
     hipLaunchKernelGGL((spmv_stream_kernel<MODE, false, TAG>), dim3(D.grid), dim3(TPB), 0, h->stream,
                        D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, e);
@@ -1082,6 +1100,23 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
     for (int p = 0; p < P; ++p) {
       const SlabDev &S = D.slabs[(size_t)p];
       hipGraphNode_t nd = nullptr;
+      if (S.sj.on()) {
+        EpiArgs pe{};
+        pe.out = D.slab_partial;
+        pe.init = D.slab_partial;
+        EpiArgs le = e;
+        le.init = D.slab_partial;
+        if (p + 1 < P) {
+          const void *fn = p == 0 ? (const void *)spmv_sj_kernel<MODE_PLAIN, false, TAG> : (const void *)spmv_sj_kernel<MODE_PLAIN, true, TAG>;
+          HIP_TRY(graph_add_kernel(graph, &nd, prev, fn, dim3(S.sj.grid), dim3(TPB), sj_view(S.sj), xin, rm, 0, pe));
+        } else {
+          HIP_TRY(graph_add_kernel(graph, &nd, prev, (const void *)spmv_sj_kernel<MODE, true, TAG>, dim3(S.sj.grid), dim3(TPB),
+                                   sj_view(S.sj), xin, rm, S.grid, le));
+          if (main_node) *main_node = nd;
+        }
+        prev.assign(1, nd);
+        continue;
+      }
       if (p + 1 < P) {
         EpiArgs pe{};
         pe.out = D.slab_partial;
@@ -1099,6 +1134,12 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
       prev.assign(1, nd);
     }
     done.push_back(prev[0]);
+  } else if (D.sj.on()) {
+    hipGraphNode_t nd = nullptr;
+    HIP_TRY(graph_add_kernel(graph, &nd, deps, (const void *)spmv_sj_kernel<MODE, false, TAG>, dim3(D.sj.grid), dim3(TPB),
+                             sj_view(D.sj), xin, rm, D.grid, e));
+    if (main_node) *main_node = nd;
+    done.push_back(nd);
   } else if (D.grid > 0) {
     hipGraphNode_t nd = nullptr;
     HIP_TRY(graph_add_kernel(graph, &nd, deps, (const void *)spmv_stream_kernel<MODE, false, TAG>, dim3(D.grid), dim3(TPB),
@@ -1137,8 +1178,15 @@ int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &du
       const SlabDev &S = A.slabs.back();
       EpiArgs le = dual_epi;
       le.init = A.slab_partial;
-      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, true, 0>, dim3(S.grid), dim3(TPB),
-                               S.view(A.rows), (const double *)h->xbar, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, rx, le));
+      if (S.sj.on())
+        HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_sj_kernel<MODE_DUAL, true, 0>, dim3(S.sj.grid), dim3(TPB),
+                                 sj_view(S.sj), (const double *)h->xbar, rm, S.grid, le));
+      else
+        HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, true, 0>, dim3(S.grid), dim3(TPB),
+                                 S.view(A.rows), (const double *)h->xbar, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, rx, le));
+    } else if (A.sj.on()) {
+      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_sj_kernel<MODE_DUAL, false, 0>, dim3(A.sj.grid), dim3(TPB),
+                               sj_view(A.sj), (const double *)h->xbar, rm, A.grid, dual_epi));
     } else {
       HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, false, 0>, dim3(A.grid), dim3(TPB),
                                A.view(), (const double *)h->xbar, (const int2 *)A.blks, A.nblk, A.per_xcd, rm, rx, dual_epi));
@@ -2044,9 +2092,12 @@ static std::string product_kernels(const CsrDev &D, int mode, int tag) {
   if (D.tiled) {
     if (D.grid > 0) add("spmv_tiled_kernel<" + m + ", " + std::to_string(D.tw_mode) + ">");
   } else if (!D.slabs.empty()) {
-    add("spmv_stream_kernel<0, false, " + t + ">");
-    if (D.slabs.size() > 2) add("spmv_stream_kernel<0, true, " + t + ">");
-    add("spmv_stream_kernel<" + m + ", true, " + t + ">");
+    const std::string k = D.slabs.front().sj.on() ? "spmv_sj_kernel<" : "spmv_stream_kernel<";
+    add(k + "0, false, " + t + ">");
+    if (D.slabs.size() > 2) add(k + "0, true, " + t + ">");
+    add(k + m + ", true, " + t + ">");
+  } else if (D.sj.on()) {
+    add("spmv_sj_kernel<" + m + ", false, " + t + ">");
   } else if (D.grid > 0) {
     add("spmv_stream_kernel<" + m + ", false, " + t + ">");
   }
@@ -4225,6 +4276,11 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   info[15] += std::min<int64_t>(h->tr_coop_calls, 16383) << 48;      // trust-region calls taken as one persistent launch
   if (!h->A.segs.empty()) info[12] = (int64_t)first(h->A).slabs.size();
   if (!h->At.segs.empty()) info[13] = (int64_t)first(h->At).slabs.size();
+  // bit 8 of the slab counts: the product runs on the sliced jagged layout (sj_kernels.hpp)
+  for (int k = 0; k < 2; ++k) {
+    const CsrDev &D = first(*Ms[k]);
+    if (D.sj.on() || (!D.slabs.empty() && D.slabs.front().sj.on())) info[12 + k] += 256;
+  }
   return 0;
 }
 

@@ -1,0 +1,260 @@
+// sj_kernels.hpp -- part of the single translation unit pdhg_hip.hip (included there, after spmv_kernels.hpp).
+// The SLICED JAGGED layout of the stream class (round 5) and its product kernel.
+//
+// Why.  The CSR "stream" kernel (spmv_kernels.hpp) parks a row block's products in LDS and lets one lane per row add
+// them: two phases, a workgroup barrier, row pointers, LDS reads with bank conflicts.  Round 5 measured what that costs
+// on a matrix whose gathers all hit L2 (banded 10M +-50000): 0.81 ms = 123 G nonzeros/s, against 0.70 ms for
+// rocSPARSE's adaptive CSR kernel and 0.58-0.60 ms for a skeleton that streams the same 12 bytes per nonzero from HBM
+// and gathers the same doubles with every lane walking ITS OWN row in registers (tools/slot_probe.hip, variant 14;
+// profiles/r05_slot_probe.txt).  This file is that skeleton as a product kernel.
+//
+// Layout.  Rows are taken in GROUPS of SJ_SIGMA = 256 consecutive rows (one workgroup trip) and, inside a group, ordered
+// by DECREASING length (stable: equal lengths keep their row order -- the layout is a deterministic function of the row
+// pointers).  64 consecutive slots of that order are a SLICE, one wave's work: slot -> (row, length) in `perm` / `len`.
+// A slice's entries are stored LEVEL-MAJOR and jagged: level j holds the j-th entry (ascending column) of every row of
+// the slice with more than j entries -- because the lengths decrease along the slice these are the first cnt_j lanes, so
+// level j is cnt_j consecutive (col, val) pairs and a wave reads it with one coalesced load pair; no padding is stored,
+// and sorting a whole group (not one slice) makes the four slices nearly uniform inside.  Lane l adds its row's
+// products level by level, i.e. strictly left to right in a register: EVERY row of this layout has the reference's
+// order of additions (saddle_point.jl:1102-1107, pdhg.jl:492; bit-identical to the CPU loops), whatever its length --
+// there is no "relaxed" mode here.  The row sums then cross the workgroup through 2 KB of LDS so that thread t runs the
+// fused epilogue of row (group base + t): y, b, x, A'y are read and y', A'y' written in ROW order, fully coalesced
+// (with the epilogue in slot order -- round 5's first cut, sorting windows of 2 048 rows -- every epilogue operand became a
+// 64-line gather and the A' product of a banded matrix ran at HALF the CSR kernel's speed).  Rows beyond
+// CsrDev::long_thr stay with the long-row kernels (slot row = -1, no epilogue here).
+// Column-slab passes (INIT) carry the row sums through e.init exactly as the CSR stream kernel does.
+// The builder uses the layout when no row of the matrix (slab) that is not "long" has more than SJ_MAX_LEN entries: a
+// lane walks its row in batches of SJ_U dependent load -> gather -> add trips, so a 2 000-entry hub row would hold its
+// workgroup for 250 memory round trips (PageRank-1M in the first cut: 1.19 ms against 0.10) -- such matrices keep the CSR
+// row blocks, whose lanes share a row block's entries whatever the row lengths.
+//
+// Launch.  Persistent: SJ_WGS_PER_CU workgroups per compute unit (the skeleton is fastest at 1-4: more waves only
+// widen the window of the gathered vector in flight), one group of four slices per workgroup and trip, XCD x walking the
+// contiguous eighth of the groups (remap) so that its L2 sees one moving window.  Block partials: one slot per
+// workgroup; the remaining slots of the stream part (the CSR kernel's grid, which the reductions still walk) are zeroed.
+#pragma once
+
+namespace {
+
+constexpr int SJ_SIGMA = TPB;        // rows per sorting group = rows per workgroup trip (4 slices)
+constexpr int SJ_MAX_LEN = 128;      // longest row (long rows apart) the builder accepts for this layout
+constexpr int SJ_U1 = 16;            // levels of a slice requested one trip ahead (registers)
+constexpr int SJ_U = 8;              // further levels: batches of this many
+constexpr int SJ_WGS_PER_CU = 2;         // (the kernel holds two trips in registers: 150-178 VGPRs, two workgroups per CU)
+
+struct SjDev {
+  int nslices = 0, grid = 0, rows = 0;
+  int64_t nnz = 0;
+  unsigned *meta = nullptr;          // [nslices * 64] slot -> (row - group base) << 16 | entries; SJ_NONE in the high half: no row
+  int *slice_off = nullptr;          // [nslices + 1] first entry of every slice
+  int *col = nullptr;                // [nnz] level-major inside a slice
+  double *val = nullptr;
+  bool on() const { return nslices > 0; }
+};
+
+constexpr unsigned SJ_NONE = 0xFFFFu;
+struct SjView {
+  int nslices, rows;
+  const unsigned *meta;
+  const int *slice_off;
+  const int *col;
+  const double *val;
+};
+inline SjView sj_view(const SjDev &J) { return SjView{J.nslices, J.rows, J.meta, J.slice_off, J.col, J.val}; }
+
+// one wave per slice: the CSR entries of its rows into the level-major order
+__global__ __launch_bounds__(TPB) void sj_fill_kernel(int nslices, const unsigned *__restrict__ meta, const int *__restrict__ slice_off,
+                                                      const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                      const double *__restrict__ val, int *__restrict__ sj_col, double *__restrict__ sj_val) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int slice = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+  if (slice >= nslices) return;
+  const unsigned w = meta[slice * WAVE + lane];
+  const int l = (int)(w & 0xFFFFu);
+  const int r = (w >> 16) == SJ_NONE ? -1 : (slice / (TPB / WAVE)) * SJ_SIGMA + (int)(w >> 16);
+  const int src = r >= 0 ? rowptr[r] : 0;
+  int off = slice_off[slice];
+  const int L = __builtin_amdgcn_readfirstlane(l);      // lane 0 holds the slice's longest row
+  for (int j = 0; j < L; ++j) {
+    const bool act = j < l;
+    const int cnt = __popcll(__ballot(act));
+    if (act) {
+      sj_col[off + lane] = col[src + j];
+      sj_val[off + lane] = val[src + j];
+    }
+    off += cnt;
+  }
+}
+
+// a slice's first SJ_U1 levels in registers (the whole slice for all but a few slices of a matrix this layout accepts)
+struct SjBatch {
+  int c[SJ_U1];
+  double v[SJ_U1];
+};
+// level j of the slice for this lane: (col, val) at off + lane when the lane's row has more than j entries; `off` moves on
+// by the number of such lanes.  Lb: levels of the slice (uniform): the branch skips levels no lane has.
+__device__ __forceinline__ void sj_load_first(const SjView &J, int &off, int l, int Lb, int lane, SjBatch &B) {
+#pragma unroll
+  for (int jj = 0; jj < SJ_U1; ++jj) {
+    B.c[jj] = 0;
+    B.v[jj] = 0.0;
+    if (jj < Lb) {                                        // wave-uniform
+      const bool act = jj < l;
+      const int k = off + lane;
+      off += __popcll(__ballot(act));
+      if (act) {
+        B.c[jj] = __builtin_nontemporal_load(J.col + k);
+        B.v[jj] = __builtin_nontemporal_load(J.val + k);
+      }
+    }
+  }
+}
+
+// Software pipeline over the workgroup's trips: while trip i gathers and adds, trip i + 1's first SJ_U1 levels and
+// epilogue operands and trip i + 2's slot words are in flight, so a trip costs one gather round trip (L2) and a
+// workgroup barrier instead of five dependent memory round trips (slot words -> entries -> gathers -> operands -> store:
+// 0.82 ms on banded 10M, the CSR kernel's time, against 0.69 with one trip of look-ahead).
+template <int MODE, bool INIT = false, int TAG = 0>
+__global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__restrict__ xin, int remap, int stream_slots, EpiArgs e) {
+  static_assert(SJ_SIGMA == TPB, "one sorting group per workgroup trip");
+  __shared__ double red[6][TPB / WAVE];
+  __shared__ double row_sum[2][TPB];
+  __shared__ int row_ok[2][TPB];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  Acc3 acc3 = acc3_zero();
+  const int ngroups = (J.nslices + TPB / WAVE - 1) / (TPB / WAVE);
+  const int per_xcd = (ngroups + NUM_XCD - 1) / NUM_XCD;
+  // remap: workgroup b runs on XCD b % 8 (round-robin dispatch); it walks groups x * per_xcd + i, i = b / 8, b / 8 + gridDim / 8, ...
+  const int first = remap ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int stride = remap ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int limit = remap ? per_xcd : ngroups;
+  const int xbase = remap ? (int)(blockIdx.x & (NUM_XCD - 1)) * per_xcd : 0;
+  row_ok[0][tid] = 0;
+  row_ok[1][tid] = 0;
+  __syncthreads();
+  // group of trip i: xbase + i (none when past the end: the XCD's last eighth can be short)
+  auto group_of = [&](int i) { const int g = xbase + i; return (i < limit && g < ngroups) ? g : -1; };
+  // ---- requested TWO trips ahead: the slot words and the slice offset (what the entry addresses depend on);
+  //      ONE trip ahead: the slice's first SJ_U1 levels, the epilogue operands, the carried row sums (INIT)
+  unsigned w_n = (SJ_NONE << 16), w_nn = (SJ_NONE << 16);
+  int off_n = 0, off_nn = 0, Lb_n = 0;
+  EpiOps ops_n{0.0, 0.0, 0.0};
+  double init_n = 0.0;
+  SjBatch B_n;
+  auto request_meta = [&](int g, unsigned &w, int &off) {
+    w = (SJ_NONE << 16);
+    off = 0;
+    const int slice = g * (TPB / WAVE) + wave;
+    if (g >= 0 && slice < J.nslices) {                    // wave-uniform
+      w = J.meta[slice * WAVE + lane];
+      off = J.slice_off[slice];
+    }
+  };
+  // the entries, operands and carried sums of group g, whose slot words (w_n, off_n) have arrived
+  auto request_rest = [&](int g) {
+    const int row = g * SJ_SIGMA + tid;
+    if (g >= 0 && row < J.rows) ops_n = epi_load<MODE>(e, row);
+    const int l = (int)(w_n & 0xFFFFu);
+    if (INIT) {
+      const int r = (w_n >> 16) == SJ_NONE ? -1 : g * SJ_SIGMA + (int)(w_n >> 16);
+      init_n = r >= 0 ? e.init[r] : 0.0;
+    }
+    Lb_n = __builtin_amdgcn_readfirstlane(l);             // lane 0 holds the slice's longest row
+    sj_load_first(J, off_n, l, Lb_n < SJ_U1 ? Lb_n : SJ_U1, lane, B_n);
+  };
+  int g = group_of(first), g_next = group_of(first + stride);
+  request_meta(g, w_n, off_n);
+  request_meta(g_next, w_nn, off_nn);
+  request_rest(g);
+  int buf = 0;
+  for (int i = first; g >= 0; i += stride) {
+    // trip i's operands out of the "next" registers
+    const unsigned w = w_n;
+    int off = off_n;
+    const int L = Lb_n;
+    const EpiOps ops = ops_n;
+    const int l = (int)(w & 0xFFFFu);
+    const int rl = (w >> 16) == SJ_NONE ? -1 : (int)(w >> 16);
+    const int base = g * SJ_SIGMA;
+    double s = INIT ? init_n : 0.0;
+    double xv[SJ_U1];
+#pragma unroll
+    for (int jj = 0; jj < SJ_U1; ++jj) {
+      xv[jj] = 0.0;
+      if (jj < L) xv[jj] = (jj < l) ? xin[B_n.c[jj]] : 0.0;        // (uniform branch: levels no lane of the slice has)
+    }
+    double vv[SJ_U1];
+#pragma unroll
+    for (int jj = 0; jj < SJ_U1; ++jj) vv[jj] = B_n.v[jj];
+    // behind this trip's gathers: trip i + 1's entries and operands (its slot words came in a trip ago), trip i + 2's slot words
+    w_n = w_nn;
+    off_n = off_nn;
+    const int g_next2 = group_of(i + 2 * stride);
+    request_meta(g_next2, w_nn, off_nn);
+    request_rest(g_next);
+#pragma unroll
+    for (int jj = 0; jj < SJ_U1; ++jj) {
+      if (jj < l) {
+        const double p = vv[jj] * xv[jj];
+        s = s + p;
+      }
+    }
+    for (int j0 = SJ_U1; j0 < L; j0 += SJ_U) {            // rows beyond the first batch (rare by construction)
+      int c[SJ_U];
+      double v[SJ_U], x2[SJ_U];
+#pragma unroll
+      for (int jj = 0; jj < SJ_U; ++jj) {
+        const bool act = j0 + jj < l;
+        const int k = off + lane;
+        off += __popcll(__ballot(act));
+        c[jj] = act ? __builtin_nontemporal_load(J.col + k) : 0;
+        v[jj] = act ? __builtin_nontemporal_load(J.val + k) : 0.0;
+      }
+#pragma unroll
+      for (int jj = 0; jj < SJ_U; ++jj) x2[jj] = (j0 + jj < l) ? xin[c[jj]] : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < SJ_U; ++jj) {
+        if (j0 + jj < l) {
+          const double p = v[jj] * x2[jj];
+          s = s + p;
+        }
+      }
+    }
+    if (rl >= 0) {
+      row_sum[buf][rl] = s;
+      row_ok[buf][rl] = 1;
+    }
+    __syncthreads();
+    // thread t: the epilogue of row base + t, operands in row order (this buffer is next written two trips from now,
+    // behind the next trip's barrier)
+    if (row_ok[buf][tid]) {
+      row_ok[buf][tid] = 0;
+      epi_apply<MODE>(e, base + tid, row_sum[buf][tid], ops, acc3);
+    }
+    buf ^= 1;
+    g = g_next;
+    g_next = g_next2;
+  }
+  constexpr int NQ = ModeNQ<MODE>::value;
+  if (NQ > 0) {
+    block_sum_dd<NQ, TPB>(acc3, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        e.partials[q * e.stride + blockIdx.x] = acc3.hi[q];
+        e.partials[e.lo_offset + q * e.stride + blockIdx.x] = acc3.lo[q];
+      }
+    }
+    // the slots of the CSR kernel's row blocks this launch does not use: the reductions add them
+    for (int sl = (int)gridDim.x + (int)blockIdx.x * TPB + (int)threadIdx.x; sl < stream_slots; sl += (int)gridDim.x * TPB) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        e.partials[q * e.stride + sl] = 0.0;
+        e.partials[e.lo_offset + q * e.stride + sl] = 0.0;
+      }
+    }
+  }
+}
+
+}  // namespace

@@ -41,28 +41,42 @@ struct EpiArgs {
   double avg_w;
 };
 
-// (dev, -DPDHG_WT_STORES: the vectors of a multi-trial kernel are stored write-through, so that the grid barrier's L2
-//  write-back finds their lines clean)
 template <bool COH>
 __device__ __forceinline__ void stc(double *p, double v) {
-#ifdef PDHG_WT_STORES
-  if (COH) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-#endif
   *p = v;
 }
+// The operands a row's epilogue reads, apart from the row sum: loaded by epi_load, consumed by epi_apply, so that a
+// kernel can request them long before the sum exists (sj_kernels.hpp).  row_epilogue is the two back to back: one
+// definition of the arithmetic for every product kernel.
+struct EpiOps {
+  double a, b, c;
+};
 template <int MODE, bool COH = false>
-__device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
-                                             Acc3 &acc) {
+__device__ __forceinline__ EpiOps epi_load(const EpiArgs &e, int r) {
+  EpiOps o{0.0, 0.0, 0.0};
+  if (MODE == MODE_DUAL) {
+    o.a = ldc<COH>(e.y + r);
+    o.b = e.b[r];
+    if (e.sum_y) o.c = ldc<COH>(e.sum_y + r);
+  } else if (MODE == MODE_ATY) {
+    o.a = ldc<COH>(e.x_next + r);
+    o.b = ldc<COH>(e.x + r);
+    o.c = ldc<COH>(e.aty + r);
+  }
+  return o;
+}
+template <int MODE, bool COH = false>
+__device__ __forceinline__ void epi_apply(const EpiArgs &e, int r, double s, const EpiOps &o, Acc3 &acc) {
   if (MODE == MODE_PLAIN) {
     e.out[r] = s;
   } else if (MODE == MODE_DUAL) {
     // compute_dual_gradient: b .- A*x              saddle_point.jl:1102-1107
-    const double yo = ldc<COH>(e.y + r);
+    const double yo = o.a;
     if (e.sum_y) {
       const double t = yo * e.avg_w;
-      stc<COH>(e.sum_y + r, ldc<COH>(e.sum_y + r) + t);
+      stc<COH>(e.sum_y + r, o.c + t);
     }
-    const double dg = e.b[r] - s;
+    const double dg = o.b - s;
     // next_dual = y .+ (pw*step) .* dual_gradient   pdhg.jl:489-490
     const double t = e.sigma * dg;
     double yn = yo + t;
@@ -74,12 +88,17 @@ __device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
   } else {
     // next_dual_product = A' * next_dual            pdhg.jl:492
     stc<COH>(e.aty_next + r, s);
-    const double dx = ldc<COH>(e.x_next + r) - ldc<COH>(e.x + r);   // pdhg.jl:534
-    const double dd = s - ldc<COH>(e.aty + r);                     // pdhg.jl:543
+    const double dx = o.a - o.b;                     // pdhg.jl:534
+    const double dd = s - o.c;                       // pdhg.jl:543
     dd_add(acc.hi[0], acc.lo[0], dx * dd);
     dd_add(acc.hi[1], acc.lo[1], dx * dx);
     dd_add(acc.hi[2], acc.lo[2], dd * dd);
   }
+}
+template <int MODE, bool COH = false>
+__device__ __forceinline__ void row_epilogue(const EpiArgs &e, int r, double s,
+                                             Acc3 &acc) {
+  epi_apply<MODE, COH>(e, r, s, epi_load<MODE, COH>(e, r), acc);
 }
 
 template <int MODE>

@@ -61,16 +61,6 @@ __device__ __forceinline__ void primal_body(
     double2 xn, xb;
     primal_one<HAS_Q, WRITE_XBAR>(xv.x, cv.x, av.x, qv.x, lv.x, uv.x, tau, theta, xn.x, xb.x);
     primal_one<HAS_Q, WRITE_XBAR>(xv.y, cv.y, av.y, qv.y, lv.y, uv.y, tau, theta, xn.y, xb.y);
-#ifdef PDHG_WT_STORES
-    if (COH) {       // dev: write-through stores -- the grid barrier's L2 write-back then finds these lines clean
-      __hip_atomic_store(x_next + 2 * p, xn.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(x_next + 2 * p + 1, xn.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (WRITE_XBAR) {
-        __hip_atomic_store(xbar + 2 * p, xb.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(xbar + 2 * p + 1, xb.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    } else
-#endif
     {
       reinterpret_cast<double2 *>(x_next)[p] = xn;
       if (WRITE_XBAR) reinterpret_cast<double2 *>(xbar)[p] = xb;

@@ -410,6 +410,9 @@ class HipPdhgEngine:
                 "A_tiled_waves", "At_tiled_waves", "A_tile_cols", "At_tile_cols",
                 "A_slabs", "At_slabs", "trial_graph", "var_tiles"]   # var_tiles: bit 0 = A, bit 1 = A'
         out = dict(zip(keys, info.tolist()))
+        for k in ("A", "At"):    # the product kernels run on the sliced jagged layout (csrc/sj_kernels.hpp)
+            out[k + "_sj"] = (out[k + "_slabs"] >> 8) & 1
+            out[k + "_slabs"] &= 255
         out["small_lp"] = (out["var_tiles"] >> 2) & 1      # batches of take_steps run in the one-workgroup LDS kernel
         out["device_loop"] = (out["var_tiles"] >> 3) & 1   # ... in the multi-step persistent kernel (small grids)
         out["steps_local"] = (out["var_tiles"] >> 4) & 1   # ... whose workgroups all sit on one XCD (<= 32 row blocks + chunks per product)

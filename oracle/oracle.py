@@ -279,6 +279,10 @@ def omp_lib():
         _omp.omp_take_step_adaptive.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
         _omp.omp_destroy.argtypes = [ctypes.c_void_p]
         _omp.omp_get_xy.argtypes = [ctypes.c_void_p, _c_double_p, _c_double_p]
+        _omp.omp_set_prefetch.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _omp.omp_index_bytes.argtypes = [ctypes.c_void_p]
+        _omp.omp_bytes_per_trial.argtypes = [ctypes.c_void_p]
+        _omp.omp_bytes_per_trial.restype = ctypes.c_double
     return _omp
 
 
@@ -300,6 +304,17 @@ class OmpCpuState:
 
     def threads(self):
         return int(self._L.omp_threads())
+
+    def set_prefetch(self, entries_ahead):
+        self._L.omp_set_prefetch(self._h, int(entries_ahead))
+
+    def index_bytes(self):
+        return int(self._L.omp_index_bytes(self._h))
+
+    def bytes_per_trial(self):
+        """Bytes one trial streams at the least (both matrix copies once + SURVEY 8d's vector traffic)."""
+        self._L.omp_bytes_per_trial.restype = ctypes.c_double
+        return float(self._L.omp_bytes_per_trial(self._h))
 
     def set_scalars(self, step_size, primal_weight):
         self._L.omp_set_scalars(self._h, step_size, primal_weight)

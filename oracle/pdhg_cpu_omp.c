@@ -20,9 +20,16 @@
 #include <string.h>
 
 typedef struct {
-  int64_t m, n, ne;
+  int64_t m, n, ne, nnz;
   int64_t *rp, *ci; double *va;      /* CSR(A)  */
   int64_t *cp, *ri; double *vt;      /* CSR(A') */
+  /* round 5: what a tuned socket code would do (the GPU side has had both since round 1) --
+   * 32-bit column / row indices when m, n, nnz < 2^31 (12 instead of 16 bytes streamed per nonzero; the 64-bit index
+   * arrays are then freed), and one contiguous row range per thread cut at equal NONZEROS (not equal row counts), with
+   * every array first-touched by the thread that will stream it; gathers are software-prefetched PF entries ahead. */
+  int idx32, nthreads, pf;
+  int32_t *ci32, *ri32;
+  int64_t *cutA, *cutT;              /* [nthreads+1] row cuts of CSR(A) / CSR(A') */
   double *c, *b, *lb, *ub;
   double *x, *y, *aty, *xn, *yn, *atyn, *xbar, *sx, *sy;
   double step_size, primal_weight;
@@ -69,12 +76,45 @@ static int64_t *cpi(const int64_t *s, int64_t k) {
   return p;
 }
 
+/* gathers can be software-prefetched `pf` entries ahead (a random 8-byte read per nonzero is what bounds the CPU too);
+ * default off (PDHG_CPU_PF, omp_set_prefetch): bench.py times both and reports the faster */
+static int pf_distance(void) { const char *e = getenv("PDHG_CPU_PF"); return e ? atoi(e) : 0; }
+
+/* row cuts at equal nonzeros: cut[t] = first row r with ptr[r] >= nnz*t/T */
+static int64_t *nnz_cuts(const int64_t *ptr, int64_t rows, int T) {
+  int64_t *cut = (int64_t *)malloc(sizeof(int64_t) * (size_t)(T + 1));
+  const int64_t nnz = ptr[rows];
+  cut[0] = 0;
+  for (int t = 1; t < T; ++t) {
+    const int64_t target = (int64_t)((__int128)nnz * t / T);
+    int64_t lo = cut[t - 1], hi = rows;
+    while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (ptr[mid] < target) lo = mid + 1; else hi = mid; }
+    cut[t] = lo;
+  }
+  cut[T] = rows;
+  return cut;
+}
+
+/* the arrays of one CSR re-allocated so that thread t first-touches (and later streams) the entries of ITS row range */
+static void place_by_cuts(const int64_t *ptr, const int64_t *cut, int T, int64_t nnz, const int64_t *idx, const double *val,
+                          int32_t **idx32_out, double **val_out) {
+  int32_t *i32 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+  double *v = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+#pragma omp parallel num_threads(T)
+  {
+    const int t = omp_get_thread_num();
+    for (int64_t k = ptr[cut[t]]; k < ptr[cut[t + 1]]; ++k) { i32[k] = (int32_t)idx[k]; v[k] = val[k]; }
+  }
+  *idx32_out = i32;
+  *val_out = v;
+}
+
 omp_state *omp_create(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval,
                       const double *nzval, const double *c, const double *b, const double *lb,
                       const double *ub, int64_t ne) {
   omp_state *s = (omp_state *)calloc(1, sizeof(omp_state));
   const int64_t nnz = colptr[n];
-  s->m = m; s->n = n; s->ne = ne;
+  s->m = m; s->n = n; s->ne = ne; s->nnz = nnz;
   s->cp = cpi(colptr, n + 1);
   s->ri = cpi(rowval, nnz);
   s->vt = cpd(nzval, nnz);
@@ -92,12 +132,26 @@ omp_state *omp_create(int64_t m, int64_t n, const int64_t *colptr, const int64_t
   s->x = zd(n); s->y = zd(m); s->aty = zd(n); s->xn = zd(n); s->yn = zd(m); s->atyn = zd(n);
   s->xbar = zd(n); s->sx = zd(n); s->sy = zd(m);
   s->primal_weight = 1.0;
+  s->nthreads = g_threads > 0 ? g_threads : omp_get_max_threads();
+  s->pf = pf_distance();
+  s->cutA = nnz_cuts(s->rp, m, s->nthreads);
+  s->cutT = nnz_cuts(s->cp, n, s->nthreads);
+  const char *force64 = getenv("PDHG_CPU_IDX64");
+  s->idx32 = m < INT32_MAX && n < INT32_MAX && nnz < INT32_MAX && !(force64 && force64[0] == '1');
+  if (s->idx32) {
+    double *v;
+    place_by_cuts(s->rp, s->cutA, s->nthreads, nnz, s->ci, s->va, &s->ci32, &v);
+    free(s->ci); free(s->va); s->ci = NULL; s->va = v;
+    place_by_cuts(s->cp, s->cutT, s->nthreads, nnz, s->ri, s->vt, &s->ri32, &v);
+    free(s->ri); free(s->vt); s->ri = NULL; s->vt = v;
+  }
   return s;
 }
 
 void omp_destroy(omp_state *s) {
   if (!s) return;
   free(s->rp); free(s->ci); free(s->va); free(s->cp); free(s->ri); free(s->vt);
+  free(s->ci32); free(s->ri32); free(s->cutA); free(s->cutT);
   free(s->c); free(s->b); free(s->lb); free(s->ub); free(s->x); free(s->y); free(s->aty);
   free(s->xn); free(s->yn); free(s->atyn); free(s->xbar); free(s->sx); free(s->sy); free(s);
 }
@@ -106,6 +160,30 @@ void omp_set_scalars(omp_state *s, double step, double pw) { s->step_size = step
 double omp_get_step_size(const omp_state *s) { return s->step_size; }
 int64_t omp_get_total_iterations(const omp_state *s) { return s->total_iterations; }
 int omp_threads(void) { return g_threads > 0 ? g_threads : omp_get_max_threads(); }
+void omp_set_prefetch(omp_state *s, int entries_ahead) { s->pf = entries_ahead > 0 ? entries_ahead : 0; }
+int omp_index_bytes(const omp_state *s) { return s->idx32 ? 4 : 8; }
+/* bytes one trial streams at the least: both matrix copies once, the vectors of SURVEY 8d's B_vec */
+double omp_bytes_per_trial(const omp_state *s) {
+  const double ib = s->idx32 ? 4.0 : 8.0;
+  return 2.0 * (double)s->nnz * (8.0 + ib) + 8.0 * (double)(s->m + s->n + 2) + 8.0 * (13.0 * (double)s->n + 6.0 * (double)s->m);
+}
+
+
+/* rows [i0, i1) of a CSR with 32-bit indices: out-of-line so that the two tight loops are compiled on their own */
+static inline double row_dot32(const double *restrict val, const int32_t *restrict idx, const double *restrict x, int64_t k0, int64_t k1) {
+  double acc = 0.0;
+  for (int64_t k = k0; k < k1; ++k) { const double p = val[k] * x[idx[k]]; acc = acc + p; }
+  return acc;
+}
+static inline double row_dot32_pf(const double *restrict val, const int32_t *restrict idx, const double *restrict x, int64_t k0, int64_t k1,
+                                  int pf) {
+  double acc = 0.0;
+  for (int64_t k = k0; k < k1; ++k) {
+    __builtin_prefetch(&x[idx[k + pf]], 0, 0);
+    const double p = val[k] * x[idx[k]]; acc = acc + p;
+  }
+  return acc;
+}
 
 static inline double dmax(double a, double b) { return a > b ? a : b; }
 static inline double dmin(double a, double b) { return a < b ? a : b; }
@@ -116,11 +194,12 @@ int omp_take_step_adaptive(omp_state *s, double red_exp, double grow_exp) {
   const double pw = s->primal_weight;
   int done = 0, iter = 0;
   const int64_t n = s->n, m = s->m, ne = s->ne;
+  const int pf = s->pf;
   while (!done) {
     ++iter; s->total_iterations += 1;
     const double tau = step / pw, sigma = pw * step;
     double dx2 = 0.0, dy2 = 0.0, inter = 0.0;
-#pragma omp parallel
+#pragma omp parallel num_threads(s->nthreads)
     {
 #pragma omp for schedule(static) reduction(+ : dx2)
       for (int64_t j = 0; j < n; ++j) {                       /* pdhg.jl:442-470, 486-487 */
@@ -133,25 +212,46 @@ int omp_take_step_adaptive(omp_state *s, double red_exp, double grow_exp) {
         s->xbar[j] = v + 1.0 * d;
         dx2 += d * d;
       }
-#pragma omp for schedule(static) reduction(+ : dy2)
-      for (int64_t i = 0; i < m; ++i) {                       /* pdhg.jl:472-494 */
+#pragma omp barrier
+      const int tid_ = omp_get_thread_num();
+      const int64_t iA0 = s->idx32 ? s->cutA[tid_] : (m * tid_) / s->nthreads, iA1 = s->idx32 ? s->cutA[tid_ + 1] : (m * (tid_ + 1)) / s->nthreads;
+      double dy2_t = 0.0;
+      for (int64_t i = iA0; i < iA1; ++i) {                   /* pdhg.jl:472-494 */
         double acc = 0.0;
-        for (int64_t k = s->rp[i]; k < s->rp[i + 1]; ++k) { const double p = s->va[k] * s->xbar[s->ci[k]]; acc = acc + p; }
+        if (s->idx32) {
+          const int64_t ke = s->rp[i + 1];
+          acc = (pf > 0 && ke + pf <= s->nnz) ? row_dot32_pf(s->va, s->ci32, s->xbar, s->rp[i], ke, pf)
+                                              : row_dot32(s->va, s->ci32, s->xbar, s->rp[i], ke);
+        } else {
+          for (int64_t k = s->rp[i]; k < s->rp[i + 1]; ++k) { const double p = s->va[k] * s->xbar[s->ci[k]]; acc = acc + p; }
+        }
         const double dg = s->b[i] - acc;
         const double t = sigma * dg;
         double yn = s->y[i] + t;
         if (i >= ne) yn = dmax(yn, 0.0);
         s->yn[i] = yn;
         const double d = yn - s->y[i];
-        dy2 += d * d;
+        dy2_t += d * d;
       }
-#pragma omp for schedule(static) reduction(+ : inter)
-      for (int64_t j = 0; j < n; ++j) {                       /* pdhg.jl:492, 527-549 */
+#pragma omp atomic
+      dy2 += dy2_t;
+#pragma omp barrier
+      const int64_t jT0 = s->idx32 ? s->cutT[tid_] : (n * tid_) / s->nthreads, jT1 = s->idx32 ? s->cutT[tid_ + 1] : (n * (tid_ + 1)) / s->nthreads;
+      double inter_t = 0.0;
+      for (int64_t j = jT0; j < jT1; ++j) {                   /* pdhg.jl:492, 527-549 */
         double acc = 0.0;
-        for (int64_t k = s->cp[j]; k < s->cp[j + 1]; ++k) { const double p = s->vt[k] * s->yn[s->ri[k]]; acc = acc + p; }
+        if (s->idx32) {
+          const int64_t ke = s->cp[j + 1];
+          acc = (pf > 0 && ke + pf <= s->nnz) ? row_dot32_pf(s->vt, s->ri32, s->yn, s->cp[j], ke, pf)
+                                              : row_dot32(s->vt, s->ri32, s->yn, s->cp[j], ke);
+        } else {
+          for (int64_t k = s->cp[j]; k < s->cp[j + 1]; ++k) { const double p = s->vt[k] * s->yn[s->ri[k]]; acc = acc + p; }
+        }
         s->atyn[j] = acc;
-        inter += (s->xn[j] - s->x[j]) * (acc - s->aty[j]);
+        inter_t += (s->xn[j] - s->x[j]) * (acc - s->aty[j]);
       }
+#pragma omp atomic
+      inter += inter_t;
     }
     const double interaction = fabs(inter);
     const double nx = sqrt(dx2), ny = sqrt(dy2);

@@ -1,0 +1,153 @@
+"""The sliced jagged layout of the stream class (csrc/sj_kernels.hpp): rows sorted by length inside 2 048-row windows,
+64 rows per wave stored level-major, every lane adding ITS row's products strictly left to right in a register.
+
+* every row of at most 2 048 entries is BIT-IDENTICAL to the oracle's sequential loops (saddle_point.jl:1102-1107,
+  pdhg.jl:492) -- in this layout also in the shipped relaxed row order, which only concerns the CSR row blocks;
+* trajectories (accept / reject decisions, iterates, averages) equal the CSR row-block layout's: bitwise in strict order
+  (both add every row left to right; the step sums are exactly rounded double-double sums), with plain launches and as
+  a HIP graph;
+* long rows (> 2 048 entries) stay with the long-row kernels, empty rows and a ragged last window are covered;
+* column-slab passes (INIT carry) on the sliced jagged copies of the slabs;
+* the builder picks the layout by itself for stream-class matrices with more than 1 024 row blocks."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from firstorderlp_jl_amd import HipPdhgEngine, linear_programming_problem
+from firstorderlp_jl_amd.generators import pagerank_lp, random_lp
+from firstorderlp_jl_amd.primal_dual_hybrid_gradient import AdaptiveStepsizeParams, PdhgSolverState, take_step
+from oracle import oracle as orc
+from tests import helpers as H
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+
+def _ragged_lp(m, n, seed):
+    """Row lengths from 0 to ~1 500 in no order, two rows and two columns beyond 2 048 entries, empty rows and columns."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum(rng.geometric(0.08, m), 1500)
+    lens[rng.random(m) < 0.05] = 0
+    lens[rng.integers(0, m, 40)] = rng.integers(300, 1500, 40)
+    rows = np.repeat(np.arange(m), lens)
+    cols = rng.integers(0, n - 50, rows.size)            # the last 50 columns stay empty
+    A = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(m, n)).tolil()
+    for r in (3, m - 2):
+        A[r, :n - 50] = rng.standard_normal(n - 50)
+    for c in (1, n - 60):
+        A[:, c] = rng.standard_normal((m, 1))
+    A = A.tocsc()
+    A.sum_duplicates()
+    A.sort_indices()
+    return linear_programming_problem(np.zeros(n), np.full(n, 5.0), rng.standard_normal(n), 0.0, A, rng.standard_normal(m), m // 3)
+
+
+def _engine(p, monkeypatch, sj, graph="1", slab_mb=None):
+    monkeypatch.setenv("PDHG_SPMV", "stream")
+    monkeypatch.setenv("PDHG_COOP", "0")                 # the products as their own kernels (graph nodes or plain launches)
+    monkeypatch.setenv("PDHG_GRAPH", graph)
+    monkeypatch.setenv("PDHG_SJ", sj)
+    if slab_mb is None:
+        monkeypatch.setenv("PDHG_SLABS", "0")
+    else:
+        monkeypatch.setenv("PDHG_SLABS", "1")
+        monkeypatch.setenv("PDHG_SLAB_MB", str(slab_mb))
+    return HipPdhgEngine.from_problem(p)
+
+
+def _run(e, p, steps=40):
+    step, pw = H.initial_step_and_weight(p)
+    st = PdhgSolverState(e, step_size=step, primal_weight=pw)
+    for _ in range(steps):
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+    return (*e.get_current(), *e.get_average(), e.get_dual_product(), st.step_size, st.total_number_iterations)
+
+
+@pytest.mark.parametrize("maker", [lambda: random_lp(30_000, 20_000, 6, seed=21), lambda: _ragged_lp(5_000, 7_001, seed=2),
+                                   lambda: H.skewed_lp(3_000, 9_000, seed=7, dense_rows=2, dense_cols=2),
+                                   lambda: random_lp(70, 50, 3, seed=1)],
+                         ids=["random", "ragged", "skewed_long_rows", "tiny"])
+def test_products_are_bit_identical_to_the_oracle_in_every_row_order(gpu_required, monkeypatch, maker):
+    p = maker()
+    A = p.constraint_matrix
+    m, n = A.shape
+    eng = _engine(p, monkeypatch, "1")
+    info = eng.layout_info()
+    assert info["A_sj"] == 1 and info["At_sj"] == 1, info
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    absA = abs(A).tocsr()
+    for got, want, nnz_per, scale in ((eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x), np.diff(A.tocsr().indptr), absA @ np.abs(x)),
+                                      (eng.spmv_t(y), orc.spmv_t(m, n, A.indptr, A.indices, A.data, y), np.diff(A.indptr), absA.T @ np.abs(y))):
+        short = nnz_per <= 2048                           # every row of the layout, whatever PDHG_ROW_ORDER says
+        assert np.array_equal(got[short], want[short])
+        assert np.all(np.abs(got - want) <= 1e-13 * scale + 1e-300)      # the long-row kernels
+    # the fused products: one trial against the oracle's trial
+    st = H.oracle_from_problem(p)
+    step, pw = H.initial_step_and_weight(p)
+    raw = eng.trial_step(step, pw, 1.0)
+    raw_o, xn, yn, an = st.trial_step(step, pw, 1.0)
+    gx, gy, ga = eng.get_trial()
+    assert np.array_equal(gx, xn)
+    short_r, short_c = np.diff(A.tocsr().indptr) <= 2048, np.diff(A.indptr) <= 2048
+    assert np.array_equal(gy[short_r], yn[short_r]) and np.allclose(gy, yn, rtol=1e-12, atol=1e-12)
+    if short_r.all():
+        assert np.array_equal(ga[short_c], an[short_c])
+    assert np.allclose(raw[:4], raw_o[:4], rtol=1e-11, atol=1e-300)
+    st.close()
+
+
+@pytest.mark.parametrize("maker", [lambda: random_lp(30_000, 20_000, 6, seed=21), lambda: _ragged_lp(5_000, 7_001, seed=2)],
+                         ids=["random", "ragged"])
+def test_trajectories_equal_the_csr_row_block_layout(gpu_required, monkeypatch, row_order_mode, maker):
+    p = maker()
+    r_sj = _run(_engine(p, monkeypatch, "1"), p)
+    r_sj_plain = _run(_engine(p, monkeypatch, "1", graph="0"), p)
+    r_csr = _run(_engine(p, monkeypatch, "0"), p)
+    for a, b, c in zip(r_sj, r_sj_plain, r_csr):
+        assert np.array_equal(a, b)                       # graph nodes vs plain launches
+        if row_order_mode == "strict" or np.diff(p.constraint_matrix.indptr).max() <= 256:
+            assert np.array_equal(a, c)                   # both layouts add every row left to right
+        else:
+            np.testing.assert_allclose(a, c, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("maker,slab_mb", [(lambda: random_lp(200_000, 150_000, 8, seed=3), 0.5),
+                                           (lambda: pagerank_lp(120_000, seed=4), 0.3)], ids=["random", "pagerank"])
+def test_slab_passes_on_the_sliced_jagged_copies(gpu_required, monkeypatch, row_order_mode, maker, slab_mb):
+    p = maker()
+    A = p.constraint_matrix
+    m, n = A.shape
+    eng = _engine(p, monkeypatch, "1", slab_mb=slab_mb)
+    info = eng.layout_info()
+    assert 2 <= info["A_slabs"] <= 4 and 2 <= info["At_slabs"] <= 4 and info["A_sj"] == 1 and info["At_sj"] == 1, info
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    ref, ref_t = orc.spmv(m, n, A.indptr, A.indices, A.data, x), orc.spmv_t(m, n, A.indptr, A.indices, A.data, y)
+    got, got_t = eng.spmv(x), eng.spmv_t(y)
+    short, short_t = np.diff(A.tocsr().indptr) <= 2048, np.diff(A.indptr) <= 2048
+    assert np.array_equal(got[short], ref[short]) and np.array_equal(got_t[short_t], ref_t[short_t])
+    r_sj = _run(eng, p)
+    r_csr = _run(_engine(p, monkeypatch, "0", slab_mb=slab_mb), p)
+    for a, c in zip(r_sj, r_csr):
+        if row_order_mode == "strict":
+            assert np.array_equal(a, c)
+        else:
+            np.testing.assert_allclose(a, c, rtol=1e-9, atol=1e-9)
+
+
+def test_the_builder_picks_the_layout_for_bandwidth_bound_stream_matrices(gpu_required, monkeypatch):
+    """banded 1.5M x 1.5M, 8 per row: > 1 024 row blocks, rows that do not scatter -> stream class -> sliced jagged."""
+    monkeypatch.delenv("PDHG_SJ", raising=False)
+    m = n = 1_500_000
+    rng = np.random.default_rng(6)
+    cols = np.clip(np.repeat(np.arange(m), 8) + rng.integers(-20_000, 20_001, m * 8), 0, n - 1)
+    M = sp.csr_matrix((rng.standard_normal(m * 8), (np.repeat(np.arange(m), 8), cols)), shape=(m, n))
+    M.sum_duplicates()
+    p = linear_programming_problem(np.zeros(n), np.full(n, 10.0), rng.standard_normal(n), 0.0, M.tocsc(), rng.standard_normal(m), m // 2)
+    eng = HipPdhgEngine.from_problem(p)
+    info = eng.layout_info()
+    assert info["A_tiled_waves"] == 0 and info["A_blocks"] > 1024 and info["A_sj"] == 1 and info["At_sj"] == 1, info
+    assert "spmv_sj_kernel" in eng.kernel_name(1) and "spmv_sj_kernel" in eng.kernel_name(2)
+    H.assert_products_match_oracle(eng, p.constraint_matrix, rng.standard_normal(n), rng.standard_normal(m), label="banded")
+    small = HipPdhgEngine.from_problem(random_lp(5000, 4000, 8, seed=7)).layout_info()
+    assert small["A_sj"] == 0 and small["At_sj"] == 0

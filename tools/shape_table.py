@@ -36,7 +36,25 @@ SHAPES = [
 
 
 def make_shape(kind, m=10_000_000, n=10_000_000, k=10, band=0):
-    """The structured test matrices of tools/tune_tiled.py (same seeds) as LP problems."""
+    """The structured test matrices of tools/tune_tiled.py (same seeds) as LP problems.
+    SHAPE_CACHE_DIR: keep the generated problems there (pickle) -- the counter passes of tools/pmc_stream.sh run the same
+    shape many times and a 100M-nonzero matrix takes a minute to generate."""
+    import pickle
+    cache = os.environ.get("SHAPE_CACHE_DIR")
+    path = os.path.join(cache, f"shape_{kind}_{m}_{n}_{k}_{band}.pkl") if cache else None
+    if path and os.path.exists(path):
+        with open(path, "rb") as fh:
+            return pickle.load(fh)
+    p = _make_shape(kind, m, n, k, band)
+    if path:
+        os.makedirs(cache, exist_ok=True)
+        with open(path + ".tmp", "wb") as fh:
+            pickle.dump(p, fh, protocol=pickle.HIGHEST_PROTOCOL)
+        os.replace(path + ".tmp", path)
+    return p
+
+
+def _make_shape(kind, m, n, k, band):
     import scipy.sparse as sp
     from firstorderlp_jl_amd import linear_programming_problem
     from firstorderlp_jl_amd.generators import l1_svm_rcv1_like_lp, pagerank_lp, random_lp

@@ -81,8 +81,12 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--nnz-per-row", type=int, default=10)
     args = ap.parse_args()
-    from tools.shape_table import make_shape, product_ms
-    p = make_shape(args.shape, args.n, args.nnz_per_row)
+    from tools.shape_table import SHAPES, make_shape, product_ms
+    named = {"banded50k": ("banded", dict(band=50_000)), "blockdiag": ("blockdiag", {}), "configS": ("random", {})}
+    if args.shape in named:
+        p = make_shape(named[args.shape][0], **named[args.shape][1])
+    else:
+        p = make_shape(args.shape, m=args.n, n=args.n, k=args.nnz_per_row)
     A = p.constraint_matrix.tocsr()
     print(f"{args.shape} {A.shape} nnz={A.nnz}")
     print("  vendor A x  :", time_csr(A))
