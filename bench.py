@@ -90,6 +90,7 @@ def parse():
                     help="do not run the short child runs under rocprofv3 (kernel trace + two --pmc passes) that fill "
                          "roofline.kernel_ms_rocprof / roofline.traffic from THIS run (tools/selfprof.py); the committed "
                          "files under profiles/ are quoted instead")
+    ap.add_argument("--no-vendor", action="store_true", help="skip the rocSPARSE comparator (roofline.vendor_spmv_ms)")
     ap.add_argument("--no-ceiling", action="store_true",
                     help="skip the sweep-pattern probe behind roofline.ceiling_frac (pdhg_measure_sweep_ceiling)")
     return ap.parse_args()
@@ -360,6 +361,24 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
             roofline["ceiling_frac_all_hit"] = round(kernel_rate / probe["all_hit_window_Ggathers_per_s"], 4)
         except Exception as exc:      # measurement extra
             roofline["ceiling"] = {"error": repr(exc)}
+
+    # ---- the vendor's CSR SpMV on the same device and the same matrix, as the INDEPENDENT comparator of the product kernel
+    # (rocSPARSE, best of its four CSR algorithms, preprocessing apart; tools/vendor_spmv.py -- a measurement aid the
+    # package never loads).  The vendor kernel computes y = A x alone; the product kernel's time includes the fused epilogue.
+    if dist is None and args.shards == 0 and not args.no_vendor and problem is not None:
+        try:
+            from tools import vendor_spmv
+            M = problem.constraint_matrix.tocsr() if dom == _lib.K_SPMV_DUAL else problem.constraint_matrix.T.tocsr()
+            vs = vendor_spmv.time_csr(M, reps=10, check=False)
+            del M
+            roofline["vendor_spmv_ms"] = vs.get("best_ms")
+            roofline["vendor_spmv"] = {"library": "rocSPARSE rocsparse_spmv (CSR, 32-bit indices, fp64)", "best_algorithm": vs.get("best_alg"),
+                                       "ms_by_algorithm": {k: v for k, v in vs.items() if k in vendor_spmv.ALGS},
+                                       "product_over_vendor": round(dk["avg_ms"] / vs["best_ms"], 3) if dk.get("avg_ms") and vs.get("best_ms") else None,
+                                       "note": "the product kernel's time includes the fused dual step / interaction sums; the vendor's is "
+                                               "y = A x alone, kernel time over 10 back-to-back products (no event-bracket overhead)"}
+        except Exception as exc:      # measurement extra
+            roofline["vendor_spmv"] = {"error": repr(exc)}
 
     # ---- CPU baseline: the literal single-thread restatement, bounded sample
     cpu_baseline = cpu_socket = None

@@ -9,13 +9,21 @@ constexpr int WAVE = 64;
 constexpr int BLOCK_NNZ = 2048;      // products staged in LDS per workgroup (16 KiB)
 constexpr int UNROLL = BLOCK_NNZ / TPB;
 constexpr int MAX_ROWS_PER_BLOCK = 4 * TPB;
+// Environment variables.  The documented run-time knobs (include/pdhg_hip.h has the table) are read with getenv as they
+// are; everything else -- tuning constants, negative-result paths kept for the measurements that settled them, fault
+// injection for tests -- is a DEVELOPMENT variable and is only honoured when PDHG_DEV=1 is set as well (tests/conftest.py
+// and the tools set it): a stray PDHG_TW_ROWS in a user's shell cannot change what the library does.
+inline const char *dev_env(const char *name) {
+  static const bool on = [] { const char *e = getenv("PDHG_DEV"); return e && e[0] == '1'; }();
+  return on ? getenv(name) : nullptr;
+}
 constexpr int LONG_CHUNK = BLOCK_NNZ;   // nnz per workgroup for rows longer than BLOCK_NNZ: read like a row block (spmv_kernels.hpp)
 // Rows with more entries than CsrDev::long_thr go to the long-row kernels (chunks of LONG_CHUNK entries + ordered combine)
 // instead of a row block / the tiled sweep.  BLOCK_NNZ is the capacity limit and the default; PDHG_LONG_THR (dev knob,
 // read when a layout is built and kept with it) lowers it: hub rows of a power-law graph then leave the sweep, whose
 // lanes sum a row's entries inside a tile one after the other.
 inline int long_row_threshold_from_env() {
-  const char *e = getenv("PDHG_LONG_THR");
+  const char *e = dev_env("PDHG_LONG_THR");
   const int v = e ? atoi(e) : BLOCK_NNZ;
   return v < 16 ? 16 : (v > BLOCK_NNZ ? BLOCK_NNZ : v);
 }

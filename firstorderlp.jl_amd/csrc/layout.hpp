@@ -197,7 +197,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     }
     int64_t fullest = 0;
     for (int64_t v : hist) fullest = std::max(fullest, v);
-    const char *vt = getenv("PDHG_VAR_TILES");                   // 0 / 1 force
+    const char *vt = dev_env("PDHG_VAR_TILES");                   // 0 / 1 force
     bool variable = nt0 > 1 && (double)fullest > 1.5 * (double)total / (double)nt0;
     if (vt) variable = vt[0] != '0' && nt0 > 1;
     if (on_device && nt0 > 1024) return 1;                    // host mode handles these
@@ -238,7 +238,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   // 256 CUs x 16 waves.  Rows per wave is chosen so that the rounds are full
   // (no tail round), within the LDS budget (160 KiB / 16 waves).
   // dev knobs (tools/tune_tiled.py): workgroups per CU the geometry is planned for, rows per wave cap
-  const char *wpc_env = getenv("PDHG_TW_WGS_PER_CU"), *mr_env = getenv("PDHG_TW_MAX_ROWS");
+  const char *wpc_env = dev_env("PDHG_TW_WGS_PER_CU"), *mr_env = dev_env("PDHG_TW_MAX_ROWS");
   const int wgs_per_cu = wpc_env ? std::max(1, atoi(wpc_env)) : 2;
   const int64_t slots = 256LL * wgs_per_cu * TW_WPB;      // resident waves per round
   // row_local must stay below all-ones in its bit field: {row_local << shift | col_local}
@@ -250,8 +250,8 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     int64_t rpw = ((int64_t)rows + slots * rounds - 1) / (slots * rounds);
     TW_ROWS = (int)std::max<int64_t>(64, std::min<int64_t>(max_rows, rpw));
   }
-  const bool rows_forced = getenv("PDHG_TW_ROWS") != nullptr;
-  if (rows_forced) TW_ROWS = std::max(1, std::min(atoi(getenv("PDHG_TW_ROWS")), max_rows));
+  const bool rows_forced = dev_env("PDHG_TW_ROWS") != nullptr;
+  if (rows_forced) TW_ROWS = std::max(1, std::min(atoi(dev_env("PDHG_TW_ROWS")), max_rows));
   const int WIN = TW_U * WAVE;  // entries a wave holds in registers per step
   // pass 1: wave row blocks.  A wave owns <= TW_ROWS rows AND <= nnz_cap
   // nonzeros: hub regions (PageRank's oldest nodes) would otherwise give one
@@ -261,11 +261,11 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   // itself (measured: 8 195 waves instead of 8 192 cost +45 %).  Rows per wave are
   // then raised, within the LDS budget (and, on a near miss, the entry cap a little),
   // until the waves fit the rounds again.
-  double cap_factor = getenv("PDHG_TW_NNZ_CAP") ? std::max(1.0, atof(getenv("PDHG_TW_NNZ_CAP"))) : 2.0;   // dev knob
+  double cap_factor = dev_env("PDHG_TW_NNZ_CAP") ? std::max(1.0, atof(dev_env("PDHG_TW_NNZ_CAP"))) : 2.0;   // dev knob
   std::vector<int2> wave_rows;
   for (int attempt = 0;; ++attempt) {
     const int64_t est_waves = std::max<int64_t>(1, ((int64_t)rows + TW_ROWS - 1) / TW_ROWS);
-    const int64_t nnz_cap = std::max<int64_t>(getenv("PDHG_TW_NNZ_CAP") ? 256 : 4096,
+    const int64_t nnz_cap = std::max<int64_t>(dev_env("PDHG_TW_NNZ_CAP") ? 256 : 4096,
                                               (int64_t)(cap_factor * (double)(D.nnz / est_waves)));   // 2x the average wave
     wave_rows.clear();
     int r = 0;
@@ -366,7 +366,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     const bool forced = mode_env && !strcmp(mode_env, "tiled");
     // stream wins below ~0.25 (4M columns, band +-500K: share 0.245, stream 0.43 ms / sweep 0.57 ms), the
     // sweep above ~0.28 (10M columns, band +-1.5M: share 0.284, sweep 1.22 ms / stream 1.60 ms)
-    const double min_share = getenv("PDHG_TW_MIN_SHARE") ? atof(getenv("PDHG_TW_MIN_SHARE")) : 0.26;
+    const double min_share = dev_env("PDHG_TW_MIN_SHARE") ? atof(dev_env("PDHG_TW_MIN_SHARE")) : 0.26;
     if (getenv("PDHG_VERBOSE"))
       fprintf(stderr, "[pdhg_hip] tiled layout %d x %d: %.3f of the (workgroup, tile) cells hold entries\n", rows, D.cols, touched_share);
     if (!forced && touched_share < min_share) return 0;
@@ -452,7 +452,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   D.tile_cols = tile_cols;
   D.var_tiles = !uniform;
   {
-    const char *ev = getenv("PDHG_TW_MIN_LDS_KB");
+    const char *ev = dev_env("PDHG_TW_MIN_LDS_KB");
     D.tw_lds_floor = (size_t)(ev ? std::max(0, atoi(ev)) : 55) * 1024;
   }
   D.ntiles = ntiles;
@@ -532,7 +532,7 @@ inline int slab_first_col(int cols, int P, int p) {
   if (p >= P) return cols;
   const int width = (cols + P - 1) / P;
   if (P == 2 && p == 1) {
-    if (const char *f = getenv("PDHG_SLAB_SPLIT")) return std::max(16, std::min(cols - 16, (int)(atof(f) * cols) / 16 * 16));
+    if (const char *f = dev_env("PDHG_SLAB_SPLIT")) return std::max(16, std::min(cols - 16, (int)(atof(f) * cols) / 16 * 16));
   }
   return std::min(cols, p * width);
 }
@@ -640,10 +640,10 @@ int build_slabs_device(CsrDev &D, int rows, int cols, const std::vector<int> &ro
 // their bits, and the block partials are exactly rounded double-double sums (common.hpp), which do not depend on
 // the grouping.  PDHG_BALANCED_CUS overrides the CU count (tests).
 inline int balanced_block_target(int greedy_blocks, int nchunks) {
-  const char *ev = getenv("PDHG_BALANCED_BLOCKS");
+  const char *ev = dev_env("PDHG_BALANCED_BLOCKS");
   if (!ev || ev[0] != '1') return 0;
   int cus = 256;
-  if (const char *cv = getenv("PDHG_BALANCED_CUS")) cus = std::max(1, atoi(cv));
+  if (const char *cv = dev_env("PDHG_BALANCED_CUS")) cus = std::max(1, atoi(cv));
   else {
     int dev = 0;
     hipDeviceProp_t prop;

@@ -609,10 +609,10 @@ int coop_prepare(pdhg_handle *h, int cap_limit, bool several_items) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));
   int cap = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
-  if (const char *ev = getenv("PDHG_COOP_WGS")) cap = std::max(8, std::min(cap, atoi(ev) / 8 * 8));
+  if (const char *ev = dev_env("PDHG_COOP_WGS")) cap = std::max(8, std::min(cap, atoi(ev) / 8 * 8));
   if (cap_limit > 0) cap = std::max(8, std::min(cap, cap_limit / 8 * 8));
   // test knob: pretend the device holds this many workgroups (more than it does: the barriers cannot complete)
-  const char *pretend = getenv("PDHG_COOP_TEST_PRETEND_WGS");
+  const char *pretend = dev_env("PDHG_COOP_TEST_PRETEND_WGS");
   if (pretend) cap = std::max(8, atoi(pretend) / 8 * 8);
   // one item per workgroup and phase where the device can hold that many: row blocks from the front, long-row chunks from the end
   int items = std::max(h->A.grid + h->A.nchunks, h->At.grid + h->At.nchunks);
@@ -621,7 +621,7 @@ int coop_prepare(pdhg_handle *h, int cap_limit, bool several_items) {
   // More items than co-resident workgroups: the persistent kernel would walk several row blocks per workgroup at
   // 5 workgroups per CU, where the separate stream kernels keep 8 per CU in flight -- measured slower (PageRank-1M,
   // 4 552 items on 1 280 workgroups: 4 380 it/s against 4 620 as a graph of slab passes).  Leave those to the graph.
-  if (items > cap && !several_items && !getenv("PDHG_COOP_FORCE")) {
+  if (items > cap && !several_items && !dev_env("PDHG_COOP_FORCE")) {
     h->coop_mode = 0;
     return 1;       // not an error: the caller falls through to the graph / plain path
   }
@@ -723,14 +723,14 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
   for (int x = 0; x < 8; ++x) a.xcd_cnt[x] = h->coop_xcd_cnt[x];
   // test knob: raise the barriers' error word in front of launch number k, as a time-out in it would (the launch
   // then runs without synchronisation and reports the error; the recovery below is what is being tested)
-  static const long break_at = getenv("PDHG_COOP_TEST_BREAK_AT") ? atol(getenv("PDHG_COOP_TEST_BREAK_AT")) : -1;
+  static const long break_at = dev_env("PDHG_COOP_TEST_BREAK_AT") ? atol(dev_env("PDHG_COOP_TEST_BREAK_AT")) : -1;
   if (break_at >= 0 && (long)h->coop_launches == break_at) {
     static const unsigned long long nine = 9ull;
     HIP_TRY(hipMemcpyAsync(&h->gsync->error[0], &nine, sizeof nine, hipMemcpyHostToDevice, h->stream));
   }
   h->coop_launches += 1;
   const auto c1 = std::chrono::steady_clock::now();
-  static const bool coh_single = getenv("PDHG_COOP_COH") && getenv("PDHG_COOP_COH")[0] == '1';   // dev: L1-bypassing loads in the single-trial kernel too
+  static const bool coh_single = dev_env("PDHG_COOP_COH") && dev_env("PDHG_COOP_COH")[0] == '1';   // dev: L1-bypassing loads in the single-trial kernel too
   if (coh_single) hipLaunchKernelGGL(trial_kernel<true>, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
   else hipLaunchKernelGGL(trial_kernel<false>, dim3(h->coop_grid), dim3(TPB), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
@@ -768,7 +768,7 @@ int coop_trial(pdhg_handle *h, double step_size, double primal_weight, double th
 static int steps_prepare(pdhg_handle *h, int n, int64_t total_number_iterations, double reduction_exponent,
                          double growth_exponent, int *max_trials_out, int *table_len_out) {
   int max_trials = n + n / 8 + 16, table_len = max_trials + 64;
-  if (const char *tv = getenv("PDHG_STEPS_TEST_TABLE")) max_trials = table_len = std::max(1, atoi(tv));   // test knob: launches end inside take_steps
+  if (const char *tv = dev_env("PDHG_STEPS_TEST_TABLE")) max_trials = table_len = std::max(1, atoi(tv));   // test knob: launches end inside take_steps
   if (!h->steps_res) {
     HIP_TRY(hipHostMalloc((void **)&h->steps_res, STEPS_RES_WORDS * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     memset(h->steps_res, 0, STEPS_RES_WORDS * sizeof(double));
@@ -832,10 +832,10 @@ static int steps_wait(pdhg_handle *h, unsigned long long seq, double r[13], doub
 static int steps_local_prepare(pdhg_handle *h) {
   if (h->local_mode >= 0) return h->local_mode ? 0 : 1;
   h->local_mode = 0;
-  const char *ev = getenv("PDHG_COOP_LOCAL");
+  const char *ev = dev_env("PDHG_COOP_LOCAL");
   if (ev && ev[0] == '0') return 1;
-  const int cap = getenv("PDHG_COOP_LOCAL_MAX") ? atoi(getenv("PDHG_COOP_LOCAL_MAX")) : 32;
-  if (h->coop_grid <= 0 || h->coop_grid > cap || getenv("PDHG_COOP_TEST_PRETEND_WGS")) return 1;
+  const int cap = dev_env("PDHG_COOP_LOCAL_MAX") ? atoi(dev_env("PDHG_COOP_LOCAL_MAX")) : 32;
+  if (h->coop_grid <= 0 || h->coop_grid > cap || dev_env("PDHG_COOP_TEST_PRETEND_WGS")) return 1;
   HIP_TRY(hipMalloc((void **)&h->lsync, sizeof(GridSync)));
   HIP_TRY(hipMemsetAsync(h->lsync, 0, sizeof(GridSync), h->stream));
   hipLaunchKernelGGL(xcd_register_kernel, dim3(8 * h->coop_grid), dim3(TPB), 0, h->stream, h->lsync);
@@ -901,7 +901,7 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   a.sync = local ? h->lsync : h->gsync; a.ctl = h->steps_ctl; a.res_host = h->steps_res;
   a.local_g = local ? h->coop_grid : 0; a.local_home = 0;
   // test knob: the kernel expects eight workgroups more than are launched on the home XCD -- its first barrier times out
-  if (local && getenv("PDHG_COOP_LOCAL_TEST_BAD")) a.local_g += 8;
+  if (local && dev_env("PDHG_COOP_LOCAL_TEST_BAD")) a.local_g += 8;
   if (local) { a.local_ticket_base = h->local_tickets; h->local_tickets += (unsigned long long)h->coop_grid; }
   a.seq = ++h->steps_seq;
   a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
@@ -1006,7 +1006,7 @@ int small_lp_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, d
   a.seq = ++h->steps_seq;
   h->pend_x = h->pend_y = false;             // the launch applies it
   const auto c1 = std::chrono::steady_clock::now();
-  static const int few_env = getenv("PDHG_SMALL_FEW_ROWS") ? atoi(getenv("PDHG_SMALL_FEW_ROWS")) : SMALL_FEW_ROWS;   // dev knob
+  static const int few_env = dev_env("PDHG_SMALL_FEW_ROWS") ? atoi(dev_env("PDHG_SMALL_FEW_ROWS")) : SMALL_FEW_ROWS;   // dev knob
   if (std::max(h->n, h->m) <= few_env) hipLaunchKernelGGL(small_lp_steps_kernel<256>, dim3(1), dim3(256), lds, h->stream, a);
   else hipLaunchKernelGGL(small_lp_steps_kernel<SMALL_TPB>, dim3(1), dim3(SMALL_TPB), lds, h->stream, a);
   HIP_TRY(hipGetLastError());
@@ -1035,7 +1035,7 @@ bool graph_eligible(pdhg_handle *h) {
     // stream layouts only.  The sweep can run as graph nodes too (PDHG_GRAPH_TILED=1) but gains nothing: with the
     // take_step loop in C the separate launches already overlap the kernels -- random 1M x 1M 5 709 it/s as a graph
     // against 5 637, 4M x 4M 1 667 / 1 672, config S 611 / 613 (profiles/r03_trial_kernel.txt).
-    const bool tiled_ok = getenv("PDHG_GRAPH_TILED") != nullptr;
+    const bool tiled_ok = dev_env("PDHG_GRAPH_TILED") != nullptr;
     bool on = !h->grp && !h->has_q && h->n > 0 && h->A.segs.empty() && h->At.segs.empty() && (tiled_ok || (!h->A.tiled && !h->At.tiled));
     if (ev) on = on && ev[0] != '0';
     h->graph_mode = on ? 1 : 0;
@@ -1430,7 +1430,7 @@ int dual_product(const Shards &L, Yin yin, Out out) {
 // PDHG_SPMV=stream|tiled forces a layout; PDHG_TILE_SHIFT sets log2(tile cols).
 int choose_tile_cols(int64_t cols, int64_t nnz, int64_t rows) {
   const char *mode = getenv("PDHG_SPMV");
-  const char *ts = getenv("PDHG_TILE_SHIFT"), *tc = getenv("PDHG_TILE_COLS");
+  const char *ts = dev_env("PDHG_TILE_SHIFT"), *tc = getenv("PDHG_TILE_COLS");
   int64_t tile = tc ? atoll(tc) : (ts ? (1LL << std::min(22, std::max(6, atoi(ts)))) : 65536);
   bool thin = false;
   if (!ts && !tc && rows > 0) {
@@ -1449,7 +1449,7 @@ int choose_tile_cols(int64_t cols, int64_t nnz, int64_t rows) {
     const int64_t rounds = std::max<int64_t>(1, (rows + slots * TW_MAX_ROWS - 1) / (slots * TW_MAX_ROWS));
     const int64_t rpw = std::max<int64_t>(64, (rows + slots * rounds - 1) / (slots * rounds));
     const double per_wave = (double)nnz / (double)rows * (double)rpw;
-    const double target = getenv("PDHG_TILE_FILL") ? atof(getenv("PDHG_TILE_FILL")) : (rounds == 1 ? 110.0 : 100.0);
+    const double target = dev_env("PDHG_TILE_FILL") ? atof(dev_env("PDHG_TILE_FILL")) : (rounds == 1 ? 110.0 : 100.0);
     // Many rounds (>= 5, i.e. beyond ~21M rows): the cells thin out at the 76K cap and the balance tips
     // towards wider tiles -- 24M x 24M 2.51 ms at 76K columns / 2.39 at 96K, 30M x 30M 3.47 / 3.08 / 2.92 at
     // 76K / 96K / 112K (128K: 3.46), 20M and below indifferent or worse -- so the cap stretches to what
@@ -1695,7 +1695,7 @@ int build_layout_pair(int dev, bool remap, bool relaxed, int64_t m, int64_t n, i
   // Off by default: measured on the 2 x 64-core host of the GPU box at config S, the two builds side by side took
   // 0.92 s against 0.83 s one after the other (0.78 || 0.60 s against 0.47 + 0.36 s) -- the per-nonzero passes are bound
   // by host memory bandwidth, not by threads (32 threads per pass instead of 16 changed nothing either).
-  const bool two = A_out && At_out && nnz >= (1 << 22) && getenv("PDHG_PARALLEL_LAYOUTS") != nullptr;
+  const bool two = A_out && At_out && nnz >= (1 << 22) && dev_env("PDHG_PARALLEL_LAYOUTS") != nullptr;
   if (device_layout) {
     if (A_out) *A_out = dev_A; else free_csr_dev(dev_A);
     if (At_out) *At_out = dev_At; else free_csr_dev(dev_At);
@@ -2065,7 +2065,7 @@ int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colpt
   } else {
     partition_rows_by_nnz(m, n, colptr, rowval, base, world, g->row_lo);
   }
-  const char *fr = getenv("PDHG_DIST_FORCE_REMOTE");
+  const char *fr = dev_env("PDHG_DIST_FORCE_REMOTE");
   g->force_remote = fr && fr[0] == '1';
   return 0;
 }
@@ -2151,7 +2151,7 @@ int pdhg_create(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
   // PDHG_MAX_SHARD_NNZ lowers the limit (tests).
   int64_t cap = (int64_t)INT32_MAX - 1;
   if (const char *ev = getenv("PDHG_MAX_SHARD_NNZ")) cap = std::max<int64_t>(1, atoll(ev));
-  const char *huge = getenv("PDHG_HUGE");
+  const char *huge = dev_env("PDHG_HUGE");
   if (nnz > cap && !(huge && !strcmp(huge, "shards"))) {
     // host-side validation first (no device needed, nothing indexed with an unchecked row index later on)
     *out = nullptr;
@@ -2466,7 +2466,7 @@ static int trial_dual_single(pdhg_handle *h, double step_size, double primal_wei
   // The five sums go straight into pinned host memory and the host polls the launch's sequence number there
   // (as on the graph path) instead of a device-to-host copy + stream synchronisation: ~10 us per trial, which
   // is 5 % of a 1M x 1M LP's iteration.  While profiling: the copy, so that the event brackets stay simple.
-  static const bool host_word = !(getenv("PDHG_TRIAL_HOST_WORD") && getenv("PDHG_TRIAL_HOST_WORD")[0] == '0');
+  static const bool host_word = !(dev_env("PDHG_TRIAL_HOST_WORD") && dev_env("PDHG_TRIAL_HOST_WORD")[0] == '0');
   if (host_word && !h->profile) {
     if ((rc = ensure_result_word(h))) return rc;
     if ((rc = launch_final(h, h->pAt, h->At.slots(), h->pAt_stride, h->pA, h->A.slots(), qcount, true))) return rc;
@@ -2500,7 +2500,7 @@ static int trial_shard_mt(DistGroup &g, pdhg_handle *s, int i, const TrialArgs &
     if ((rc = mt_reduce_scatter(g, s, i, [](pdhg_handle *q) { return q->aty_next; }, g.S))) return rc;
   } else {
     // see trial_dual_group: the product in residency rounds, slice k reduced as soon as its rows are complete
-    const char *rw_env = getenv("PDHG_DIST_ROUND_WGS");
+    const char *rw_env = dev_env("PDHG_DIST_ROUND_WGS");
     const int round_wgs = rw_env ? std::max(1, atoi(rw_env)) : 256 * 2;
     const CsrDev &T = s->At;
     int issued = 0, next_wg = 0;
@@ -2574,7 +2574,7 @@ static int group_coop_prepare(const Shards &L) {
   for (int i = 0; i < L.count; ++i) devs.push_back(L.p[i]->device);
   std::sort(devs.begin(), devs.end());
   devs.erase(std::unique(devs.begin(), devs.end()), devs.end());
-  const char *pretend = getenv("PDHG_COOP_TEST_PRETEND_WGS");       // test knob: a grid the device cannot hold
+  const char *pretend = dev_env("PDHG_COOP_TEST_PRETEND_WGS");       // test knob: a grid the device cannot hold
   for (int dev : devs) {
     HIP_TRY(hipSetDevice(dev));
     GroupDevLaunch D;
@@ -2830,7 +2830,7 @@ static int trial_dual_group(const Shards &L, double step_size, double primal_wei
     // the comm stream while the next round computes.  The sequence of collectives (slice
     // 0, 1, ..., P-1) is the same on every rank however the local product is cut.
     FOR_SHARDS(L, s) { if ((rc = launch_dual(s, primal_weight * step_size))) return rc; }
-    const char *rw_env = getenv("PDHG_DIST_ROUND_WGS");            // tests use a finer granule on small problems
+    const char *rw_env = dev_env("PDHG_DIST_ROUND_WGS");            // tests use a finer granule on small problems
     const int round_wgs = rw_env ? std::max(1, atoi(rw_env)) : 256 * 2;
     std::vector<int> issued((size_t)L.count, 0), next_wg((size_t)L.count, 0);
     int k_issued = 0;
@@ -3027,7 +3027,7 @@ static bool device_loop_for(pdhg_handle *h) {
   const char *dl_env = getenv("PDHG_DEVICE_LOOP");
   bool device_loop = dl_env && dl_env[0] == '1';
   if (!dl_env && !h->grp && !h->profile && !h->has_q && check_handle(h) == 0 && coop_eligible(h)) {
-    static const int max_wgs = getenv("PDHG_DEVICE_LOOP_MAX_WGS") ? atoi(getenv("PDHG_DEVICE_LOOP_MAX_WGS")) : (1 << 30);
+    static const int max_wgs = dev_env("PDHG_DEVICE_LOOP_MAX_WGS") ? atoi(dev_env("PDHG_DEVICE_LOOP_MAX_WGS")) : (1 << 30);
     device_loop = h->coop_grid <= max_wgs;
   }
   return device_loop;
@@ -3244,7 +3244,7 @@ static int ev_alloc(pdhg_handle *h) {
     // the evaluation kernels reduce up to 30 quantities per workgroup and a second stage reads every workgroup's
     // partials: two elements per thread and at most 1024 workgroups measured best (L1-SVM 229K elements: 448
     // workgroups 67 us per trust-region call against 82 with 895; 2M elements: 977 workgroups 123 us against 147 with 2048)
-    static const int per_thread = getenv("PDHG_EV_ELEMS") ? std::max(1, atoi(getenv("PDHG_EV_ELEMS"))) : 2;
+    static const int per_thread = dev_env("PDHG_EV_ELEMS") ? std::max(1, atoi(dev_env("PDHG_EV_ELEMS"))) : 2;
     h->ev_grid = std::min(1024, ew_grid((h->n + h->m + per_thread) / per_thread));
   }
   if ((rc = alloc_zero(&h->ev_partials, (int64_t)EV_MAXQ * h->ev_grid))) return rc;
@@ -3294,7 +3294,7 @@ static int ev_wait_host(pdhg_handle *h, int k, unsigned long long seq, double *o
 
 static int ev_finish(const Shards &L, int ns, int nm, double *out, unsigned max_mask = 0) {
   if (ns + nm > EV_MAXQ) return fail(-1, "too many scalars in one reduction");
-  static const bool host_word = !(getenv("PDHG_EVAL_HOST_WORD") && getenv("PDHG_EVAL_HOST_WORD")[0] == '0');
+  static const bool host_word = !(dev_env("PDHG_EVAL_HOST_WORD") && dev_env("PDHG_EVAL_HOST_WORD")[0] == '0');
   if (!L.g && host_word) {
     // one handle: the second stage publishes into pinned memory and the host polls (see multi_final_kernel)
     pdhg_handle *h = L.p[0];
@@ -3343,7 +3343,7 @@ static int select_point(pdhg_handle *h, int point, const double **px, const doub
 // h->pt_ax / pt_aty / pt_qx together with the point itself in h->pt_x / pt_y.
 static int point_products(const Shards &L, int point) {
   int rc;
-  static const bool cache_off = getenv("PDHG_NO_EVAL_CACHE") != nullptr;   // debugging aid
+  static const bool cache_off = dev_env("PDHG_NO_EVAL_CACHE") != nullptr;   // debugging aid
   const bool cached = !cache_off && (point == PDHG_POINT_CURRENT || point == PDHG_POINT_AVERAGE ||
                                      point == PDHG_POINT_RESTART);
   bool fresh = true;
@@ -3424,7 +3424,7 @@ int pdhg_eval_point(pdhg_handle *h0, int point, double out[24]) {
   const Shards L = shards_of(h0);
   if ((rc = flush_pending(L))) return rc;
   if ((rc = point_products(L, point))) return rc;
-  const char *hw = getenv("PDHG_EVAL_HOST_WORD");          // (read per call: tests compare the two forms in one process)
+  const char *hw = dev_env("PDHG_EVAL_HOST_WORD");          // (read per call: tests compare the two forms in one process)
   if (!L.g && !(hw && hw[0] == '0')) {
     // one handle: the row and the column kernels leave their block partials side by side (8 + 14 quantities), ONE second
     // stage reduces all 22 and the host makes one round trip instead of two.  Same partials, same order per quantity:
@@ -3524,12 +3524,12 @@ static int tr_coop_prepare(pdhg_handle *h) {
   const char *ev = getenv("PDHG_TR_COOP");
   if (ev && ev[0] == '0') return 1;
   const int64_t total = h->n + h->m;
-  const int64_t cap = getenv("PDHG_TR_COOP_MAX") ? atoll(getenv("PDHG_TR_COOP_MAX")) : 1000000;
+  const int64_t cap = dev_env("PDHG_TR_COOP_MAX") ? atoll(dev_env("PDHG_TR_COOP_MAX")) : 1000000;
   if (total > cap || total < 1) return 1;
   HIP_TRY(hipSetDevice(h->device));
   int grid = (int)std::min<int64_t>(TRC_MAX_WGS, (total + TPB * 4 - 1) / (TPB * 4));
   grid = std::max(8, (grid + 7) / 8 * 8);
-  if (const char *g = getenv("PDHG_TR_COOP_WGS")) grid = std::max(8, std::min(TRC_MAX_WGS, atoi(g) / 8 * 8));
+  if (const char *g = dev_env("PDHG_TR_COOP_WGS")) grid = std::max(8, std::min(TRC_MAX_WGS, atoi(g) / 8 * 8));
   HIP_TRY(hipMalloc((void **)&h->tr_sync, sizeof(GridSync)));
   HIP_TRY(hipMemsetAsync(h->tr_sync, 0, sizeof(GridSync), h->stream));
   HIP_TRY(hipMalloc((void **)&h->tr_partials, sizeof(double) * 2 * EV_MAXQ * (size_t)grid));
@@ -3544,7 +3544,7 @@ static int tr_coop_prepare(pdhg_handle *h) {
   for (int x = 0; x < 8; ++x) { seen += host.xcd_count[x][0]; h->tr_nxcd += host.xcd_count[x][0] > 0; h->tr_xcd_cnt[x] = (unsigned)host.xcd_count[x][0]; }
   if (seen != (unsigned long long)grid || h->tr_nxcd == 0) return 1;     // no census: the multi-launch form
   // test knob: a census that expects one workgroup too many -- the first barrier cannot complete (spin limit, error word)
-  if (getenv("PDHG_TR_COOP_TEST_BAD_CENSUS")) h->tr_xcd_cnt[0] += 1;
+  if (dev_env("PDHG_TR_COOP_TEST_BAD_CENSUS")) h->tr_xcd_cnt[0] += 1;
   h->tr_grid = grid;
   h->tr_epoch = 0;
   h->tr_coop = 1;
@@ -3601,7 +3601,7 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
   if ((rc = point_products(L, point))) return rc;
   {
     // small problems on one handle: set-up, search and results in ONE workgroup and one launch (tr_small_kernel)
-    const char *se = getenv("PDHG_SMALL_EVAL");
+    const char *se = dev_env("PDHG_SMALL_EVAL");
     pdhg_handle *h = L.p[0];
     if (!L.g && h->n + h->m <= TRS_MAX && !(se && se[0] == '0') && !h->profile) {
       HIP_TRY(hipSetDevice(h->device));

@@ -113,7 +113,10 @@ __device__ __forceinline__ void sj_load_first(const SjView &J, int &off, int l, 
 // Software pipeline over the workgroup's trips: while trip i gathers and adds, trip i + 1's first SJ_U1 levels and
 // epilogue operands and trip i + 2's slot words are in flight, so a trip costs one gather round trip (L2) and a
 // workgroup barrier instead of five dependent memory round trips (slot words -> entries -> gathers -> operands -> store:
-// 0.82 ms on banded 10M, the CSR kernel's time, against 0.69 with one trip of look-ahead).
+// 0.82 ms on banded 10M, the CSR kernel's time; 0.69 with one trip of look-ahead; 0.62 with two).  The barrier that
+// hands the row sums to the row-order epilogue is also PACING: a variant without it (every wave its own pipeline, the
+// epilogue in the lane that walked the row) ran at 0.74 -- the waves of an XCD drift apart and the window of the
+// gathered vector in flight widens, exactly as in the sweep (profiles/r05_sj_layout.txt).
 template <int MODE, bool INIT = false, int TAG = 0>
 __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__restrict__ xin, int remap, int stream_slots, EpiArgs e) {
   static_assert(SJ_SIGMA == TPB, "one sorting group per workgroup trip");

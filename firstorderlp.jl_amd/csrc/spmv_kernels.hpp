@@ -306,36 +306,6 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
 // (tile-major order preserves it) => bit-identical to the sequential CPU
 // loops.  Entries of one row inside a tile are adjacent; the run head adds
 // them left to right via lane shuffles.
-#ifdef TWD_DPP
-// lane i <- lane i+1 (wave_shl:1) / lane i <- lane i-1 (wave_shr:1); lanes without a source get `fill`
-__device__ __forceinline__ unsigned dpp_from_next(unsigned v, unsigned fill) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xF, 0xF, false);
-}
-__device__ __forceinline__ unsigned dpp_from_prev(unsigned v, unsigned fill) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
-}
-__device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, double xv,
-                                            int tile_shift, int lane) {
-  const bool valid = p != TW_PAD;
-  const unsigned row = valid ? (p >> tile_shift) : 0xFFFFFFFFu;
-  const double prod = v * xv;
-  const unsigned rowp = dpp_from_prev(row, 0xFFFFFFFEu);
-  const bool head = valid && rowp != row;
-  double s = head ? acc[row] : 0.0;
-  if (head) s = s + prod;
-  unsigned rj = row;
-  unsigned lo = (unsigned)__double2loint(prod), hi = (unsigned)__double2hiint(prod);
-  for (int j = 1; j < WAVE; ++j) {
-    rj = dpp_from_next(rj, 0xFFFFFFFFu);
-    lo = dpp_from_next(lo, 0u);
-    hi = dpp_from_next(hi, 0u);
-    const bool take = head && (rj == row);
-    if (!__any(take)) break;
-    if (take) s = s + __hiloint2double((int)hi, (int)lo);
-  }
-  if (head) acc[row] = s;
-}
-#else
 __device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, double xv,
                                             int tile_shift, int lane) {
   const bool valid = p != TW_PAD;
@@ -353,7 +323,6 @@ __device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, d
   }
   if (head) acc[row] = s;
 }
-#endif
 
 // Variant for matrices with long same-row runs inside a tile (rows with hundreds
 // of entries): run lengths from two ballots, followers' products handed to the
@@ -485,16 +454,8 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
     for (int i = 0; i < U; ++i) {
       const int k = kbeg + i * WAVE + lane;
       const bool ok = k < kend;
-#ifdef TWD_UNCOND   // dev variant: every lane loads (lanes without an entry re-read the cell's first one), so that the loads are straight-line code and the compiler counts them (exact vmcnt)
-      const int kk = ok ? k : kbeg;
-      const unsigned pl = __builtin_nontemporal_load(pk + kk);
-      const double vl = __builtin_nontemporal_load(tv + kk);
-      pp[i] = ok ? pl : TW_PAD;
-      vv[i] = ok ? vl : 0.0;
-#else
       pp[i] = ok ? __builtin_nontemporal_load(pk + k) : TW_PAD;
       vv[i] = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
-#endif
     }
   };
 
@@ -520,30 +481,20 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
       const int t = t0 + s;
       if (t < ntiles) {  // workgroup-uniform
         const int f = (s + D) % R;       // ring slot being refilled (held tile t-1)
-#ifdef TWD_ONE_TILE   // timing diagnostic, wrong results (tools/variants.sh): every gather hits tile 0
-        const double *xt = xin;
-#else
         const double *xt = xin + (size_t)tl[s];      // the step table holds the tile's first column
-#endif
         // 1. gathers for tile t (entries requested D steps ago).  Issued BEFORE
         //    the prefetch: a wave's loads return in order, so the L2-latency
         //    gathers must not queue behind HBM-latency streaming loads.
         //    (Gathering one tile ahead was measured slower: it widens the L2
         //    working window of the sweep.)
 #pragma unroll
-#ifdef TWD_NO_GATHER  // timing diagnostic, wrong results: stream + accumulate only
-        for (int i = 0; i < U; ++i) xv[i] = 1.0 + (double)(size_t)xt * 0.0;
-#else
         for (int i = 0; i < U; ++i) xv[i] = (p[s][i] != TW_PAD) ? xt[p[s][i] & cmask] : 0.0;
-#endif
         // 2. entry loads for tile t+D
-#ifndef TWD_PREFETCH_LATE
         ks[f] = ke[(s + D - 1) % R];
         ke[f] = ke_ahead;
         tl[f] = (t + D < ntiles) ? stile[t + D] : 0;
         load_set(p[f], v[f], ks[f], ke[f]);
         ke_ahead = (live && t + D + 1 < ntiles) ? tp[t + D + 2] : ke_ahead;  // end of tile t+D+1
-#endif
         // 3. accumulate tile t
 #pragma unroll
         for (int i = 0; i < U; ++i) {
@@ -563,13 +514,6 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
           else if (CH == 2) tiled_chunk_relaxed(acc, pp, vv, xx, tile_shift, lane);
           else tiled_chunk(acc, pp, vv, xx, tile_shift, lane);
         }
-#ifdef TWD_PREFETCH_LATE   // dev variant: the entry loads for tile t+D behind the accumulate instead of between the gathers and their wait
-        ks[f] = ke[(s + D - 1) % R];
-        ke[f] = ke_ahead;
-        tl[f] = (t + D < ntiles) ? stile[t + D] : 0;
-        load_set(p[f], v[f], ks[f], ke[f]);
-        ke_ahead = (live && t + D + 1 < ntiles) ? tp[t + D + 2] : ke_ahead;  // end of tile t+D+1
-#endif
         // 4. pacing barrier: keep the workgroup inside one column tile
         //    (without it the kernel is 1.7x slower: waves drift apart and the
         //    gathers stop hitting L2)

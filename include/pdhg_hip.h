@@ -19,6 +19,39 @@
  *    drained whenever they produce host-visible results.
  *  - fp64 throughout; kernels are built with -ffp-contract=off so elementwise
  *    updates round exactly like the reference's unfused Julia broadcasts.
+ *
+ * Environment variables (read when a handle is created unless noted).  These 25 are the
+ * library's run-time knobs; every other PDHG_* name in the sources is a development
+ * variable (tuning constants, negative-result paths, fault injection) and is IGNORED unless
+ * PDHG_DEV=1 is set as well (tests/conftest.py and tools/ set it).
+ *
+ *   name                 values (default first)        effect
+ *   PDHG_SPMV            auto | stream | tiled         force the product layout: CSR row blocks / L2-tiled sweep
+ *   PDHG_SJ              auto | 0 | 1                  sliced jagged copy of stream-class matrices (csrc/sj_kernels.hpp)
+ *   PDHG_SLABS           auto | 0 | 1                  column-slab passes of the stream layout
+ *   PDHG_SLAB_MB         4                             slab size in MiB
+ *   PDHG_TILE_COLS       auto | <columns>              tile width of the sweep
+ *   PDHG_ROW_ORDER       relaxed | strict              rows of > 256 entries summed by their wave / strictly left to right
+ *   PDHG_XCD_REMAP       1 | 0                         every XCD walks a contiguous eighth of the row blocks
+ *   PDHG_DEVICE_LAYOUT   1 | 0                         build the layouts on the device / on the host
+ *   PDHG_HOST_THREADS    min(16, cores) | <n>          host threads of the layout builders
+ *   PDHG_MAX_SHARD_NNZ   2^31 - 2 | <n>                entries per row segment (64-bit extents; lowered by tests)
+ *   PDHG_LAZY_ACCEPT     1 | 0                         the average's update rides on the next trial's kernels
+ *   PDHG_GRAPH           1 | 0                         one HIP-graph launch per trial / separate launches (0 also turns
+ *                                                      the persistent trial kernels off)
+ *   PDHG_COOP            1 | 0                         one persistent kernel per trial (csrc/trial_kernel.hpp)
+ *   PDHG_DEVICE_LOOP     1 | 0                         several take_steps per launch of the persistent kernel
+ *   PDHG_SMALL_LP        1 | 0                         whole batches of steps in one workgroup (csrc/small_lp_kernel.hpp)
+ *   PDHG_TR_COOP         1 | 0                         a trust-region search as one persistent launch
+ *   PDHG_COOP_TRACE      0 | 1                         phase-boundary clock stamps in the persistent kernels (pdhg_trial_timeline)
+ *   PDHG_RCCL_LIB        (unset) | <path>              the RCCL library to bind at run time
+ *   PDHG_COMM            auto | p2p                    peer kernels instead of RCCL inside one process
+ *   PDHG_DIST_OVERLAP    auto | 0 | 1                  per-slice reductions overlapped with the A_p' product
+ *   PDHG_SHARD_THREADS   1 | 0                         one issuing host thread per local shard
+ *   PDHG_GROUP_COOP      auto | 0 | 1                  persistent group kernels (1: also across devices)
+ *   PDHG_ROCTX           0 | 1                         roctx ranges around entry points and products
+ *   PDHG_VERBOSE         0 | 1                         layout / path decisions on stderr
+ *   PDHG_DEV             0 | 1                         honour the development variables
  */
 #ifndef PDHG_HIP_H_
 #define PDHG_HIP_H_

@@ -11,6 +11,10 @@ import folp_loader  # noqa: E402
 
 folp_loader.load()
 
+# The tests drive the library's DEVELOPMENT variables too (tile geometry, fault injection, forced paths): the library only
+# honours those beside PDHG_DEV=1 (csrc/common.hpp: dev_env).  Set for this process and everything it spawns.
+os.environ.setdefault("PDHG_DEV", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line(

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # usage: tools/ab.sh "ENV1=.. ENV2=.." ...   -> one bench line per configuration
 for cfg in "$@"; do
   env $cfg python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "

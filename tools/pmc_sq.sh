@@ -1,4 +1,5 @@
 set -x
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_sq

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # SQ / TA / TCP / TCC counter passes for the products of ONE matrix shape (default: banded 10M +-50000, where the stream
 # kernel's gathers all hit L2): separate `rocprofv3 --kernel-trace --pmc` runs (no other trace domain) of
 # tools/shape_table.py --only "<shape>" --no-vendor.  Run on the GPU box:   tools/pmc_stream.sh "<shape title substring>" <out label> [kernel substring]

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # HBM/fabric bytes per fused product from hardware counters, the way MI355X_MICROARCH.md
 # prescribes: separate `rocprofv3 --pmc` passes (kernel-trace only) of the SAME bench.py
 # command with the separate-launch path (PDHG_GRAPH=0: the kernels are the ones the one-launch

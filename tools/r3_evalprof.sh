@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # cProfile of optimize() (solve_qp.jl defaults) on one generated workload: where the time outside take_step goes
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r3w
 for W in ${WORKLOADS:-l1svm pagerank}; do

@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/r3full
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/r3full/tests.log
 cat gpurun_out/r3full/tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3

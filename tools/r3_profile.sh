@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # Round-3 measurement set (run on the GPU box): bench lines, rocprofv3 kernel stats of the same commands,
 # PMC traffic.  Outputs under gpurun_out/r3prof/.
 set -x

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # small LPs: one launch per trial against the batch of steps in one workgroup with the vectors in LDS (small_lp_kernel.hpp)
 cd "$GRAFT_REPO_ROOT"
 timeout 900 python -m pytest tests/test_gpu_small_lp.py -x -q 2>&1 | grep -v "^[A-Z][A-Za-z]* \(version\|path\) *:\|Hostname" | tail -5

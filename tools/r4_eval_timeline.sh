@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # one termination / restart check of an L1-SVM solve on the GPU timeline: the kernels between two steps_kernel launches
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 W=${1:-l1svm}

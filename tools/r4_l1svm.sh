@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # round 4: the multi-step kernel variants on the latency-bound LPs (run on the GPU box)
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r4_l1svm.txt

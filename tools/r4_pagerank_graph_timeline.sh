@@ -1,4 +1,5 @@
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 rm -rf gpurun_out/prtl; mkdir -p gpurun_out/prtl
 rocprofv3 --kernel-trace -d gpurun_out/prtl/kt -- python bench.py --workload pagerank --steps 60 --warmup 20 --no-cpu-baseline --no-other-configs --no-self-profile --no-ceiling --profile-steps 0 > /dev/null 2>&1
 python - <<'PY'

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # the two fused products on a range of matrix shapes with the shipped build (tools/tune_tiled.py: HIP-event brackets of
 # pdhg_trial_step's products from a fixed iterate); round 2's table (profiles/r02_final_shape_table.txt) re-measured
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out/r4shape

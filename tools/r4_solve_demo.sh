@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # optimize() end to end with solve_qp.jl's defaults on the four benchmark LPs, stage by stage (tools/solve_demo.py --breakdown)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r4solve
 O=gpurun_out/r4solve/r04_solve_demo.txt

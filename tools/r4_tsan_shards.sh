@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # ThreadSanitizer run of the shard pool (one issuing host thread per shard) on the GPU box: 4 shards on one device,
 # peer-kernel exchange, 80 adaptive steps, getters.  The HIP runtime and the interpreter are not instrumented, so reports
 # whose racing accesses lie inside libamdhip64 / libhsa-runtime are noise of the method; tools/tsan_classify.py counts the

@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/r5b
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 export SHAPE_CACHE_DIR=/tmp/shape_cache
 (time python tools/shape_table.py) > gpurun_out/r5b/shape_table_vendor.txt 2> gpurun_out/r5b/shape_table_vendor.err
 tail -20 gpurun_out/r5b/shape_table_vendor.txt

@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/r5c
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 (tools/slot_probe 100 100000 8; tools/slot_probe 100 100000 4) > gpurun_out/r5c/slot_probe4.txt 2>&1
 grep "^  1 \|^  12\|^entries" gpurun_out/r5c/slot_probe4.txt
 export SHAPE_CACHE_DIR=/tmp/shape_cache

@@ -7,6 +7,7 @@ CSR arrays beside every product.  Measurement aid: prints one line per shape (pr
 """
 import argparse
 import os
+os.environ.setdefault("PDHG_DEV", "1")     # development variables on (csrc/common.hpp: dev_env)
 import sys
 import time
 

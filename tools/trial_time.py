@@ -4,6 +4,7 @@ whatever library PDHG_HIP_LIB points at (tools/variants.sh builds -D variants).
 The same trial is repeated from a fixed iterate, so diagnostic variants that
 compute wrong values cannot derail the step-size logic."""
 import argparse, os, sys
+os.environ.setdefault("PDHG_DEV", "1")     # development variables on (csrc/common.hpp: dev_env)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import folp_loader

@@ -3,6 +3,7 @@
 process, interleaved and repeated (per-kernel HIP-event averages).
 usage: tune_tiled.py [--m M --n N] "K=V K=V" "K=V" ..."""
 import argparse, os, sys, time
+os.environ.setdefault("PDHG_DEV", "1")     # development variables on (csrc/common.hpp: dev_env)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import folp_loader

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 # usage: tools/variants.sh NAME "-DFLAG ..." [NAME "-D..."]...   (run in the build container)
 # builds firstorderlp.jl_amd/csrc/variants/libpdhg_NAME.so for tools/trial_time.py
 cd "$(dirname "$0")/.."
