@@ -56,6 +56,22 @@ def socket0_cores(all_threads=False):
     return cpus or list(range(max(1, (os.cpu_count() or 2) // 2)))
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max / v1 cfs quota); None: unlimited / unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+            q, per = float(fq.read()), float(fp.read())
+            return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -409,9 +425,18 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
             try:
                 from oracle.oracle import OmpCpuState
                 cores, smt = socket0_cores(), socket0_cores(all_threads=True)
-                variants = [("physical cores", cores, 0), ("physical cores, prefetch 16", cores, 16)]
-                if len(smt) > len(cores):
+                # a container's CPU quota (cgroup cpu.max) caps the CPU TIME whatever the thread count: 64 pinned threads
+                # under a 16-CPU quota are throttled to a quarter of the wall clock and run SLOWER than 16 (measured on the
+                # GPU box, tools/omp_scale.py: 1 / 4 / 16 / 32 / 64 threads = 3.8 / 15.6 / 49.1 / 44.5 / 22.5 it/s on a
+                # 4M x 4M LP).  The comparator therefore uses as many of the socket's physical cores as the quota pays for,
+                # says so, and never claims more cores than it had.
+                quota = cgroup_cpu_quota()
+                usable = cores if quota is None else cores[:max(1, min(len(cores), int(quota)))]
+                variants = [(f"{len(usable)} physical cores", usable, 0), (f"{len(usable)} physical cores, prefetch 16", usable, 16)]
+                if len(usable) == len(cores) and len(smt) > len(cores):
                     variants += [("all hardware threads", smt, 0), ("all hardware threads, prefetch 16", smt, 16)]
+                elif len(usable) > 2:
+                    variants += [(f"{len(usable) // 2} physical cores", usable[:len(usable) // 2], 0)]
                 budget = max(1.2 * cpu_seconds, 6.0) / len(variants)
                 tried, best = [], None
                 for label, cpus, pf in variants:
@@ -446,8 +471,15 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
                                                      "8(13n+6m) of vectors) x trials / time: what the socket's memory system delivered, "
                                                      "random gathers included",
                               "variants": tried,
+                              "host": {"cpu_count": os.cpu_count(), "socket0_physical_cores": len(cores),
+                                       "cgroup_cpu_quota_cpus": quota,
+                                       "note": None if quota is None or quota >= len(cores) else
+                                       f"the container may use {quota:g} CPUs' worth of time (cgroup cpu.max): the comparator ran on "
+                                       f"{len(usable)} cores, NOT on the {len(cores)}-core socket the north star names; the socket would "
+                                       "be faster by at most the ratio of the core counts (memory bandwidth permitting)"},
                               "sample": f"{best['steps']} adaptive take_step calls on the same LP, oracle/pdhg_cpu_omp.c "
-                                        f"({best['variant']}; socket 0 has {len(cores)} physical cores, {len(smt)} hardware threads), "
+                                        f"({best['variant']}; socket 0 has {len(cores)} physical cores, {len(smt)} hardware threads, "
+                                        f"CPU quota {quota if quota is not None else 'none'}), "
                                         "the fastest of the variants listed"}
             except Exception as exc:   # measurement extra: never fail the bench line for it
                 cpu_socket = {"error": repr(exc)}

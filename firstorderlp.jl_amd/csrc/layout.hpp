@@ -15,6 +15,8 @@ struct SlabDev {
   int nblk = 0, per_xcd = 0, grid = 0;
   int64_t nnz = 0;
   SjDev sj;                        // the slab's entries in the sliced jagged layout (sj_kernels.hpp), when built
+  int4 *ext = nullptr;             // (r0, r1, k0, k1) per row block + the persistent kernel's grid (spmv_stream_pipe_kernel), when built
+  int pipe_grid = 0;
   CsrView view(int rows) const { return CsrView{rows, rowptr, col, val}; }
 };
 
@@ -57,6 +59,9 @@ struct CsrDev {
   // blocks than the persistent trial kernels take (the CSR arrays and row blocks above stay: evaluation-time callers,
   // the one-launch paths and the long-row kernels use them)
   SjDev sj;
+  // the CSR row blocks as a persistent software-pipelined launch (spmv_stream_pipe_kernel): extent words + grid, when built
+  int4 *ext = nullptr;
+  int pipe_grid = 0;
   // ---- 64-bit extents (quadratic_programming.jl:64: the reference's indices are Int64).  The kernels index entries with
   // 32 bits; a matrix with more entries than that is held as SEGMENTS of whole consecutive rows, each a complete CsrDev
   // of its own (own arrays and tables, offsets local to the segment: the 64-bit part of an entry's address is the
@@ -894,10 +899,10 @@ int build_sj(SjDev &J, int rows, const std::vector<int> &rowptr, const std::vect
 // (trial_kernel.hpp: <= 1 024 items; such LPs are latency-bound and stay on the CSR row blocks) -- i.e. products that are
 // bandwidth work -- whose rows (the long ones apart) have at most SJ_MAX_LEN entries (sj_kernels.hpp: a lane walks its
 // row).  PDHG_SJ=0 / 1 forces it off / on whatever the shape (tests compare the two layouts bitwise).
-// ... and whose 256-row groups are nearly uniform inside: a workgroup trip lasts as long as its longest row, so the
-// layout pays when entries / (256 x longest row of the group), summed over the groups, is >= 0.8.  Measured (round 5,
-// profiles/r05_sj_layout.txt, banded 10M +-50000): rows of exactly 10 entries 0.80 -> 0.62 ms (rocSPARSE 0.70); its
-// transpose, column counts Poisson(10), fill 0.5: 0.79 ms on either layout -> stays on the CSR row blocks.
+// ... and whose 256-row groups are not too ragged: a workgroup trip lasts as long as its longest row, so the layout is used
+// when entries / (256 x longest row of the group), summed over the groups, is >= 0.4.  Measured (round 5,
+// profiles/r05_sj_layout.txt, banded 10M +-50000 / block-diagonal 10M): rows of exactly 10 entries (fill 1.0) 0.80 -> 0.58-0.61
+// ms (rocSPARSE 0.70); the transposes, column counts Poisson(10) (fill 0.47), 0.74-0.78 -> 0.67-0.74.
 inline bool sj_wanted(int nblk, int rows, const std::vector<int> &rowptr, const std::vector<int> &full_rowptr, int long_thr) {
   if (const char *ev = getenv("PDHG_SJ")) return ev[0] != '0';
   if (nblk <= 1024) return false;
@@ -913,11 +918,62 @@ inline bool sj_wanted(int nblk, int rows, const std::vector<int> &rowptr, const 
     }
     capacity += (int64_t)SJ_SIGMA * longest;
   }
-  return capacity > 0 && 10 * entries >= 8 * capacity;
+  return capacity > 0 && 10 * entries >= 4 * capacity;
+}
+
+// The persistent software-pipelined form of the CSR row blocks (spmv_stream_pipe_kernel): the blocks' extent words and the
+// grid.  For the same products as the sliced jagged copy -- more row blocks than the persistent trial kernels take --
+// whatever the row lengths; PDHG_STREAM_PIPE=0 / 1 (dev) forces it off / on.  `rowptr`: the row pointers `blks` was cut from.
+// Row blocks of very different cost (a hub row fills a block by itself and is added by one lane or one wave) want the
+// hardware's dynamic dispatch of the plain kernel, not a fixed walk: PageRank-1M lost 6 % on the pipelined launch (0.105
+// against 0.099 ms per product) where banded / block-diagonal matrices with Poisson(10) rows gained 5-6 % (0.77 -> 0.73 ms;
+// profiles/r05_sj_layout.txt).  So: only matrices whose rows (the long-row path's apart) stay within SJ_MAX_LEN entries.
+inline bool stream_pipe_wanted(int nblk, int64_t max_row_nnz, int long_thr) {
+  if (const char *ev = dev_env("PDHG_STREAM_PIPE")) return ev[0] != '0';
+  return nblk > 1024 && std::min<int64_t>(max_row_nnz, long_thr) <= SJ_MAX_LEN;
+}
+int build_block_extents(int4 **ext_out, int *grid_out, const int2 *d_blks, int nblk, int max_wgs, const std::vector<int> &rowptr, bool remap) {
+  if (nblk <= 0) return 0;
+  std::vector<int2> blks((size_t)nblk);
+  HIP_TRY(hipMemcpy(blks.data(), d_blks, sizeof(int2) * (size_t)nblk, hipMemcpyDeviceToHost));
+  std::vector<int4> ext((size_t)nblk);
+  for (int b = 0; b < nblk; ++b) ext[(size_t)b] = make_int4(blks[(size_t)b].x, blks[(size_t)b].y, rowptr[(size_t)blks[(size_t)b].x], rowptr[(size_t)blks[(size_t)b].y]);
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  // never more workgroups than the plain kernel's grid: every workgroup owns a block-partial slot of that grid
+  int grid = std::max(1, std::min(std::min(STREAM_PIPE_WGS_PER_CU * cus, nblk), std::max(1, max_wgs)));
+  if (remap) grid = std::max(NUM_XCD, (grid + NUM_XCD - 1) / NUM_XCD * NUM_XCD > max_wgs ? grid / NUM_XCD * NUM_XCD : (grid + NUM_XCD - 1) / NUM_XCD * NUM_XCD);
+  *grid_out = grid;
+  return upload(ext_out, ext);
 }
 
 // after the stream tables / slabs exist and D.rowptr / D.col / D.val are in HBM
+int build_sj_copies_only(CsrDev &D, int rows, const std::vector<int> &rowptr, bool remap);
 int build_sj_copies(CsrDev &D, int rows, const std::vector<int> &rowptr, bool remap) {
+  int rc = build_sj_copies_only(D, rows, rowptr, remap);
+  if (rc || D.tiled || !D.segs.empty()) return rc;
+  // products that did not get the sliced jagged copy: the pipelined launch of the row blocks
+  if (!D.slabs.empty()) {
+    if (D.slabs.front().sj.on()) return 0;
+    int nblk_max = 0;
+    for (const SlabDev &S : D.slabs) nblk_max = std::max(nblk_max, S.nblk);
+    if (!stream_pipe_wanted(nblk_max, D.max_row_nnz, D.long_thr)) return 0;
+    for (SlabDev &S : D.slabs) {
+      std::vector<int> rp((size_t)rows + 1);
+      HIP_TRY(hipMemcpy(rp.data(), S.rowptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost));
+      if ((rc = build_block_extents(&S.ext, &S.pipe_grid, S.blks, S.nblk, S.grid, rp, remap))) return rc;
+    }
+    return 0;
+  }
+  if (D.sj.on() || D.grid <= 0 || !stream_pipe_wanted(D.nblk, D.max_row_nnz, D.long_thr)) return 0;
+  return build_block_extents(&D.ext, &D.pipe_grid, D.blks, D.nblk, D.grid, rowptr, remap);
+}
+int build_sj_copies_only(CsrDev &D, int rows, const std::vector<int> &rowptr, bool remap) {
   if (D.tiled || !D.segs.empty()) return 0;
   int rc;
   if (!D.slabs.empty()) {
@@ -943,11 +999,12 @@ void free_csr_dev(CsrDev &D) {
                   D.wave_step_off, D.step_tile, D.wg_step_off};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (SlabDev &S : D.slabs) {
-    void *sp[] = {S.rowptr, S.col, S.val, S.blks};
+    void *sp[] = {S.rowptr, S.col, S.val, S.blks, S.ext};
     for (void *p : sp) if (p) (void)hipFree(p);
     free_sj(S.sj);
   }
   free_sj(D.sj);
+  if (D.ext) (void)hipFree(D.ext);
   if (D.slab_partial) (void)hipFree(D.slab_partial);
   D = CsrDev();
 }

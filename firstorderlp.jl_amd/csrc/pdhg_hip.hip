@@ -324,6 +324,23 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
           hipLaunchKernelGGL((spmv_sj_kernel<MODE, true, TAG>), dim3(S.sj.grid), dim3(TPB), 0, h->stream, sj_view(S.sj), xin, rm, S.grid, le);
         continue;
       }
+      if (S.pipe_grid > 0) {  // the slab's row blocks as a persistent pipelined launch (spmv_stream_pipe_kernel)
+        EpiArgs pe{};
+        pe.out = D.slab_partial;
+        pe.init = D.slab_partial;
+        EpiArgs le = e;
+        le.init = D.slab_partial;
+        if (p + 1 < P && p == 0)
+          hipLaunchKernelGGL((spmv_stream_pipe_kernel<MODE_PLAIN, false, TAG>), dim3(S.pipe_grid), dim3(TPB), 0, h->stream, S.view(D.rows), xin,
+                             (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx, 0, pe);
+        else if (p + 1 < P)
+          hipLaunchKernelGGL((spmv_stream_pipe_kernel<MODE_PLAIN, true, TAG>), dim3(S.pipe_grid), dim3(TPB), 0, h->stream, S.view(D.rows), xin,
+                             (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx, 0, pe);
+        else
+          hipLaunchKernelGGL((spmv_stream_pipe_kernel<MODE, true, TAG>), dim3(S.pipe_grid), dim3(TPB), 0, h->stream, S.view(D.rows), xin,
+                             (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx, S.grid, le);
+        continue;
+      }
       if (p + 1 < P) {
         EpiArgs pe{};
         pe.out = D.slab_partial;
@@ -344,6 +361,9 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
   } else if (D.sj.on()) {
     hipLaunchKernelGGL((spmv_sj_kernel<MODE, false, TAG>), dim3(D.sj.grid), dim3(TPB), 0, h->stream, sj_view(D.sj), xin,
                        h->remap ? 1 : 0, D.grid, e);
+  } else if (D.pipe_grid > 0) {
+    hipLaunchKernelGGL((spmv_stream_pipe_kernel<MODE, false, TAG>), dim3(D.pipe_grid), dim3(TPB), 0, h->stream, D.view(), xin,
+                       (const int4 *)D.ext, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, D.grid, e);
   } else if (D.grid > 0) {
     hipLaunchKernelGGL((spmv_stream_kernel<MODE, false, TAG>), dim3(D.grid), dim3(TPB), 0, h->stream,
                        D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, e);
@@ -1117,6 +1137,24 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
         prev.assign(1, nd);
         continue;
       }
+      if (S.pipe_grid > 0) {
+        EpiArgs pe{};
+        pe.out = D.slab_partial;
+        pe.init = D.slab_partial;
+        EpiArgs le = e;
+        le.init = D.slab_partial;
+        if (p + 1 < P) {
+          const void *fn = p == 0 ? (const void *)spmv_stream_pipe_kernel<MODE_PLAIN, false, TAG> : (const void *)spmv_stream_pipe_kernel<MODE_PLAIN, true, TAG>;
+          HIP_TRY(graph_add_kernel(graph, &nd, prev, fn, dim3(S.pipe_grid), dim3(TPB), S.view(D.rows), xin, (const int4 *)S.ext, S.nblk,
+                                   S.per_xcd, rm, rx, 0, pe));
+        } else {
+          HIP_TRY(graph_add_kernel(graph, &nd, prev, (const void *)spmv_stream_pipe_kernel<MODE, true, TAG>, dim3(S.pipe_grid), dim3(TPB),
+                                   S.view(D.rows), xin, (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx, S.grid, le));
+          if (main_node) *main_node = nd;
+        }
+        prev.assign(1, nd);
+        continue;
+      }
       if (p + 1 < P) {
         EpiArgs pe{};
         pe.out = D.slab_partial;
@@ -1138,6 +1176,12 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
     hipGraphNode_t nd = nullptr;
     HIP_TRY(graph_add_kernel(graph, &nd, deps, (const void *)spmv_sj_kernel<MODE, false, TAG>, dim3(D.sj.grid), dim3(TPB),
                              sj_view(D.sj), xin, rm, D.grid, e));
+    if (main_node) *main_node = nd;
+    done.push_back(nd);
+  } else if (D.pipe_grid > 0) {
+    hipGraphNode_t nd = nullptr;
+    HIP_TRY(graph_add_kernel(graph, &nd, deps, (const void *)spmv_stream_pipe_kernel<MODE, false, TAG>, dim3(D.pipe_grid), dim3(TPB),
+                             D.view(), xin, (const int4 *)D.ext, D.nblk, D.per_xcd, rm, rx, D.grid, e));
     if (main_node) *main_node = nd;
     done.push_back(nd);
   } else if (D.grid > 0) {
@@ -1181,12 +1225,18 @@ int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &du
       if (S.sj.on())
         HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_sj_kernel<MODE_DUAL, true, 0>, dim3(S.sj.grid), dim3(TPB),
                                  sj_view(S.sj), (const double *)h->xbar, rm, S.grid, le));
+      else if (S.pipe_grid > 0)
+        HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_pipe_kernel<MODE_DUAL, true, 0>, dim3(S.pipe_grid), dim3(TPB),
+                                 S.view(A.rows), (const double *)h->xbar, (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx, S.grid, le));
       else
         HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, true, 0>, dim3(S.grid), dim3(TPB),
                                  S.view(A.rows), (const double *)h->xbar, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, rx, le));
     } else if (A.sj.on()) {
       HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_sj_kernel<MODE_DUAL, false, 0>, dim3(A.sj.grid), dim3(TPB),
                                sj_view(A.sj), (const double *)h->xbar, rm, A.grid, dual_epi));
+    } else if (A.pipe_grid > 0) {
+      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_pipe_kernel<MODE_DUAL, false, 0>, dim3(A.pipe_grid), dim3(TPB),
+                               A.view(), (const double *)h->xbar, (const int4 *)A.ext, A.nblk, A.per_xcd, rm, rx, A.grid, dual_epi));
     } else {
       HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, false, 0>, dim3(A.grid), dim3(TPB),
                                A.view(), (const double *)h->xbar, (const int2 *)A.blks, A.nblk, A.per_xcd, rm, rx, dual_epi));
@@ -2092,12 +2142,14 @@ static std::string product_kernels(const CsrDev &D, int mode, int tag) {
   if (D.tiled) {
     if (D.grid > 0) add("spmv_tiled_kernel<" + m + ", " + std::to_string(D.tw_mode) + ">");
   } else if (!D.slabs.empty()) {
-    const std::string k = D.slabs.front().sj.on() ? "spmv_sj_kernel<" : "spmv_stream_kernel<";
+    const std::string k = D.slabs.front().sj.on() ? "spmv_sj_kernel<" : (D.slabs.front().pipe_grid > 0 ? "spmv_stream_pipe_kernel<" : "spmv_stream_kernel<");
     add(k + "0, false, " + t + ">");
     if (D.slabs.size() > 2) add(k + "0, true, " + t + ">");
     add(k + m + ", true, " + t + ">");
   } else if (D.sj.on()) {
     add("spmv_sj_kernel<" + m + ", false, " + t + ">");
+  } else if (D.pipe_grid > 0) {
+    add("spmv_stream_pipe_kernel<" + m + ", false, " + t + ">");
   } else if (D.grid > 0) {
     add("spmv_stream_kernel<" + m + ", false, " + t + ">");
   }
@@ -2577,13 +2629,19 @@ static int group_coop_prepare(const Shards &L) {
   const char *pretend = dev_env("PDHG_COOP_TEST_PRETEND_WGS");       // test knob: a grid the device cannot hold
   for (int dev : devs) {
     HIP_TRY(hipSetDevice(dev));
-    GroupDevLaunch D;
+    // (the record enters g.coop_dev FIRST: whatever fails below, the caller's group_coop_release frees what it holds by then)
+    g.coop_dev.emplace_back();
+    GroupDevLaunch &D = g.coop_dev.back();
     D.device = dev;
     for (int i = 0; i < L.count; ++i) if (L.p[i]->device == dev) D.members.push_back(i);
     D.stream = L.p[D.members[0]]->stream;
-    int per_cu = 0;
+    int per_cu = 0, per_cu_inline = 0;
     hipDeviceProp_t prop;
+    // co-residency of the kernel that WILL be launched: up to GROUP_INLINE_SHARDS members per device take the inline-argument
+    // variant (group_coop_trial), whose registers and kernel arguments differ -- size for the smaller of the two
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, group_trial_kernel, TPB, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_inline, group_trial_inline_kernel, TPB, 0));
+    per_cu = std::min(per_cu, per_cu_inline);
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     const int cap = std::max(8, per_cu * prop.multiProcessorCount / 8 * 8);
     // every shard one workgroup per item where the device holds that many side by side, else in proportion
@@ -2649,7 +2707,6 @@ static int group_coop_prepare(const Shards &L) {
       for (int x = 0; x < 8; ++x) { seen += host.xcd_count[x][0]; s->coop_nxcd += host.xcd_count[x][0] > 0; s->coop_xcd_cnt[x] = (unsigned)host.xcd_count[x][0]; }
       if (seen != (unsigned long long)grid[k] || s->coop_nxcd == 0) return fail(996, "group trial kernel: workgroup census does not add up");
     }
-    g.coop_dev.push_back(D);
   }
   if (!g.gsync) {
     HIP_TRY(hipSetDevice(L.p[0]->device));
@@ -3292,9 +3349,18 @@ static int ev_wait_host(pdhg_handle *h, int k, unsigned long long seq, double *o
   return fail(998, "evaluation reduction finished without publishing its results");
 }
 
+// The evaluation reductions publish into pinned host memory (one handle) unless PDHG_EVAL_HOST_WORD=0 (dev): decided in
+// ONE place and per call -- pdhg_eval_point's combined 22-quantity reduction (which needs the max mask) and ev_finish
+// must never disagree (a cached copy here once could: sums where maxima belong).
+static bool eval_host_word() {
+  const char *hw = dev_env("PDHG_EVAL_HOST_WORD");
+  return !(hw && hw[0] == '0');
+}
+
 static int ev_finish(const Shards &L, int ns, int nm, double *out, unsigned max_mask = 0) {
   if (ns + nm > EV_MAXQ) return fail(-1, "too many scalars in one reduction");
-  static const bool host_word = !(dev_env("PDHG_EVAL_HOST_WORD") && dev_env("PDHG_EVAL_HOST_WORD")[0] == '0');
+  const bool host_word = eval_host_word();
+  if (max_mask != 0 && (L.g || !host_word)) return fail(-1, "a mixed sum / max reduction needs the host-word form");
   if (!L.g && host_word) {
     // one handle: the second stage publishes into pinned memory and the host polls (see multi_final_kernel)
     pdhg_handle *h = L.p[0];
@@ -3424,8 +3490,7 @@ int pdhg_eval_point(pdhg_handle *h0, int point, double out[24]) {
   const Shards L = shards_of(h0);
   if ((rc = flush_pending(L))) return rc;
   if ((rc = point_products(L, point))) return rc;
-  const char *hw = dev_env("PDHG_EVAL_HOST_WORD");          // (read per call: tests compare the two forms in one process)
-  if (!L.g && !(hw && hw[0] == '0')) {
+  if (!L.g && eval_host_word()) {                              // (read per call: tests compare the two forms in one process)
     // one handle: the row and the column kernels leave their block partials side by side (8 + 14 quantities), ONE second
     // stage reduces all 22 and the host makes one round trip instead of two.  Same partials, same order per quantity:
     // the same bits as the two-round form below.
@@ -4280,6 +4345,7 @@ int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   for (int k = 0; k < 2; ++k) {
     const CsrDev &D = first(*Ms[k]);
     if (D.sj.on() || (!D.slabs.empty() && D.slabs.front().sj.on())) info[12 + k] += 256;
+    if (D.pipe_grid > 0 || (!D.slabs.empty() && D.slabs.front().pipe_grid > 0)) info[12 + k] += 512;   // bit 9: spmv_stream_pipe_kernel
   }
   return 0;
 }

@@ -38,9 +38,14 @@ namespace {
 
 constexpr int SJ_SIGMA = TPB;        // rows per sorting group = rows per workgroup trip (4 slices)
 constexpr int SJ_MAX_LEN = 128;      // longest row (long rows apart) the builder accepts for this layout
-constexpr int SJ_U1 = 16;            // levels of a slice requested one trip ahead (registers)
-constexpr int SJ_U = 8;              // further levels: batches of this many
-constexpr int SJ_WGS_PER_CU = 2;         // (the kernel holds two trips in registers: 150-178 VGPRs, two workgroups per CU)
+#ifndef PDHG_SJ_U
+#define PDHG_SJ_U 16
+#endif
+constexpr int SJ_U = PDHG_SJ_U;      // levels per batch (one batch in registers, the next in flight)
+#ifndef PDHG_SJ_WGS
+#define PDHG_SJ_WGS 2
+#endif
+constexpr int SJ_WGS_PER_CU = PDHG_SJ_WGS;
 
 struct SjDev {
   int nslices = 0, grid = 0, rows = 0;
@@ -86,20 +91,21 @@ __global__ __launch_bounds__(TPB) void sj_fill_kernel(int nslices, const unsigne
   }
 }
 
-// a slice's first SJ_U1 levels in registers (the whole slice for all but a few slices of a matrix this layout accepts)
+// SJ_U levels of a slice in registers
 struct SjBatch {
-  int c[SJ_U1];
-  double v[SJ_U1];
+  int c[SJ_U];
+  double v[SJ_U];
 };
-// level j of the slice for this lane: (col, val) at off + lane when the lane's row has more than j entries; `off` moves on
-// by the number of such lanes.  Lb: levels of the slice (uniform): the branch skips levels no lane has.
-__device__ __forceinline__ void sj_load_first(const SjView &J, int &off, int l, int Lb, int lane, SjBatch &B) {
+// levels j0 .. j0 + SJ_U - 1 of the slice for this lane: (col, val) of level j at off + lane when the lane's row has more
+// than j entries; `off` moves on by the number of such lanes.  L: levels of the slice (uniform): the branch skips levels
+// no lane has.
+__device__ __forceinline__ void sj_load_batch(const SjView &J, int &off, int l, int L, int j0, int lane, SjBatch &B) {
 #pragma unroll
-  for (int jj = 0; jj < SJ_U1; ++jj) {
+  for (int jj = 0; jj < SJ_U; ++jj) {
     B.c[jj] = 0;
     B.v[jj] = 0.0;
-    if (jj < Lb) {                                        // wave-uniform
-      const bool act = jj < l;
+    if (j0 + jj < L) {                                    // wave-uniform
+      const bool act = j0 + jj < l;
       const int k = off + lane;
       off += __popcll(__ballot(act));
       if (act) {
@@ -110,13 +116,14 @@ __device__ __forceinline__ void sj_load_first(const SjView &J, int &off, int l, 
   }
 }
 
-// Software pipeline over the workgroup's trips: while trip i gathers and adds, trip i + 1's first SJ_U1 levels and
-// epilogue operands and trip i + 2's slot words are in flight, so a trip costs one gather round trip (L2) and a
-// workgroup barrier instead of five dependent memory round trips (slot words -> entries -> gathers -> operands -> store:
-// 0.82 ms on banded 10M, the CSR kernel's time; 0.69 with one trip of look-ahead; 0.62 with two).  The barrier that
-// hands the row sums to the row-order epilogue is also PACING: a variant without it (every wave its own pipeline, the
-// epilogue in the lane that walked the row) ran at 0.74 -- the waves of an XCD drift apart and the window of the
-// gathered vector in flight widens, exactly as in the sweep (profiles/r05_sj_layout.txt).
+// Software pipeline at BATCH granularity (SJ_U levels): while a batch's gathers are in flight the next batch -- of the same
+// slice, or the first of the wave's slice in the workgroup's next group -- is already requested, together with that group's
+// epilogue operands; the slot words run two groups ahead.  So a batch costs one gather round trip (L2) and a group one
+// workgroup barrier, instead of the chain slot words -> entries -> gathers -> operands -> store (0.82 ms on banded 10M, the
+// CSR kernel's time; 0.62 pipelined).  The barrier that hands the row sums to the row-order epilogue is also PACING: a
+// variant without it (every wave its own pipeline, the epilogue in the lane that walked the row) ran at 0.74 -- the waves
+// of an XCD drift apart and the window of the gathered vector in flight widens, exactly as in the sweep
+// (profiles/r05_sj_layout.txt).
 template <int MODE, bool INIT = false, int TAG = 0>
 __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__restrict__ xin, int remap, int stream_slots, EpiArgs e) {
   static_assert(SJ_SIGMA == TPB, "one sorting group per workgroup trip");
@@ -136,12 +143,10 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
   row_ok[0][tid] = 0;
   row_ok[1][tid] = 0;
   __syncthreads();
-  // group of trip i: xbase + i (none when past the end: the XCD's last eighth can be short)
   auto group_of = [&](int i) { const int g = xbase + i; return (i < limit && g < ngroups) ? g : -1; };
-  // ---- requested TWO trips ahead: the slot words and the slice offset (what the entry addresses depend on);
-  //      ONE trip ahead: the slice's first SJ_U1 levels, the epilogue operands, the carried row sums (INIT)
+  // ---- in flight: the slot words of the next two groups (w_n, w_nn), the next batch (B_n), the next group's operands
   unsigned w_n = (SJ_NONE << 16), w_nn = (SJ_NONE << 16);
-  int off_n = 0, off_nn = 0, Lb_n = 0;
+  int off_n = 0, off_nn = 0;
   EpiOps ops_n{0.0, 0.0, 0.0};
   double init_n = 0.0;
   SjBatch B_n;
@@ -154,8 +159,8 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
       off = J.slice_off[slice];
     }
   };
-  // the entries, operands and carried sums of group g, whose slot words (w_n, off_n) have arrived
-  auto request_rest = [&](int g) {
+  // the first batch, the epilogue operands and the carried sums of group g, whose slot words (w_n, off_n) have arrived
+  auto request_group = [&](int g) {
     const int row = g * SJ_SIGMA + tid;
     if (g >= 0 && row < J.rows) ops_n = epi_load<MODE>(e, row);
     const int l = (int)(w_n & 0xFFFFu);
@@ -163,67 +168,49 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
       const int r = (w_n >> 16) == SJ_NONE ? -1 : g * SJ_SIGMA + (int)(w_n >> 16);
       init_n = r >= 0 ? e.init[r] : 0.0;
     }
-    Lb_n = __builtin_amdgcn_readfirstlane(l);             // lane 0 holds the slice's longest row
-    sj_load_first(J, off_n, l, Lb_n < SJ_U1 ? Lb_n : SJ_U1, lane, B_n);
+    sj_load_batch(J, off_n, l, __builtin_amdgcn_readfirstlane(l), 0, lane, B_n);
   };
   int g = group_of(first), g_next = group_of(first + stride);
   request_meta(g, w_n, off_n);
   request_meta(g_next, w_nn, off_nn);
-  request_rest(g);
+  request_group(g);
   int buf = 0;
   for (int i = first; g >= 0; i += stride) {
-    // trip i's operands out of the "next" registers
     const unsigned w = w_n;
-    int off = off_n;
-    const int L = Lb_n;
     const EpiOps ops = ops_n;
     const int l = (int)(w & 0xFFFFu);
+    const int L = __builtin_amdgcn_readfirstlane(l);      // lane 0 holds the slice's longest row
     const int rl = (w >> 16) == SJ_NONE ? -1 : (int)(w >> 16);
     const int base = g * SJ_SIGMA;
     double s = INIT ? init_n : 0.0;
-    double xv[SJ_U1];
-#pragma unroll
-    for (int jj = 0; jj < SJ_U1; ++jj) {
-      xv[jj] = 0.0;
-      if (jj < L) xv[jj] = (jj < l) ? xin[B_n.c[jj]] : 0.0;        // (uniform branch: levels no lane of the slice has)
-    }
-    double vv[SJ_U1];
-#pragma unroll
-    for (int jj = 0; jj < SJ_U1; ++jj) vv[jj] = B_n.v[jj];
-    // behind this trip's gathers: trip i + 1's entries and operands (its slot words came in a trip ago), trip i + 2's slot words
-    w_n = w_nn;
-    off_n = off_nn;
     const int g_next2 = group_of(i + 2 * stride);
-    request_meta(g_next2, w_nn, off_nn);
-    request_rest(g_next);
-#pragma unroll
-    for (int jj = 0; jj < SJ_U1; ++jj) {
-      if (jj < l) {
-        const double p = vv[jj] * xv[jj];
-        s = s + p;
-      }
-    }
-    for (int j0 = SJ_U1; j0 < L; j0 += SJ_U) {            // rows beyond the first batch (rare by construction)
-      int c[SJ_U];
-      double v[SJ_U], x2[SJ_U];
+    int j0 = 0;
+    do {                                                  // the slice's batches (at least one trip: it requests what follows)
+      double xv[SJ_U], vv[SJ_U];
 #pragma unroll
       for (int jj = 0; jj < SJ_U; ++jj) {
-        const bool act = j0 + jj < l;
-        const int k = off + lane;
-        off += __popcll(__ballot(act));
-        c[jj] = act ? __builtin_nontemporal_load(J.col + k) : 0;
-        v[jj] = act ? __builtin_nontemporal_load(J.val + k) : 0.0;
+        xv[jj] = 0.0;
+        if (j0 + jj < L) xv[jj] = (j0 + jj < l) ? xin[B_n.c[jj]] : 0.0;      // (uniform branch: levels no lane of the slice has)
+        vv[jj] = B_n.v[jj];
       }
-#pragma unroll
-      for (int jj = 0; jj < SJ_U; ++jj) x2[jj] = (j0 + jj < l) ? xin[c[jj]] : 0.0;
+      // behind these gathers: the batch that follows
+      if (j0 + SJ_U < L) {                                // wave-uniform: the same slice goes on
+        sj_load_batch(J, off_n, l, L, j0 + SJ_U, lane, B_n);
+      } else {                                            // the wave's slice of the next group; slot words for the one after
+        w_n = w_nn;
+        off_n = off_nn;
+        request_meta(g_next2, w_nn, off_nn);
+        request_group(g_next);
+      }
 #pragma unroll
       for (int jj = 0; jj < SJ_U; ++jj) {
         if (j0 + jj < l) {
-          const double p = v[jj] * x2[jj];
+          const double p = vv[jj] * xv[jj];
           s = s + p;
         }
       }
-    }
+      j0 += SJ_U;
+    } while (j0 < L);
     if (rl >= 0) {
       row_sum[buf][rl] = s;
       row_ok[buf][rl] = 1;

@@ -153,49 +153,29 @@ __device__ __forceinline__ void stream_block_load(const CsrView &A, int2 rr, Str
 // lane adds 256 products in ~0.85 us, so only rows beyond that are worth a wave.
 constexpr int RELAXED_MIN_ROW = 256;
 
-// second half: gathers, products into LDS, per-row sums, fused epilogue.  acc[] receives this
-// thread's contributions to the block partials.
-// relaxed == 0 (PDHG_ROW_ORDER=strict): every row is added strictly left to right by one lane.
-// relaxed != 0 (default): rows of more than RELAXED_MIN_ROW (256) entries are summed by their whole wave --
-// lane l adds products l, l + 64, ... in ascending order, then a shuffle tree -- a fixed order
-// (bitwise reproducible), but not the sequential one: |result - sequential| <= 1e-13 * sum |a x|,
-// the bar the rows beyond BLOCK_NNZ have always had.  The row stays OWNED by the lane that
-// would have added it (epilogue, partial sums): nothing else changes.
-// PIPE: the two-register-set software pipeline of the strict per-lane row sum (32 VGPRs).  The one-launch trial
-// kernel, which keeps a prefetched item's 24 registers alive across its phases, runs the plain 8-at-a-time loop
-// instead (same order of additions, hence the same bits) to stay within 96 VGPRs.
-template <int MODE, bool INIT, bool PIPE = true, bool COH = false>
-__device__ __forceinline__ void stream_block_finish(const CsrView &A, const double *xin, const StreamRegs &g,
-                                                    const EpiArgs &e, int relaxed, Acc3 &acc, double *prod) {
+// What a pipelined caller has requested a trip ahead for the row (r0 + tid) of a block: its extent, its epilogue
+// operands and (column-slab passes) its carried sum.
+struct RowPre {
+  int rs, re;
+  EpiOps ops;
+  double init;
+};
+
+// The row phase of a stream block whose products lie in prod[]: one lane per row adds them left to right (rows beyond
+// RELAXED_MIN_ROW entries by their wave in relaxed order) and runs the fused epilogue.  pre != nullptr: the data of the
+// rows r0 .. r0 + TPB - 1 is in *pre (spmv_stream_pipe_kernel); further row trips of a block of very short rows read theirs here.
+template <int MODE, bool INIT, bool PIPE, bool COH>
+__device__ __forceinline__ void stream_rows_phase(const CsrView &A, int r0, int r1, int k0, const EpiArgs &e, int relaxed, Acc3 &acc,
+                                                  const double *prod, const RowPre *pre) {
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
-  const int k0 = g.k0, k1 = g.k1;
-  double xv[UNROLL];
-#pragma unroll
-  for (int i = 0; i < UNROLL; ++i) {
-    const int k = k0 + tid + i * TPB;
-    if (COH) {
-      // unconditional: a lane without an entry holds column 0 (stream_block_load), a valid address -- an ATOMIC load
-      // under a condition becomes a branch per load, and the waits the compiler puts in front of each serialise the
-      // gathers.  (For plain loads the conditional form measured 1-2 % faster: kept.)
-      const double t = ldc<true>(xin + g.cidx[i]);
-      xv[i] = (k < k1) ? t : 0.0;
-    } else {
-      xv[i] = (k < k1) ? xin[g.cidx[i]] : 0.0;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < UNROLL; ++i) {
-    const int k = tid + i * TPB;
-    if (k0 + k < k1) prod[k] = g.v[i] * xv[i];
-  }
-  __syncthreads();
-  for (int base = g.r0; base < g.r1; base += TPB) {     // workgroup-uniform trip count (the wave sums below need all lanes)
+  for (int base = r0; base < r1; base += TPB) {     // workgroup-uniform trip count (the wave sums below need all lanes)
     const int r = base + tid;
-    const bool have = r < g.r1;
-    const int ks = have ? A.rowptr[r] - k0 : 0;
-    const int ke = have ? A.rowptr[r + 1] - k0 : 0;
-    double s = (INIT && have) ? e.init[r] : 0.0;
+    const bool have = r < r1;
+    const bool first = pre && base == r0;                 // this trip's row data came in ahead of time (workgroup-uniform)
+    const int ks = have ? (first ? pre->rs : A.rowptr[r]) - k0 : 0;
+    const int ke = have ? (first ? pre->re : A.rowptr[r + 1]) - k0 : 0;
+    double s = (INIT && have) ? (first ? pre->init : e.init[r]) : 0.0;
     const bool wide = relaxed && (ke - ks > RELAXED_MIN_ROW);
     if (have && !wide) {
       int k = ks;
@@ -254,8 +234,51 @@ __device__ __forceinline__ void stream_block_finish(const CsrView &A, const doub
         if (lane == l) s = s + total;
       }
     }
-    if (have) row_epilogue<MODE, COH>(e, r, s, acc);
+    if (have) {
+      if (first) epi_apply<MODE, COH>(e, r, s, pre->ops, acc);
+      else row_epilogue<MODE, COH>(e, r, s, acc);
+    }
   }
+}
+
+// second half: gathers, products into LDS, per-row sums, fused epilogue.  acc[] receives this
+// thread's contributions to the block partials.
+// relaxed == 0 (PDHG_ROW_ORDER=strict): every row is added strictly left to right by one lane.
+// relaxed != 0 (default): rows of more than RELAXED_MIN_ROW (256) entries are summed by their whole wave --
+// lane l adds products l, l + 64, ... in ascending order, then a shuffle tree -- a fixed order
+// (bitwise reproducible), but not the sequential one: |result - sequential| <= 1e-13 * sum |a x|,
+// the bar the rows beyond BLOCK_NNZ have always had.  The row stays OWNED by the lane that
+// would have added it (epilogue, partial sums): nothing else changes.
+// PIPE: the two-register-set software pipeline of the strict per-lane row sum (32 VGPRs).  The one-launch trial
+// kernel, which keeps a prefetched item's 24 registers alive across its phases, runs the plain 8-at-a-time loop
+// instead (same order of additions, hence the same bits) to stay within 96 VGPRs.
+template <int MODE, bool INIT, bool PIPE = true, bool COH = false>
+__device__ __forceinline__ void stream_block_finish(const CsrView &A, const double *xin, const StreamRegs &g,
+                                                    const EpiArgs &e, int relaxed, Acc3 &acc, double *prod) {
+  const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1);
+  const int k0 = g.k0, k1 = g.k1;
+  double xv[UNROLL];
+#pragma unroll
+  for (int i = 0; i < UNROLL; ++i) {
+    const int k = k0 + tid + i * TPB;
+    if (COH) {
+      // unconditional: a lane without an entry holds column 0 (stream_block_load), a valid address -- an ATOMIC load
+      // under a condition becomes a branch per load, and the waits the compiler puts in front of each serialise the
+      // gathers.  (For plain loads the conditional form measured 1-2 % faster: kept.)
+      const double t = ldc<true>(xin + g.cidx[i]);
+      xv[i] = (k < k1) ? t : 0.0;
+    } else {
+      xv[i] = (k < k1) ? xin[g.cidx[i]] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < UNROLL; ++i) {
+    const int k = tid + i * TPB;
+    if (k0 + k < k1) prod[k] = g.v[i] * xv[i];
+  }
+  __syncthreads();
+  stream_rows_phase<MODE, INIT, PIPE, COH>(A, g.r0, g.r1, g.k0, e, relaxed, acc, prod, nullptr);
 }
 
 // TAG names the product in profiler output (0: the constraint matrix A, 1: its transpose,
@@ -284,6 +307,105 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
       for (int q = 0; q < NQ; ++q) {
         e.partials[q * e.stride + b] = acc.hi[q];
         e.partials[e.lo_offset + q * e.stride + b] = acc.lo[q];
+      }
+    }
+  }
+}
+
+// The same product as a PERSISTENT, software-pipelined kernel (round 5), for stream-class matrices whose product is
+// bandwidth work (more row blocks than the persistent trial kernels take).  spmv_stream_kernel walks a chain of dependent
+// memory round trips per row block -- block table -> row pointers -> (col, val) -> gathers -> [LDS] -> row extents ->
+// epilogue operands -> store -- with eight short-lived workgroups per CU to hide them; counters on a banded 10M matrix
+// showed waves alive for 31 us each, 47 % of it in s_waitcnt (profiles/r05_stream_kernel_pmc_banded50k.json).  Here a
+// workgroup stays and walks its blocks: while block t's gathers are in flight, block t + 1's entries, row extents and
+// epilogue operands and block t + 2's extent word are already requested, so a trip costs one L2 round trip and one
+// barrier.  Same lane-per-row sums in the same order (stream_rows_phase): the same bits as spmv_stream_kernel.
+// `ext`: (r0, r1, k0, k1) per row block, so that a block's entry addresses do not wait for two more loads.
+// Block partials: one slot per workgroup; the CSR grid's remaining slots (which the reductions walk) are zeroed.
+constexpr int STREAM_PIPE_WGS_PER_CU = 4;
+template <int MODE, bool INIT = false, int TAG = 0>
+__global__ __launch_bounds__(TPB) void spmv_stream_pipe_kernel(
+    CsrView A, const double *__restrict__ xin, const int4 *__restrict__ ext, int nblk, int per_xcd, int remap, int relaxed,
+    int stream_slots, EpiArgs e) {
+  __shared__ double prod[2][BLOCK_NNZ];
+  __shared__ double red[6][TPB / WAVE];
+  const int tid = threadIdx.x;
+  Acc3 acc = acc3_zero();
+  // remap: workgroup b runs on XCD b % 8 (round-robin dispatch) and walks that XCD's contiguous eighth of the blocks
+  const int first = remap ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int stride = remap ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int limit = remap ? per_xcd : nblk;
+  const int xbase = remap ? (int)(blockIdx.x & (NUM_XCD - 1)) * per_xcd : 0;
+  auto block_of = [&](int t) { const int i = first + t * stride, b = xbase + i; return (i < limit && b < nblk) ? b : -1; };
+  int4 x_n = make_int4(0, 0, 0, 0), x_nn = make_int4(0, 0, 0, 0);
+  int c_n[UNROLL];
+  double v_n[UNROLL];
+  RowPre pre_n{0, 0, EpiOps{0.0, 0.0, 0.0}, 0.0};
+  auto request_rest = [&](const int4 &x) {     // entries, row extents, epilogue operands of the block whose extent word is x
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+      const int k = x.z + tid + i * TPB;
+      const bool ok = k < x.w;
+      c_n[i] = ok ? __builtin_nontemporal_load(A.col + k) : 0;
+      v_n[i] = ok ? __builtin_nontemporal_load(A.val + k) : 0.0;
+    }
+    const int r = x.x + tid;
+    if (r < x.y) {
+      pre_n.rs = A.rowptr[r];
+      pre_n.re = A.rowptr[r + 1];
+      pre_n.ops = epi_load<MODE>(e, r);
+      if (INIT) pre_n.init = e.init[r];
+    }
+  };
+  int b = block_of(0), b_next = block_of(1);
+  if (b >= 0) x_n = ext[b];
+  if (b_next >= 0) x_nn = ext[b_next];
+  if (b >= 0) request_rest(x_n);
+  int buf = 0;
+  for (int t = 0; b >= 0; ++t) {
+    const int4 cur = x_n;
+    const RowPre pre = pre_n;
+    double xv[UNROLL], vv[UNROLL];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+      const int k = cur.z + tid + i * TPB;
+      xv[i] = (k < cur.w) ? xin[c_n[i]] : 0.0;
+      vv[i] = v_n[i];
+    }
+    // behind this block's gathers: the next block's entries and row data (its extent word came in a trip ago), and the
+    // extent word of the block after it
+    x_n = x_nn;
+    const int b_next2 = block_of(t + 2);
+    if (b_next2 >= 0) x_nn = ext[b_next2];
+    if (b_next >= 0) request_rest(x_n);
+    double *pr = prod[buf];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+      const int k = tid + i * TPB;
+      if (cur.z + k < cur.w) pr[k] = vv[i] * xv[i];
+    }
+    __syncthreads();
+    // (the other buffer is written next trip; this one again two trips on, behind the next trip's barrier)
+    stream_rows_phase<MODE, INIT, true, false>(A, cur.x, cur.y, cur.z, e, relaxed, acc, pr, &pre);
+    buf ^= 1;
+    b = b_next;
+    b_next = b_next2;
+  }
+  constexpr int NQ = ModeNQ<MODE>::value;
+  if (NQ > 0) {
+    block_sum_dd<NQ, TPB>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        e.partials[q * e.stride + blockIdx.x] = acc.hi[q];
+        e.partials[e.lo_offset + q * e.stride + blockIdx.x] = acc.lo[q];
+      }
+    }
+    for (int sl = (int)gridDim.x + (int)blockIdx.x * TPB + tid; sl < stream_slots; sl += (int)gridDim.x * TPB) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        e.partials[q * e.stride + sl] = 0.0;
+        e.partials[e.lo_offset + q * e.stride + sl] = 0.0;
       }
     }
   }

@@ -412,6 +412,7 @@ class HipPdhgEngine:
         out = dict(zip(keys, info.tolist()))
         for k in ("A", "At"):    # the product kernels run on the sliced jagged layout (csrc/sj_kernels.hpp)
             out[k + "_sj"] = (out[k + "_slabs"] >> 8) & 1
+            out[k + "_pipe"] = (out[k + "_slabs"] >> 9) & 1    # the row blocks as a persistent pipelined launch
             out[k + "_slabs"] &= 255
         out["small_lp"] = (out["var_tiles"] >> 2) & 1      # batches of take_steps run in the one-workgroup LDS kernel
         out["device_loop"] = (out["var_tiles"] >> 3) & 1   # ... in the multi-step persistent kernel (small grids)

@@ -135,10 +135,10 @@ def test_slab_passes_on_the_sliced_jagged_copies(gpu_required, monkeypatch, row_
             np.testing.assert_allclose(a, c, rtol=1e-9, atol=1e-9)
 
 
-def test_the_builder_picks_the_layout_for_bandwidth_bound_stream_matrices_with_uniform_rows(gpu_required, monkeypatch):
-    """banded 1.5M x 1.5M, 8 per row: > 1 024 row blocks, rows that do not scatter -> stream class.  A (every row 8 entries,
-    7-8 after duplicate columns merge) takes the sliced jagged layout; A' (column counts Poisson(8): a 256-row group is
-    half empty against its longest row) keeps the CSR row blocks."""
+def test_the_builder_picks_the_layout_for_bandwidth_bound_stream_matrices(gpu_required, monkeypatch):
+    """banded 1.5M x 1.5M, 8 per row: > 1 024 row blocks, rows that do not scatter -> stream class (three column slabs).  Both
+    A (every row 8 entries, 7-8 after duplicate columns merge) and A' (column counts Poisson(8): a 256-row group is ~44 %
+    full against its longest row) take the sliced jagged layout; a matrix with ragged groups does not."""
     monkeypatch.delenv("PDHG_SJ", raising=False)
     m = n = 1_500_000
     rng = np.random.default_rng(6)
@@ -148,13 +148,17 @@ def test_the_builder_picks_the_layout_for_bandwidth_bound_stream_matrices_with_u
     p = linear_programming_problem(np.zeros(n), np.full(n, 10.0), rng.standard_normal(n), 0.0, M.tocsc(), rng.standard_normal(m), m // 2)
     eng = HipPdhgEngine.from_problem(p)
     info = eng.layout_info()
-    assert info["A_tiled_waves"] == 0 and info["A_blocks"] > 1024 and info["A_sj"] == 1 and info["At_sj"] == 0, info
-    assert "spmv_sj_kernel" in eng.kernel_name(1) and "spmv_stream_kernel" in eng.kernel_name(2)
+    assert info["A_tiled_waves"] == 0 and info["A_blocks"] > 1024 and info["A_sj"] == 1 and info["At_sj"] == 1, info
+    assert "spmv_sj_kernel" in eng.kernel_name(1) and "spmv_sj_kernel" in eng.kernel_name(2)
     H.assert_products_match_oracle(eng, p.constraint_matrix, rng.standard_normal(n), rng.standard_normal(m), label="banded")
     r_auto = _run(eng, p, 20)
     monkeypatch.setenv("PDHG_SJ", "0")
+    monkeypatch.setenv("PDHG_STREAM_PIPE", "0")
     r_csr = _run(HipPdhgEngine.from_problem(p), p, 20)
     for a, c in zip(r_auto, r_csr):
-        assert np.array_equal(a, c)                       # rows of <= 8 entries: left to right in every layout and row order
+        assert np.array_equal(a, c)                       # rows of <= 30 entries: left to right in every layout and row order
+    monkeypatch.delenv("PDHG_SJ", raising=False)
+    ragged = HipPdhgEngine.from_problem(_ragged_lp(400_000, 300_000, seed=3)).layout_info()
+    assert ragged["A_sj"] == 0, ragged                    # rows of up to 1 500 entries: not this layout
     small = HipPdhgEngine.from_problem(random_lp(5000, 4000, 8, seed=7)).layout_info()
     assert small["A_sj"] == 0 and small["At_sj"] == 0
