@@ -3823,6 +3823,15 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
       if (S.nnz > 0)
         hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(D.rows)), dim3(TPB), 0, h->stream, D.rows, S.rowptr,
                            S.col, S.val, inv_e, inv_d, k, 0);
+    // the sliced jagged copies (sj_kernels.hpp) hold the same entries in another order: copied again from the CSR arrays
+    // just scaled, so that they carry the same bits (two multiplications in a fixed order per entry, done once)
+    auto refill = [&](const SjDev &J, const int *rowptr, const int *col, const double *val) {
+      if (J.on() && J.nnz > 0)
+        hipLaunchKernelGGL(sj_fill_kernel, dim3((J.nslices + TPB / WAVE - 1) / (TPB / WAVE)), dim3(TPB), 0, h->stream, J.nslices,
+                           (const unsigned *)J.meta, (const int *)J.slice_off, rowptr, col, val, J.col, J.val);
+    };
+    refill(D.sj, D.rowptr, D.col, D.val);
+    for (const SlabDev &S : D.slabs) refill(S.sj, S.rowptr, S.col, S.val);
   };
   scale_one(h->A, t.inv_e, t.inv_d, 0);
   scale_one(h->At, t.inv_e, t.inv_d, 1);

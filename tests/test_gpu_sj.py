@@ -135,6 +135,21 @@ def test_slab_passes_on_the_sliced_jagged_copies(gpu_required, monkeypatch, row_
             np.testing.assert_allclose(a, c, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("slab_mb", [None, 0.5], ids=["one_pass", "slabs"])
+def test_device_rescaling_reaches_the_sliced_jagged_copies(gpu_required, monkeypatch, slab_mb):
+    """pdhg_rescale scales every resident copy of the matrix: the sliced jagged copy must come out with the CSR copy's bits
+    (Ruiz 10 + Pock-Chambolle, the reference's default preprocessing, preprocess.jl:412-573)."""
+    p = random_lp(200_000, 150_000, 8, seed=5)
+    sj, csr = _engine(p, monkeypatch, "1", slab_mb=slab_mb), _engine(p, monkeypatch, "0", slab_mb=slab_mb)
+    assert sj.layout_info()["A_sj"] == 1 and csr.layout_info()["A_sj"] == 0
+    for e in (sj, csr):
+        e.rescale(10, False, 1.0)
+    rng = np.random.default_rng(2)
+    x, y = rng.standard_normal(150_000), rng.standard_normal(200_000)
+    assert np.array_equal(sj.spmv(x), csr.spmv(x)) and np.array_equal(sj.spmv_t(y), csr.spmv_t(y))
+    assert sj.matrix_max_abs() == csr.matrix_max_abs()
+
+
 def test_the_builder_picks_the_layout_for_bandwidth_bound_stream_matrices(gpu_required, monkeypatch):
     """banded 1.5M x 1.5M, 8 per row: > 1 024 row blocks, rows that do not scatter -> stream class (three column slabs).  Both
     A (every row 8 entries, 7-8 after duplicate columns merge) and A' (column counts Poisson(8): a 256-row group is ~44 %
