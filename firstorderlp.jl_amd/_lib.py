@@ -33,13 +33,13 @@ EXPORTS = [
     "pdhg_dist_info", "pdhg_profile_enable", "pdhg_profile_read",
     "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info", "pdhg_measure_triad", "pdhg_measure_sweep_ceiling", "pdhg_trial_timeline",
     "pdhg_set_original_problem", "pdhg_eval_point", "pdhg_save_restart_point",
-    "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound",
+    "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound", "pdhg_trust_region_bounds",
     "pdhg_point_sumsq", "pdhg_rescale", "pdhg_get_problem_vectors", "pdhg_matrix_max_abs",
     "pdhg_partition_rows", "pdhg_create_dist_rows", "pdhg_rccl_info", "pdhg_host_issue_stats",
     "pdhg_measure_launch_overhead", "pdhg_layout_checksums",
 ]
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 UNIQUE_ID_BYTES = 128
 (K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_ALLGATHER, K_REDUCE_SCATTER,
  K_INTERACTION, K_COUNT) = range(9)
@@ -227,6 +227,8 @@ def lib():
     L.pdhg_matrix_max_abs.argtypes = [_vp, _dp]
     L.pdhg_trust_region_bound.restype = i32
     L.pdhg_trust_region_bound.argtypes = [_vp, i32, d, d, d, i32, i32, _dp]
+    L.pdhg_trust_region_bounds.restype = i32
+    L.pdhg_trust_region_bounds.argtypes = [_vp, i32, _vp, d, d, _dp, _vp, i32, _dp]
     _lib = L
     return L
 

@@ -115,6 +115,9 @@ struct pdhg_handle {
   unsigned tr_nxcd = 0, tr_xcd_cnt[8] = {};
   double *tr_partials = nullptr;
   long tr_coop_calls = 0;
+  // several searches in one launch (tr_coop_batch_kernel): their own scratch vectors and partials
+  double *trb_scratch = nullptr, *trb_partials = nullptr;
+  long trb_calls = 0;
   double *ev_partials = nullptr;
   double *ev_xg = nullptr;                         // [n_alloc] full x at the evaluated point (group only)
   // the point being evaluated and its products (set by point_products)
@@ -1993,6 +1996,8 @@ void destroy_shard(pdhg_handle *h) {
   if (h->tr_sync) (void)hipFree(h->tr_sync);
   if (h->lsync) (void)hipFree(h->lsync);
   if (h->tr_partials) (void)hipFree(h->tr_partials);
+  if (h->trb_scratch) (void)hipFree(h->trb_scratch);
+  if (h->trb_partials) (void)hipFree(h->trb_partials);
   if (h->coop_trace) (void)hipFree(h->coop_trace);
   if (h->res_host) (void)hipHostFree((void *)h->res_host);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
@@ -2127,7 +2132,7 @@ int init_group_geometry(DistGroup *g, int64_t m, int64_t n, const int64_t *colpt
 extern "C" {
 
 const char *pdhg_last_error(void) { return g_last_error.c_str(); }
-int pdhg_abi_version(void) { return 9; }
+int pdhg_abi_version(void) { return 10; }
 
 // The kernels behind one fused product, as rocprofv3 prints them (template arguments <MODE,
 // INIT, TAG> / <MODE, CH> / <TAG>; MODE 0 plain, 1 dual epilogue, 2 A'y epilogue; TAG 0 = A,
@@ -3764,6 +3769,73 @@ int pdhg_trust_region_bound(pdhg_handle *h0, int point, double primal_weight_nor
   out[1] = S.at.v[0] + S.tstar * S.at.v[1];
   out[2] = S.at.v[2] + S.tstar * S.at.v[3];
   out[5] = S.tstar; out[6] = (double)S.passes;     // probe passes (the set-up pass evaluates t = tmax itself)
+  return 0;
+}
+
+int pdhg_trust_region_bounds(pdhg_handle *h0, int count, const int *points, double primal_weight_norm, double dual_weight_norm,
+                             const double *radii, const int *ranges, int approximate, double *out) {
+  int rc = check_handle(h0);
+  if (rc) return rc;
+  if (count < 1 || count > TRB_MAX || !points || !radii || !ranges || !out) return fail(-1, "count must be 1..3 and the arrays non-null");
+  for (int p = 0; p < count; ++p) if (ranges[p] < 0 || ranges[p] > 2) return fail(-1, "range must be 0, 1 or 2");
+  const Shards L = shards_of(h0);
+  pdhg_handle *h = L.p[0];
+  const char *se = dev_env("PDHG_SMALL_EVAL");
+  const bool small = !L.g && h->n + h->m <= TRS_MAX && !(se && se[0] == '0');
+  const char *be = dev_env("PDHG_TR_BATCH");
+  bool batch = count > 1 && !L.g && !h->profile && !small && !(be && be[0] == '0');
+  if (batch) {
+    if ((rc = flush_pending(L))) return rc;
+    rc = tr_coop_prepare(h);
+    if (rc > 1 || rc < 0) return rc;
+    batch = rc == 0;
+  }
+  if (batch) {
+    if ((rc = ev_ensure_host(h))) return rc;
+    const int64_t total = h->n + h->m;
+    if (!h->trb_scratch) {
+      if ((rc = alloc_zero(&h->trb_scratch, 3 * (int64_t)TRB_MAX * total))) return rc;
+      if ((rc = alloc_zero(&h->trb_partials, 2 * (int64_t)TRB_MAX * EV_MAXQ * h->tr_grid))) return rc;
+    }
+    TrBatchArgs a{};
+    a.n = (int)h->n; a.m = (int)h->m; a.ne = (int)h->num_eq; a.approximate = approximate ? 1 : 0; a.count = count;
+    a.c = h->c; a.b = h->b; a.lb = h->lb; a.ub = h->ub;
+    a.wp = primal_weight_norm; a.wd = dual_weight_norm;
+    for (int p = 0; p < count; ++p) {
+      if ((rc = point_products(L, points[p]))) return rc;       // (cached per point: nothing is recomputed for a point seen before)
+      TrBatchProblem &q = a.pb[p];
+      q.range = ranges[p]; q.radius = radii[p];
+      q.px = h->pt_x; q.py = h->pt_y; q.aty = h->pt_aty; q.qx = h->pt_qx; q.ax = h->pt_ax;
+      q.gdv = h->trb_scratch + (3 * (int64_t)p + 0) * total;
+      q.wd2v = h->trb_scratch + (3 * (int64_t)p + 1) * total;
+      q.thr = h->trb_scratch + (3 * (int64_t)p + 2) * total;
+    }
+    a.partials = h->trb_partials;
+    a.sync = h->tr_sync;
+    a.epoch = h->tr_epoch;
+    a.nxcd = h->tr_nxcd;
+    for (int x = 0; x < 8; ++x) a.xcd_cnt[x] = h->tr_xcd_cnt[x];
+    a.host_out = h->ev_host;
+    a.seq = ++h->ev_seq;
+    double r[8 * TRB_MAX + 2];
+    {
+      std::lock_guard<std::mutex> lock(coop_device_mutex(h->device));
+      hipLaunchKernelGGL(tr_coop_batch_kernel, dim3(h->tr_grid), dim3(TPB), 0, h->stream, a);
+      HIP_TRY(hipGetLastError());
+      if ((rc = ev_wait_host(h, 8 * count + 2, a.seq, r))) return rc;
+    }
+    h->tr_epoch = (unsigned long long)r[8 * count + 1];
+    if (r[8 * count] == 0.0) {
+      for (int q = 0; q < 8 * count; ++q) out[q] = r[q];
+      h->trb_calls += 1;
+      h->tr_coop_calls += count;
+      return 0;
+    }
+    h->tr_coop = 0;             // a barrier timed out: this handle goes back to one launch per pass, starting with these problems
+    if (getenv("PDHG_VERBOSE")) fprintf(stderr, "[pdhg_hip] trust-region batch: a grid barrier timed out (code %g); back to one launch per pass\n", r[8 * count]);
+  }
+  for (int p = 0; p < count; ++p)
+    if ((rc = pdhg_trust_region_bound(h0, points[p], primal_weight_norm, dual_weight_norm, radii[p], ranges[p], approximate, out + 8 * p))) return rc;
   return 0;
 }
 

@@ -203,4 +203,197 @@ __global__ __launch_bounds__(TPB) void tr_coop_kernel(TrCoopArgs a) {
   }
 }
 
+// ---- several trust-region problems in ONE persistent launch (round 5) -------------------------------------------------
+// A restart check asks for three bounds -- at the average, at the current iterate, at the last restart point
+// (saddle_point.jl:432-496, 551-596) -- and a recorded iteration for two more; each was a launch of its own with a grid
+// barrier per pass, 4-6 passes: on the L1-SVM LP five calls of ~80 us were 70 % of a 0.55 ms check.  The problems are
+// independent, so their passes can share the barriers: here every pass works through the elements of EVERY problem still
+// searching, then ONE barrier, then every workgroup reduces each problem's partials and advances each search -- the
+// launch lasts as long as the problem with the most passes, not the sum.  Per problem the statements, the grouping of
+// the sums (this grid) and therefore the BITS are those of tr_coop_kernel.
+constexpr int TRB_MAX = 3;
+struct TrBatchProblem {
+  int range;
+  const double *px, *py, *aty, *qx, *ax;
+  double radius;
+  double *gdv, *wd2v, *thr;                        // n + m each, this problem's own
+};
+struct TrBatchArgs {
+  int n, m, ne, approximate, count;
+  const double *c, *b, *lb, *ub;
+  double wp, wd;
+  TrBatchProblem pb[TRB_MAX];
+  double *partials;                                // 2 x TRB_MAX x EV_MAXQ x gridDim.x
+  GridSync *sync;
+  unsigned long long epoch;
+  unsigned nxcd;
+  unsigned xcd_cnt[8];
+  double *host_out;                                // pinned: 8 x count results, error word, epoch after the launch
+  unsigned long long seq;
+};
+
+__global__ __launch_bounds__(TPB) void tr_coop_batch_kernel(TrBatchArgs a) {
+  __shared__ double res[TRB_MAX][EV_MAXQ];
+  __shared__ TrProbes s_pr[TRB_MAX];
+  __shared__ int s_go[TRB_MAX];
+  __shared__ int s_any;
+  __shared__ double s_out[TRB_MAX][8];
+  __shared__ TrSearch S[TRB_MAX];
+  const int n = a.n, total = a.n + a.m, P = a.count;
+  const int gtid = blockIdx.x * TPB + threadIdx.x, gstride = gridDim.x * TPB, stride = gridDim.x;
+  const size_t pstride = (size_t)EV_MAXQ * stride;          // one problem's partials of one pass
+  unsigned long long epoch = a.epoch;
+  int buf = 0;
+  for (int p = 0; p < P; ++p) {
+    // the set-up pass of problem p: tr_coop_kernel's statements
+    const TrBatchProblem &q = a.pb[p];
+    RedAcc<TR_SETUP_NS, 1> acc;
+    for (int k = gtid; k < total; k += gstride) {
+      const bool primal = k < n;
+      const int i = primal ? k : k - n;
+      double z, g, lo, hi, w;
+      if (primal) {
+        z = q.px[i]; lo = a.lb[i]; hi = a.ub[i]; w = a.wp;
+        if (q.qx) { g = (q.qx[i] + a.c[i]) - q.aty[i]; acc.s[10] += z * q.qx[i]; }
+        else g = a.c[i] - q.aty[i];
+        acc.s[0] += a.c[i] * z; acc.s[1] += z * q.aty[i]; acc.s[8] += z * z;
+      } else {
+        z = q.py[i]; g = -(a.b[i] - q.ax[i]); lo = (i < a.ne) ? -INFINITY : 0.0; hi = INFINITY; w = a.wd;
+        acc.s[2] += z * a.b[i]; acc.s[9] += z * z;
+      }
+      const bool in_range = (q.range == 0) || (q.range == 1 && primal) || (q.range == 2 && !primal);
+      double d = 0.0, t = 0.0;
+      if (in_range && !((z >= hi && g <= 0.0) || (z <= lo && g >= 0.0))) {
+        d = -g / w;
+        if (d > 0.0) t = (hi - z) / d;
+        else if (d < 0.0) t = (lo - z) / d;
+        else t = 0.0;
+      }
+      const double wd2 = w * d * d, gd = g * d;
+      q.gdv[k] = gd; q.wd2v[k] = wd2; q.thr[k] = t;           // read back by this very thread in the probe passes
+      if (in_range) {
+        acc.s[4] += g * g;
+        acc.s[5] += wd2;
+        if (primal) acc.s[6] += gd; else acc.s[7] += gd;
+        if (isinf(t)) {
+          acc.s[3] += wd2;
+          if (primal) acc.s[14] += gd; else acc.s[15] += gd;
+        } else {
+          acc.m[0] = fmax(acc.m[0], t);
+          if (wd2 != 0.0) {
+            acc.s[11] += wd2 * t * t;
+            if (primal) acc.s[12] += gd * t; else acc.s[13] += gd * t;
+          }
+        }
+      }
+    }
+    block_reduce_store<TR_SETUP_NS, 1>(acc, a.partials + p * pstride, stride);
+  }
+  grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
+  for (int p = 0; p < P; ++p) trc_reduce<TR_SETUP_NS, 1>(a.partials + p * pstride, stride, (int)gridDim.x, res[p]);
+  buf ^= 1;
+  if (threadIdx.x == 0) {
+    int any = 0;
+    for (int p = 0; p < P; ++p) {
+      const double *r = res[p];
+      double *o = s_out[p];
+      o[0] = 0.5 * r[10] + r[0] - r[1] + r[2];
+      o[1] = o[2] = 0.0;
+      o[3] = r[8]; o[4] = r[9];
+      o[5] = 0.0; o[6] = 0.0; o[7] = 0.0;
+      const double hinf = r[3], g2 = r[4], wd2_all = r[5], tmax = r[TR_SETUP_NS];
+      const double radius = a.pb[p].radius, r2 = radius * radius;
+      s_go[p] = 0;
+      if (a.approximate) {
+        const double dn = sqrt(wd2_all);
+        const double sc = dn > 0.0 ? radius / dn : 1.0;
+        o[1] = sc * r[6]; o[2] = sc * r[7];
+      } else if (!(radius == 0.0 || g2 == 0.0)) {
+        tr_search_begin(S[p], r2, tmax, hinf, TrEnd{r[11], hinf, {r[12], r[14], r[13], r[15]}});
+        s_go[p] = tr_search_next(S[p], s_pr[p]) ? 1 : 2;
+      }
+      any |= s_go[p] == 1;
+    }
+    s_any = any;
+  }
+  __syncthreads();
+  while (s_any) {
+    double *part = a.partials + (size_t)buf * TRB_MAX * pstride;
+    // one walk over the elements for ALL the problems still searching: their loads are independent, so a thread has three
+    // times the requests in flight for the same latency (problem by problem a pass is ~9 us of mostly waiting)
+    RedAcc<TRC_Q, 0> acc[TRB_MAX];
+    bool act[TRB_MAX];
+#pragma unroll
+    for (int p = 0; p < TRB_MAX; ++p) act[p] = p < P && s_go[p] == 1;       // workgroup-uniform, and the same in every workgroup
+    for (int k = gtid; k < total; k += gstride) {
+      const bool primal = k < n;
+      double wd2[TRB_MAX], t[TRB_MAX], gd[TRB_MAX];
+#pragma unroll
+      for (int p = 0; p < TRB_MAX; ++p) {
+        wd2[p] = 0.0; t[p] = 0.0; gd[p] = 0.0;
+        if (act[p]) { wd2[p] = a.pb[p].wd2v[k]; t[p] = a.pb[p].thr[k]; gd[p] = a.pb[p].gdv[k]; }
+      }
+#pragma unroll
+      for (int p = 0; p < TRB_MAX; ++p) {
+        if (!act[p] || wd2[p] == 0.0) continue;                // d == 0: blocked by its bound, or outside the range
+        const double lowc = wd2[p] * t[p] * t[p], vlow = gd[p] * t[p];
+#pragma unroll
+        for (int j = 0; j < TR_K; ++j) {
+          if (t[p] <= s_pr[p].t[j]) {
+            acc[p].s[TR_Q * j] += lowc;
+            if (primal) acc[p].s[TR_Q * j + 2] += vlow; else acc[p].s[TR_Q * j + 4] += vlow;
+          } else {
+            acc[p].s[TR_Q * j + 1] += wd2[p];
+            if (primal) acc[p].s[TR_Q * j + 3] += gd[p]; else acc[p].s[TR_Q * j + 5] += gd[p];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < TRB_MAX; ++p)
+      if (act[p]) block_reduce_store<TRC_Q, 0>(acc[p], part + p * pstride, stride);
+    grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
+    for (int p = 0; p < P; ++p)
+      if (s_go[p] == 1) trc_reduce<TRC_Q, 0>(part + p * pstride, stride, (int)gridDim.x, res[p]);
+    buf ^= 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int any = 0;
+      const bool broken = __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      for (int p = 0; p < P; ++p) {
+        if (s_go[p] != 1) continue;
+        tr_search_feed(S[p], s_pr[p], res[p]);
+        s_go[p] = tr_search_next(S[p], s_pr[p]) ? 1 : 2;
+        if (broken) s_go[p] = 3;                               // a barrier timed out: the host repeats the calls one by one
+        any |= s_go[p] == 1;
+      }
+      s_any = any;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int k = 8 * P + 2;
+    unsigned long long ck = EV_CHECK_SALT ^ a.seq ^ ((unsigned long long)k << 56);
+    int slot = 0;
+    auto put = [&](double v) {
+      a.host_out[slot] = v;
+      ck ^= (unsigned long long)__double_as_longlong(v) * (2ull * (unsigned long long)slot + 1ull);
+      ++slot;
+    };
+    for (int p = 0; p < P; ++p) {
+      double *o = s_out[p];
+      if (s_go[p] == 2) {
+        o[1] = S[p].at.v[0] + S[p].tstar * S[p].at.v[1];
+        o[2] = S[p].at.v[2] + S[p].tstar * S[p].at.v[3];
+        o[5] = S[p].tstar; o[6] = (double)S[p].passes;
+      }
+      for (int j = 0; j < 8; ++j) put(o[j]);
+    }
+    put((double)__hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    put((double)epoch);
+    a.host_out[EV_HOST_CK] = __longlong_as_double((long long)ck);
+    a.host_out[EV_HOST_SEQ] = __longlong_as_double((long long)a.seq);
+  }
+}
+
 }  // namespace

@@ -342,6 +342,18 @@ class HipPdhgEngine:
             int(bool(approximate)), _pd(out)))
         return out
 
+    def trust_region_bounds(self, points, primal_weight_norm, dual_weight_norm, radii, norm_ranges, approximate=False):
+        """Up to three trust-region problems in one call (pdhg_trust_region_bounds): one row of eight per problem."""
+        k = len(points)
+        pts = np.ascontiguousarray(points, dtype=np.int32)
+        rad = np.ascontiguousarray(radii, dtype=np.float64)
+        rng = np.ascontiguousarray(norm_ranges, dtype=np.int32)
+        out = np.empty(8 * k)
+        _lib.check(self._L.pdhg_trust_region_bounds(
+            self._h, k, ctypes.c_void_p(pts.ctypes.data), primal_weight_norm, dual_weight_norm, _pd(rad),
+            ctypes.c_void_p(rng.ctypes.data), int(bool(approximate)), _pd(out)))
+        return out.reshape(k, 8)
+
     def measure_triad(self, length=1 << 26, reps=5):
         """GB/s of a = b + s*c over ``length`` doubles on this device (measurement only)."""
         out = ctypes.c_double()

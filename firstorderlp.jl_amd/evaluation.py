@@ -83,6 +83,11 @@ class HostEvaluator:
         x, y = self.engine.get_current()
         self.x_r, self.y_r = x.copy(), y.copy()
 
+    def bounds(self, requests, primal_w, dual_w, norm, approximate=False):
+        """[(point, radius), ...] -> [bound(...), ...] (the device evaluator batches these into one launch)."""
+        return [self.bound(point, primal_w, dual_w, radius, norm, approximate) for point, radius in requests]
+
+
 
 class DeviceEvaluator:
     def __init__(self, engine, scaled_problem, qp_cache):
@@ -178,6 +183,28 @@ class DeviceEvaluator:
         od = self.engine.trust_region_bound(point, primal_w, dual_w, radius, 2, approximate)
         lag = float(op[0]) + const
         return OptimalObjectiveBoundResult(lag, lag + float(op[1]), lag - float(od[2]), None, None)
+
+    def bounds(self, requests, primal_w, dual_w, norm, approximate=False):
+        """Several bound_optimal_objective problems at once: requests = [(point, radius), ...] -> one
+        OptimalObjectiveBoundResult each, the very numbers ``bound`` returns one by one (pdhg_trust_region_bounds: on
+        medium single handles the searches share one persistent launch)."""
+        const = self.objective_constant_scaled
+        if norm == EUCLIDEAN_NORM:
+            out = []
+            for i in range(0, len(requests), 3):
+                chunk = requests[i:i + 3]
+                rows = self.engine.trust_region_bounds([p for p, _ in chunk], primal_w, dual_w, [r for _, r in chunk],
+                                                       [0] * len(chunk), approximate)
+                for o in rows:
+                    lag = float(o[0]) + const
+                    out.append(OptimalObjectiveBoundResult(lag, lag + float(o[1]), lag - float(o[2]), None, None))
+            return out
+        out = []
+        for point, radius in requests:           # MAX_NORM: the primal and the dual half of one point share a launch
+            op, od = self.engine.trust_region_bounds([point, point], primal_w, dual_w, [radius, radius], [1, 2], approximate)
+            lag = float(op[0]) + const
+            out.append(OptimalObjectiveBoundResult(lag, lag + float(op[1]), lag - float(od[2]), None, None))
+        return out
 
     def restart(self, reset_to_average):
         if reset_to_average:

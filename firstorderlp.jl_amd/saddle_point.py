@@ -120,26 +120,30 @@ def create_last_restart_info():
 
 
 def compute_localized_duality_gaps(ev, primal_weight_norm, dual_weight_norm,
-                                   use_approximate_localized_duality_gap):
+                                   use_approximate_localized_duality_gap, extra_request=None):
     """saddle_point.jl:432-496.  ``ev`` is an evaluator (evaluation.py); the norm
     weights are uniform per block in PDHG (define_norms, pdhg.jl:265-277), so
-    weighted_norm(v, w)^2 == w * sum(v^2)."""
+    weighted_norm(v, w)^2 == w * sum(v^2).
+    The two trust-region problems (and ``extra_request`` = (point, radius), the bound at the last restart point that
+    should_do_adaptive_restart_normalized_duality_gap is about to ask for) go to the evaluator as ONE request: on the
+    device their searches share one persistent launch (pdhg_trust_region_bounds); each result is what the call on its
+    own returns."""
     from .evaluation import POINT_AVERAGE, POINT_CURRENT
     dx2, dy2 = ev.distance_sq_to_restart(POINT_AVERAGE)
     distance_traveled_by_average = math.sqrt(primal_weight_norm * dx2 + dual_weight_norm * dy2)
-    gap_at_average = ev.bound(POINT_AVERAGE, primal_weight_norm, dual_weight_norm,
-                              distance_traveled_by_average, EUCLIDEAN_NORM,
-                              use_approximate_localized_duality_gap)
     cx2, cy2 = ev.distance_sq_to_restart(POINT_CURRENT)
     distance_traveled_by_current = math.sqrt(primal_weight_norm * cx2 + dual_weight_norm * cy2)
-    gap_at_current = ev.bound(POINT_CURRENT, primal_weight_norm, dual_weight_norm,
-                              distance_traveled_by_current, EUCLIDEAN_NORM,
-                              use_approximate_localized_duality_gap)
-    return dict(gap_at_average=gap_at_average,
+    requests = [(POINT_AVERAGE, distance_traveled_by_average), (POINT_CURRENT, distance_traveled_by_current)]
+    if extra_request is not None:
+        requests.append(extra_request)
+    got = ev.bounds(requests, primal_weight_norm, dual_weight_norm, EUCLIDEAN_NORM,
+                    use_approximate_localized_duality_gap)
+    return dict(gap_at_average=got[0],
                 distance_traveled_by_average=distance_traveled_by_average,
-                gap_at_current=gap_at_current,
+                gap_at_current=got[1],
                 distance_traveled_by_current=distance_traveled_by_current,
-                average_distance_sq=(dx2, dy2))
+                average_distance_sq=(dx2, dy2),
+                extra=got[2] if extra_request is not None else None)
 
 
 def should_reset_to_average(current, distance_traveled_by_current, average,
@@ -156,19 +160,26 @@ def should_reset_to_average(current, distance_traveled_by_current, average,
     return True
 
 
+def distance_traveled_in_last_restart_period(last_restart_info, primal_weight):
+    """saddle_point.jl:561-565"""
+    lri = last_restart_info
+    return math.sqrt(lri.primal_distance_moved_last_restart_period ** 2 * primal_weight +
+                     lri.dual_distance_moved_last_restart_period ** 2 / primal_weight)
+
+
 def should_do_adaptive_restart_normalized_duality_gap(
         ev, primal_weight_norm, dual_weight_norm, candidate_localized_gap,
         candidate_distance_traveled, restart_params, last_restart_info,
-        use_approximate_localized_duality_gap, primal_weight):
-    """saddle_point.jl:551-596"""
+        use_approximate_localized_duality_gap, primal_weight, last_restart_bound=None):
+    """saddle_point.jl:551-596.  ``last_restart_bound``: the bound at the last restart point when the caller already
+    has it (run_restart_scheme asks for it together with the two candidate bounds)."""
     from .evaluation import POINT_RESTART
     lri = last_restart_info
-    distance_traveled_last_restart = math.sqrt(
-        lri.primal_distance_moved_last_restart_period ** 2 * primal_weight +
-        lri.dual_distance_moved_last_restart_period ** 2 / primal_weight)
-    last_restart = ev.bound(POINT_RESTART, primal_weight_norm, dual_weight_norm,
-                            distance_traveled_last_restart, EUCLIDEAN_NORM,
-                            use_approximate_localized_duality_gap)
+    distance_traveled_last_restart = distance_traveled_in_last_restart_period(lri, primal_weight)
+    last_restart = last_restart_bound if last_restart_bound is not None else \
+        ev.bound(POINT_RESTART, primal_weight_norm, dual_weight_norm,
+                 distance_traveled_last_restart, EUCLIDEAN_NORM,
+                 use_approximate_localized_duality_gap)
     do_restart = False
     normalized_candidate_gap = _div(get_gap(candidate_localized_gap), candidate_distance_traveled)
     normalized_last_restart_gap = _div(get_gap(last_restart), distance_traveled_last_restart)
@@ -237,9 +248,14 @@ def run_restart_scheme(ev, last_restart_info, iterations_completed,
         candidate_localized_gap = None
         candidate_distance_traveled = None
     else:
+        # (the bound at the last restart point, which the adaptive-normalized test below needs, rides in the same request)
+        extra = None
+        if not do_restart and restart_params.restart_scheme == RestartScheme.ADAPTIVE_NORMALIZED:
+            from .evaluation import POINT_RESTART
+            extra = (POINT_RESTART, distance_traveled_in_last_restart_period(last_restart_info, primal_weight))
         gaps = compute_localized_duality_gaps(
             ev, primal_weight_norm, dual_weight_norm,
-            restart_params.use_approximate_localized_duality_gap)
+            restart_params.use_approximate_localized_duality_gap, extra)
         average_distance_sq = gaps["average_distance_sq"]
         reset_to_average = should_reset_to_average(
             gaps["gap_at_current"], gaps["distance_traveled_by_current"],
@@ -259,7 +275,7 @@ def run_restart_scheme(ev, last_restart_info, iterations_completed,
                 ev, primal_weight_norm, dual_weight_norm,
                 candidate_localized_gap, candidate_distance_traveled,
                 restart_params, last_restart_info,
-                restart_params.use_approximate_localized_duality_gap, primal_weight)
+                restart_params.use_approximate_localized_duality_gap, primal_weight, gaps["extra"])
         elif scheme in (RestartScheme.ADAPTIVE_LOCALIZED, RestartScheme.ADAPTIVE_DISTANCE) and \
                 last_restart_info.last_restart_localized_duality_gap is None:
             do_restart = True
@@ -322,10 +338,11 @@ def update_objective_bound_estimates(method_specific_stats, ev, point,
     sx2, sy2 = ev.point_sumsq(point)
     estimated_primal_distance_to_optimality = max(1e-8, math.sqrt(primal_weight_norm * sx2))
     estimated_dual_distance_to_optimality = max(1e-8, math.sqrt(dual_weight_norm * sy2))
-    gap = ev.bound(point,
-                   _div(primal_weight_norm, estimated_primal_distance_to_optimality ** 2),
-                   _div(dual_weight_norm, estimated_dual_distance_to_optimality ** 2),
-                   1.0, MAX_NORM, False)
+    # (through `bounds`: the primal and the dual half of MAX_NORM are two trust-region problems, one launch on the device)
+    gap = ev.bounds([(point, 1.0)],
+                    _div(primal_weight_norm, estimated_primal_distance_to_optimality ** 2),
+                    _div(dual_weight_norm, estimated_dual_distance_to_optimality ** 2),
+                    MAX_NORM, False)[0]
     method_specific_stats["lagrangian_value"] = gap.lagrangian_value
     method_specific_stats["estimated_lower_bound"] = gap.lower_bound_value
     method_specific_stats["estimated_upper_bound"] = gap.upper_bound_value

@@ -347,6 +347,19 @@ int pdhg_trust_region_bound(pdhg_handle *h, int point, double primal_weight_norm
                             int approximate, double out[8]);
 
 /*
+ * `count` (1..3) such problems in one call: points[p], radii[p], ranges[p] -> out[8 p .. 8 p + 7], each exactly what
+ * pdhg_trust_region_bound returns for it (same statements, same grouping of the sums: the same bits as the one-launch
+ * form of the single call).  A restart check needs three bounds -- at the average, at the current iterate, at the last
+ * restart point (saddle_point.jl:432-496, 551-596) -- and a recorded iteration two more (the halves of MAX_NORM); on
+ * single handles of medium size they run as ONE persistent launch whose probe passes share the grid barriers
+ * (csrc/tr_coop_kernel.hpp: tr_coop_batch_kernel): the call lasts as long as the problem with the most passes, not the sum.
+ * Elsewhere (small problems, shard groups, profiling) it is `count` single calls.  (abi 10)
+ */
+int pdhg_trust_region_bounds(pdhg_handle *h, int count, const int *points, double primal_weight_norm,
+                             double dual_weight_norm, const double *radii, const int *ranges,
+                             int approximate, double *out /* 8 * count */);
+
+/*
  * ---- rescaling on the device ("next" row N2) --------------------------------
  * rescale_problem (src/preprocess.jl:631-687) in place on a handle created from
  * the ORIGINAL problem: l_inf_ruiz_iterations of ruiz_rescaling with p = Inf

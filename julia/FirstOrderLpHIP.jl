@@ -26,7 +26,7 @@ using SparseArrays
 import Random
 
 const LIB = get(ENV, "PDHG_HIP_LIB", "libpdhg_hip.so")
-const ABI_VERSION = 9
+const ABI_VERSION = 10
 const POINT_CURRENT = Cint(0)
 const POINT_AVERAGE = Cint(1)
 const POINT_RESTART = Cint(2)
@@ -460,6 +460,20 @@ function trust_region_bound(s::HipSolverState, point, primal_w, dual_w, radius, 
     (Ptr{Cvoid}, Cint, Float64, Float64, Float64, Cint, Cint, Ptr{Float64}),
     s.handle, point, primal_w, dual_w, radius, range, approximate ? 1 : 0, out))
   return out
+end
+
+"""
+Up to three such problems in one call (abi 10): on medium single handles their searches share one persistent launch;
+row p of the result is what `trust_region_bound` returns for problem p, bit for bit.
+"""
+function trust_region_bounds(s::HipSolverState, points::Vector{Cint}, primal_w, dual_w, radii::Vector{Float64},
+                             ranges::Vector{Cint}, approximate)
+  count = length(points)
+  out = zeros(8 * count)
+  check(ccall((:pdhg_trust_region_bounds, LIB), Cint,
+    (Ptr{Cvoid}, Cint, Ptr{Cint}, Float64, Float64, Ptr{Float64}, Ptr{Cint}, Cint, Ptr{Float64}),
+    s.handle, count, points, primal_w, dual_w, radii, ranges, approximate ? 1 : 0, out))
+  return reshape(out, 8, count)
 end
 
 """

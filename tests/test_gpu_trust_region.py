@@ -105,3 +105,84 @@ def test_one_launch_search_falls_back_when_a_barrier_cannot_complete(gpu_require
     got, info = _bounds(p, monkeypatch, "1", steps=10, env=(("PDHG_TR_COOP_TEST_BAD_CENSUS", "1"),))
     assert info["tr_coop_calls"] == 0                    # the first call timed out (~0.1 s) and the handle left that form
     assert np.array_equal(got, want)                     # ... for the pass-by-pass form: the same bits
+
+
+# ---- round 5: several searches in ONE persistent launch (pdhg_trust_region_bounds, tr_coop_batch_kernel) ----------------
+def _state_with_restart_point(p, steps=30):
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import AdaptiveStepsizeParams, PdhgSolverState, take_steps
+    from tests import helpers as H
+    eng = HipPdhgEngine.from_problem(p)
+    step, pw = H.initial_step_and_weight(p)
+    st = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+    take_steps(AdaptiveStepsizeParams(0.3, 0.6), st, steps)
+    eng.save_restart_point()
+    take_steps(AdaptiveStepsizeParams(0.3, 0.6), st, steps)
+    return eng
+
+
+@pytest.mark.parametrize("name", ["random", "pagerank", "qp", "small"])
+def test_batched_searches_return_the_single_calls_bits(gpu_required, monkeypatch, name):
+    """Three bounds of a restart check (average, current iterate, last restart point) and the two halves of MAX_NORM, asked
+    for in one call: each row must be bit for bit what pdhg_trust_region_bound returns for that problem -- on medium single
+    handles the batch shares one persistent launch (same statements, same grouping of the sums), elsewhere it is a loop."""
+    from firstorderlp_jl_amd.generators import pagerank_lp, random_lp
+    if name == "random":
+        p = random_lp(40000, 30000, 6, seed=5)
+    elif name == "pagerank":
+        p = pagerank_lp(50000, seed=3)
+    elif name == "small":
+        p = random_lp(900, 700, 5, seed=2)           # n + m <= 4 096: the one-workgroup kernel, call by call
+    else:
+        import scipy.sparse as sp
+        from dataclasses import replace
+        p = random_lp(9000, 12000, 5, seed=8)
+        q = sp.random(12000, 12000, density=2e-4, random_state=1, format="csc")
+        p = replace(p, objective_matrix=(q @ q.T + sp.identity(12000) * 0.1).tocsc())
+    eng = _state_with_restart_point(p)
+    requests = [([1, 0, 2], [0.3, 5.0, 0.7], [0, 0, 0]),       # average, current, restart point: the restart check
+                ([0, 0], [1.0, 1.0], [1, 2]),                 # the halves of MAX_NORM at one point
+                ([1], [2.5], [0]), ([2, 1, 0], [0.0, 1e6, 0.3], [0, 2, 1])]
+    for approx in (0, 1):
+        for points, radii, ranges in requests:
+            got = eng.trust_region_bounds(points, 1.7, 0.6, radii, ranges, approx)
+            for row, pt, rad, rg in zip(got, points, radii, ranges):
+                want = np.array(eng.trust_region_bound(pt, 1.7, 0.6, rad, rg, approx))
+                assert np.array_equal(row, want), (name, points, radii, ranges, approx)
+    info = eng.layout_info()
+    assert (info["tr_coop_calls"] > 0) == (name != "small")
+    eng.close()
+
+
+def test_batched_searches_fall_back_when_a_barrier_cannot_complete(gpu_required, monkeypatch):
+    from firstorderlp_jl_amd.generators import random_lp
+    p = random_lp(20000, 15000, 6, seed=6)
+    monkeypatch.setenv("PDHG_TR_COOP", "0")
+    eng = _state_with_restart_point(p, steps=10)
+    want = eng.trust_region_bounds([1, 0, 2], 1.7, 0.6, [0.3, 5.0, 0.7], [0, 0, 0], 0)       # pass by pass, call by call
+    eng.close()
+    monkeypatch.setenv("PDHG_TR_COOP", "1")
+    monkeypatch.setenv("PDHG_TR_COOP_TEST_BAD_CENSUS", "1")
+    eng = _state_with_restart_point(p, steps=10)
+    got = eng.trust_region_bounds([1, 0, 2], 1.7, 0.6, [0.3, 5.0, 0.7], [0, 0, 0], 0)
+    assert eng.layout_info()["tr_coop_calls"] == 0       # the launch timed out (~0.1 s); the handle left the one-launch forms
+    assert np.array_equal(got, want)
+    eng.close()
+
+
+def test_a_solve_takes_the_same_restart_decisions_with_and_without_the_batch(gpu_required, monkeypatch):
+    """optimize() with solve_qp.jl's defaults (adaptive-normalized restarts: three bounds per check): iteration count,
+    restart record and final objectives must not depend on whether the three searches share a launch."""
+    from firstorderlp_jl_amd.generators import random_lp
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import optimize
+    from tests.test_gpu_end_to_end import _params
+    p = random_lp(12000, 10000, 8, seed=42)
+    runs = {}
+    for batch in ("1", "0"):
+        monkeypatch.setenv("PDHG_TR_BATCH", batch)
+        out = optimize(_params(1e-6, 40000), p)
+        runs[batch] = (out.termination_string, out.iteration_count,
+                       [str(s.restart_used) for s in out.iteration_stats],
+                       out.iteration_stats[-1].convergence_information[0].primal_objective,
+                       out.iteration_stats[-1].convergence_information[0].dual_objective)
+    assert runs["1"] == runs["0"], (runs["1"][:2], runs["0"][:2])
+    assert runs["1"][0] == "OPTIMAL"
