@@ -523,6 +523,7 @@ int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int,
 #include "host_trial_graph.hpp"
 #include "host_trial_coop.hpp"
 #include "host_small_lp.hpp"
+#include "host_trial_graph_build.hpp"
 #include "host_shards.hpp"
 }  // namespace
 
