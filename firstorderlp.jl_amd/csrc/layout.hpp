@@ -47,7 +47,7 @@ struct CsrDev {
   int *wg_step_off = nullptr;     // [grid+1] start of a workgroup's steps inside step_tile
   int64_t total_steps = 0;
   int64_t tw_entries = 0, step_ptr_len = 0;   // lengths of pk / tv and of wave_ent (checksums, tests)
-  int tw_mode = 0;                // chunk accumulation: 0 lane shuffles, 1 LDS scratch (long runs, strict order), 2 relaxed order
+  int tw_mode = 0;                // chunk accumulation: 0 lane shuffles, 1 LDS scratch (long runs, strict order), 2 relaxed order, 3 lane to lane (runs of 9 ... 32)
   unsigned *pk = nullptr;
   double *tv = nullptr;
   std::vector<int> wg_first_row;  // host copy: first row of every tiled workgroup (+ rows), for partial launches
@@ -476,7 +476,11 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   }
   // relaxed order only where strict order is hopeless (a forced sweep over long runs); the automatically
   // chosen sweeps (runs <= 32) keep the strict-order variants and stay bit-exact with the CPU loops
-  D.tw_mode = max_run > 8 ? ((relaxed && max_run > 32) ? 2 : 1) : 0;
+  // runs of 9 ... 32: lane to lane (3; in both row orders: the sequential sums); beyond (PDHG_SPMV=tiled only, see above):
+  // the shuffle tree in relaxed order (2), the LDS scratch in strict order (1 -- one workgroup per CU when rows per wave
+  // are near the cap)
+  D.tw_mode = max_run > 8 ? (max_run > 32 ? (relaxed ? 2 : 1) : 3) : 0;
+  if (const char *ev = dev_env("PDHG_TW_MODE")) D.tw_mode = std::max(0, std::min(3, atoi(ev)));    // dev knob
   int rc;
   if (on_device) { D.wave_rows = d_wave_rows; d_wave_rows = nullptr; }
   else if ((rc = upload(&D.wave_rows, wave_rows))) return rc;

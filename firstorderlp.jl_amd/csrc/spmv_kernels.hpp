@@ -446,6 +446,41 @@ __device__ __forceinline__ void tiled_chunk(double *acc, unsigned p, double v, d
   if (head) acc[row] = s;
 }
 
+// Variant for runs of 9 ... 32 entries (rows whose entries cluster in a few tiles): the run sums travel lane to lane.
+// Lane i takes lane i - 1's partial sum with one DPP move per register half (wave_shr:1 -- a VALU operation; CDNA keeps
+// GFX9's whole-wave shifts) and adds its own product, position by position along the runs, so that a run's LAST lane
+// ends up with ((acc + p0) + p1) + ... -- the sequential order -- and stores it.  The shuffle loop above costs three
+// LDS-pipe operations per position; the LDS scratch of the next variant costs the second workgroup per CU its LDS
+// (8 x 1 221 rows + scratch > 80 KiB: a 10M-row matrix with runs of 10 ran in two residency rounds at 1.47 ms; 1.03 so).
+// On runs of 1 - 2 (config S) the shuffle loop is faster (0.76 ms against 0.92), hence a variant and not a replacement.
+__device__ __forceinline__ unsigned wave_shr1(unsigned x, unsigned lane0) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)lane0, (int)x, 0x138, 0xF, 0xF, false);   // lane i <- lane i - 1
+}
+__device__ __forceinline__ unsigned wave_shl1(unsigned x, unsigned lane63) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)lane63, (int)x, 0x130, 0xF, 0xF, false);  // lane i <- lane i + 1
+}
+__device__ __forceinline__ double wave_shr1(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void tiled_chunk_scan(double *acc, unsigned p, double v, double xv, int tile_shift, int lane) {
+  const bool valid = p != TW_PAD;
+  // padding lanes get pairwise different pseudo-rows (no real row_local reaches 0xFFFFFF00: it is < 2^31): runs of one, never stored
+  const unsigned row = valid ? (p >> tile_shift) : (0xFFFFFF00u | (unsigned)lane);
+  const double prod = v * xv;
+  const bool head = wave_shr1(row, ~row) != row;
+  const bool tail = wave_shl1(row, ~row) != row;
+  const unsigned long long hmask = __ballot(head);                                       // (lane 0 is a head)
+  const int pos = lane - (63 - __clzll((long long)(hmask & ((2ull << lane) - 1ull))));   // place in the run
+  double s = (head && valid) ? acc[row] + prod : prod;
+  for (int j = 1; __any(pos >= j); ++j) {
+    const double left = wave_shr1(s);
+    if (pos == j) s = left + prod;
+  }
+  if (tail && valid) acc[row] = s;
+}
+
 // Variant for matrices with long same-row runs inside a tile (rows with hundreds
 // of entries): run lengths from two ballots, followers' products handed to the
 // run head through a 64-double LDS scratch per wave and added left to right
@@ -533,7 +568,7 @@ __device__ __forceinline__ void tiled_chunk_relaxed(double *acc, unsigned p, dou
 }
 
 // CH: how a 64-entry chunk is accumulated -- 0 lane shuffles (strict order), 1 LDS scratch
-// (strict order, long runs), 2 relaxed (see tiled_chunk_relaxed)
+// (strict order, long runs), 2 relaxed (see tiled_chunk_relaxed), 3 lane-to-lane (strict order, runs of 9 ... 32)
 template <int MODE, int CH>
 __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
     const int2 *__restrict__ wave_rows, const int *__restrict__ step_ptr,
@@ -622,6 +657,7 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
         for (int i = 0; i < U; ++i) {
           if (ks[s] + i * WAVE < ke[s]) {  // wave-uniform
             if (CH == 1) tiled_chunk_scratch(acc, scratch, p[s][i], v[s][i], xv[i], tile_shift, lane);
+            else if (CH == 3) tiled_chunk_scan(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
             else if (CH == 2) tiled_chunk_relaxed(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
             else tiled_chunk(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
           }
@@ -633,6 +669,7 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
           const double vv = ok ? __builtin_nontemporal_load(tv + k) : 0.0;
           const double xx = ok ? xt[pp & cmask] : 0.0;
           if (CH == 1) tiled_chunk_scratch(acc, scratch, pp, vv, xx, tile_shift, lane);
+          else if (CH == 3) tiled_chunk_scan(acc, pp, vv, xx, tile_shift, lane);
           else if (CH == 2) tiled_chunk_relaxed(acc, pp, vv, xx, tile_shift, lane);
           else tiled_chunk(acc, pp, vv, xx, tile_shift, lane);
         }

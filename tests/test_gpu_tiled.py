@@ -256,3 +256,63 @@ def test_hub_rows_do_not_spill_into_an_extra_round(gpu_required, monkeypatch):
     x, y = rng.standard_normal(n), rng.standard_normal(m)
     H.assert_products_match_oracle(eng, A, x, y, forced_sweep=True)
     eng.close()
+
+
+@pytest.mark.own_row_order
+@pytest.mark.parametrize("order", ["strict", "relaxed"])
+@pytest.mark.parametrize("lo,hi", [(9, 12), (10, 30), (1, 20)], ids=["runs<=12", "runs<=30", "runs<=20"])
+def test_runs_of_9_to_32_travel_lane_to_lane(gpu_required, monkeypatch, order, lo, hi):
+    """Rows of `lo` .. `hi` entries within +-300 columns of a random centre (the "clustered" shape of tools/shape_table.py):
+    every row sits in one or two column tiles, so the sweep sees same-row runs of 9 .. 32 entries inside a tile and picks
+    the lane-to-lane chunk variant (spmv_tiled_kernel<., 3>, csrc/spmv_kernels.hpp: tiled_chunk_scan) -- in BOTH row
+    orders, because it adds a run in the sequential order: A x must equal the oracle's loops bit for bit on every row
+    (the reference's `mul!` order, src/primal_dual_hybrid_gradient.jl:401-417 through SparseArrays)."""
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd import linear_programming_problem, _lib
+    monkeypatch.setenv("PDHG_ROW_ORDER", order)
+    monkeypatch.setenv("PDHG_TILE_COLS", "4096")
+    monkeypatch.setenv("PDHG_SPMV", "tiled")                # (the builder streams a matrix this small)
+    rng = np.random.default_rng(lo * 100 + hi)
+    m, n = 40_000, 30_000
+    lens = rng.integers(lo, hi + 1, m)
+    rows = np.repeat(np.arange(m), lens)
+    cols = np.clip(np.repeat(rng.integers(0, n, m), lens) + rng.integers(-300, 301, rows.size), 0, n - 1)
+    A = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    p = linear_programming_problem(np.zeros(n), np.full(n, 10.0), rng.standard_normal(n), 0.0, A.tocsc(),
+                                   rng.standard_normal(m), m // 2)
+    eng = HipPdhgEngine.from_problem(p)
+    info = eng.layout_info()
+    assert info["A_tiled_waves"] > 0, info
+    assert ", 3>" in eng.kernel_name(_lib.K_SPMV_DUAL), eng.kernel_name(_lib.K_SPMV_DUAL)
+    Ac = p.constraint_matrix
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    assert np.array_equal(eng.spmv(x), orc.spmv(m, n, Ac.indptr, Ac.indices, Ac.data, x))
+    if info["At_tiled_waves"] > 0 and ", 3>" in eng.kernel_name(_lib.K_SPMV_ATY):
+        assert np.array_equal(eng.spmv_t(y), orc.spmv_t(m, n, Ac.indptr, Ac.indices, Ac.data, y))
+    else:
+        H.assert_products_match_oracle(eng, Ac, x, y, forced_sweep=True)
+    # and the fused products inside a trial step (A xbar with the dual step, A'y' with the interaction sums) from a
+    # non-trivial iterate: the trial vectors bit for bit wherever the row sums are (tests/test_gpu_step_parity.py)
+    o = H.oracle_from_problem(p)
+    x0 = np.clip(rng.standard_normal(n), np.maximum(p.variable_lower_bound, -5), np.minimum(p.variable_upper_bound, 5))
+    y0 = rng.standard_normal(m)
+    y0[p.num_equalities:] = np.abs(y0[p.num_equalities:])
+    eng.set_current(x0, y0)
+    o.x, o.y = x0, y0
+    o.recompute_dual_product()
+    step, pw = H.initial_step_and_weight(p)
+    both_exact = order == "strict" or ", 3>" in eng.kernel_name(_lib.K_SPMV_ATY)
+    for theta in (1.0, 0.37):
+        raw = eng.trial_step(step, pw, theta)
+        raw_o, xn, yn, an = o.trial_step(step, pw, theta)
+        gx, gy, ga = eng.get_trial()
+        if both_exact:
+            assert np.array_equal(gy, yn) and np.array_equal(gx, xn) and np.array_equal(ga, an)
+        else:                                                          # (x' comes from A'y, summed by the relaxed rules)
+            np.testing.assert_allclose(gy, yn, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(gx, xn, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(ga, an, rtol=1e-11, atol=1e-11)
+        scale = np.array([np.abs(raw_o[1] * raw_o[2]) ** 0.5 + abs(raw_o[0]), raw_o[1], raw_o[2]])
+        assert np.all(np.abs(raw[:3] - raw_o[:3]) <= 1e-12 * scale + 1e-300)
+    eng.close()

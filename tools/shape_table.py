@@ -128,6 +128,15 @@ def product_ms(p, steps=30):
     return out
 
 
+def _short(names):
+    """'spmv_tiled_kernel<1, 3> + spmv_long_partial_kernel<0> + ...' -> 'tiled<1, 3>+long'"""
+    parts = [n.strip() for n in names.split(" + ")]
+    out = [parts[0].replace("spmv_", "").replace("_kernel", "")]
+    if len(parts) > 1:
+        out.append("slabs" if "stream" in parts[1] or "sj" in parts[1] else "long")
+    return "+".join(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -148,7 +157,8 @@ def main():
         p = make_shape(kind, **kw)
         r = product_ms(p)
         line = (f"{title:42s} dual {r['dual_ms']:.4f} ms ({r['dual_bytes'] / r['dual_ms'] / 8e9:.3f})  "
-                f"aty {r['aty_ms']:.4f} ms ({r['aty_bytes'] / r['aty_ms'] / 8e9:.3f})  waves={r['waves']} var={r['var']}")
+                f"aty {r['aty_ms']:.4f} ms ({r['aty_bytes'] / r['aty_ms'] / 8e9:.3f})  waves={r['waves']} var={r['var']}"
+                f"  [{_short(r['kernels'][0])} | {_short(r['kernels'][1])}]")
         if not args.no_vendor:
             A = p.constraint_matrix.tocsr()
             va = vendor_spmv.time_csr(A)
