@@ -35,9 +35,12 @@ constexpr int TW_WPB = 8;              // waves per workgroup (512 threads), 2 w
 constexpr int TW_MAX_ROWS = 1272;      // rows owned by one wave: 2 x 8 x 1272 x 8 B fits the 160 KiB LDS
 constexpr unsigned TW_PAD = 0xFFFFFFFFu;
 #ifndef TWD_U            // dev builds (tools/variants.sh) may override
-#define TWD_U 3
+#define TWD_U 4
 #endif
-constexpr int TW_U = TWD_U;           // 64-entry chunks prefetched per wave per tile
+// 64-entry chunks prefetched per wave per tile.  4 since round 5 (73 - 89 VGPRs: still four waves per SIMD): a (wave, tile)
+// cell beyond the window costs its whole workgroup a second step, and cells of 95 +- 30 entries (rows clustered inside
+// a tile) passed 192 often enough for 8 % of the product's time; on uniform matrices 3, 4 and 5 measure the same.
+constexpr int TW_U = TWD_U;
 
 thread_local std::string g_last_error;
 
