@@ -266,7 +266,10 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   // itself (measured: 8 195 waves instead of 8 192 cost +45 %).  Rows per wave are
   // then raised, within the LDS budget (and, on a near miss, the entry cap a little),
   // until the waves fit the rounds again.
-  double cap_factor = dev_env("PDHG_TW_NNZ_CAP") ? std::max(1.0, atof(dev_env("PDHG_TW_NNZ_CAP"))) : 2.0;   // dev knob
+  const bool cap_forced = dev_env("PDHG_TW_NNZ_CAP") != nullptr;
+  double cap_factor = cap_forced ? std::max(1.0, atof(dev_env("PDHG_TW_NNZ_CAP"))) : 2.0;   // dev knob
+  bool balanced = false;
+  const int ntiles_planned = (int)tstart.size() - 1;
   std::vector<int2> wave_rows;
   for (int attempt = 0;; ++attempt) {
     const int64_t est_waves = std::max<int64_t>(1, ((int64_t)rows + TW_ROWS - 1) / TW_ROWS);
@@ -282,9 +285,19 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
       wave_rows.push_back(make_int2(r0, r));
     }
     const int64_t planned = slots * std::max<int64_t>(1, ((int64_t)est_waves + slots - 1) / slots);
-    if (rows_forced || (int64_t)wave_rows.size() <= planned || attempt >= 40) break;
-    if (TW_ROWS < max_rows) TW_ROWS = std::min(max_rows, TW_ROWS + std::max(1, TW_ROWS / 48));
-    else if ((double)wave_rows.size() <= 1.03 * (double)planned && cap_factor < 4.0) cap_factor *= 1.2;   // a near miss: let hub waves grow a little
+    if (rows_forced || (int64_t)wave_rows.size() <= planned || attempt >= 40 || balanced) break;
+    if (TW_ROWS < max_rows) { TW_ROWS = std::min(max_rows, TW_ROWS + std::max(1, TW_ROWS / 48)); continue; }
+    if (cap_forced) break;
+    // A near miss: let the waves at the entry cap grow a little -- as long as their (wave, tile) cells still fit the
+    // register window (with a quarter's margin for the spread): a cell beyond it costs the whole workgroup a second step
+    // on that tile.  When they would not (rows of very different lengths: many waves sit at the cap), the extra
+    // residency round is taken and the waves are BALANCED instead -- cap 1.3 x the average.  Column-skewed 10M, A'y'
+    // (tools/r5_colskew_sweep.sh): cap grown to 2.9 to fit two rounds 1.64 ms (257 steps for the heavy workgroups, at 4.9 us
+    // each: long same-row runs); cap 1.0 / 1.3 / 1.6, three rounds of 129 steps, 1.13 / 1.11 / 1.11 ms.
+    const double avg_cell = (double)D.nnz / (double)est_waves / (double)std::max(1, ntiles_planned);
+    const bool near_miss = (double)wave_rows.size() <= 1.03 * (double)planned && cap_factor < 4.0;
+    if (near_miss && 1.2 * cap_factor * avg_cell * 1.25 <= (double)WIN) cap_factor *= 1.2;
+    else if (near_miss) { cap_factor = 1.3; balanced = true; }
     else break;
   }
   D.tw_rows = TW_ROWS;
