@@ -62,10 +62,11 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
       int rc = tiled_node_func<MODE>(h, D, &fn, &lds);
       if (rc) return rc;
       hipGraphNode_t nd = nullptr;
-      HIP_TRY(graph_add_kernel_lds(graph, &nd, deps, fn, dim3(D.grid), dim3(TW_WPB * WAVE), lds, (const int2 *)D.wave_rows,
-                                   (const int *)D.wave_ent, (const int *)D.wave_step_off, (const int *)D.step_tile,
-                                   (const int *)D.wg_step_off, D.nwaves, D.tile_shift, D.tw_rows, (const unsigned *)D.pk,
-                                   (const double *)D.tv, xin, e));
+      const int per_xcd = tiled_per_xcd(h, D, D.grid);
+      HIP_TRY(graph_add_kernel_lds(graph, &nd, deps, fn, dim3(per_xcd > 0 ? per_xcd * NUM_XCD : D.grid), dim3(TW_WPB * WAVE), lds,
+                                   (const int2 *)D.wave_rows, (const int *)D.wave_ent, (const int *)D.wave_step_off,
+                                   (const int *)D.step_tile, (const int *)D.wg_step_off, D.nwaves, D.tile_shift, D.tw_rows,
+                                   (const unsigned *)D.pk, (const double *)D.tv, xin, e, D.grid, per_xcd));
       if (main_node) *main_node = nd;
       done.push_back(nd);
     }
@@ -169,10 +170,11 @@ int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &du
       size_t lds;
       int rc = tiled_node_func<MODE_DUAL>(h, A, &fn, &lds);
       if (rc) return rc;
-      HIP_TRY(graph_set_kernel_lds(G.exec, G.n_dual, fn, dim3(A.grid), dim3(TW_WPB * WAVE), lds, (const int2 *)A.wave_rows,
-                                   (const int *)A.wave_ent, (const int *)A.wave_step_off, (const int *)A.step_tile,
-                                   (const int *)A.wg_step_off, A.nwaves, A.tile_shift, A.tw_rows, (const unsigned *)A.pk,
-                                   (const double *)A.tv, (const double *)h->xbar, dual_epi));
+      const int per_xcd = tiled_per_xcd(h, A, A.grid);
+      HIP_TRY(graph_set_kernel_lds(G.exec, G.n_dual, fn, dim3(per_xcd > 0 ? per_xcd * NUM_XCD : A.grid), dim3(TW_WPB * WAVE), lds,
+                                   (const int2 *)A.wave_rows, (const int *)A.wave_ent, (const int *)A.wave_step_off,
+                                   (const int *)A.step_tile, (const int *)A.wg_step_off, A.nwaves, A.tile_shift, A.tw_rows,
+                                   (const unsigned *)A.pk, (const double *)A.tv, (const double *)h->xbar, dual_epi, A.grid, per_xcd));
     } else if (!A.slabs.empty()) {
       const SlabDev &S = A.slabs.back();
       EpiArgs le = dual_epi;

@@ -47,6 +47,7 @@ struct CsrDev {
   int *wg_step_off = nullptr;     // [grid+1] start of a workgroup's steps inside step_tile
   int64_t total_steps = 0;
   int64_t tw_entries = 0, step_ptr_len = 0;   // lengths of pk / tv and of wave_ent (checksums, tests)
+  bool tw_band = false;           // a workgroup touches < 90 % of the tiles (banded / block-local rows): row groups dealt to the XCDs in contiguous eighths
   int tw_mode = 0;                // chunk accumulation: 0 lane shuffles, 1 LDS scratch (long runs, strict order), 2 relaxed order, 3 lane to lane (runs of 9 ... 32)
   unsigned *pk = nullptr;
   double *tv = nullptr;
@@ -466,6 +467,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   for (int g = 0; g < grid; ++g) D.wg_first_row[g] = wave_rows[(size_t)g * TW_WPB].x;
   D.wg_first_row[grid] = rows;
   D.tiled = true;
+  D.tw_band = touched_share < 0.9;
   D.tile_shift = tile_shift;
   D.tile_cols = tile_cols;
   D.var_tiles = !uniform;

@@ -260,18 +260,30 @@ size_t tiled_lds_bytes(const CsrDev &D) {
   return std::max(need, D.tw_lds_floor);
 }
 
+// XCD remap of the sweep's row groups (spmv_tiled_kernel): row groups per XCD, 0 = workgroup b takes row group b.
+// Only for matrices whose workgroups touch a band of the tiles (10M, +-3M columns: 0.97 / 0.98 -> 0.85 / 0.87 ms); rows that
+// scatter over every tile gain nothing, and where the row groups' work falls with the index (column-skewed A': the first
+// eighth holds the heaviest) contiguous eighths leave one XCD with the most work: 1.11 -> 1.43 ms.
+int tiled_per_xcd(const pdhg_handle *h, const CsrDev &D, int ngroups) {
+  const char *ev = dev_env("PDHG_TW_REMAP");                                                  // dev knob: 0 / 1 force
+  const bool on = ev ? ev[0] != '0' : D.tw_band;
+  return (h->remap && on && ngroups >= 2 * NUM_XCD) ? (ngroups + NUM_XCD - 1) / NUM_XCD : 0;
+}
+
 // the tiled kernel's four chunk variants behind one call
 template <int MODE>
 int launch_tiled(pdhg_handle *h, const CsrDev &D, const double *xin, const EpiArgs &e, int g0, int g1) {
   const size_t lds = tiled_lds_bytes(D);
   const int w0 = g0 * TW_WPB;
+  const int per_xcd = tiled_per_xcd(h, D, g1 - g0);
+  const int grid = per_xcd > 0 ? per_xcd * NUM_XCD : g1 - g0;
   int rc;
 #define PDHG_TILED(CH)                                                                                              \
   do {                                                                                                             \
     if ((rc = ensure_lds_limit(h, MODE, CH, lds, (const void *)spmv_tiled_kernel<MODE, CH>))) return rc;           \
-    hipLaunchKernelGGL((spmv_tiled_kernel<MODE, CH>), dim3(g1 - g0), dim3(TW_WPB * WAVE), lds, h->stream,          \
+    hipLaunchKernelGGL((spmv_tiled_kernel<MODE, CH>), dim3(grid), dim3(TW_WPB * WAVE), lds, h->stream,             \
                        D.wave_rows + w0, D.wave_ent, D.wave_step_off + w0, D.step_tile, D.wg_step_off + g0,        \
-                       D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e);                                \
+                       D.nwaves - w0, D.tile_shift, D.tw_rows, D.pk, D.tv, xin, e, g1 - g0, per_xcd);              \
   } while (0)
   if (D.tw_mode == 1) PDHG_TILED(1);
   else if (D.tw_mode == 2) PDHG_TILED(2);

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
     const int *__restrict__ wave_step_off, const int *__restrict__ step_tile,
     const int *__restrict__ wg_step_off, int nwaves, int tile_shift, int TW_ROWS,
     const unsigned *__restrict__ pk, const double *__restrict__ tv,
-    const double *__restrict__ xin, EpiArgs e) {
+    const double *__restrict__ xin, EpiArgs e, int ngroups, int per_xcd) {
   constexpr int TW_THREADS = TW_WPB * WAVE;
   constexpr int U = TW_U;   // 64-entry chunks held in registers per (wave, tile)
   constexpr int D = 3;      // entry loads run D tiles ahead of the accumulate
@@ -585,8 +585,14 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   const int lane = threadIdx.x & (WAVE - 1);
   const int wid = threadIdx.x / WAVE;
   double *scratch = tw_lds + TW_WPB * TW_ROWS + 6 * TW_WPB + wid * WAVE;   // CH == 1 only: 64 doubles per wave
-  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * TW_WPB + wid);
-  const bool live = w < nwaves;
+  // XCD remap (per_xcd > 0; the grid is 8 x per_xcd): workgroup b runs on XCD b % 8 and takes row group
+  // (b % 8) * per_xcd + b / 8, so that an XCD's resident workgroups own CONSECUTIVE row groups.  All the same to a matrix
+  // whose rows scatter over every tile; on a wide band (10M, +-3M columns) the row groups resident together start their
+  // sweeps up to 64 tiles apart, and dealt round robin every XCD's L2 saw all of those tiles at once.
+  const int g = per_xcd > 0 ? (int)(blockIdx.x & (NUM_XCD - 1)) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const bool wg_live = g < ngroups;
+  const int w = __builtin_amdgcn_readfirstlane(g * TW_WPB + wid);
+  const bool live = wg_live && w < nwaves;
   Acc3 acc3 = acc3_zero();
   double *acc = tw_lds + wid * TW_ROWS;
   int2 rr = make_int2(0, 0);
@@ -596,8 +602,8 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   // heavy tile (cells are cut on the host so that no wave has more than
   // TW_U*64 entries in a step); tiles in which none of the 8 waves has an entry
   // are skipped.  ntiles below is the number of STEPS of this workgroup.
-  const int ntiles = wg_step_off[blockIdx.x + 1] - wg_step_off[blockIdx.x];
-  const int *stile = step_tile + wg_step_off[blockIdx.x];
+  const int ntiles = wg_live ? wg_step_off[g + 1] - wg_step_off[g] : 0;
+  const int *stile = step_tile + (wg_live ? wg_step_off[g] : 0);
   const int *tp = step_ptr + (live ? wave_step_off[w] : 0);
   const unsigned cmask = (1u << tile_shift) - 1u;
 
@@ -685,11 +691,11 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   constexpr int NQ = ModeNQ<MODE>::value;
   if (NQ > 0) {
     block_sum_dd<NQ, TW_THREADS>(acc3, red);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && wg_live) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        e.partials[q * e.stride + blockIdx.x] = acc3.hi[q];
-        e.partials[e.lo_offset + q * e.stride + blockIdx.x] = acc3.lo[q];
+        e.partials[q * e.stride + g] = acc3.hi[q];
+        e.partials[e.lo_offset + q * e.stride + g] = acc3.lo[q];
       }
     }
   }

@@ -316,3 +316,39 @@ def test_runs_of_9_to_32_travel_lane_to_lane(gpu_required, monkeypatch, order, l
         scale = np.array([np.abs(raw_o[1] * raw_o[2]) ** 0.5 + abs(raw_o[0]), raw_o[1], raw_o[2]])
         assert np.all(np.abs(raw[:3] - raw_o[:3]) <= 1e-12 * scale + 1e-300)
     eng.close()
+
+
+def test_row_groups_dealt_to_the_xcds_in_contiguous_eighths(gpu_required, monkeypatch):
+    """spmv_tiled_kernel's XCD remap (per_xcd > 0: workgroup b takes row group (b % 8) * per_xcd + b / 8; the builder turns
+    it on for banded sweeps, PDHG_TW_REMAP forces it): the same row groups, the same block-partial slots -- products,
+    trial vectors AND the trial's scalars must be bit for bit those of the plain numbering, on a grid that is not a
+    multiple of 8 (idle workgroups at the end of the last XCD's share)."""
+    monkeypatch.setenv("PDHG_SPMV", "tiled")
+    monkeypatch.setenv("PDHG_TILE_COLS", "4096")
+    p = random_lp(21_000, 30_000, 10, seed=77)
+    A = p.constraint_matrix
+    m, n = A.shape
+    rng = np.random.default_rng(5)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    x0 = np.clip(rng.standard_normal(n), np.maximum(p.variable_lower_bound, -5), np.minimum(p.variable_upper_bound, 5))
+    y0 = rng.standard_normal(m)
+    y0[p.num_equalities:] = np.abs(y0[p.num_equalities:])
+    step, pw = H.initial_step_and_weight(p)
+    out = []
+    for remap in ("0", "1"):
+        monkeypatch.setenv("PDHG_TW_REMAP", remap)
+        for graph in ("0", "1"):
+            monkeypatch.setenv("PDHG_GRAPH", graph)
+            monkeypatch.setenv("PDHG_GRAPH_TILED", "1")
+            eng = HipPdhgEngine.from_problem(p)
+            info = eng.layout_info()
+            assert info["A_tiled_waves"] >= 16 * 8 and info["A_tiled_waves"] % 64 != 0, info
+            H.assert_products_match_oracle(eng, A, x, y, forced_sweep=True)
+            eng.set_current(x0, y0)
+            raw = [np.array(eng.trial_step(step, pw, theta)) for theta in (1.0, 0.37)]
+            out.append((eng.spmv(x), eng.spmv_t(y), raw, eng.get_trial()))
+            eng.close()
+    for o in out[1:]:
+        assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
+        assert all(np.array_equal(a, b) for a, b in zip(o[2], out[0][2]))
+        assert all(np.array_equal(a, b) for a, b in zip(o[3], out[0][3]))
