@@ -209,9 +209,40 @@ int pdhg_eval_point(pdhg_handle *h0, int point, double out[24]) {
     hipLaunchKernelGGL(eval_cols_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, h->pt_aty,
                        h->pt_qx, h->pt_x, h->Dv, h->c_o, h->lb_o, h->ub_o, h->ev_partials + (size_t)8 * h->ev_grid, h->ev_grid);
     HIP_TRY(hipGetLastError());
-    double r[22];
-    // quantities 0-3 sums, 4-7 maxes (rows); 8-14 sums, 15-21 maxes (columns)
-    if ((rc = ev_finish(L, 22, 0, r, 0xF0u | (0x7Fu << 15)))) return rc;
+    // What the rest of a termination / restart check asks for next (saddle_point.jl:432-477: the distances of the
+    // average and the current iterate to the last restart point; :1015-1047: the sum of squares of the evaluated point)
+    // rides in the same reduction: three more launches of dist2_kernel, partials behind the 22, ONE second stage, one
+    // round trip.  pdhg_distance_to_restart / pdhg_point_sumsq answer from these until the state moves -- the same
+    // kernel, grid and per-quantity second stage as their own launches: the same bits.  (three round trips of a check's six)
+    const char *pf = dev_env("PDHG_EVAL_PREFETCH");                   // dev knob, read per call: the test compares both forms in one process
+    const bool pre = !(pf && pf[0] == '0');
+    bool have_avg = false;
+    if (pre) {
+      have_avg = h->sum_x_count != 0 && h->sum_y_count != 0;
+      const double *ax = nullptr, *ay = nullptr;
+      if (have_avg && (rc = select_point(h, PDHG_POINT_AVERAGE, &ax, &ay))) return rc;
+      double *extra = h->ev_partials + (size_t)22 * h->ev_grid;
+      if (have_avg)
+        hipLaunchKernelGGL(dist2_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)h->m, ax, (const double *)h->x_r, ay,
+                           (const double *)h->y_r, extra, h->ev_grid);
+      else
+        HIP_TRY(hipMemsetAsync(extra, 0, sizeof(double) * 2 * (size_t)h->ev_grid, h->stream));
+      hipLaunchKernelGGL(dist2_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)h->m, (const double *)h->x,
+                         (const double *)h->x_r, (const double *)h->y, (const double *)h->y_r, extra + (size_t)2 * h->ev_grid, h->ev_grid);
+      hipLaunchKernelGGL(dist2_kernel, dim3(h->ev_grid), dim3(TPB), 0, h->stream, (int)h->cn, (int)h->m, h->pt_x, (const double *)nullptr,
+                         h->pt_y, (const double *)nullptr, extra + (size_t)4 * h->ev_grid, h->ev_grid);
+      HIP_TRY(hipGetLastError());
+    }
+    double r[28];
+    // quantities 0-3 sums, 4-7 maxes (rows); 8-14 sums, 15-21 maxes (columns); 22-27 sums (the prefetched scalars)
+    if ((rc = ev_finish(L, pre ? 28 : 22, 0, r, 0xF0u | (0x7Fu << 15)))) return rc;
+    if (pre) {
+      for (int q = 0; q < 6; ++q) h->chk_vals[q] = r[22 + q];
+      h->chk_state = h->state_version;
+      h->chk_restart = h->restart_version;
+      h->chk_point = point;
+      h->chk_have_avg = have_avg;
+    }
     for (int q = 0; q < 8; ++q) out[q] = r[q];
     for (int q = 0; q < 6; ++q) { out[8 + q] = r[8 + q]; out[14 + q] = r[8 + 7 + q]; }
     out[20] = r[8 + 6]; out[21] = r[8 + 13]; out[22] = out[23] = 0.0;
@@ -258,6 +289,18 @@ static int dist2_common(pdhg_handle *h0, int point, bool to_restart, double out[
   if (rc) return rc;
   const Shards L = shards_of(h0);
   if ((rc = flush_pending(L))) return rc;
+  if (!L.g && h0->chk_state == h0->state_version) {          // reduced with the last pdhg_eval_point (see there)?
+    const pdhg_handle *h = h0;
+    if (to_restart && h->chk_restart == h->restart_version && (point == PDHG_POINT_CURRENT || (point == PDHG_POINT_AVERAGE && h->chk_have_avg))) {
+      const int k = point == PDHG_POINT_AVERAGE ? 0 : 2;
+      out[0] = h->chk_vals[k]; out[1] = h->chk_vals[k + 1];
+      return 0;
+    }
+    if (!to_restart && point == h->chk_point && point != PDHG_POINT_RESTART) {
+      out[0] = h->chk_vals[4]; out[1] = h->chk_vals[5];
+      return 0;
+    }
+  }
   FOR_SHARDS(L, h) {
     const double *px, *py;
     if ((rc = select_point(h, point, &px, &py))) return rc;

@@ -104,6 +104,12 @@ struct pdhg_handle {
   double *ev_cax[3] = {nullptr, nullptr, nullptr}, *ev_caty[3] = {nullptr, nullptr, nullptr};
   double *ev_cqx[3] = {nullptr, nullptr, nullptr}, *ev_qx = nullptr;   // Q*x at those points (QP only)
   uint64_t restart_version = 1, matrix_version = 1, ev_rkey = 0;
+  // the scalars the rest of a check asks for next (distances of AVERAGE / CURRENT to the restart point, sum of squares of
+  // the evaluated point), reduced WITH pdhg_eval_point's 22 quantities and kept until the state moves (abi_eval.hpp)
+  double chk_vals[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t chk_state = 0, chk_restart = ~0ull;     // state_version / restart_version the values belong to
+  int chk_point = -1;                              // the point whose sum of squares chk_vals[4..5] is
+  bool chk_have_avg = false;
   uint64_t state_version = 1;                      // bumped by everything that moves x, y, the sums or A
   uint64_t ev_cversion[2] = {0, 0}, avg_version = 0;
   double *tr_g = nullptr, *tr_dir = nullptr, *tr_thr = nullptr;  // n+m each: g d, w d^2, breakpoint (tr_setup_kernel)

@@ -312,6 +312,9 @@ int pdhg_set_original_problem(pdhg_handle *h, const double *constraint_rescaling
  *        out[17] max|g-rc| (c=0)  out[18] max|rc| (c=0)  out[19] max ray bound violation
  *        out[20] x_o.(Q_o x_o)   out[21] max|Q_o x_o|   (both 0 for an LP; out[22..23] reserved)
  * with g = Q_o x_o + c_o - A_o'y_o and rc the reduced costs (iteration_stats_utils.jl:128-148).
+ * On one handle the same reduction also carries what a check asks for next -- pdhg_distance_to_restart of the average and
+ * of the current iterate, pdhg_point_sumsq of `point` -- and those calls answer from it (the values their own launches
+ * produce, bit for bit) until the iterates, the sums or the restart point change.
  */
 int pdhg_eval_point(pdhg_handle *h, int point, double out[24]);
 

@@ -215,3 +215,48 @@ def test_eval_point_one_round_trip_is_bitwise_the_two_round_form(gpu_required, m
             monkeypatch.delenv("PDHG_EVAL_HOST_WORD")
             assert np.array_equal(one, two)
         eng.close()
+
+
+def test_check_scalars_reduced_with_eval_point_are_bitwise_their_own_launches(gpu_required, monkeypatch):
+    """pdhg_eval_point also reduces what the rest of a check asks for next -- the distances of the average and the current
+    iterate to the last restart point (saddle_point.jl:432-477) and the sum of squares of the evaluated point
+    (saddle_point.jl:1015-1047) -- and pdhg_distance_to_restart / pdhg_point_sumsq answer from that until the state moves
+    (three of a check's six host round trips).  Same kernel, grid and per-quantity second stage as the calls' own launches:
+    not a bit may differ (PDHG_EVAL_PREFETCH=0: the calls launch for themselves); a step, a new restart point or a
+    different point must not be answered from stale values."""
+    for p in (random_lp(30000, 20000, 6, seed=2), pagerank_lp(40000, seed=1)):
+        eng, _, ev_d, st = _setup(p)
+        eng.save_restart_point()
+        for _ in range(7):
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+
+        def check(point):
+            ev = np.array(eng.eval_point(point))
+            return (ev, eng.distance_to_restart(POINT_AVERAGE), eng.distance_to_restart(POINT_CURRENT), eng.point_sumsq(point),
+                    eng.point_sumsq(POINT_CURRENT), eng.point_sumsq(POINT_RESTART))
+
+        for point in (POINT_AVERAGE, POINT_CURRENT):
+            fast = check(point)
+            monkeypatch.setenv("PDHG_EVAL_PREFETCH", "0")
+            slow = check(point)
+            monkeypatch.delenv("PDHG_EVAL_PREFETCH")
+            for a, b in zip(fast, slow):
+                assert np.array_equal(np.asarray(a), np.asarray(b))
+        # stale values: after a step / a new restart point the answers are those of fresh launches
+        eng.eval_point(POINT_AVERAGE)
+        take_step(AdaptiveStepsizeParams(0.3, 0.6), st)
+        after_step = (eng.distance_to_restart(POINT_AVERAGE), eng.distance_to_restart(POINT_CURRENT), eng.point_sumsq(POINT_AVERAGE))
+        eng.eval_point(POINT_AVERAGE)
+        eng.save_restart_point()
+        after_save = (eng.distance_to_restart(POINT_AVERAGE), eng.distance_to_restart(POINT_CURRENT))
+        assert tuple(after_save[1]) == (0.0, 0.0)
+        monkeypatch.setenv("PDHG_EVAL_PREFETCH", "0")
+        ref_save = (eng.distance_to_restart(POINT_AVERAGE), eng.distance_to_restart(POINT_CURRENT))
+        monkeypatch.delenv("PDHG_EVAL_PREFETCH")
+        assert np.array_equal(np.asarray(after_save), np.asarray(ref_save))
+        x, y = eng.get_current()
+        xa, ya = eng.get_average()
+        xr, yr = eng.get_point(POINT_RESTART)
+        np.testing.assert_allclose(np.asarray(after_step[2]), [xa @ xa, ya @ ya], rtol=1e-12)
+        np.testing.assert_allclose(np.asarray(after_save[0]), [(xa - xr) @ (xa - xr), (ya - yr) @ (ya - yr)], rtol=1e-10, atol=1e-300)
+        eng.close()
