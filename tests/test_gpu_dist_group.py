@@ -99,17 +99,25 @@ def test_tiled_shards_match_single_engine_and_overlap_is_bitwise_neutral(gpu_req
     monkeypatch.setenv("PDHG_DIST_ROUND_WGS", "64")     # default granule: a residency round of 512 workgroups
     p = random_lp(1_100_000, 600_000, 5, seed=21)
     runs = {}
-    for overlap in ("1", "0"):
+    # third run: the sweep's row groups dealt to the XCDs in contiguous eighths (what the builder does for banded matrices,
+    # forced here), also inside the launches of one residency round each -- same row groups, same bits
+    for overlap, remap in (("1", None), ("0", None), ("1", "1")):
         monkeypatch.setenv("PDHG_DIST_OVERLAP", overlap)
+        if remap is None:
+            monkeypatch.delenv("PDHG_TW_REMAP", raising=False)
+        else:
+            monkeypatch.setenv("PDHG_TW_REMAP", remap)
         geng = HipPdhgEngine.from_problem(p, device_ids=[0] * shards)
         info = geng.layout_info()
         # 2 shards: A_p' (600k x 600k) is tiled and launched in parts; 3 shards: its gathered
         # vector (400k rows of y) fits an XCD's L2, so it streams and is computed whole
         assert info["A_tiled_waves"] > 0 and (info["At_tiled_waves"] > 0) == (shards == 2)
-        runs[overlap] = _run(geng, p, 40, 10)
+        runs[overlap + (remap or "")] = _run(geng, p, 40, 10)
         geng.close()
+    monkeypatch.delenv("PDHG_TW_REMAP", raising=False)
     for key, val in runs["1"].items():
         assert np.array_equal(np.asarray(val), np.asarray(runs["0"][key])), key
+        assert np.array_equal(np.asarray(val), np.asarray(runs["11"][key])), key + " (XCD remap of the sweep)"
     s = _run(HipPdhgEngine.from_problem(p), p, 40, 10)
     _compare(runs["1"], s, p)
 
