@@ -47,6 +47,7 @@ struct CsrDev {
   int *wg_step_off = nullptr;     // [grid+1] start of a workgroup's steps inside step_tile
   int64_t total_steps = 0;
   int64_t tw_entries = 0, step_ptr_len = 0;   // lengths of pk / tv and of wave_ent (checksums, tests)
+  double tw_touched = 1.0;        // share of the sweep's (workgroup, tile) cells that hold entries, as build_tiled last measured it (also when it declined)
   bool tw_band = false;           // a workgroup touches < 90 % of the tiles (banded / block-local rows): row groups dealt to the XCDs in contiguous eighths
   int tw_mode = 0;                // chunk accumulation: 0 lane shuffles, 1 LDS scratch (long runs, strict order), 2 relaxed order, 3 lane to lane (runs of 9 ... 32)
   unsigned *pk = nullptr;
@@ -386,6 +387,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     // stream wins below ~0.25 (4M columns, band +-500K: share 0.245, stream 0.43 ms / sweep 0.57 ms), the
     // sweep above ~0.28 (10M columns, band +-1.5M: share 0.284, sweep 1.22 ms / stream 1.60 ms)
     const double min_share = dev_env("PDHG_TW_MIN_SHARE") ? atof(dev_env("PDHG_TW_MIN_SHARE")) : 0.26;
+    D.tw_touched = touched_share;
     if (getenv("PDHG_VERBOSE"))
       fprintf(stderr, "[pdhg_hip] tiled layout %d x %d: %.3f of the (workgroup, tile) cells hold entries\n", rows, D.cols, touched_share);
     if (!forced && touched_share < min_share) return 0;
@@ -564,8 +566,13 @@ inline int slab_first_col(int cols, int P, int p) {
 // Column-slab copies for the stream layout (see spmv_stream_kernel).  Used when the
 // gathered vector is 1.25 .. 4 slabs long (slab = PDHG_SLAB_MB MiB, default 4 = one XCD's
 // L2); beyond that the tiled sweep is the tool.  PDHG_SLABS=0 disables.
-int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, const ivec &col,
-                const dvec &val, bool remap) {
+// ... and only for rows that scatter: where the sweep was declined because a few thousand consecutive rows touch a sliver
+// of the columns (banded, block-local: build_tiled's D.tw_touched), the row blocks an XCD works on at one time gather
+// from a window its L2 holds anyway, and slab passes only walk the rows twice.  1M x 1M, +-5 000 columns / 100 diagonal
+// blocks: 0.099 / 0.100 ms per product with two slab passes against 0.05 without (the vendor's CSR kernel: 0.048),
+// profiles/r05_shape_table_1m.txt.  PDHG_SLABS=2 (dev use): slabs whatever the locality.
+// Returns the number of slabs (0: none) -- ONE rule for the host and the device construction.
+int slab_count(const CsrDev &D, int cols) {
   const char *off = getenv("PDHG_SLABS");
   if (off && off[0] == '0') return 0;
   const char *mb = getenv("PDHG_SLAB_MB");
@@ -574,6 +581,15 @@ int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, c
   if (vec_bytes <= 1.25 * slab_bytes || D.nnz < (1 << 20)) return 0;
   const int P = (int)std::ceil(vec_bytes / slab_bytes);
   if (P < 2 || P > 4) return 0;
+  const bool local_rows = D.tw_touched * vec_bytes <= 0.5 * slab_bytes;
+  if (local_rows && !(off && off[0] == '2')) return 0;
+  return P;
+}
+
+int build_slabs(CsrDev &D, int rows, int cols, const std::vector<int> &rowptr, const ivec &col,
+                const dvec &val, bool remap) {
+  const int P = slab_count(D, cols);
+  if (P == 0) return 0;
   const int width = (cols + P - 1) / P;
   int rc;
   for (int p = 0; p < P; ++p) {
@@ -831,12 +847,9 @@ int build_csr_dev_resident(CsrDev &D, int rows, int cols, const std::vector<int>
     if (rc) return rc;
   }
   if (!D.tiled) {
-    // column slabs apply to 1.25 .. 4 slab widths of gathered vector and >= 1M nonzeros (build_slabs)
-    const char *off = getenv("PDHG_SLABS");
-    const char *mb = getenv("PDHG_SLAB_MB");
-    const double slab_bytes = (mb ? std::max(0.25, atof(mb)) : 4.0) * 1048576.0, vec_bytes = 8.0 * (double)cols;
-    const int P = (int)std::ceil(vec_bytes / slab_bytes);
-    const bool slabs = !(off && off[0] == '0') && vec_bytes > 1.25 * slab_bytes && D.nnz >= (1 << 20) && P >= 2 && P <= 4;
+    // column slabs: slab_count() -- 1.25 .. 4 slab widths of gathered vector, >= 1M nonzeros, rows that scatter
+    const int P = slab_count(D, cols);
+    const bool slabs = P > 0;
     if (slabs) {
       if (fetched) rc = build_slabs(D, rows, cols, rowptr, col, val, remap);
       else rc = build_slabs_device(D, rows, cols, rowptr, remap, P);

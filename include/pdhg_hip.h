@@ -28,7 +28,7 @@
  *   name                 values (default first)        effect
  *   PDHG_SPMV            auto | stream | tiled         force the product layout: CSR row blocks / L2-tiled sweep
  *   PDHG_SJ              auto | 0 | 1                  sliced jagged copy of stream-class matrices (csrc/sj_kernels.hpp)
- *   PDHG_SLABS           auto | 0 | 1                  column-slab passes of the stream layout
+ *   PDHG_SLABS           auto | 0 | 1 | 2              column-slab passes of the stream layout (auto: not for banded / block-local rows; 2: also there)
  *   PDHG_SLAB_MB         4                             slab size in MiB
  *   PDHG_TILE_COLS       auto | <columns>              tile width of the sweep
  *   PDHG_ROW_ORDER       relaxed | strict              rows of > 256 entries summed by their wave / strictly left to right
