@@ -34,18 +34,21 @@ SHAPES = [
     ("pagerank 1M", "pagerank", dict(n=1_000_000)),
     ("l1svm rcv1-shaped SUBSTITUTE", "l1svm", {}),
 ]
-# the structured shapes at 1M x 1M (--only "1M-"): one residency round, short waves, vectors of 8 MB
-SHAPES += [
-    ("1M-column-skewed", "colskew", dict(m=1_000_000, n=1_000_000)),
-    ("1M-banded +-5000", "banded", dict(m=1_000_000, n=1_000_000, band=5_000)),
-    ("1M-banded +-300000", "banded", dict(m=1_000_000, n=1_000_000, band=300_000)),
-    ("1M-blockdiag", "blockdiag", dict(m=1_000_000, n=1_000_000)),
-    ("1M-clustered", "clustered", dict(m=1_000_000, n=1_000_000)),
-    ("1M-twodensity", "twodensity", dict(m=1_000_000, n=1_000_000)),
-    ("1M-arrowhead", "arrowhead", dict(m=1_000_000, n=1_000_000)),
-    ("1M-wide 300K x 3M", "random", dict(m=300_000, n=3_000_000)),
-    ("1M-30 per row", "random", dict(m=1_000_000, n=1_000_000, k=30)),
-]
+# the structured shapes at other sizes (--only "1M-", "4M-", "200K-": never part of the default table): one residency round,
+# short waves, vectors of 1.6 / 8 / 32 MB
+for _tag, _n in (("200K", 200_000), ("1M", 1_000_000), ("4M", 4_000_000)):
+    SHAPES += [
+        (f"{_tag}-uniform", "random", dict(m=_n, n=_n)),
+        (f"{_tag}-column-skewed", "colskew", dict(m=_n, n=_n)),
+        (f"{_tag}-banded +-{_n // 200}", "banded", dict(m=_n, n=_n, band=_n // 200)),
+        (f"{_tag}-banded +-{3 * _n // 10}", "banded", dict(m=_n, n=_n, band=3 * _n // 10)),
+        (f"{_tag}-blockdiag", "blockdiag", dict(m=_n, n=_n)),
+        (f"{_tag}-clustered", "clustered", dict(m=_n, n=_n)),
+        (f"{_tag}-twodensity", "twodensity", dict(m=_n, n=_n)),
+        (f"{_tag}-arrowhead", "arrowhead", dict(m=_n, n=_n)),
+        (f"{_tag}-wide {3 * _n // 10} x {3 * _n}", "random", dict(m=3 * _n // 10, n=3 * _n)),
+        (f"{_tag}-30 per row", "random", dict(m=_n, n=_n, k=30)),
+    ]
 
 
 def make_shape(kind, m=10_000_000, n=10_000_000, k=10, band=0):
@@ -164,7 +167,7 @@ def main():
           "frac = algorithmic bytes of the fused product / time / 8 TB/s", flush=True)
     only = [s.strip() for s in args.only.split(",") if s.strip()]
     for title, kind, kw in SHAPES:
-        if (only and not any(o in title for o in only)) or (not only and title.startswith("1M-")):
+        if (only and not any(o in title for o in only)) or (not only and title.split("-")[0] in ("200K", "1M", "4M")):
             continue
         p = make_shape(kind, **kw)
         r = product_ms(p)
