@@ -327,7 +327,14 @@ int coop_steps(pdhg_handle *h, int64_t n_steps, double reduction_exponent, doubl
   a.local_g = local ? h->coop_grid : 0; a.local_home = 0;
   // test knob: the kernel expects eight workgroups more than are launched on the home XCD -- its first barrier times out
   if (local && dev_env("PDHG_COOP_LOCAL_TEST_BAD")) a.local_g += 8;
-  if (local) { a.local_ticket_base = h->local_tickets; h->local_tickets += (unsigned long long)h->coop_grid; }
+  // The stayers number themselves with a ticket; the word is zeroed before every launch (one 8-byte fill in stream order,
+  // once per batch of steps) instead of the host adding coop_grid per launch to a running base: a launch that placed
+  // more than the census' workgroups on the home XCD drew more tickets than the host assumed, and every later launch
+  // numbered its workers wrongly until the barriers' time-out dropped the mode.
+  if (local) {
+    HIP_TRY(hipMemsetAsync(&h->lsync->ticket[0][0], 0, sizeof(unsigned long long), h->stream));
+    a.local_ticket_base = 0;
+  }
   a.seq = ++h->steps_seq;
   a.nxcd = h->coop_nxcd; a.relaxed = h->relaxed ? 1 : 0;
   a.trace = h->coop_trace;

@@ -178,7 +178,7 @@ struct pdhg_handle {
   // the multi-step kernel's XCD-local mode (small grids: every working workgroup on one XCD, trial_kernel.hpp)
   int local_mode = -1;                  // -1 not decided, 0 off, 1 on
   GridSync *lsync = nullptr;
-  unsigned long long local_epoch = 0, local_tickets = 0;
+  unsigned long long local_epoch = 0;
   long local_launches = 0;
   GridSync *gsync = nullptr;
   unsigned long long *coop_trace = nullptr;   // PDHG_COOP_TRACE=1: phase stamps of the last launch
