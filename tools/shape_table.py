@@ -167,7 +167,10 @@ def main():
           "frac = algorithmic bytes of the fused product / time / 8 TB/s", flush=True)
     only = [s.strip() for s in args.only.split(",") if s.strip()]
     for title, kind, kw in SHAPES:
-        if (only and not any(o in title for o in only)) or (not only and title.split("-")[0] in ("200K", "1M", "4M")):
+        sized = title.split("-")[0] in ("200K", "1M", "4M")
+        # (a size-tagged shape is selected only by a token that names a size tag: "clustered" stays the 10M shape alone)
+        if (only and not any(o in title and (not sized or any(t in o for t in ("200K-", "1M-", "4M-"))) for o in only)) or \
+                (not only and sized):
             continue
         p = make_shape(kind, **kw)
         r = product_ms(p)
