@@ -303,7 +303,7 @@ int pdhg_layout_checksums(pdhg_handle *h, uint64_t out[32]) {
       }
     }
     // the plan's scalars ride in the last slot
-    out[16 * k + 15] = (uint64_t)D.tiled + 2ull * (uint64_t)D.tw_mode + 8ull * (uint64_t)D.tile_shift + 1024ull * (uint64_t)D.tw_rows +
+    out[16 * k + 15] = (uint64_t)D.tiled + 2ull * (uint64_t)std::min(D.tw_mode, 3) + 8ull * (uint64_t)D.tile_shift + 1024ull * (uint64_t)D.tw_rows +
                        (1ull << 32) * (uint64_t)D.grid;
   }
   return 0;

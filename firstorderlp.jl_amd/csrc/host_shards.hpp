@@ -467,6 +467,40 @@ int build_segments(int dev, pdhg_handle *h, int64_t m, int64_t n, int64_t nnz, c
 
 // One shard: device layouts + vectors for the rows it is given.  n_alloc >= n is the
 // allocation length of the n-vectors that take part in collectives.
+// The sweep's chunk variant for matrices with same-row runs of 9 ... 32 entries, chosen by TIMING the plain product with
+// variants 3 and 4 on the matrix at hand (spmv_kernels.hpp: tiled_chunk_hybrid says why no rule on run lengths would do):
+// one warm-up and three launches each, 4 only when it is >= 4 % faster.  Both add every run in the sequential order --
+// the choice cannot change a bit of any result, only the kernel's name.  PDHG_TW_MODE (dev) pins a variant.
+int tune_tiled_variant(pdhg_handle *h, CsrDev &D, const double *xin, double *out) {
+  if (!D.tiled || D.tw_mode != 3 || D.grid <= 0 || dev_env("PDHG_TW_MODE") || !xin || !out) return 0;
+  const char *ev = dev_env("PDHG_TW_TUNE");
+  if (ev && ev[0] == '0') return 0;
+  float ms[2] = {0.f, 0.f};
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  hipError_t ce = hipEventCreate(&e1);
+  if (ce != hipSuccess) { (void)hipEventDestroy(e0); return fail((int)ce, "hipEventCreate failed"); }
+  EpiArgs e{};
+  e.out = out;
+  int rc = 0;
+  for (int v = 0; v < 2 && !rc; ++v) {
+    D.tw_mode = 3 + v;
+    rc = launch_tiled<MODE_PLAIN>(h, D, xin, e, 0, D.grid);
+    if (rc) break;
+    (void)hipEventRecord(e0, h->stream);
+    for (int k = 0; k < 3 && !rc; ++k) rc = launch_tiled<MODE_PLAIN>(h, D, xin, e, 0, D.grid);
+    (void)hipEventRecord(e1, h->stream);
+    if (!rc && hipEventSynchronize(e1) != hipSuccess) rc = fail(-3, "the sweep's tuning launches failed");
+    if (!rc) (void)hipEventElapsedTime(&ms[v], e0, e1);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  D.tw_mode = (ms[1] > 0.f && ms[1] < 0.96f * ms[0]) ? 4 : 3;
+  if (getenv("PDHG_VERBOSE"))
+    fprintf(stderr, "[pdhg_hip] sweep %d x %d: chunk variant 3 %.3f ms, 4 %.3f ms per product -> %d\n", D.rows, D.cols, ms[0] / 3.f, ms[1] / 3.f, D.tw_mode);
+  return 0;
+}
+
 int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
                  const int64_t *colptr, const int64_t *rowval, const double *nzval,
                  int index_base, const double *c, const double *b, const double *lb,
@@ -530,6 +564,8 @@ int create_shard(pdhg_handle **out, int64_t m, int64_t n, int64_t nnz,
     e = hipEventCreate(&h->ev0); if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) { destroy_shard(h); return fail((int)e, "hipEventCreate failed"); }
   }
+  CK(tune_tiled_variant(h, h->A, h->xbar, h->tmp_m));
+  CK(tune_tiled_variant(h, h->At, h->y, h->tmp_n));
 #undef CK
   HIP_TRY(hipDeviceSynchronize());
   *out = h;

@@ -43,6 +43,7 @@ int tiled_node_func(pdhg_handle *h, const CsrDev &D, const void **fn, size_t *ld
   *fn = D.tw_mode == 1   ? (const void *)spmv_tiled_kernel<MODE, 1>
         : D.tw_mode == 2 ? (const void *)spmv_tiled_kernel<MODE, 2>
         : D.tw_mode == 3 ? (const void *)spmv_tiled_kernel<MODE, 3>
+        : D.tw_mode == 4 ? (const void *)spmv_tiled_kernel<MODE, 4>
                          : (const void *)spmv_tiled_kernel<MODE, 0>;
   return ensure_lds_limit(h, MODE, D.tw_mode, *lds, *fn);
 }

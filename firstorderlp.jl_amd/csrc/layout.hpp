@@ -49,7 +49,7 @@ struct CsrDev {
   int64_t tw_entries = 0, step_ptr_len = 0;   // lengths of pk / tv and of wave_ent (checksums, tests)
   double tw_touched = 1.0;        // share of the sweep's (workgroup, tile) cells that hold entries, as build_tiled last measured it (also when it declined)
   bool tw_band = false;           // a workgroup touches < 90 % of the tiles (banded / block-local rows): row groups dealt to the XCDs in contiguous eighths
-  int tw_mode = 0;                // chunk accumulation: 0 lane shuffles, 1 LDS scratch (long runs, strict order), 2 relaxed order, 3 lane to lane (runs of 9 ... 32)
+  int tw_mode = 0;                // chunk accumulation: 0 lane shuffles, 1 LDS scratch (long runs, strict order), 2 relaxed order, 3 lane to lane (runs of 9 ... 32), 4 = 3 / 0 per chunk (chosen over 3 by timing: tune_tiled_variant)
   unsigned *pk = nullptr;
   double *tv = nullptr;
   std::vector<int> wg_first_row;  // host copy: first row of every tiled workgroup (+ rows), for partial launches
@@ -497,7 +497,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
   // the shuffle tree in relaxed order (2), the LDS scratch in strict order (1 -- one workgroup per CU when rows per wave
   // are near the cap)
   D.tw_mode = max_run > 8 ? (max_run > 32 ? (relaxed ? 2 : 1) : 3) : 0;
-  if (const char *ev = dev_env("PDHG_TW_MODE")) D.tw_mode = std::max(0, std::min(3, atoi(ev)));    // dev knob
+  if (const char *ev = dev_env("PDHG_TW_MODE")) D.tw_mode = std::max(0, std::min(4, atoi(ev)));    // dev knob (4: see tune_tiled_variant)
   int rc;
   if (on_device) { D.wave_rows = d_wave_rows; d_wave_rows = nullptr; }
   else if ((rc = upload(&D.wave_rows, wave_rows))) return rc;

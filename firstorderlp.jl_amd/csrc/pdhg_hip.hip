@@ -244,7 +244,7 @@ struct ProfScope {
 // and must only ever grow: another handle on the same device may need more than
 // this one (hipFuncSetAttribute sets the limit, it does not raise it).
 int ensure_lds_limit(pdhg_handle *h, int mode, int chunk_mode, size_t lds, const void *func) {
-  static size_t limit[64][3][4] = {};
+  static size_t limit[64][3][5] = {};
   static std::mutex mu;            // handles may be created / driven from several host threads (shard pool, Julia tasks)
   std::lock_guard<std::mutex> lock(mu);
   size_t &cur = limit[h->device & 63][mode][chunk_mode];
@@ -276,7 +276,7 @@ int tiled_per_xcd(const pdhg_handle *h, const CsrDev &D, int ngroups) {
   return (h->remap && on && ngroups >= 2 * NUM_XCD) ? (ngroups + NUM_XCD - 1) / NUM_XCD : 0;
 }
 
-// the tiled kernel's four chunk variants behind one call
+// the tiled kernel's five chunk variants behind one call
 template <int MODE>
 int launch_tiled(pdhg_handle *h, const CsrDev &D, const double *xin, const EpiArgs &e, int g0, int g1) {
   const size_t lds = tiled_lds_bytes(D);
@@ -294,6 +294,7 @@ int launch_tiled(pdhg_handle *h, const CsrDev &D, const double *xin, const EpiAr
   if (D.tw_mode == 1) PDHG_TILED(1);
   else if (D.tw_mode == 2) PDHG_TILED(2);
   else if (D.tw_mode == 3) PDHG_TILED(3);
+  else if (D.tw_mode == 4) PDHG_TILED(4);
   else PDHG_TILED(0);
 #undef PDHG_TILED
   return 0;

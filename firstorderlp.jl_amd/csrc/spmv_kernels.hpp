@@ -481,6 +481,41 @@ __device__ __forceinline__ void tiled_chunk_scan(double *acc, unsigned p, double
   if (tail && valid) acc[row] = s;
 }
 
+// Variant 4: variant 3 for chunks that hold a run of more than three entries, variant 0's shuffle loop for the others.
+// Which of 3 and 4 is faster depends on the memory regime, not on the run lengths: rows of log-normal length over uniform
+// columns (10M: most chunks hold short runs) 0.89 ms with 3, 0.76 with 4; the transpose of the clustered matrix (its
+// gathers hit a handful of lines per cell) 0.49 with 3, 0.59 with 4 -- so pdhg_create TIMES both on the matrix at hand
+// (tune_tiled_variant).  Same sequential sums either way: not a bit depends on the choice.
+constexpr int TW_HYBRID_RUN = 3;
+__device__ __forceinline__ void tiled_chunk_hybrid(double *acc, unsigned p, double v, double xv, int tile_shift, int lane) {
+  const bool valid = p != TW_PAD;
+  const unsigned row = valid ? (p >> tile_shift) : (0xFFFFFF00u | (unsigned)lane);
+  const double prod = v * xv;
+  const bool head = wave_shr1(row, ~row) != row;
+  const bool tail = wave_shl1(row, ~row) != row;
+  const unsigned long long hmask = __ballot(head);
+  const int pos = lane - (63 - __clzll((long long)(hmask & ((2ull << lane) - 1ull))));
+  if (!__any(pos >= TW_HYBRID_RUN)) {
+    const bool h = head && valid;
+    double s0 = h ? acc[row] : 0.0;
+    for (int j = 0; j < TW_HYBRID_RUN; ++j) {
+      const double pj = __shfl_down(prod, j, WAVE);
+      const unsigned rj = __shfl_down(row, j, WAVE);
+      const bool take = h && (lane + j < WAVE) && (rj == row);
+      if (!__any(take)) break;
+      if (take) s0 = s0 + pj;
+    }
+    if (h) acc[row] = s0;
+    return;
+  }
+  double s = (head && valid) ? acc[row] + prod : prod;
+  for (int j = 1; __any(pos >= j); ++j) {
+    const double left = wave_shr1(s);
+    if (pos == j) s = left + prod;
+  }
+  if (tail && valid) acc[row] = s;
+}
+
 // Variant for matrices with long same-row runs inside a tile (rows with hundreds
 // of entries): run lengths from two ballots, followers' products handed to the
 // run head through a 64-double LDS scratch per wave and added left to right
@@ -568,7 +603,7 @@ __device__ __forceinline__ void tiled_chunk_relaxed(double *acc, unsigned p, dou
 }
 
 // CH: how a 64-entry chunk is accumulated -- 0 lane shuffles (strict order), 1 LDS scratch
-// (strict order, long runs), 2 relaxed (see tiled_chunk_relaxed), 3 lane-to-lane (strict order, runs of 9 ... 32)
+// (strict order, long runs), 2 relaxed (see tiled_chunk_relaxed), 3 lane-to-lane (strict order, runs of 9 ... 32), 4 = 3 with the shuffle loop for chunks of short runs
 template <int MODE, int CH>
 __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
     const int2 *__restrict__ wave_rows, const int *__restrict__ step_ptr,
@@ -664,6 +699,7 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
           if (ks[s] + i * WAVE < ke[s]) {  // wave-uniform
             if (CH == 1) tiled_chunk_scratch(acc, scratch, p[s][i], v[s][i], xv[i], tile_shift, lane);
             else if (CH == 3) tiled_chunk_scan(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
+            else if (CH == 4) tiled_chunk_hybrid(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
             else if (CH == 2) tiled_chunk_relaxed(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
             else tiled_chunk(acc, p[s][i], v[s][i], xv[i], tile_shift, lane);
           }
@@ -676,6 +712,7 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
           const double xx = ok ? xt[pp & cmask] : 0.0;
           if (CH == 1) tiled_chunk_scratch(acc, scratch, pp, vv, xx, tile_shift, lane);
           else if (CH == 3) tiled_chunk_scan(acc, pp, vv, xx, tile_shift, lane);
+          else if (CH == 4) tiled_chunk_hybrid(acc, pp, vv, xx, tile_shift, lane);
           else if (CH == 2) tiled_chunk_relaxed(acc, pp, vv, xx, tile_shift, lane);
           else tiled_chunk(acc, pp, vv, xx, tile_shift, lane);
         }

@@ -260,18 +260,25 @@ def test_hub_rows_do_not_spill_into_an_extra_round(gpu_required, monkeypatch):
 
 @pytest.mark.own_row_order
 @pytest.mark.parametrize("order", ["strict", "relaxed"])
+@pytest.mark.parametrize("variant", ["timed", "3", "4"])
 @pytest.mark.parametrize("lo,hi", [(9, 12), (10, 30), (1, 20)], ids=["runs<=12", "runs<=30", "runs<=20"])
-def test_runs_of_9_to_32_travel_lane_to_lane(gpu_required, monkeypatch, order, lo, hi):
+def test_runs_of_9_to_32_travel_lane_to_lane(gpu_required, monkeypatch, order, lo, hi, variant):
     """Rows of `lo` .. `hi` entries within +-300 columns of a random centre (the "clustered" shape of tools/shape_table.py):
     every row sits in one or two column tiles, so the sweep sees same-row runs of 9 .. 32 entries inside a tile and picks
     the lane-to-lane chunk variant (spmv_tiled_kernel<., 3>, csrc/spmv_kernels.hpp: tiled_chunk_scan) -- in BOTH row
     orders, because it adds a run in the sequential order: A x must equal the oracle's loops bit for bit on every row
-    (the reference's `mul!` order, src/primal_dual_hybrid_gradient.jl:401-417 through SparseArrays)."""
+    (the reference's `mul!` order, src/primal_dual_hybrid_gradient.jl:401-417 through SparseArrays).
+    `variant`: pdhg_create times variant 3 against variant 4 (= 3, with variant 0's shuffle loop for chunks of short runs
+    only) on the matrix and keeps the faster (tune_tiled_variant); PDHG_TW_MODE pins one.  Whichever runs, the same bits."""
     import scipy.sparse as sp
     from firstorderlp_jl_amd import linear_programming_problem, _lib
     monkeypatch.setenv("PDHG_ROW_ORDER", order)
     monkeypatch.setenv("PDHG_TILE_COLS", "4096")
     monkeypatch.setenv("PDHG_SPMV", "tiled")                # (the builder streams a matrix this small)
+    if variant == "timed":
+        monkeypatch.delenv("PDHG_TW_MODE", raising=False)
+    else:
+        monkeypatch.setenv("PDHG_TW_MODE", variant)
     rng = np.random.default_rng(lo * 100 + hi)
     m, n = 40_000, 30_000
     lens = rng.integers(lo, hi + 1, m)
@@ -284,11 +291,13 @@ def test_runs_of_9_to_32_travel_lane_to_lane(gpu_required, monkeypatch, order, l
     eng = HipPdhgEngine.from_problem(p)
     info = eng.layout_info()
     assert info["A_tiled_waves"] > 0, info
-    assert ", 3>" in eng.kernel_name(_lib.K_SPMV_DUAL), eng.kernel_name(_lib.K_SPMV_DUAL)
+    want = (", 3>", ", 4>") if variant == "timed" else (f", {variant}>",)
+    assert any(w in eng.kernel_name(_lib.K_SPMV_DUAL) for w in want), eng.kernel_name(_lib.K_SPMV_DUAL)
     Ac = p.constraint_matrix
     x, y = rng.standard_normal(n), rng.standard_normal(m)
     assert np.array_equal(eng.spmv(x), orc.spmv(m, n, Ac.indptr, Ac.indices, Ac.data, x))
-    if info["At_tiled_waves"] > 0 and ", 3>" in eng.kernel_name(_lib.K_SPMV_ATY):
+    seq_t = any(w in eng.kernel_name(_lib.K_SPMV_ATY) for w in (", 3>", ", 4>"))
+    if info["At_tiled_waves"] > 0 and seq_t:
         assert np.array_equal(eng.spmv_t(y), orc.spmv_t(m, n, Ac.indptr, Ac.indices, Ac.data, y))
     else:
         H.assert_products_match_oracle(eng, Ac, x, y, forced_sweep=True)
@@ -302,7 +311,7 @@ def test_runs_of_9_to_32_travel_lane_to_lane(gpu_required, monkeypatch, order, l
     o.x, o.y = x0, y0
     o.recompute_dual_product()
     step, pw = H.initial_step_and_weight(p)
-    both_exact = order == "strict" or ", 3>" in eng.kernel_name(_lib.K_SPMV_ATY)
+    both_exact = order == "strict" or seq_t
     for theta in (1.0, 0.37):
         raw = eng.trial_step(step, pw, theta)
         raw_o, xn, yn, an = o.trial_step(step, pw, theta)

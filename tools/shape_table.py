@@ -48,7 +48,9 @@ for _tag, _n in (("200K", 200_000), ("1M", 1_000_000), ("4M", 4_000_000)):
         (f"{_tag}-arrowhead", "arrowhead", dict(m=_n, n=_n)),
         (f"{_tag}-wide {3 * _n // 10} x {3 * _n}", "random", dict(m=3 * _n // 10, n=3 * _n)),
         (f"{_tag}-30 per row", "random", dict(m=_n, n=_n, k=30)),
+        (f"{_tag}-lognormal rows", "lognormal", dict(m=_n, n=_n)),
     ]
+SHAPES += [("10M-lognormal rows", "lognormal", {})]
 
 
 def make_shape(kind, m=10_000_000, n=10_000_000, k=10, band=0):
@@ -96,6 +98,10 @@ def _make_shape(kind, m, n, k, band):
         cols = np.clip(centre + rng.integers(-500, 501, m * k), 0, n - 1)
     elif kind == "twodensity":          # alternating rows of k/3 and 5k/3 entries
         lens = np.where(np.arange(m) % 2 == 0, max(1, k // 3), 5 * k // 3)
+        rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+        cols = rng.integers(0, n, rows.size)
+    elif kind == "lognormal":           # row lengths exp(N(log k - 0.5, 1)) (mean ~k, a tail of rows with hundreds of entries), uniform columns
+        lens = np.clip(np.exp(rng.normal(np.log(k) - 0.5, 1.0, m)).astype(np.int64), 1, 4000)
         rows = np.repeat(np.arange(m, dtype=np.int64), lens)
         cols = rng.integers(0, n, rows.size)
     elif kind == "arrowhead":           # uniform + 5 dense rows + 5 dense columns
@@ -167,9 +173,9 @@ def main():
           "frac = algorithmic bytes of the fused product / time / 8 TB/s", flush=True)
     only = [s.strip() for s in args.only.split(",") if s.strip()]
     for title, kind, kw in SHAPES:
-        sized = title.split("-")[0] in ("200K", "1M", "4M")
+        sized = title.split("-")[0] in ("200K", "1M", "4M", "10M")
         # (a size-tagged shape is selected only by a token that names a size tag: "clustered" stays the 10M shape alone)
-        if (only and not any(o in title and (not sized or any(t in o for t in ("200K-", "1M-", "4M-"))) for o in only)) or \
+        if (only and not any(o in title and (not sized or any(t in o for t in ("200K-", "1M-", "4M-", "10M-"))) for o in only)) or \
                 (not only and sized):
             continue
         p = make_shape(kind, **kw)
