@@ -467,15 +467,24 @@ int build_segments(int dev, pdhg_handle *h, int64_t m, int64_t n, int64_t nnz, c
 
 // One shard: device layouts + vectors for the rows it is given.  n_alloc >= n is the
 // allocation length of the n-vectors that take part in collectives.
-// The sweep's chunk variant for matrices with same-row runs of 9 ... 32 entries, chosen by TIMING the plain product with
-// variants 3 and 4 on the matrix at hand (spmv_kernels.hpp: tiled_chunk_hybrid says why no rule on run lengths would do):
-// one warm-up and three launches each, 4 only when it is >= 4 % faster.  Both add every run in the sequential order --
-// the choice cannot change a bit of any result, only the kernel's name.  PDHG_TW_MODE (dev) pins a variant.
+// Two of the sweep's policies are settled by TIMING the plain product on the matrix at hand, because what decides them is
+// the memory regime and the builder has no cheap measure of it:
+//  * the chunk variant for matrices with same-row runs of 9 ... 32 entries, 3 against 4 (spmv_kernels.hpp:
+//    tiled_chunk_hybrid says why no rule on run lengths would do);
+//  * whether row groups are dealt to the XCDs round robin or in contiguous eighths (tiled_per_xcd: good for bands, bad
+//    when the work per row group falls with the index) -- the builder's guess (D.tw_band) against its opposite.
+// One warm-up and three launches per candidate; the builder's choice stays unless another is >= 4 % faster.  Every
+// candidate computes the same sums in the same order: the outcome cannot change a bit of any result, only a kernel's
+// name / grid.  PDHG_TW_MODE / PDHG_TW_REMAP (dev) pin the respective choice, PDHG_TW_TUNE=0 skips the timing.
 int tune_tiled_variant(pdhg_handle *h, CsrDev &D, const double *xin, double *out) {
-  if (!D.tiled || D.tw_mode != 3 || D.grid <= 0 || dev_env("PDHG_TW_MODE") || !xin || !out) return 0;
+  if (!D.tiled || D.grid <= 0 || !xin || !out) return 0;
   const char *ev = dev_env("PDHG_TW_TUNE");
   if (ev && ev[0] == '0') return 0;
-  float ms[2] = {0.f, 0.f};
+  struct Cand { int mode; bool band; float ms; };
+  std::vector<Cand> cands{{D.tw_mode, D.tw_band, 0.f}};
+  if (D.tw_mode == 3 && !dev_env("PDHG_TW_MODE")) cands.push_back({4, D.tw_band, 0.f});
+  if (h->remap && D.grid >= 2 * NUM_XCD && !dev_env("PDHG_TW_REMAP")) cands.push_back({D.tw_mode, !D.tw_band, 0.f});
+  if (cands.size() < 2) return 0;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   hipError_t ce = hipEventCreate(&e1);
@@ -483,21 +492,34 @@ int tune_tiled_variant(pdhg_handle *h, CsrDev &D, const double *xin, double *out
   EpiArgs e{};
   e.out = out;
   int rc = 0;
-  for (int v = 0; v < 2 && !rc; ++v) {
-    D.tw_mode = 3 + v;
+  for (Cand &c : cands) {
+    D.tw_mode = c.mode; D.tw_band = c.band;
     rc = launch_tiled<MODE_PLAIN>(h, D, xin, e, 0, D.grid);
     if (rc) break;
     (void)hipEventRecord(e0, h->stream);
     for (int k = 0; k < 3 && !rc; ++k) rc = launch_tiled<MODE_PLAIN>(h, D, xin, e, 0, D.grid);
     (void)hipEventRecord(e1, h->stream);
     if (!rc && hipEventSynchronize(e1) != hipSuccess) rc = fail(-3, "the sweep's tuning launches failed");
-    if (!rc) (void)hipEventElapsedTime(&ms[v], e0, e1);
+    if (rc) break;
+    (void)hipEventElapsedTime(&c.ms, e0, e1);
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  D.tw_mode = cands[0].mode; D.tw_band = cands[0].band;
   if (rc) return rc;
-  D.tw_mode = (ms[1] > 0.f && ms[1] < 0.96f * ms[0]) ? 4 : 3;
-  if (getenv("PDHG_VERBOSE"))
-    fprintf(stderr, "[pdhg_hip] sweep %d x %d: chunk variant 3 %.3f ms, 4 %.3f ms per product -> %d\n", D.rows, D.cols, ms[0] / 3.f, ms[1] / 3.f, D.tw_mode);
+  // the chunk variant first, then the dealing (each against the builder's choice; the two are independent enough)
+  size_t best = 0;
+  for (size_t k = 1; k < cands.size(); ++k)
+    if (cands[k].ms > 0.f && cands[k].ms < 0.96f * cands[0].ms) {
+      if (cands[k].mode != cands[0].mode) D.tw_mode = cands[k].mode;
+      else D.tw_band = cands[k].band;
+      best = k;
+    }
+  (void)best;
+  if (getenv("PDHG_VERBOSE")) {
+    fprintf(stderr, "[pdhg_hip] sweep %d x %d timed:", D.rows, D.cols);
+    for (const Cand &c : cands) fprintf(stderr, "  variant %d %s %.3f ms", c.mode, c.band ? "eighths" : "round-robin", c.ms / 3.f);
+    fprintf(stderr, "  -> variant %d, %s\n", D.tw_mode, D.tw_band ? "eighths" : "round-robin");
+  }
   return 0;
 }
 
