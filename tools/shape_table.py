@@ -50,7 +50,8 @@ for _tag, _n in (("200K", 200_000), ("1M", 1_000_000), ("4M", 4_000_000)):
         (f"{_tag}-30 per row", "random", dict(m=_n, n=_n, k=30)),
         (f"{_tag}-lognormal rows", "lognormal", dict(m=_n, n=_n)),
     ]
-SHAPES += [("10M-lognormal rows", "lognormal", {})]
+SHAPES += [("10M-lognormal rows", "lognormal", {}), ("10M-banded +-50000, lognormal rows", "bandlog", dict(band=50_000)),
+           ("1M-banded +-5000, lognormal rows", "bandlog", dict(m=1_000_000, n=1_000_000, band=5_000))]
 
 
 def make_shape(kind, m=10_000_000, n=10_000_000, k=10, band=0):
@@ -104,6 +105,10 @@ def _make_shape(kind, m, n, k, band):
         lens = np.clip(np.exp(rng.normal(np.log(k) - 0.5, 1.0, m)).astype(np.int64), 1, 4000)
         rows = np.repeat(np.arange(m, dtype=np.int64), lens)
         cols = rng.integers(0, n, rows.size)
+    elif kind == "bandlog":             # log-normal row lengths, columns within +-band of the row's own position
+        lens = np.clip(np.exp(rng.normal(np.log(k) - 0.5, 1.0, m)).astype(np.int64), 1, 4000)
+        rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+        cols = np.clip((rows * n) // m + rng.integers(-band, band + 1, rows.size), 0, n - 1)
     elif kind == "arrowhead":           # uniform + 5 dense rows + 5 dense columns
         cols = rng.integers(0, n, m * k)
         dr = np.repeat(np.arange(5, dtype=np.int64) * (m // 5), n // 4)
