@@ -50,7 +50,7 @@ for _tag, _n in (("200K", 200_000), ("1M", 1_000_000), ("4M", 4_000_000)):
         (f"{_tag}-30 per row", "random", dict(m=_n, n=_n, k=30)),
         (f"{_tag}-lognormal rows", "lognormal", dict(m=_n, n=_n)),
     ]
-SHAPES += [("10M-lognormal rows", "lognormal", {}), ("10M-banded +-50000, lognormal rows", "bandlog", dict(band=50_000)),
+SHAPES += [("4M-pagerank", "pagerank", dict(n=4_000_000)), ("10M-lognormal rows", "lognormal", {}), ("10M-banded +-50000, lognormal rows", "bandlog", dict(band=50_000)),
            ("1M-banded +-5000, lognormal rows", "bandlog", dict(m=1_000_000, n=1_000_000, band=5_000))]
 
 
