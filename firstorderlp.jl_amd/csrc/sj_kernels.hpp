@@ -10,7 +10,7 @@
 //
 // Layout.  Rows are taken in GROUPS of SJ_SIGMA = 256 consecutive rows (one workgroup trip) and, inside a group, ordered
 // by DECREASING length (stable: equal lengths keep their row order -- the layout is a deterministic function of the row
-// pointers).  64 consecutive slots of that order are a SLICE, one wave's work: slot -> (row, length) in `perm` / `len`.
+// pointers).  64 consecutive slots of that order are a SLICE, one wave's work: slot -> (row, length) in one word of `meta`.
 // A slice's entries are stored LEVEL-MAJOR and jagged: level j holds the j-th entry (ascending column) of every row of
 // the slice with more than j entries -- because the lengths decrease along the slice these are the first cnt_j lanes, so
 // level j is cnt_j consecutive (col, val) pairs and a wave reads it with one coalesced load pair; no padding is stored,
