@@ -50,7 +50,8 @@ for _tag, _n in (("200K", 200_000), ("1M", 1_000_000), ("4M", 4_000_000)):
         (f"{_tag}-30 per row", "random", dict(m=_n, n=_n, k=30)),
         (f"{_tag}-lognormal rows", "lognormal", dict(m=_n, n=_n)),
     ]
-SHAPES += [("4M-pagerank", "pagerank", dict(n=4_000_000)), ("10M-lognormal rows", "lognormal", {}), ("10M-banded +-50000, lognormal rows", "bandlog", dict(band=50_000)),
+SHAPES += [("10M-linking rows", "manylong", {}), ("1M-linking rows", "manylong", dict(m=1_000_000, n=1_000_000)),
+           ("4M-pagerank", "pagerank", dict(n=4_000_000)), ("10M-lognormal rows", "lognormal", {}), ("10M-banded +-50000, lognormal rows", "bandlog", dict(band=50_000)),
            ("1M-banded +-5000, lognormal rows", "bandlog", dict(m=1_000_000, n=1_000_000, band=5_000))]
 
 
@@ -109,6 +110,14 @@ def _make_shape(kind, m, n, k, band):
         lens = np.clip(np.exp(rng.normal(np.log(k) - 0.5, 1.0, m)).astype(np.int64), 1, 4000)
         rows = np.repeat(np.arange(m, dtype=np.int64), lens)
         cols = np.clip((rows * n) // m + rng.integers(-band, band + 1, rows.size), 0, n - 1)
+    elif kind == "manylong":            # k/2 per row uniform + m/5000 linking rows of 2.5 k * 1000 entries each (half the nonzeros in long rows)
+        kk = max(1, k // 2)
+        rows = np.repeat(np.arange(m, dtype=np.int64), kk)
+        cols = rng.integers(0, n, rows.size)
+        nl, ll = max(1, m // 5000), 2500 * k
+        lr = np.repeat(rng.choice(m, nl, replace=False), ll)
+        rows = np.concatenate([rows, lr])
+        cols = np.concatenate([cols, rng.integers(0, n, lr.size)])
     elif kind == "arrowhead":           # uniform + 5 dense rows + 5 dense columns
         cols = rng.integers(0, n, m * k)
         dr = np.repeat(np.arange(5, dtype=np.int64) * (m // 5), n // 4)
