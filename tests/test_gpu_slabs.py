@@ -92,3 +92,40 @@ def test_default_thresholds(gpu_required):
     """Default: slabs of one XCD L2 (4 MiB) for vectors of 1.25 .. 4 slabs; PageRank-1M is the case in point."""
     small = HipPdhgEngine.from_problem(random_lp(5000, 4000, 8, seed=7)).layout_info()
     assert small["A_slabs"] == 0 and small["At_slabs"] == 0
+
+
+def test_no_slab_passes_for_banded_rows(gpu_required, monkeypatch):
+    """A banded matrix whose gathered vector (700 000 doubles: 5.3 MiB) is in the slab range: the sweep is declined because
+    a few thousand consecutive rows touch a sliver of the columns -- and for the same reason the stream layout takes NO
+    slab passes (layout.hpp: slab_count; 1M x 1M +-5 000 ran 2x slower than the vendor kernel with them).  PDHG_SLABS=2
+    forces the passes: same bits either way, and the same as the oracle."""
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd import linear_programming_problem
+    monkeypatch.delenv("PDHG_SPMV", raising=False)
+    monkeypatch.delenv("PDHG_SLABS", raising=False)
+    m = n = 700_000
+    rng = np.random.default_rng(12)
+    rows = np.repeat(np.arange(m), 3)
+    cols = np.clip(rows + rng.integers(-2000, 2001, rows.size), 0, n - 1)
+    A = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    p = linear_programming_problem(np.zeros(n), np.full(n, 10.0), rng.standard_normal(n), 0.0, A.tocsc(),
+                                   rng.standard_normal(m), m // 2)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    auto = HipPdhgEngine.from_problem(p)
+    info = auto.layout_info()
+    assert info["A_tiled_waves"] == 0 and info["At_tiled_waves"] == 0, info      # (banded: streamed)
+    assert info["A_slabs"] == 0 and info["At_slabs"] == 0, info
+    H.assert_products_match_oracle(auto, p.constraint_matrix, x, y)
+    monkeypatch.setenv("PDHG_SLABS", "2")
+    forced = HipPdhgEngine.from_problem(p)
+    finfo = forced.layout_info()
+    assert finfo["A_slabs"] == 2 and finfo["At_slabs"] == 2, finfo
+    assert np.array_equal(forced.spmv(x), auto.spmv(x)) and np.array_equal(forced.spmv_t(y), auto.spmv_t(y))
+    forced.close()
+    auto.close()
+    # rows that scatter over the same vector keep their slab passes (stream layout forced: the builder would sweep them)
+    monkeypatch.setenv("PDHG_SLABS", "1")
+    monkeypatch.setenv("PDHG_SPMV", "stream")
+    scattered = HipPdhgEngine.from_problem(random_lp(300_000, 700_000, 5, seed=3)).layout_info()
+    assert scattered["A_slabs"] == 2, scattered

@@ -361,3 +361,41 @@ def test_row_groups_dealt_to_the_xcds_in_contiguous_eighths(gpu_required, monkey
         assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
         assert all(np.array_equal(a, b) for a, b in zip(o[2], out[0][2]))
         assert all(np.array_equal(a, b) for a, b in zip(o[3], out[0][3]))
+
+
+def test_timed_sweep_policies_cannot_change_a_bit(gpu_required, monkeypatch):
+    """pdhg_create times the sweep's chunk variant (3 against 4) and the dealing of row groups to the XCDs on the matrix
+    (tune_tiled_variant).  Whatever wins, products, trial vectors and the trial's scalars are those of the untimed
+    choice: PDHG_TW_TUNE=0 against the default, on a matrix whose runs put it on variant 3."""
+    import scipy.sparse as sp
+    from firstorderlp_jl_amd import linear_programming_problem
+    monkeypatch.setenv("PDHG_SPMV", "tiled")
+    monkeypatch.setenv("PDHG_TILE_COLS", "4096")
+    monkeypatch.delenv("PDHG_TW_MODE", raising=False)
+    monkeypatch.delenv("PDHG_TW_REMAP", raising=False)
+    rng = np.random.default_rng(31)
+    m, n = 50_000, 30_000
+    lens = np.clip(np.exp(rng.normal(1.8, 1.0, m)).astype(np.int64), 1, 25)
+    rows = np.repeat(np.arange(m), lens)
+    cols = np.clip(np.repeat(rng.integers(0, n, m), lens) + rng.integers(-40, 41, rows.size), 0, n - 1)
+    A = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    p = linear_programming_problem(np.zeros(n), np.full(n, 10.0), rng.standard_normal(n), 0.0, A.tocsc(),
+                                   rng.standard_normal(m), m // 2)
+    x, y = rng.standard_normal(n), rng.standard_normal(m)
+    x0 = np.clip(rng.standard_normal(n), 0.0, 5.0)
+    y0 = rng.standard_normal(m)
+    y0[p.num_equalities:] = np.abs(y0[p.num_equalities:])
+    step, pw = H.initial_step_and_weight(p)
+    out = []
+    for tune in ("0", "1"):
+        monkeypatch.setenv("PDHG_TW_TUNE", tune)
+        eng = HipPdhgEngine.from_problem(p)
+        assert eng.layout_info()["A_tiled_waves"] > 0
+        eng.set_current(x0, y0)
+        raw = [np.array(eng.trial_step(step, pw, theta)) for theta in (1.0, 0.37)]
+        out.append((eng.spmv(x), eng.spmv_t(y), raw, eng.get_trial()))
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][2], out[1][2]))
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][3], out[1][3]))
