@@ -11,5 +11,6 @@ d = json.load(open("/tmp/sjm.json"))
 for k in d.get("kernels", []):
     n = k["name"]
     if "spmv_sj" in n or "spmv_stream" in n or "spmv_long" in n:
-        print(n[n.find("spmv_"):n.find("(")], k["calls"], round(k["avg_us"], 1))
+        i = n.find("spmv_")
+        print(n[i:n.find("(", i)], k["calls"], round(k["avg_us"], 1))
 PY
