@@ -14,10 +14,15 @@ all-gather over xGMI) is issued by the library itself (csrc/dist.hpp) --
 torch.distributed (gloo) is used here only for the harness: handing out the
 communicator id, the barriers around the timed region and the max over ranks.
 
-Prints ONE JSON line on rank 0.  At N=1 the line also carries, under
-"other_configs", the same measurement for BASELINE configs[2] (PageRank LP,
-1M nodes) and configs[3] (L1-SVM LP on rcv1-shaped data) unless
---no-other-configs is given; --workload picks one of them as the headline.
+Prints ONE compact JSON line (<= 4 KB: the contract's keys, `roofline`,
+`cpu_baseline`, one short row per other config) as the LAST line of rank 0's
+stdout; the whole record -- `kernels`, `scaling_model`, `ceiling`,
+`self_profile`, the CPU comparator's variants, `trial_timeline`, the full
+`other_configs` legs -- goes to bench_details.json next to this script and to
+stderr.  At N=1 the record also carries, under "other_configs", the same
+measurement for BASELINE configs[2] (PageRank LP, 1M nodes) and configs[3]
+(L1-SVM LP on rcv1-shaped data) unless --no-other-configs is given;
+--workload picks one of them as the headline.
 """
 import argparse
 import json
@@ -107,6 +112,11 @@ def parse():
                          "roofline.kernel_ms_rocprof / roofline.traffic from THIS run (tools/selfprof.py); the committed "
                          "files under profiles/ are quoted instead")
     ap.add_argument("--no-vendor", action="store_true", help="skip the rocSPARSE comparator (roofline.vendor_spmv_ms)")
+    ap.add_argument("--no-details", action="store_true",
+                    help="do not write bench_details.json (the short child runs of tools/selfprof.py: the parent's record is the one kept)")
+    ap.add_argument("--replay", metavar="DETAILS_JSON", default=None,
+                    help="dev / CPU test: no measurement -- read a whole record (a bench_details.json) and print the compact line "
+                         "for it through the same final-print path")
     ap.add_argument("--no-ceiling", action="store_true",
                     help="skip the sweep-pattern probe behind roofline.ceiling_frac (pdhg_measure_sweep_ceiling)")
     return ap.parse_args()
@@ -514,7 +524,8 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
     out = {
         "value": round(value, 3), "unit": "iterations/s", "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_per_step, 5),
-        "config": {"workload": wl + ", adaptive step, zero start, no restarts/rescaling",
+        "config": {"id": {"random": "configs[4]", "pagerank": "configs[2]", "l1svm": "configs[3]"}[workload],
+                   "workload": wl + ", adaptive step, zero start, no restarts/rescaling",
                    "m": m, "n": n, "nnz": nnz, "parallelism": parallelism},
         "trials_per_step": round(trials / steps, 4),
         "steady_rate": steady,
@@ -626,6 +637,147 @@ def scaling_model(m, n, nnz, world, trials_per_step=1.0):
     return out
 
 
+# ---- the line the driver parses: compact (<= 4 KB), everything else in bench_details.json (round 5's
+# line had grown to 22.9 KB and the driver could not read it)
+COMPACT_LIMIT = 4096
+DETAILS_FILE = "bench_details.json"
+_ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_rocprof", "kernel_ms_rocprof", "avg_launch_ms",
+                  "algorithmic_bytes_per_launch", "traffic", "traffic_over_algorithmic", "vendor_spmv_ms", "ceiling_frac",
+                  "peak_measured_triad", "rocprof_measured_in_this_run")
+
+
+def _short(text, limit):
+    text = str(text)
+    return text if len(text) <= limit else text[:limit - 3] + "..."
+
+
+def _compact_roofline(rf):
+    if not isinstance(rf, dict):
+        return rf
+    out = {k: rf[k] for k in _ROOFLINE_KEYS if k in rf}
+    if "kernel" in out:
+        out["kernel"] = _short(out["kernel"], 160)
+    return out
+
+
+def _compact_cpu(cb):
+    if not isinstance(cb, dict):
+        return cb
+    out = {k: cb[k] for k in ("value", "unit", "cores", "kind", "effective_GBps") if k in cb}
+    if "sample" in cb:
+        out["sample"] = _short(cb["sample"], 200)
+    st = cb.get("single_thread")
+    if isinstance(st, dict) and "value" in st:
+        out["single_thread_value"] = st["value"]
+    return out
+
+
+def _compact_model(sm):
+    """Five numbers of the scaling model: what N GPUs should deliver, as built / fully overlapped."""
+    if not isinstance(sm, dict):
+        return None
+    out = {}
+    for key in ("predicted_it_per_s", "predicted_speedup"):
+        if key in sm:
+            out[key] = sm[key]
+    for key in ("kernel_ms_per_trial", "collectives_ms_per_trial", "link_floor_ms_per_trial", "as_built"):
+        if key in sm:
+            out[key] = sm[key]
+    if "at_2_4_8_gpus" in sm:
+        out["predicted_speedup_at_2_4_8"] = {p: v.get("predicted_speedup") for p, v in sm["at_2_4_8_gpus"].items()}
+    return out
+
+
+def compact_line(full, details_path=DETAILS_FILE):
+    """The ONE stdout line: the contract's keys, `roofline`, `cpu_baseline`, the other configs as one short row each.
+    `full` is the whole record (what goes to bench_details.json).  Never longer than COMPACT_LIMIT bytes: optional
+    blocks are dropped in a fixed order until it fits."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    out["config"] = {"workload": _short(cfg.get("workload", ""), 220)}
+    for k in ("id", "m", "n", "nnz"):
+        if k in cfg:
+            out["config"][k] = cfg[k]
+    if "parallelism" in cfg:
+        out["config"]["parallelism"] = _short(cfg["parallelism"], 120)
+    if full.get("error"):
+        out["error"] = _short(full["error"], 400)
+    out["roofline"] = _compact_roofline(full.get("roofline"))
+    out["cpu_baseline"] = _compact_cpu(full.get("cpu_baseline"))
+    for k in ("speedup_vs_cpu_port", "speedup_vs_cpu_socket", "trials_per_step", "whole_iteration_GBps", "launch_path", "transport"):
+        if full.get(k) is not None:
+            out[k] = _short(full[k], 100) if isinstance(full[k], str) else full[k]
+    if isinstance(full.get("steady_rate"), dict):
+        out["steady_rate"] = {k: full["steady_rate"].get(k) for k in ("steps", "value")}
+    sm = _compact_model(full.get("scaling_model"))
+    if sm:
+        out["scaling_model"] = sm
+    rows = []
+    for leg in full.get("other_configs") or []:
+        lcfg = leg.get("config") or {}
+        row = {"id": lcfg.get("id"), "workload": _short(lcfg.get("workload", ""), 60)}
+        if "error" in leg:
+            row["error"] = _short(leg["error"], 120)
+        else:
+            lrf = leg.get("roofline") or {}
+            row.update({k: lcfg.get(k) for k in ("m", "n", "nnz")})
+            row.update(value=leg.get("value"), ms_per_step=leg.get("ms_per_step"), steps=leg.get("steps"),
+                       kernel=_short(lrf.get("kernel", ""), 90), frac=lrf.get("frac"), frac_rocprof=lrf.get("frac_rocprof"),
+                       kernel_ms_rocprof=lrf.get("kernel_ms_rocprof"), vendor_spmv_ms=lrf.get("vendor_spmv_ms"),
+                       traffic_over_algorithmic=lrf.get("traffic_over_algorithmic"),
+                       speedup_vs_cpu_port=leg.get("speedup_vs_cpu_port"))
+        rows.append(row)
+    if rows:
+        out["other_configs"] = rows
+    out["details"] = details_path
+    for drop in (None, "scaling_model", "steady_rate", "launch_path", "other_configs", "whole_iteration_GBps", "trials_per_step"):
+        if drop is not None:
+            out.pop(drop, None)
+        line = json.dumps(out, separators=(",", ":"))
+        if len(line) <= COMPACT_LIMIT:
+            return line
+    # still too long: only a pathological kernel name or workload string can do that -- cut them
+    out["config"] = {k: (_short(v, 60) if isinstance(v, str) else v) for k, v in out["config"].items()}
+    if isinstance(out.get("roofline"), dict) and "kernel" in out["roofline"]:
+        out["roofline"]["kernel"] = _short(out["roofline"]["kernel"], 60)
+    if isinstance(out.get("cpu_baseline"), dict):
+        out["cpu_baseline"].pop("sample", None)
+    return json.dumps(out, separators=(",", ":"))
+
+
+def write_details(full):
+    """The whole record (other_configs, scaling_model, ceiling, self_profile, variants, kernels, notes, trial_timeline) next
+    to the script; a read-only tree sends it to the temporary directory.  Returns the path written (or None)."""
+    import tempfile
+    text = json.dumps(full, indent=1)
+    for base in (ROOT, tempfile.gettempdir()):
+        try:
+            path = os.path.join(base, DETAILS_FILE)
+            with open(path + ".tmp", "w") as fh:
+                fh.write(text + "\n")
+            os.replace(path + ".tmp", path)
+            return path
+        except OSError:
+            continue
+    return None
+
+
+def emit(full, real_stdout, details=True):
+    """Details to the file and to stderr, then the compact line as the LAST line of stdout."""
+    path = write_details(full) if details else None
+    name = DETAILS_FILE if path == os.path.join(ROOT, DETAILS_FILE) else (path or "stderr")
+    sys.stdout.flush()
+    sys.stderr.write(json.dumps(full) + "\n")
+    sys.stderr.flush()
+    line = compact_line(full, name)
+    if real_stdout is not None:
+        os.dup2(real_stdout, 1)
+    print(line, flush=True)
+    if real_stdout is not None:
+        os.dup2(2, 1)
+
+
 def multi_gpu_failure(args, world, rank, exc, real_stdout):
     """N > 1 has never run in the builder's environment (one GPU per box): whatever fails first -- a device that is not
     there, RCCL initialisation, peer access, a barrier another rank never reaches -- must leave ONE parseable line that
@@ -641,18 +793,22 @@ def multi_gpu_failure(args, world, rank, exc, real_stdout):
     except OSError:
         first = False
     if first:
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps({"metric": "pdhg_iterations_per_sec", "value": None, "unit": "iterations/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
-                          "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": args.workload},
-                          "error": f"rank {rank}: {exc!r} (the multi-GPU path failed; nothing was measured)"}), flush=True)
+        emit({"metric": "pdhg_iterations_per_sec", "value": None, "unit": "iterations/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+              "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+              "config": {"workload": args.workload},
+              "error": f"rank {rank}: {exc!r} (the multi-GPU path failed; nothing was measured)"}, real_stdout)
     os._exit(1)
 
 
 def main():
     args = parse()
+    if args.replay:
+        with open(args.replay) as fh:
+            full = json.load(fh)
+        sys.stderr.write(json.dumps(full) + "\n")
+        print(compact_line(full, os.path.basename(args.replay)), flush=True)
+        return
     if args.plain_launches:
         os.environ["PDHG_GRAPH"] = "0"
     # Native libraries print to stdout too (RCCL's version banner on communicator
@@ -775,12 +931,15 @@ def main():
                                          "share the visible GPUs): a functional run of the multi-rank route, not a scaling measurement")
         if others:
             out["other_configs"] = others
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # the compact line is the LAST thing this process writes: nothing (interpreter shutdown messages of native libraries
+        # included) may follow it on a stream the driver might have merged into stdout
+        emit(out, real_stdout, details=not args.no_details)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -105,7 +105,7 @@ def child_command(workload, extra):
     # the separate-launch path (PDHG_GRAPH=0 in the child's environment): the kernels are the ones the one-launch paths
     # run, launched one by one so that durations and counters attribute to them
     return [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "4", "--warmup", "2",
-            "--no-cpu-baseline", "--no-other-configs", "--profile-steps", "0", "--no-self-profile", "--no-vendor"] + list(extra)
+            "--no-cpu-baseline", "--no-other-configs", "--profile-steps", "0", "--no-self-profile", "--no-vendor", "--no-details"] + list(extra)
 
 
 def run(workload, product, extra=(), timeout=180, keep=None, deadline=None):
