@@ -934,12 +934,9 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
-        # the compact line is the LAST thing this process writes: nothing (interpreter shutdown messages of native libraries
-        # included) may follow it on a stream the driver might have merged into stdout
+        # the compact line is the LAST thing this script writes (the process then exits NORMALLY: rocprofv3 writes its
+        # databases from exit handlers, so the child runs of tools/selfprof.py must not be cut short)
         emit(out, real_stdout, details=not args.no_details)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -72,18 +72,11 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
   if (h->has_q) {
     // objective_matrix = (D^-1 Q) D^-1 (preprocess.jl:562-564); Qt holds Q' entry by entry, so the
     // "transposed" order reproduces the same two roundings on it
-    hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Q.rows)), dim3(TPB), 0, h->stream, h->Q.rows, h->Q.rowptr,
-                       h->Q.col, h->Q.val, t.inv_d, t.inv_d, 0, 0);
-    hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Qt.rows)), dim3(TPB), 0, h->stream, h->Qt.rows, h->Qt.rowptr,
-                       h->Qt.col, h->Qt.val, t.inv_d, t.inv_d, 1, 0);
-    for (const SlabDev &S : h->Q.slabs)
-      if (S.nnz > 0)
-        hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Q.rows)), dim3(TPB), 0, h->stream, h->Q.rows, S.rowptr,
-                           S.col, S.val, t.inv_d, t.inv_d, 0, 0);
-    for (const SlabDev &S : h->Qt.slabs)
-      if (S.nnz > 0)
-        hipLaunchKernelGGL(scale_csr_kernel, dim3(row_grid(h->Qt.rows)), dim3(TPB), 0, h->stream, h->Qt.rows, S.rowptr,
-                           S.col, S.val, t.inv_d, t.inv_d, 1, 0);
+    // Both through scale_one like A and A': every resident copy of Q and Q' -- CSR, long-row chunks, column slabs, a
+    // tiled copy, and the sliced jagged copies (refilled from the scaled CSR arrays; round 5 scaled only the CSR and slab
+    // arrays here, so a QP whose Q ran spmv_sj_kernel multiplied by the UNSCALED Hessian after pdhg_rescale).
+    scale_one(h->Q, t.inv_d, t.inv_d, 0);
+    scale_one(h->Qt, t.inv_d, t.inv_d, 1);
   }
   hipLaunchKernelGGL(resc_apply_vectors_kernel, dim3(h->ew_grid_nm), dim3(TPB), 0, h->stream, n, m, t.dv, t.ev,
                      h->c, h->lb, h->ub, h->b, t.cum_d, t.cum_e);

@@ -865,45 +865,75 @@ int build_csr_dev_resident(CsrDev &D, int rows, int cols, const std::vector<int>
 // which rows are LONG (they belong to the long-row kernels: slot row -1); `rowptr` gives the lengths (a column slab's
 // row pointers, or the same array).
 void free_sj(SjDev &J) {
-  void *ptrs[] = {J.meta, J.slice_off, J.col, J.val};
+  void *ptrs[] = {J.meta, J.slice_off, J.col, J.val, J.hub};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   J = SjDev();
 }
 
+// What the builder decided for a matrix (all column slabs of it alike): the sorting window (G = 1: 256 rows, SJ_WIDE_G:
+// 2 048 rows) and the hub threshold.
+struct SjPlan {
+  bool use = false;
+  int G = 1;
+  int max_len = SJ_MAX_LEN;
+  double fill_narrow = 0.0, fill_wide = 0.0, hub_share = 0.0;
+};
+
 int build_sj(SjDev &J, int rows, const std::vector<int> &rowptr, const std::vector<int> &full_rowptr, int long_thr,
-             const int *d_rowptr, const int *d_col, const double *d_val, bool remap, int max_wgs) {
+             const int *d_rowptr, const int *d_col, const double *d_val, bool remap, int max_wgs, const SjPlan &plan) {
   const int nslices = (rows + WAVE - 1) / WAVE;
   if (nslices == 0) return 0;
+  const int G = plan.G > 1 ? SJ_WIDE_G : 1, sigma = SJ_SIGMA * G, max_len = plan.max_len;
   const size_t nslots = (size_t)nslices * WAVE;
   std::vector<int> slice_off((size_t)nslices + 1, 0);
   std::vector<unsigned> meta(nslots, SJ_NONE << 16);
-  const int nwin = (rows + SJ_SIGMA - 1) / SJ_SIGMA;
+  const int nwin = (rows + sigma - 1) / sigma;
+  std::vector<std::vector<int2>> hub_parts((size_t)std::max(1, std::min(nwin, 64)));
+  std::atomic<int> part_next{0};
   parallel_ranges(nwin, 64, [&](int wb, int we) {
     std::vector<int> start((size_t)BLOCK_NNZ + 2);
+    std::vector<int2> hubs;
     for (int w = wb; w < we; ++w) {
-      const int r0 = w * SJ_SIGMA, r1 = std::min(rows, r0 + SJ_SIGMA);
-      // stable counting sort by decreasing length; long rows sort as empty ones and keep no slot row
+      const int r0 = w * sigma, r1 = std::min(rows, r0 + sigma);
+      // stable counting sort by decreasing length; long and hub rows sort as empty ones and keep no slot row
       std::fill(start.begin(), start.end(), 0);
-      auto len_of = [&](int r) { return full_rowptr[r + 1] - full_rowptr[r] > long_thr ? 0 : rowptr[r + 1] - rowptr[r]; };
+      auto is_long = [&](int r) { return full_rowptr[r + 1] - full_rowptr[r] > long_thr; };
+      auto is_hub = [&](int r) { return !is_long(r) && rowptr[r + 1] - rowptr[r] > max_len; };
+      auto len_of = [&](int r) { return (is_long(r) || is_hub(r)) ? 0 : rowptr[r + 1] - rowptr[r]; };
       for (int r = r0; r < r1; ++r) start[(size_t)(BLOCK_NNZ - len_of(r)) + 1] += 1;       // bucket = BLOCK_NNZ - length: ascending bucket = descending length
       for (int b = 0; b <= BLOCK_NNZ; ++b) start[(size_t)b + 1] += start[(size_t)b];
       for (int r = r0; r < r1; ++r) {
         const int l = len_of(r);
         const size_t slot = (size_t)r0 + (size_t)start[(size_t)(BLOCK_NNZ - l)]++;
-        const bool is_long = full_rowptr[r + 1] - full_rowptr[r] > long_thr;
-        meta[slot] = ((is_long ? SJ_NONE : (unsigned)(r - r0)) << 16) | (unsigned)l;
+        const bool no_slot = is_long(r) || is_hub(r);
+        meta[slot] = ((no_slot ? SJ_NONE : (unsigned)(r - r0)) << 16) | (unsigned)l;
+        if (is_hub(r)) hubs.push_back(make_int2(r, r + 1));
       }
     }
+    if (!hubs.empty()) {      // (ranges are handed out in ascending order of wb; the parts are sorted by first row below)
+      const int k = part_next.fetch_add(1);
+      if (k < (int)hub_parts.size()) hub_parts[(size_t)k] = std::move(hubs);
+      else { static std::mutex mu; std::lock_guard<std::mutex> lock(mu); auto &v = hub_parts.back(); v.insert(v.end(), hubs.begin(), hubs.end()); }
+    }
   });
-  int64_t total = 0;
+  std::vector<int2> hub;
+  for (auto &v : hub_parts) hub.insert(hub.end(), v.begin(), v.end());
+  std::sort(hub.begin(), hub.end(), [](const int2 &a, const int2 &b) { return a.x < b.x; });
+  int64_t total = 0, hub_nnz = 0;
   for (int s = 0; s < nslices; ++s) {
     slice_off[(size_t)s] = (int)total;
     for (int q = 0; q < WAVE; ++q) total += meta[(size_t)s * WAVE + q] & 0xFFFFu;
   }
   slice_off[(size_t)nslices] = (int)total;
+  for (const int2 &hb : hub) hub_nnz += rowptr[(size_t)hb.y] - rowptr[(size_t)hb.x];
   J.nslices = nslices;
   J.rows = rows;
   J.nnz = total;
+  J.G = G;
+  J.max_len = max_len;
+  J.nhub = (int)hub.size();
+  J.hub_nnz = hub_nnz;
+  J.csr_rowptr = d_rowptr; J.csr_col = d_col; J.csr_val = d_val;
   int cus = 256;
   {
     int dev = 0;
@@ -911,46 +941,89 @@ int build_sj(SjDev &J, int rows, const std::vector<int> &rowptr, const std::vect
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
   }
-  const int ngroups = (nslices + TPB / WAVE - 1) / (TPB / WAVE);
+  const int spw = (TPB / WAVE) * G;
+  const int ngroups = (nslices + spw - 1) / spw;
   // never more workgroups than the CSR kernel's grid: every workgroup owns a block-partial slot of that grid
   J.grid = std::max(1, std::min(std::min(SJ_WGS_PER_CU * cus, ngroups), std::max(1, max_wgs)));
   if (remap) J.grid = std::max(NUM_XCD, (J.grid + NUM_XCD - 1) / NUM_XCD * NUM_XCD > max_wgs ? J.grid / NUM_XCD * NUM_XCD : (J.grid + NUM_XCD - 1) / NUM_XCD * NUM_XCD);
   int rc;
   if ((rc = upload(&J.meta, meta))) return rc;
   if ((rc = upload(&J.slice_off, slice_off))) return rc;
+  if (!hub.empty() && (rc = upload(&J.hub, hub))) return rc;
   HIP_TRY(hipMalloc((void **)&J.col, sizeof(int) * (size_t)std::max<int64_t>(total, 1)));
   HIP_TRY(hipMalloc((void **)&J.val, sizeof(double) * (size_t)std::max<int64_t>(total, 1)));
-  hipLaunchKernelGGL(sj_fill_kernel, dim3((nslices + TPB / WAVE - 1) / (TPB / WAVE)), dim3(TPB), 0, nullptr, nslices, J.meta,
+  hipLaunchKernelGGL(sj_fill_kernel, dim3((nslices + TPB / WAVE - 1) / (TPB / WAVE)), dim3(TPB), 0, nullptr, nslices, spw, J.meta,
                      J.slice_off, d_rowptr, d_col, d_val, J.col, J.val);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(nullptr));
   return 0;
 }
 
-// Which stream layouts get the sliced jagged copy: those with more row blocks than the persistent trial kernels take
-// (trial_kernel.hpp: <= 1 024 items; such LPs are latency-bound and stay on the CSR row blocks) -- i.e. products that are
-// bandwidth work -- whose rows (the long ones apart) have at most SJ_MAX_LEN entries (sj_kernels.hpp: a lane walks its
-// row).  PDHG_SJ=0 / 1 forces it off / on whatever the shape (tests compare the two layouts bitwise).
-// ... and whose 256-row groups are not too ragged: a workgroup trip lasts as long as its longest row, so the layout is used
-// when entries / (256 x longest row of the group), summed over the groups, is >= 0.4.  Measured (round 5,
-// profiles/r05_sj_layout.txt, banded 10M +-50000 / block-diagonal 10M): rows of exactly 10 entries (fill 1.0) 0.80 -> 0.58-0.61
-// ms (rocSPARSE 0.70); the transposes, column counts Poisson(10) (fill 0.47), 0.74-0.78 -> 0.67-0.74.
-inline bool sj_wanted(int nblk, int rows, const std::vector<int> &rowptr, const std::vector<int> &full_rowptr, int long_thr) {
-  if (const char *ev = getenv("PDHG_SJ")) return ev[0] != '0';
-  if (nblk <= 1024) return false;
-  int64_t entries = 0, capacity = 0;
-  for (int r0 = 0; r0 < rows; r0 += SJ_SIGMA) {
-    int longest = 0;
-    for (int r = r0; r < std::min(rows, r0 + SJ_SIGMA); ++r) {
-      if (full_rowptr[r + 1] - full_rowptr[r] > long_thr) continue;
-      const int l = rowptr[r + 1] - rowptr[r];
-      if (l > SJ_MAX_LEN) return false;
-      longest = std::max(longest, l);
-      entries += l;
+// Which stream layouts get the sliced jagged copy, and in which form: those with more row blocks than the persistent trial
+// kernels take (trial_kernel.hpp: <= 1 024 items; such LPs are latency-bound and stay on the CSR row blocks) -- i.e. products
+// that are bandwidth work.  Rows of more than SJ_MAX_LEN entries (the long-row path's apart) are HUB rows: the kernel runs them
+// as whole-workgroup row blocks of the CSR arrays; a matrix that keeps more than a quarter of its entries there stays with
+// the CSR kernels.  The window: a wave's trip lasts as long as the longest row of its slice, so the FILL of a form is
+// entries / sum over slices of 64 x the slice's longest row -- for the narrow form (256-row windows, one barrier per window:
+// the four slices wait for the longest) 256 x the window's longest row.  The wide form (2 048-row windows, round 6) is taken
+// when it fills at least 0.08 more than the narrow one (Poisson or power-law lengths; rows of one length tie and keep the
+// narrow form with its operands prefetched a trip ahead); either form needs a fill >= 0.4.  Measured, round 5
+// (profiles/r05_sj_layout.txt, banded 10M +-50000 / block-diagonal 10M): rows of exactly 10 entries (fill 1.0) 0.80 -> 0.58-0.61
+// ms (rocSPARSE 0.70); the transposes, column counts Poisson(10) (narrow fill 0.47), 0.74-0.78 -> 0.67-0.74; round 6: DESIGN.md.
+// PDHG_SJ=0 / 1 forces the layout off / on whatever the shape (tests compare the layouts bitwise), any other value means the
+// automatic rule; PDHG_SJ_WIDE=0 / 1 and PDHG_SJ_MAXLEN (dev) force the form and the hub threshold.
+inline SjPlan sj_plan(int nblk, int rows, const std::vector<int> &rowptr, const std::vector<int> &full_rowptr, int long_thr) {
+  SjPlan P;
+  if (const char *ev = dev_env("PDHG_SJ_MAXLEN")) P.max_len = std::max(1, std::min(atoi(ev), std::min(long_thr, BLOCK_NNZ)));
+  const char *ev = getenv("PDHG_SJ");
+  const int force = (ev && ev[0] == '0' && !ev[1]) ? 0 : ((ev && ev[0] == '1' && !ev[1]) ? 1 : -1);
+  if (force == 0) return P;
+  if (force < 0 && nblk <= 1024) return P;
+  const int wide_sigma = SJ_SIGMA * SJ_WIDE_G;
+  const int nwin = (rows + wide_sigma - 1) / wide_sigma;
+  std::vector<int64_t> acc((size_t)4 * std::max(1, std::min(nwin, 64)), 0);     // per range: entries, narrow capacity, wide capacity, hub entries
+  std::atomic<int> part_next{0};
+  parallel_ranges(nwin, 64, [&](int wb, int we) {
+    int64_t entries = 0, cap_narrow = 0, cap_wide = 0, hub_entries = 0;
+    std::vector<int> hist((size_t)P.max_len + 1);
+    for (int w = wb; w < we; ++w) {
+      const int r0 = w * wide_sigma, r1 = std::min(rows, r0 + wide_sigma);
+      std::fill(hist.begin(), hist.end(), 0);
+      for (int g0 = r0; g0 < r1; g0 += SJ_SIGMA) {
+        int longest = 0;
+        for (int r = g0; r < std::min(r1, g0 + SJ_SIGMA); ++r) {
+          if (full_rowptr[r + 1] - full_rowptr[r] > long_thr) continue;
+          const int l = rowptr[r + 1] - rowptr[r];
+          if (l > P.max_len) { hub_entries += l; continue; }
+          hist[(size_t)l] += 1;
+          longest = std::max(longest, l);
+          entries += l;
+        }
+        cap_narrow += (int64_t)SJ_SIGMA * longest;
+      }
+      // the window's rows by decreasing length: the longest row of every 64
+      int seen = 0, next_head = 0;
+      for (int l = P.max_len; l >= 1; --l) {
+        const int c = hist[(size_t)l];
+        while (next_head < seen + c) { cap_wide += (int64_t)WAVE * l; next_head += WAVE; }
+        seen += c;
+      }
     }
-    capacity += (int64_t)SJ_SIGMA * longest;
-  }
-  return capacity > 0 && 10 * entries >= 4 * capacity;
+    const int k = std::min(part_next.fetch_add(1), (int)(acc.size() / 4) - 1);
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    acc[(size_t)4 * k] += entries; acc[(size_t)4 * k + 1] += cap_narrow; acc[(size_t)4 * k + 2] += cap_wide; acc[(size_t)4 * k + 3] += hub_entries;
+  });
+  int64_t entries = 0, cap_narrow = 0, cap_wide = 0, hub_entries = 0;
+  for (size_t k = 0; k < acc.size() / 4; ++k) { entries += acc[4 * k]; cap_narrow += acc[4 * k + 1]; cap_wide += acc[4 * k + 2]; hub_entries += acc[4 * k + 3]; }
+  P.fill_narrow = cap_narrow > 0 ? (double)entries / (double)cap_narrow : 0.0;
+  P.fill_wide = cap_wide > 0 ? (double)entries / (double)cap_wide : 0.0;
+  P.hub_share = entries + hub_entries > 0 ? (double)hub_entries / (double)(entries + hub_entries) : 0.0;
+  P.G = P.fill_wide >= P.fill_narrow + 0.08 ? SJ_WIDE_G : 1;
+  if (const char *wv = dev_env("PDHG_SJ_WIDE")) P.G = wv[0] != '0' ? SJ_WIDE_G : 1;
+  if (force == 1) { P.use = true; return P; }
+  P.use = entries > 0 && P.hub_share <= 0.25 && (P.G > 1 ? P.fill_wide : P.fill_narrow) >= 0.4;
+  return P;
 }
 
 // The persistent software-pipelined form of the CSR row blocks (spmv_stream_pipe_kernel): the blocks' extent words and the
@@ -1012,16 +1085,19 @@ int build_sj_copies_only(CsrDev &D, int rows, const std::vector<int> &rowptr, bo
     // all slabs or none (the passes hand the row sums on in one format either way; one rule keeps the kernel names simple)
     int nblk_max = 0;
     for (const SlabDev &S : D.slabs) nblk_max = std::max(nblk_max, S.nblk);
-    if (!sj_wanted(nblk_max, rows, rowptr, rowptr, D.long_thr)) return 0;
+    const SjPlan plan = sj_plan(nblk_max, rows, rowptr, rowptr, D.long_thr);
+    if (!plan.use) return 0;
     for (SlabDev &S : D.slabs) {
       std::vector<int> rp((size_t)rows + 1);
       HIP_TRY(hipMemcpy(rp.data(), S.rowptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost));
-      if ((rc = build_sj(S.sj, rows, rp, rowptr, D.long_thr, S.rowptr, S.col, S.val, remap, S.grid))) return rc;
+      if ((rc = build_sj(S.sj, rows, rp, rowptr, D.long_thr, S.rowptr, S.col, S.val, remap, S.grid, plan))) return rc;
     }
     return 0;
   }
-  if (D.grid <= 0 || !sj_wanted(D.nblk, rows, rowptr, rowptr, D.long_thr)) return 0;
-  return build_sj(D.sj, rows, rowptr, rowptr, D.long_thr, D.rowptr, D.col, D.val, remap, D.grid);
+  if (D.grid <= 0) return 0;
+  const SjPlan plan = sj_plan(D.nblk, rows, rowptr, rowptr, D.long_thr);
+  if (!plan.use) return 0;
+  return build_sj(D.sj, rows, rowptr, rowptr, D.long_thr, D.rowptr, D.col, D.val, remap, D.grid, plan);
 }
 
 void free_csr_dev(CsrDev &D) {

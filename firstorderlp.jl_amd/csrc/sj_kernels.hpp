@@ -8,7 +8,8 @@
 // and gathers the same doubles with every lane walking ITS OWN row in registers (tools/slot_probe.hip, variant 14;
 // profiles/r05_slot_probe.txt).  This file is that skeleton as a product kernel.
 //
-// Layout.  Rows are taken in GROUPS of SJ_SIGMA = 256 consecutive rows (one workgroup trip) and, inside a group, ordered
+// Layout.  Rows are taken in GROUPS of SJ_SIGMA = 256 consecutive rows (one workgroup trip; the wide form of round 6:
+// windows of 2 048 rows, see the kernel) and, inside a group, ordered
 // by DECREASING length (stable: equal lengths keep their row order -- the layout is a deterministic function of the row
 // pointers).  64 consecutive slots of that order are a SLICE, one wave's work: slot -> (row, length) in one word of `meta`.
 // A slice's entries are stored LEVEL-MAJOR and jagged: level j holds the j-th entry (ascending column) of every row of
@@ -36,8 +37,9 @@
 
 namespace {
 
-constexpr int SJ_SIGMA = TPB;        // rows per sorting group = rows per workgroup trip (4 slices)
-constexpr int SJ_MAX_LEN = 128;      // longest row (long rows apart) the builder accepts for this layout
+constexpr int SJ_SIGMA = TPB;        // rows per workgroup trip of the narrow form (4 slices); the wide form sorts SJ_SIGMA * SJ_WIDE_G rows
+constexpr int SJ_WIDE_G = 8;         // wide form (round 6): windows of 2 048 rows, every wave walks 8 of the window's 32 slices
+constexpr int SJ_MAX_LEN = 128;      // longest row a lane walks; longer ones (long rows apart) are HUB rows: whole-workgroup row blocks
 #ifndef PDHG_SJ_U
 #define PDHG_SJ_U 16
 #endif
@@ -49,11 +51,18 @@ constexpr int SJ_WGS_PER_CU = PDHG_SJ_WGS;
 
 struct SjDev {
   int nslices = 0, grid = 0, rows = 0;
-  int64_t nnz = 0;
-  unsigned *meta = nullptr;          // [nslices * 64] slot -> (row - group base) << 16 | entries; SJ_NONE in the high half: no row
+  int G = 1;                         // slices per wave and window: 1 (256-row windows) or SJ_WIDE_G (2 048-row windows)
+  int max_len = SJ_MAX_LEN;          // rows beyond this many entries (in this matrix / slab) are hub rows
+  int64_t nnz = 0;                   // entries in the slices (hub and long rows hold theirs in the CSR arrays only)
+  unsigned *meta = nullptr;          // [nslices * 64] slot -> (row - window base) << 16 | entries; SJ_NONE in the high half: no row
   int *slice_off = nullptr;          // [nslices + 1] first entry of every slice
   int *col = nullptr;                // [nnz] level-major inside a slice
   double *val = nullptr;
+  int2 *hub = nullptr;               // [nhub] (r, r + 1): hub rows, one stream-kernel row block each, on the CSR arrays below
+  int nhub = 0;
+  int64_t hub_nnz = 0;
+  const int *csr_rowptr = nullptr, *csr_col = nullptr;     // the CSR arrays the copy was filled from (not owned)
+  const double *csr_val = nullptr;
   bool on() const { return nslices > 0; }
 };
 
@@ -64,11 +73,16 @@ struct SjView {
   const int *slice_off;
   const int *col;
   const double *val;
+  const int2 *hub;
+  int nhub, relaxed;
+  CsrView csr;
 };
-inline SjView sj_view(const SjDev &J) { return SjView{J.nslices, J.rows, J.meta, J.slice_off, J.col, J.val}; }
+inline SjView sj_view(const SjDev &J, int relaxed = 1) {
+  return SjView{J.nslices, J.rows, J.meta, J.slice_off, J.col, J.val, J.hub, J.nhub, relaxed, CsrView{J.rows, J.csr_rowptr, J.csr_col, J.csr_val}};
+}
 
-// one wave per slice: the CSR entries of its rows into the level-major order
-__global__ __launch_bounds__(TPB) void sj_fill_kernel(int nslices, const unsigned *__restrict__ meta, const int *__restrict__ slice_off,
+// one wave per slice: the CSR entries of its rows into the level-major order.  slices_per_window = 4 * G.
+__global__ __launch_bounds__(TPB) void sj_fill_kernel(int nslices, int slices_per_window, const unsigned *__restrict__ meta, const int *__restrict__ slice_off,
                                                       const int *__restrict__ rowptr, const int *__restrict__ col,
                                                       const double *__restrict__ val, int *__restrict__ sj_col, double *__restrict__ sj_val) {
   const int lane = threadIdx.x & (WAVE - 1);
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(TPB) void sj_fill_kernel(int nslices, const unsigne
   if (slice >= nslices) return;
   const unsigned w = meta[slice * WAVE + lane];
   const int l = (int)(w & 0xFFFFu);
-  const int r = (w >> 16) == SJ_NONE ? -1 : (slice / (TPB / WAVE)) * SJ_SIGMA + (int)(w >> 16);
+  const int r = (w >> 16) == SJ_NONE ? -1 : (slice / slices_per_window) * (slices_per_window * WAVE) + (int)(w >> 16);
   const int src = r >= 0 ? rowptr[r] : 0;
   int off = slice_off[slice];
   const int L = __builtin_amdgcn_readfirstlane(l);      // lane 0 holds the slice's longest row
@@ -124,66 +138,104 @@ __device__ __forceinline__ void sj_load_batch(const SjView &J, int &off, int l, 
 // variant without it (every wave its own pipeline, the epilogue in the lane that walked the row) ran at 0.74 -- the waves
 // of an XCD drift apart and the window of the gathered vector in flight widens, exactly as in the sweep
 // (profiles/r05_sj_layout.txt).
-template <int MODE, bool INIT = false, int TAG = 0>
+//
+// Round 6, the WIDE form (G = SJ_WIDE_G): the sorting window is 2 048 rows -- 32 slices, wave w walks slices w, w + 4, ... of
+// the window (long and short ones alike) -- and the row sums of the whole window cross the workgroup through LDS before the
+// epilogue runs in ROW order, eight rows per thread.  What it is for: rows of power-law or Poisson length.  Sorted inside
+// 256 rows, a group's four slices last as long as their longest rows (Poisson(10) columns of a banded matrix: 82 % of the
+// lane-levels carry an entry; PageRank's rows: a fraction); sorted inside 2 048 rows the slices are nearly uniform.  The
+// epilogue's operands are requested just before the window's barrier (24 coalesced loads per thread in flight) instead of a
+// trip ahead.  HUB rows (round 6; more than SjDev::max_len entries, the long-row path's apart): no lane walks them --
+// every workgroup first takes its share of them as row blocks of the CSR arrays (stream_block_load / _finish: the
+// products through LDS, added left to right by one lane, or by a wave in relaxed order beyond 256 entries: the CSR
+// kernel's bits), which is what lets PageRank's matrices (rows of 5 ... 4 000 entries) use the layout at all.
+template <int MODE, bool INIT = false, int TAG = 0, int G = 1>
 __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__restrict__ xin, int remap, int stream_slots, EpiArgs e) {
-  static_assert(SJ_SIGMA == TPB, "one sorting group per workgroup trip");
+  constexpr int SIGMA = SJ_SIGMA * G;                     // rows per window
+  constexpr int SPW = (TPB / WAVE) * G;                   // slices per window
+  constexpr size_t SUM_BYTES = sizeof(double) * 2 * SIGMA;
+  constexpr size_t LDS_BYTES = SUM_BYTES > sizeof(double) * BLOCK_NNZ ? SUM_BYTES : sizeof(double) * BLOCK_NNZ;
   __shared__ double red[6][TPB / WAVE];
-  __shared__ double row_sum[2][TPB];
-  __shared__ int row_ok[2][TPB];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];     // hub phase: prod[BLOCK_NNZ]; then row_sum[2][SIGMA]
+  __shared__ unsigned char row_ok[2][SIGMA];
+  double (*row_sum)[SIGMA] = reinterpret_cast<double (*)[SIGMA]>(lds_raw);
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
   Acc3 acc3 = acc3_zero();
-  const int ngroups = (J.nslices + TPB / WAVE - 1) / (TPB / WAVE);
+  // ---- hub rows first: one row block each, dealt round robin
+  if (J.nhub > 0) {
+    double *prod = reinterpret_cast<double *>(lds_raw);
+    for (int hb = (int)blockIdx.x; hb < J.nhub; hb += (int)gridDim.x) {
+      StreamRegs sg;
+      stream_block_load(J.csr, J.hub[hb], sg);
+      stream_block_finish<MODE, INIT>(J.csr, xin, sg, e, J.relaxed, acc3, prod);
+      __syncthreads();
+    }
+  }
+  const int ngroups = (J.nslices + SPW - 1) / SPW;
   const int per_xcd = (ngroups + NUM_XCD - 1) / NUM_XCD;
   // remap: workgroup b runs on XCD b % 8 (round-robin dispatch); it walks groups x * per_xcd + i, i = b / 8, b / 8 + gridDim / 8, ...
   const int first = remap ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int stride = remap ? (int)(gridDim.x >> 3) : (int)gridDim.x;
   const int limit = remap ? per_xcd : ngroups;
   const int xbase = remap ? (int)(blockIdx.x & (NUM_XCD - 1)) * per_xcd : 0;
-  row_ok[0][tid] = 0;
-  row_ok[1][tid] = 0;
+#pragma unroll
+  for (int qq = 0; qq < G; ++qq) {
+    row_ok[0][qq * TPB + tid] = 0;
+    row_ok[1][qq * TPB + tid] = 0;
+  }
   __syncthreads();
   auto group_of = [&](int i) { const int g = xbase + i; return (i < limit && g < ngroups) ? g : -1; };
-  // ---- in flight: the slot words of the next two groups (w_n, w_nn), the next batch (B_n), the next group's operands
+  // the wave's walk: (trip i, slice q of the window) -> (i, q + 1) ... (i, G - 1) -> (i + stride, 0)
+  struct Pos { int i, g, q; };
+  auto next_pos = [&](Pos p) {
+    if (G > 1 && p.q + 1 < G) return Pos{p.i, p.g, p.q + 1};
+    const int i2 = p.i + stride;
+    return Pos{i2, p.g >= 0 ? group_of(i2) : -1, 0};
+  };
+  // ---- in flight: the slot words of the next two slices (w_n, w_nn), the next batch (B_n), (G == 1) the next group's operands
   unsigned w_n = (SJ_NONE << 16), w_nn = (SJ_NONE << 16);
   int off_n = 0, off_nn = 0;
   EpiOps ops_n{0.0, 0.0, 0.0};
   double init_n = 0.0;
   SjBatch B_n;
-  auto request_meta = [&](int g, unsigned &w, int &off) {
+  auto request_meta = [&](Pos p, unsigned &w, int &off) {
     w = (SJ_NONE << 16);
     off = 0;
-    const int slice = g * (TPB / WAVE) + wave;
-    if (g >= 0 && slice < J.nslices) {                    // wave-uniform
+    const int slice = p.g * SPW + p.q * (TPB / WAVE) + wave;
+    if (p.g >= 0 && slice < J.nslices) {                  // wave-uniform
       w = J.meta[slice * WAVE + lane];
       off = J.slice_off[slice];
     }
   };
-  // the first batch, the epilogue operands and the carried sums of group g, whose slot words (w_n, off_n) have arrived
-  auto request_group = [&](int g) {
-    const int row = g * SJ_SIGMA + tid;
-    if (g >= 0 && row < J.rows) ops_n = epi_load<MODE>(e, row);
+  // the first batch, (G == 1) the epilogue operands, and the carried sums of the slice at p, whose slot words (w_n, off_n) have arrived
+  auto request_slice = [&](Pos p) {
+    if (G == 1) {
+      const int row = p.g * SIGMA + tid;
+      if (p.g >= 0 && row < J.rows) ops_n = epi_load<MODE>(e, row);
+    }
     const int l = (int)(w_n & 0xFFFFu);
     if (INIT) {
-      const int r = (w_n >> 16) == SJ_NONE ? -1 : g * SJ_SIGMA + (int)(w_n >> 16);
+      const int r = (w_n >> 16) == SJ_NONE ? -1 : p.g * SIGMA + (int)(w_n >> 16);
       init_n = r >= 0 ? e.init[r] : 0.0;
     }
     sj_load_batch(J, off_n, l, __builtin_amdgcn_readfirstlane(l), 0, lane, B_n);
   };
-  int g = group_of(first), g_next = group_of(first + stride);
-  request_meta(g, w_n, off_n);
-  request_meta(g_next, w_nn, off_nn);
-  request_group(g);
+  Pos cur{first, group_of(first), 0};
+  Pos nxt = next_pos(cur);
+  request_meta(cur, w_n, off_n);
+  request_meta(nxt, w_nn, off_nn);
+  request_slice(cur);
   int buf = 0;
-  for (int i = first; g >= 0; i += stride) {
+  while (cur.g >= 0) {
     const unsigned w = w_n;
     const EpiOps ops = ops_n;
     const int l = (int)(w & 0xFFFFu);
     const int L = __builtin_amdgcn_readfirstlane(l);      // lane 0 holds the slice's longest row
     const int rl = (w >> 16) == SJ_NONE ? -1 : (int)(w >> 16);
-    const int base = g * SJ_SIGMA;
+    const int base = cur.g * SIGMA;
     double s = INIT ? init_n : 0.0;
-    const int g_next2 = group_of(i + 2 * stride);
+    const Pos nxt2 = next_pos(nxt);
     int j0 = 0;
     do {                                                  // the slice's batches (at least one trip: it requests what follows)
       double xv[SJ_U], vv[SJ_U];
@@ -196,11 +248,11 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
       // behind these gathers: the batch that follows
       if (j0 + SJ_U < L) {                                // wave-uniform: the same slice goes on
         sj_load_batch(J, off_n, l, L, j0 + SJ_U, lane, B_n);
-      } else {                                            // the wave's slice of the next group; slot words for the one after
+      } else {                                            // the wave's next slice; slot words for the one after
         w_n = w_nn;
         off_n = off_nn;
-        request_meta(g_next2, w_nn, off_nn);
-        request_group(g_next);
+        request_meta(nxt2, w_nn, off_nn);
+        request_slice(nxt);
       }
 #pragma unroll
       for (int jj = 0; jj < SJ_U; ++jj) {
@@ -215,16 +267,38 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
       row_sum[buf][rl] = s;
       row_ok[buf][rl] = 1;
     }
-    __syncthreads();
-    // thread t: the epilogue of row base + t, operands in row order (this buffer is next written two trips from now,
-    // behind the next trip's barrier)
-    if (row_ok[buf][tid]) {
-      row_ok[buf][tid] = 0;
-      epi_apply<MODE>(e, base + tid, row_sum[buf][tid], ops, acc3);
+    if (G == 1) {
+      __syncthreads();
+      // thread t: the epilogue of row base + t, operands in row order (this buffer is next written two trips from now,
+      // behind the next trip's barrier)
+      if (row_ok[buf][tid]) {
+        row_ok[buf][tid] = 0;
+        epi_apply<MODE>(e, base + tid, row_sum[buf][tid], ops, acc3);
+      }
+      buf ^= 1;
+    } else if (cur.q == G - 1) {                          // the window's last slice of this wave (the same trip for all four waves)
+      // the operands of the window's rows, in row order, requested before the barrier that delivers the sums (a row's
+      // slot is static: long and hub rows have none, rows past the matrix neither)
+      EpiOps wo[G];
+#pragma unroll
+      for (int qq = 0; qq < G; ++qq) {
+        const int row = base + qq * TPB + tid;
+        wo[qq] = EpiOps{0.0, 0.0, 0.0};
+        if (row < J.rows) wo[qq] = epi_load<MODE>(e, row);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int qq = 0; qq < G; ++qq) {
+        const int rr = qq * TPB + tid;
+        if (row_ok[buf][rr]) {
+          row_ok[buf][rr] = 0;
+          epi_apply<MODE>(e, base + rr, row_sum[buf][rr], wo[qq], acc3);
+        }
+      }
+      buf ^= 1;
     }
-    buf ^= 1;
-    g = g_next;
-    g_next = g_next2;
+    cur = nxt;
+    nxt = nxt2;
   }
   constexpr int NQ = ModeNQ<MODE>::value;
   if (NQ > 0) {

@@ -177,3 +177,30 @@ def test_the_builder_picks_the_layout_for_bandwidth_bound_stream_matrices(gpu_re
     assert ragged["A_sj"] == 0, ragged                    # rows of up to 1 500 entries: not this layout
     small = HipPdhgEngine.from_problem(random_lp(5000, 4000, 8, seed=7)).layout_info()
     assert small["A_sj"] == 0 and small["At_sj"] == 0
+
+
+def test_device_rescaling_reaches_the_hessians_sliced_jagged_copies(gpu_required, monkeypatch):
+    """A QP whose objective matrix runs `spmv_sj_kernel` (forced here; by itself for a sparse Hessian of n >~ 0.4M): after
+    pdhg_rescale the sliced jagged copies of Q and Q' must hold (D^-1 Q) D^-1 (preprocess.jl:562-564) like the CSR
+    arrays -- round 5 scaled only the CSR and slab arrays, so the products by Q used the UNSCALED Hessian (advisor r5,
+    high).  Trial steps (x' = x - tau (c + Q x - A'y), pdhg.jl:462-477, and dx'Q dx) and 30 free-running steps bitwise the
+    CSR layout's."""
+    n, m = 60_000, 40_000
+    p = random_lp(m, n, 6, seed=31)
+    rng = np.random.default_rng(4)
+    B = sp.random(n, n, density=3.0 / n, random_state=9, format="csc")
+    p.objective_matrix = sp.csc_matrix(B.T @ B + sp.diags(rng.uniform(0.5, 3.0, n)))
+    p.objective_matrix.sum_duplicates()
+    p.objective_matrix.sort_indices()
+    sj, csr = _engine(p, monkeypatch, "1"), _engine(p, monkeypatch, "0")
+    assert sj.layout_info()["A_sj"] == 1 and csr.layout_info()["A_sj"] == 0
+    assert sj.layout_info().get("Q_sj") == 1 and csr.layout_info().get("Q_sj") == 0
+    x0, y0 = np.abs(rng.standard_normal(n)), rng.standard_normal(m)
+    for e in (sj, csr):
+        e.rescale(10, False, 1.0)
+        e.set_current(x0, y0)
+    ra, rb = sj.trial_step(0.05, 1.3), csr.trial_step(0.05, 1.3)
+    assert np.array_equal(ra, rb)
+    assert all(np.array_equal(u, v) for u, v in zip(sj.get_trial(), csr.get_trial()))
+    for a, c in zip(_run(sj, p, 30), _run(csr, p, 30)):
+        assert np.array_equal(a, c)
