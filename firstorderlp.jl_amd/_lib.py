@@ -31,7 +31,7 @@ EXPORTS = [
     "pdhg_get_current", "pdhg_set_current", "pdhg_get_trial", "pdhg_spmv",
     "pdhg_spmv_t", "pdhg_dist_get_unique_id", "pdhg_create_dist", "pdhg_create_multi",
     "pdhg_dist_info", "pdhg_profile_enable", "pdhg_profile_read",
-    "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info", "pdhg_measure_triad", "pdhg_measure_sweep_ceiling", "pdhg_trial_timeline",
+    "pdhg_kernel_algorithmic_bytes", "pdhg_kernel_name", "pdhg_layout_info", "pdhg_layout_describe", "pdhg_measure_triad", "pdhg_measure_sweep_ceiling", "pdhg_trial_timeline",
     "pdhg_set_original_problem", "pdhg_eval_point", "pdhg_save_restart_point",
     "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound", "pdhg_trust_region_bounds",
     "pdhg_point_sumsq", "pdhg_rescale", "pdhg_get_problem_vectors", "pdhg_matrix_max_abs",
@@ -39,7 +39,7 @@ EXPORTS = [
     "pdhg_measure_launch_overhead", "pdhg_layout_checksums",
 ]
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 UNIQUE_ID_BYTES = 128
 (K_PRIMAL, K_SPMV_DUAL, K_SPMV_ATY, K_FINAL, K_ACCEPT, K_ALLGATHER, K_REDUCE_SCATTER,
  K_INTERACTION, K_COUNT) = range(9)
@@ -64,7 +64,7 @@ def build(force=False, verbose=False):
 # ---- sanitizer builds of the HOST side (the kernels are compiled as usual: -fno-gpu-sanitize) ----------------------
 # libpdhg_hip_asan.so: AddressSanitizer + UndefinedBehaviorSanitizer.  tests/test_sanitizer_host.py drives the
 # host-only entry points (row partition, argument validation) through it in a child process that preloads the ASan
-# runtime; libpdhg_hip_tsan.so: ThreadSanitizer, for the shard pool's issuing threads (tools/r4_tsan_shards.sh, GPU box).
+# runtime; libpdhg_hip_tsan.so: ThreadSanitizer, for the shard pool's issuing threads (tools/archive/r4_tsan_shards.sh, GPU box).
 SANITIZED = {"asan": (os.path.join(CSRC, "libpdhg_hip_asan.so"),
                       ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]),
              "tsan": (os.path.join(CSRC, "libpdhg_hip_tsan.so"), ["-fsanitize=thread"])}
@@ -203,6 +203,8 @@ def lib():
     L.pdhg_profile_read.argtypes = [_vp, i32, _ip, _dp]
     L.pdhg_kernel_algorithmic_bytes.restype = i64
     L.pdhg_kernel_algorithmic_bytes.argtypes = [_vp, i32]
+    L.pdhg_layout_describe.restype = i32
+    L.pdhg_layout_describe.argtypes = [_vp, ctypes.c_char_p, i32]
     L.pdhg_kernel_name.restype = ctypes.c_char_p
     L.pdhg_kernel_name.argtypes = [_vp, i32]
     L.pdhg_layout_info.restype = i32

@@ -530,7 +530,10 @@ int pdhg_trust_region_bounds(pdhg_handle *h0, int count, const int *points, doub
   const char *se = dev_env("PDHG_SMALL_EVAL");
   const bool small = !L.g && h->n + h->m <= TRS_MAX && !(se && se[0] == '0');
   const char *be = dev_env("PDHG_TR_BATCH");
-  bool batch = count > 1 && !L.g && !h->profile && !small && !(be && be[0] == '0');
+  // (the batch snapshots every point's products, which needs the per-point buffers: with the evaluation cache switched off
+  //  -- PDHG_NO_EVAL_CACHE, dev -- all points share one set and only the last point's products would survive)
+  const char *nc = dev_env("PDHG_NO_EVAL_CACHE");
+  bool batch = count > 1 && !L.g && !h->profile && !small && !(be && be[0] == '0') && nc == nullptr;
   if (batch) {
     if ((rc = flush_pending(L))) return rc;
     rc = tr_coop_prepare(h);
@@ -569,7 +572,10 @@ int pdhg_trust_region_bounds(pdhg_handle *h0, int count, const int *points, doub
       std::lock_guard<std::mutex> lock(coop_device_mutex(h->device));
       hipLaunchKernelGGL(tr_coop_batch_kernel, dim3(h->tr_grid), dim3(TPB), 0, h->stream, a);
       HIP_TRY(hipGetLastError());
-      if ((rc = ev_wait_host(h, 8 * count + 2, a.seq, r))) return rc;
+      if ((rc = ev_wait_host(h, 8 * count + 2, a.seq, r))) {
+        h->tr_coop = 0;         // the launch may have passed barriers without reporting its epoch: never reuse this GridSync's counters
+        return rc;
+      }
     }
     h->tr_epoch = (unsigned long long)r[8 * count + 1];
     if (r[8 * count] == 0.0) {

@@ -309,6 +309,62 @@ int pdhg_layout_checksums(pdhg_handle *h, uint64_t out[32]) {
   return 0;
 }
 
+// One matrix's resident layout as a JSON object (pdhg_layout_describe).
+static std::string describe_matrix(const pdhg_handle *h, const CsrDev &D0, int mode, int tag) {
+  const CsrDev &D = D0.segs.empty() ? D0 : D0.segs.front();
+  char b[512];
+  std::string out = "{";
+  snprintf(b, sizeof b, "\"rows\": %d, \"cols\": %d, \"nnz\": %lld, \"segments\": %d, \"kernels\": \"%s\"", D0.rows, D0.cols, (long long)D0.nnz,
+           (int)D0.segs.size(), product_kernels(D0, mode, tag).c_str());
+  out += b;
+  const char *kind = D.tiled ? "sweep" : ((D.sj.on() || (!D.slabs.empty() && D.slabs.front().sj.on())) ? "sliced jagged"
+                     : ((D.pipe_grid > 0 || (!D.slabs.empty() && D.slabs.front().pipe_grid > 0)) ? "row blocks, pipelined" : "row blocks"));
+  snprintf(b, sizeof b, ", \"layout\": \"%s\", \"row_blocks\": %d, \"long_rows\": %d, \"long_threshold\": %d, \"column_slabs\": %d, \"max_row_nnz\": %lld",
+           kind, D.nblk, D.nlong, D.long_thr, (int)D.slabs.size(), (long long)D0.max_row_nnz);
+  out += b;
+  if (D.tiled) {
+    snprintf(b, sizeof b, ", \"sweep\": {\"waves\": %d, \"tile_cols\": %d, \"equal_nonzero_tiles\": %s, \"chunk_variant\": %d, \"xcd_dealing\": \"%s\", "
+             "\"chosen_by\": \"%s\", \"candidates\": [", D.nwaves, D.tile_cols, D.var_tiles ? "true" : "false", D.tw_mode,
+             tiled_per_xcd(h, D, D.grid) > 0 ? "contiguous eighths" : "round robin", D.tw_tuned > 1 ? "timing at create (tune_tiled_variant)" : "static rule");
+    out += b;
+    for (int k = 0; k < D.tw_tuned; ++k) {
+      snprintf(b, sizeof b, "%s{\"chunk_variant\": %d, \"xcd_dealing\": \"%s\", \"ms\": %.4f}", k ? ", " : "", D.tw_tune_mode[k],
+               D.tw_tune_band[k] ? "contiguous eighths" : "round robin", (double)D.tw_tune_ms[k]);
+      out += b;
+    }
+    out += "]}";
+  }
+  const SjDev *J = D.sj.on() ? &D.sj : ((!D.slabs.empty() && D.slabs.front().sj.on()) ? &D.slabs.front().sj : nullptr);
+  if (J) {
+    int64_t hub = 0, hub_nnz = 0;
+    if (D.sj.on()) { hub = D.sj.nhub; hub_nnz = D.sj.hub_nnz; }
+    else for (const SlabDev &S : D.slabs) { hub += S.sj.nhub; hub_nnz += S.sj.hub_nnz; }
+    snprintf(b, sizeof b, ", \"sliced_jagged\": {\"window_rows\": %d, \"slices_per_wave\": %d, \"hub_threshold\": %d, \"hub_rows\": %lld, \"hub_nnz\": %lld, "
+             "\"fill_narrow\": %.3f, \"fill_wide\": %.3f, \"ragged_share\": %.3f, \"grid\": %d}", SJ_SIGMA * J->G, J->G, J->max_len, (long long)hub, (long long)hub_nnz,
+             J->fill_narrow, J->fill_wide, J->ragged, J->grid);
+    out += b;
+  }
+  return out + "}";
+}
+
+// The resident layouts and every choice pdhg_create made for them -- including the ones settled by TIMING the product on the
+// matrix (the sweep's chunk variant and XCD dealing: tune_tiled_variant) -- as one JSON object, so that a bench line or a
+// profile can say which variant it ran (a handle's dispatch depends on a measurement taken at create; PDHG_TUNE=0 pins the
+// static rules).  Returns the length of the text (without the terminator); writes at most cap - 1 characters + NUL.
+int pdhg_layout_describe(pdhg_handle *h, char *buf, int cap) {
+  if (!h) return fail(-1, "null handle");
+  std::string out = "{\"A\": " + describe_matrix(h, h->A, MODE_DUAL, 0) + ", \"At\": " + describe_matrix(h, h->At, h->grp ? MODE_PLAIN : MODE_ATY, 1);
+  if (h->has_q) out += ", \"Q\": " + describe_matrix(h, h->Q, MODE_PLAIN, 2) + ", \"Qt\": " + describe_matrix(h, h->Qt, MODE_PLAIN, 2);
+  const char *tv = getenv("PDHG_TUNE");
+  out += std::string(", \"row_order\": \"") + (h->relaxed ? "relaxed" : "strict") + "\", \"timing_at_create\": " + ((tv && tv[0] == '0') ? "false" : "true") + "}";
+  if (buf && cap > 0) {
+    const size_t k = std::min(out.size(), (size_t)cap - 1);
+    memcpy(buf, out.data(), k);
+    buf[k] = 0;
+  }
+  return (int)out.size();
+}
+
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]) {
   if (!h) return fail(-1, "null handle");
   info[12] = (int64_t)h->A.slabs.size(); info[13] = (int64_t)h->At.slabs.size();

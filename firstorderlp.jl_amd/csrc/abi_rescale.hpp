@@ -61,7 +61,7 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
     // just scaled, so that they carry the same bits (two multiplications in a fixed order per entry, done once)
     auto refill = [&](const SjDev &J, const int *rowptr, const int *col, const double *val) {
       if (J.on() && J.nnz > 0)
-        hipLaunchKernelGGL(sj_fill_kernel, dim3((J.nslices + TPB / WAVE - 1) / (TPB / WAVE)), dim3(TPB), 0, h->stream, J.nslices,
+        hipLaunchKernelGGL(sj_fill_kernel, dim3((J.nslices + TPB / WAVE - 1) / (TPB / WAVE)), dim3(TPB), 0, h->stream, J.nslices, (TPB / WAVE) * J.G,
                            (const unsigned *)J.meta, (const int *)J.slice_off, rowptr, col, val, J.col, J.val);
     };
     refill(D.sj, D.rowptr, D.col, D.val);

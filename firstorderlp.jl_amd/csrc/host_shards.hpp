@@ -480,6 +480,9 @@ int tune_tiled_variant(pdhg_handle *h, CsrDev &D, const double *xin, double *out
   if (!D.tiled || D.grid <= 0 || !xin || !out) return 0;
   const char *ev = dev_env("PDHG_TW_TUNE");
   if (ev && ev[0] == '0') return 0;
+  // PDHG_TUNE=0 (public): no timing at create -- the builder's static choices stand, so that kernel names, grids and
+  // create time are the same from run to run and from rank to rank (pdhg_layout_describe reports what was chosen and how)
+  if (const char *pv = getenv("PDHG_TUNE")) if (pv[0] == '0') return 0;
   struct Cand { int mode; bool band; float ms; };
   std::vector<Cand> cands{{D.tw_mode, D.tw_band, 0.f}};
   if (D.tw_mode == 3 && !dev_env("PDHG_TW_MODE")) cands.push_back({4, D.tw_band, 0.f});
@@ -506,6 +509,8 @@ int tune_tiled_variant(pdhg_handle *h, CsrDev &D, const double *xin, double *out
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   D.tw_mode = cands[0].mode; D.tw_band = cands[0].band;
   if (rc) return rc;
+  D.tw_tuned = (int)std::min<size_t>(cands.size(), 3);
+  for (int k = 0; k < D.tw_tuned; ++k) { D.tw_tune_mode[k] = cands[(size_t)k].mode; D.tw_tune_band[k] = cands[(size_t)k].band ? 1 : 0; D.tw_tune_ms[k] = cands[(size_t)k].ms / 3.f; }
   // the chunk variant first, then the dealing (each against the builder's choice; the two are independent enough)
   size_t best = 0;
   for (size_t k = 1; k < cands.size(); ++k)

@@ -84,11 +84,11 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
         EpiArgs le = e;
         le.init = D.slab_partial;
         if (p + 1 < P) {
-          const void *fn = p == 0 ? (const void *)spmv_sj_kernel<MODE_PLAIN, false, TAG> : (const void *)spmv_sj_kernel<MODE_PLAIN, true, TAG>;
-          HIP_TRY(graph_add_kernel(graph, &nd, prev, fn, dim3(S.sj.grid), dim3(TPB), sj_view(S.sj), xin, rm, 0, pe));
+          const void *fn = p == 0 ? sj_kernel_fn<MODE_PLAIN, false, TAG>(S.sj) : sj_kernel_fn<MODE_PLAIN, true, TAG>(S.sj);
+          HIP_TRY(graph_add_kernel(graph, &nd, prev, fn, dim3(S.sj.grid), dim3(TPB), sj_view(S.sj, rx), xin, rm, 0, pe));
         } else {
-          HIP_TRY(graph_add_kernel(graph, &nd, prev, (const void *)spmv_sj_kernel<MODE, true, TAG>, dim3(S.sj.grid), dim3(TPB),
-                                   sj_view(S.sj), xin, rm, S.grid, le));
+          HIP_TRY(graph_add_kernel(graph, &nd, prev, sj_kernel_fn<MODE, true, TAG>(S.sj), dim3(S.sj.grid), dim3(TPB),
+                                   sj_view(S.sj, rx), xin, rm, S.grid, le));
           if (main_node) *main_node = nd;
         }
         prev.assign(1, nd);
@@ -131,8 +131,8 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
     done.push_back(prev[0]);
   } else if (D.sj.on()) {
     hipGraphNode_t nd = nullptr;
-    HIP_TRY(graph_add_kernel(graph, &nd, deps, (const void *)spmv_sj_kernel<MODE, false, TAG>, dim3(D.sj.grid), dim3(TPB),
-                             sj_view(D.sj), xin, rm, D.grid, e));
+    HIP_TRY(graph_add_kernel(graph, &nd, deps, sj_kernel_fn<MODE, false, TAG>(D.sj), dim3(D.sj.grid), dim3(TPB),
+                             sj_view(D.sj, rx), xin, rm, D.grid, e));
     if (main_node) *main_node = nd;
     done.push_back(nd);
   } else if (D.pipe_grid > 0) {
@@ -181,8 +181,8 @@ int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &du
       EpiArgs le = dual_epi;
       le.init = A.slab_partial;
       if (S.sj.on())
-        HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_sj_kernel<MODE_DUAL, true, 0>, dim3(S.sj.grid), dim3(TPB),
-                                 sj_view(S.sj), (const double *)h->xbar, rm, S.grid, le));
+        HIP_TRY(graph_set_kernel(G.exec, G.n_dual, sj_kernel_fn<MODE_DUAL, true, 0>(S.sj), dim3(S.sj.grid), dim3(TPB),
+                                 sj_view(S.sj, rx), (const double *)h->xbar, rm, S.grid, le));
       else if (S.pipe_grid > 0)
         HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_pipe_kernel<MODE_DUAL, true, 0>, dim3(S.pipe_grid), dim3(TPB),
                                  S.view(A.rows), (const double *)h->xbar, (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx, S.grid, le));
@@ -190,8 +190,8 @@ int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &du
         HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, true, 0>, dim3(S.grid), dim3(TPB),
                                  S.view(A.rows), (const double *)h->xbar, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, rx, le));
     } else if (A.sj.on()) {
-      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_sj_kernel<MODE_DUAL, false, 0>, dim3(A.sj.grid), dim3(TPB),
-                               sj_view(A.sj), (const double *)h->xbar, rm, A.grid, dual_epi));
+      HIP_TRY(graph_set_kernel(G.exec, G.n_dual, sj_kernel_fn<MODE_DUAL, false, 0>(A.sj), dim3(A.sj.grid), dim3(TPB),
+                               sj_view(A.sj, rx), (const double *)h->xbar, rm, A.grid, dual_epi));
     } else if (A.pipe_grid > 0) {
       HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_pipe_kernel<MODE_DUAL, false, 0>, dim3(A.pipe_grid), dim3(TPB),
                                A.view(), (const double *)h->xbar, (const int4 *)A.ext, A.nblk, A.per_xcd, rm, rx, A.grid, dual_epi));

@@ -49,6 +49,9 @@ struct CsrDev {
   int64_t tw_entries = 0, step_ptr_len = 0;   // lengths of pk / tv and of wave_ent (checksums, tests)
   double tw_touched = 1.0;        // share of the sweep's (workgroup, tile) cells that hold entries, as build_tiled last measured it (also when it declined)
   bool tw_band = false;           // a workgroup touches < 90 % of the tiles (banded / block-local rows): row groups dealt to the XCDs in contiguous eighths
+  int tw_tuned = 0;               // tune_tiled_variant timed candidates on this matrix at create: how many; their times (ms per product) below
+  int tw_tune_mode[3] = {0, 0, 0}, tw_tune_band[3] = {0, 0, 0};
+  float tw_tune_ms[3] = {0.f, 0.f, 0.f};
   int tw_mode = 0;                // chunk accumulation: 0 lane shuffles, 1 LDS scratch (long runs, strict order), 2 relaxed order, 3 lane to lane (runs of 9 ... 32), 4 = 3 / 0 per chunk (chosen over 3 by timing: tune_tiled_variant)
   unsigned *pk = nullptr;
   double *tv = nullptr;
@@ -877,6 +880,7 @@ struct SjPlan {
   int G = 1;
   int max_len = SJ_MAX_LEN;
   double fill_narrow = 0.0, fill_wide = 0.0, hub_share = 0.0;
+  double ragged_narrow = 0.0, ragged_wide = 0.0;      // share of the form's lane-levels in slices whose longest row exceeds two batches
 };
 
 int build_sj(SjDev &J, int rows, const std::vector<int> &rowptr, const std::vector<int> &full_rowptr, int long_thr,
@@ -934,6 +938,7 @@ int build_sj(SjDev &J, int rows, const std::vector<int> &rowptr, const std::vect
   J.nhub = (int)hub.size();
   J.hub_nnz = hub_nnz;
   J.csr_rowptr = d_rowptr; J.csr_col = d_col; J.csr_val = d_val;
+  J.fill_narrow = plan.fill_narrow; J.fill_wide = plan.fill_wide; J.ragged = plan.G > 1 ? plan.ragged_wide : plan.ragged_narrow;
   int cus = 256;
   {
     int dev = 0;
@@ -962,8 +967,8 @@ int build_sj(SjDev &J, int rows, const std::vector<int> &rowptr, const std::vect
 // Which stream layouts get the sliced jagged copy, and in which form: those with more row blocks than the persistent trial
 // kernels take (trial_kernel.hpp: <= 1 024 items; such LPs are latency-bound and stay on the CSR row blocks) -- i.e. products
 // that are bandwidth work.  Rows of more than SJ_MAX_LEN entries (the long-row path's apart) are HUB rows: the kernel runs them
-// as whole-workgroup row blocks of the CSR arrays; a matrix that keeps more than a quarter of its entries there stays with
-// the CSR kernels.  The window: a wave's trip lasts as long as the longest row of its slice, so the FILL of a form is
+// as whole-workgroup row blocks of the CSR arrays; a matrix that keeps more than 2 % of its entries there stays with
+// the CSR kernels (see the end of the function).  The window: a wave's trip lasts as long as the longest row of its slice, so the FILL of a form is
 // entries / sum over slices of 64 x the slice's longest row -- for the narrow form (256-row windows, one barrier per window:
 // the four slices wait for the longest) 256 x the window's longest row.  The wide form (2 048-row windows, round 6) is taken
 // when it fills at least 0.08 more than the narrow one (Poisson or power-law lengths; rows of one length tie and keep the
@@ -981,10 +986,11 @@ inline SjPlan sj_plan(int nblk, int rows, const std::vector<int> &rowptr, const 
   if (force < 0 && nblk <= 1024) return P;
   const int wide_sigma = SJ_SIGMA * SJ_WIDE_G;
   const int nwin = (rows + wide_sigma - 1) / wide_sigma;
-  std::vector<int64_t> acc((size_t)4 * std::max(1, std::min(nwin, 64)), 0);     // per range: entries, narrow capacity, wide capacity, hub entries
+  constexpr int NACC = 6;
+  std::vector<int64_t> acc((size_t)NACC * std::max(1, std::min(nwin, 64)), 0);  // per range: entries, narrow capacity, wide capacity, hub entries, ragged narrow / wide capacity
   std::atomic<int> part_next{0};
   parallel_ranges(nwin, 64, [&](int wb, int we) {
-    int64_t entries = 0, cap_narrow = 0, cap_wide = 0, hub_entries = 0;
+    int64_t entries = 0, cap_narrow = 0, cap_wide = 0, hub_entries = 0, rag_narrow = 0, rag_wide = 0;
     std::vector<int> hist((size_t)P.max_len + 1);
     for (int w = wb; w < we; ++w) {
       const int r0 = w * wide_sigma, r1 = std::min(rows, r0 + wide_sigma);
@@ -1000,29 +1006,42 @@ inline SjPlan sj_plan(int nblk, int rows, const std::vector<int> &rowptr, const 
           entries += l;
         }
         cap_narrow += (int64_t)SJ_SIGMA * longest;
+        if (longest > 2 * SJ_U) rag_narrow += (int64_t)SJ_SIGMA * longest;
       }
       // the window's rows by decreasing length: the longest row of every 64
       int seen = 0, next_head = 0;
       for (int l = P.max_len; l >= 1; --l) {
         const int c = hist[(size_t)l];
-        while (next_head < seen + c) { cap_wide += (int64_t)WAVE * l; next_head += WAVE; }
+        while (next_head < seen + c) { cap_wide += (int64_t)WAVE * l; if (l > 2 * SJ_U) rag_wide += (int64_t)WAVE * l; next_head += WAVE; }
         seen += c;
       }
     }
-    const int k = std::min(part_next.fetch_add(1), (int)(acc.size() / 4) - 1);
+    const int k = std::min(part_next.fetch_add(1), (int)(acc.size() / NACC) - 1);
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
-    acc[(size_t)4 * k] += entries; acc[(size_t)4 * k + 1] += cap_narrow; acc[(size_t)4 * k + 2] += cap_wide; acc[(size_t)4 * k + 3] += hub_entries;
+    int64_t *a = &acc[(size_t)NACC * k];
+    a[0] += entries; a[1] += cap_narrow; a[2] += cap_wide; a[3] += hub_entries; a[4] += rag_narrow; a[5] += rag_wide;
   });
-  int64_t entries = 0, cap_narrow = 0, cap_wide = 0, hub_entries = 0;
-  for (size_t k = 0; k < acc.size() / 4; ++k) { entries += acc[4 * k]; cap_narrow += acc[4 * k + 1]; cap_wide += acc[4 * k + 2]; hub_entries += acc[4 * k + 3]; }
+  int64_t entries = 0, cap_narrow = 0, cap_wide = 0, hub_entries = 0, rag_narrow = 0, rag_wide = 0;
+  for (size_t k = 0; k < acc.size() / NACC; ++k) {
+    const int64_t *a = &acc[NACC * k];
+    entries += a[0]; cap_narrow += a[1]; cap_wide += a[2]; hub_entries += a[3]; rag_narrow += a[4]; rag_wide += a[5];
+  }
+  P.ragged_narrow = cap_narrow > 0 ? (double)rag_narrow / (double)cap_narrow : 0.0;
+  P.ragged_wide = cap_wide > 0 ? (double)rag_wide / (double)cap_wide : 0.0;
   P.fill_narrow = cap_narrow > 0 ? (double)entries / (double)cap_narrow : 0.0;
   P.fill_wide = cap_wide > 0 ? (double)entries / (double)cap_wide : 0.0;
   P.hub_share = entries + hub_entries > 0 ? (double)hub_entries / (double)(entries + hub_entries) : 0.0;
   P.G = P.fill_wide >= P.fill_narrow + 0.08 ? SJ_WIDE_G : 1;
   if (const char *wv = dev_env("PDHG_SJ_WIDE")) P.G = wv[0] != '0' ? SJ_WIDE_G : 1;
   if (force == 1) { P.use = true; return P; }
-  P.use = entries > 0 && P.hub_share <= 0.25 && (P.G > 1 ? P.fill_wide : P.fill_narrow) >= 0.4;
+  // ... and not a power-law body: a slice is walked in batches of 16 levels, one dependent round trip each whatever the
+  // number of lanes still active, so slices of 30 ... 128 levels with a handful of long rows run at the latency of their
+  // batches (PageRank-1M on this layout, hub rows split off: 0.22-0.37 ms per product against 0.10 on the CSR row blocks,
+  // profiles/r06_sj_wide.txt).  Such matrices keep the row blocks: at most a tenth of the lane-levels may sit in slices
+  // beyond two batches, at most 2 % of the entries in hub rows.
+  P.use = entries > 0 && P.hub_share <= 0.02 && (P.G > 1 ? P.fill_wide : P.fill_narrow) >= 0.4 &&
+          (P.G > 1 ? P.ragged_wide : P.ragged_narrow) <= 0.10;
   return P;
 }
 

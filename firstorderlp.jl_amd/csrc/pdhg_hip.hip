@@ -340,11 +340,11 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
         EpiArgs le = e;
         le.init = D.slab_partial;
         if (p + 1 < P && p == 0)
-          hipLaunchKernelGGL((spmv_sj_kernel<MODE_PLAIN, false, TAG>), dim3(S.sj.grid), dim3(TPB), 0, h->stream, sj_view(S.sj), xin, rm, 0, pe);
+          launch_sj<MODE_PLAIN, false, TAG>(h->stream, S.sj, xin, rm, rx, 0, pe);
         else if (p + 1 < P)
-          hipLaunchKernelGGL((spmv_sj_kernel<MODE_PLAIN, true, TAG>), dim3(S.sj.grid), dim3(TPB), 0, h->stream, sj_view(S.sj), xin, rm, 0, pe);
+          launch_sj<MODE_PLAIN, true, TAG>(h->stream, S.sj, xin, rm, rx, 0, pe);
         else
-          hipLaunchKernelGGL((spmv_sj_kernel<MODE, true, TAG>), dim3(S.sj.grid), dim3(TPB), 0, h->stream, sj_view(S.sj), xin, rm, S.grid, le);
+          launch_sj<MODE, true, TAG>(h->stream, S.sj, xin, rm, rx, S.grid, le);
         continue;
       }
       if (S.pipe_grid > 0) {  // the slab's row blocks as a persistent pipelined launch (spmv_stream_pipe_kernel)
@@ -382,8 +382,7 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
       }
     }
   } else if (D.sj.on()) {
-    hipLaunchKernelGGL((spmv_sj_kernel<MODE, false, TAG>), dim3(D.sj.grid), dim3(TPB), 0, h->stream, sj_view(D.sj), xin,
-                       h->remap ? 1 : 0, D.grid, e);
+    launch_sj<MODE, false, TAG>(h->stream, D.sj, xin, h->remap ? 1 : 0, rx, D.grid, e);
   } else if (D.pipe_grid > 0) {
     hipLaunchKernelGGL((spmv_stream_pipe_kernel<MODE, false, TAG>), dim3(D.pipe_grid), dim3(TPB), 0, h->stream, D.view(), xin,
                        (const int4 *)D.ext, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, D.grid, e);
@@ -552,7 +551,7 @@ int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int,
 extern "C" {
 
 const char *pdhg_last_error(void) { return g_last_error.c_str(); }
-int pdhg_abi_version(void) { return 10; }
+int pdhg_abi_version(void) { return 11; }
 
 // The kernels behind one fused product, as rocprofv3 prints them (template arguments <MODE,
 // INIT, TAG> / <MODE, CH> / <TAG>; MODE 0 plain, 1 dual epilogue, 2 A'y epilogue; TAG 0 = A,
@@ -567,12 +566,14 @@ static std::string product_kernels(const CsrDev &D, int mode, int tag) {
   if (D.tiled) {
     if (D.grid > 0) add("spmv_tiled_kernel<" + m + ", " + std::to_string(D.tw_mode) + ">");
   } else if (!D.slabs.empty()) {
-    const std::string k = D.slabs.front().sj.on() ? "spmv_sj_kernel<" : (D.slabs.front().pipe_grid > 0 ? "spmv_stream_pipe_kernel<" : "spmv_stream_kernel<");
-    add(k + "0, false, " + t + ">");
-    if (D.slabs.size() > 2) add(k + "0, true, " + t + ">");
-    add(k + m + ", true, " + t + ">");
+    const SjDev &J = D.slabs.front().sj;
+    const std::string k = J.on() ? "spmv_sj_kernel<" : (D.slabs.front().pipe_grid > 0 ? "spmv_stream_pipe_kernel<" : "spmv_stream_kernel<");
+    const std::string g = J.on() ? ", " + std::to_string(J.G) + ">" : ">";      // the sliced jagged kernel's fourth argument: its form (sj_kernels.hpp)
+    add(k + "0, false, " + t + g);
+    if (D.slabs.size() > 2) add(k + "0, true, " + t + g);
+    add(k + m + ", true, " + t + g);
   } else if (D.sj.on()) {
-    add("spmv_sj_kernel<" + m + ", false, " + t + ">");
+    add("spmv_sj_kernel<" + m + ", false, " + t + ", " + std::to_string(D.sj.G) + ">");
   } else if (D.pipe_grid > 0) {
     add("spmv_stream_pipe_kernel<" + m + ", false, " + t + ">");
   } else if (D.grid > 0) {

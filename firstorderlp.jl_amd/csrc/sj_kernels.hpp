@@ -61,6 +61,7 @@ struct SjDev {
   int2 *hub = nullptr;               // [nhub] (r, r + 1): hub rows, one stream-kernel row block each, on the CSR arrays below
   int nhub = 0;
   int64_t hub_nnz = 0;
+  double fill_narrow = 0.0, fill_wide = 0.0, ragged = 0.0;      // what the builder's rule measured (layout.hpp: sj_plan)
   const int *csr_rowptr = nullptr, *csr_col = nullptr;     // the CSR arrays the copy was filled from (not owned)
   const double *csr_val = nullptr;
   bool on() const { return nslices > 0; }
@@ -154,15 +155,24 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
   constexpr int SIGMA = SJ_SIGMA * G;                     // rows per window
   constexpr int SPW = (TPB / WAVE) * G;                   // slices per window
   constexpr size_t SUM_BYTES = sizeof(double) * 2 * SIGMA;
+#ifdef PDHG_SJ_NOHUB
+  constexpr size_t LDS_BYTES = SUM_BYTES;
+#else
   constexpr size_t LDS_BYTES = SUM_BYTES > sizeof(double) * BLOCK_NNZ ? SUM_BYTES : sizeof(double) * BLOCK_NNZ;
+#endif
   __shared__ double red[6][TPB / WAVE];
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];     // hub phase: prod[BLOCK_NNZ]; then row_sum[2][SIGMA]
+#ifdef PDHG_SJ_OKINT
+  __shared__ int row_ok[2][SIGMA];
+#else
   __shared__ unsigned char row_ok[2][SIGMA];
+#endif
   double (*row_sum)[SIGMA] = reinterpret_cast<double (*)[SIGMA]>(lds_raw);
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
   Acc3 acc3 = acc3_zero();
   // ---- hub rows first: one row block each, dealt round robin
+#ifndef PDHG_SJ_NOHUB
   if (J.nhub > 0) {
     double *prod = reinterpret_cast<double *>(lds_raw);
     for (int hb = (int)blockIdx.x; hb < J.nhub; hb += (int)gridDim.x) {
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
       __syncthreads();
     }
   }
+#endif
   const int ngroups = (J.nslices + SPW - 1) / SPW;
   const int per_xcd = (ngroups + NUM_XCD - 1) / NUM_XCD;
   // remap: workgroup b runs on XCD b % 8 (round-robin dispatch); it walks groups x * per_xcd + i, i = b / 8, b / 8 + gridDim / 8, ...
@@ -221,6 +232,12 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
     }
     sj_load_batch(J, off_n, l, __builtin_amdgcn_readfirstlane(l), 0, lane, B_n);
   };
+  // wide form: the epilogue operands of the window's rows (row order, G per thread), requested behind the first batch of
+  // the window's FIRST slice -- a whole window ahead of their use; requested just before the window's barrier they cost a
+  // round trip to HBM per window with nothing to hide it (A x on banded 10M 0.61 -> 0.69 ms)
+  EpiOps wo[G];
+#pragma unroll
+  for (int qq = 0; qq < G; ++qq) wo[qq] = EpiOps{0.0, 0.0, 0.0};
   Pos cur{first, group_of(first), 0};
   Pos nxt = next_pos(cur);
   request_meta(cur, w_n, off_n);
@@ -239,6 +256,14 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
     int j0 = 0;
     do {                                                  // the slice's batches (at least one trip: it requests what follows)
       double xv[SJ_U], vv[SJ_U];
+#ifndef PDHG_SJ_NOWAIT
+      // Every column index of the batch must have arrived before its gather can be issued, and loads return in order:
+      // ONE wait for all of them here costs nothing (the batch was requested a gather round trip ago) and lets the 16
+      // gathers go out back to back.  Without it the compiler, which cannot count the conditionally issued loads of
+      // sj_load_batch across the loop, put `s_waitcnt vmcnt(1)` in front of EVERY gather -- two gathers in flight per
+      // wave: banded 10M 0.61 -> 0.68 ms when round 6 restructured the loop (profiles/r06_sj_waitcnt.txt).
+      __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0), expcnt / lgkmcnt untouched
+#endif
 #pragma unroll
       for (int jj = 0; jj < SJ_U; ++jj) {
         xv[jj] = 0.0;
@@ -253,6 +278,13 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
         off_n = off_nn;
         request_meta(nxt2, w_nn, off_nn);
         request_slice(nxt);
+      }
+      if (G > 1 && cur.q == 0 && j0 == 0) {               // (wave-uniform)
+#pragma unroll
+        for (int qq = 0; qq < G; ++qq) {
+          const int row = base + qq * TPB + tid;
+          if (row < J.rows) wo[qq] = epi_load<MODE>(e, row);
+        }
       }
 #pragma unroll
       for (int jj = 0; jj < SJ_U; ++jj) {
@@ -277,15 +309,6 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
       }
       buf ^= 1;
     } else if (cur.q == G - 1) {                          // the window's last slice of this wave (the same trip for all four waves)
-      // the operands of the window's rows, in row order, requested before the barrier that delivers the sums (a row's
-      // slot is static: long and hub rows have none, rows past the matrix neither)
-      EpiOps wo[G];
-#pragma unroll
-      for (int qq = 0; qq < G; ++qq) {
-        const int row = base + qq * TPB + tid;
-        wo[qq] = EpiOps{0.0, 0.0, 0.0};
-        if (row < J.rows) wo[qq] = epi_load<MODE>(e, row);
-      }
       __syncthreads();
 #pragma unroll
       for (int qq = 0; qq < G; ++qq) {
@@ -319,6 +342,19 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
       }
     }
   }
+}
+
+// the form a copy was built in picks the kernel instance
+template <int MODE, bool INIT, int TAG>
+inline const void *sj_kernel_fn(const SjDev &J) {
+  return J.G > 1 ? (const void *)spmv_sj_kernel<MODE, INIT, TAG, SJ_WIDE_G> : (const void *)spmv_sj_kernel<MODE, INIT, TAG, 1>;
+}
+template <int MODE, bool INIT, int TAG>
+inline void launch_sj(hipStream_t stream, const SjDev &J, const double *xin, int remap, int relaxed, int stream_slots, const EpiArgs &e) {
+  if (J.G > 1)
+    hipLaunchKernelGGL((spmv_sj_kernel<MODE, INIT, TAG, SJ_WIDE_G>), dim3(J.grid), dim3(TPB), 0, stream, sj_view(J, relaxed), xin, remap, stream_slots, e);
+  else
+    hipLaunchKernelGGL((spmv_sj_kernel<MODE, INIT, TAG, 1>), dim3(J.grid), dim3(TPB), 0, stream, sj_view(J, relaxed), xin, remap, stream_slots, e);
 }
 
 }  // namespace

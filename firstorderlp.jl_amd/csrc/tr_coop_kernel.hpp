@@ -6,7 +6,7 @@
 //
 // Why.  A termination / restart check makes five such calls of four to six passes each; on the L1-SVM LP a pass is
 // 9 us of probe kernel + 4.4 us of second stage + 10-11 us of host round trip = 24 us, 30 passes = 0.72 of the check's
-// 1.07 ms under the profiler (tools/r4_eval_timeline.sh), and the checks are 30 % of a whole solve.  Here a pass is the
+// 1.07 ms under the profiler (tools/archive/r4_eval_timeline.sh), and the checks are 30 % of a whole solve.  Here a pass is the
 // probe arithmetic on elements the thread already owns + one XCD-scoped grid barrier (trial_kernel.hpp: ~3.3 us) + a
 // reduction of <= 256 block partials per quantity that every workgroup repeats for itself (so the search state -- the
 // tr_search_* machine of eval_kernels.hpp, thread 0 of every workgroup -- needs no broadcast: same sums, same

@@ -414,6 +414,17 @@ class HipPdhgEngine:
     def kernel_name(self, kernel_id):
         return self._L.pdhg_kernel_name(self._h, kernel_id).decode()
 
+    def layout_describe(self):
+        """pdhg_layout_describe: the resident layouts and every choice pdhg_create made (incl. those settled by timing)."""
+        import ctypes
+        import json
+        need = self._L.pdhg_layout_describe(self._h, None, 0)
+        if need < 0:
+            _lib.check(need)
+        buf = ctypes.create_string_buffer(need + 1)
+        self._L.pdhg_layout_describe(self._h, buf, need + 1)
+        return json.loads(buf.value.decode())
+
     def layout_info(self):
         info = np.zeros(16, dtype=np.int64)
         _lib.check(self._L.pdhg_layout_info(self._h, _pi(info)))
@@ -438,6 +449,17 @@ class HipPdhgEngine:
         # trust-region calls taken as one persistent launch (tr_coop_kernel.hpp)
         out["tr_coop_calls"] = (out["var_tiles"] >> 48) & 16383
         out["var_tiles"] &= 3
+        try:      # the sliced jagged copies of the objective matrix, the form of every copy (pdhg_layout_describe)
+            desc = self.layout_describe()
+            for k in ("A", "At", "Q", "Qt"):
+                if k in desc:
+                    sj = desc[k].get("sliced_jagged")
+                    if k in ("Q", "Qt"):
+                        out[k + "_sj"] = 1 if sj else 0
+                    out[k + "_sj_wide"] = 1 if sj and sj["slices_per_wave"] > 1 else 0
+                    out[k + "_sj_hub_rows"] = sj["hub_rows"] if sj else 0
+        except Exception:      # a diagnostic: never fail layout_info for it
+            pass
         for k in ("A", "At"):    # width in bits of an entry's column field
             out[k + "_tile_shift"] = max(1, (out[k + "_tile_cols"] - 1).bit_length()) if out[k + "_tile_cols"] else 0
         return out

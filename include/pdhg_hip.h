@@ -20,14 +20,17 @@
  *  - fp64 throughout; kernels are built with -ffp-contract=off so elementwise
  *    updates round exactly like the reference's unfused Julia broadcasts.
  *
- * Environment variables (read when a handle is created unless noted).  These 25 are the
+ * Environment variables (read when a handle is created unless noted).  These 26 are the
  * library's run-time knobs; every other PDHG_* name in the sources is a development
  * variable (tuning constants, negative-result paths, fault injection) and is IGNORED unless
  * PDHG_DEV=1 is set as well (tests/conftest.py and tools/ set it).
  *
  *   name                 values (default first)        effect
  *   PDHG_SPMV            auto | stream | tiled         force the product layout: CSR row blocks / L2-tiled sweep
- *   PDHG_SJ              auto | 0 | 1                  sliced jagged copy of stream-class matrices (csrc/sj_kernels.hpp)
+ *   PDHG_SJ              auto | 0 | 1                  sliced jagged copy of stream-class matrices (csrc/sj_kernels.hpp); any other value = auto
+ *   PDHG_TUNE            1 | 0                         settle the sweep's chunk variant / XCD dealing by timing the product at create
+ *                                                      (0: the static rules stand -- reproducible kernel names and create times;
+ *                                                      the bits are the same either way; pdhg_layout_describe reports the choice)
  *   PDHG_SLABS           auto | 0 | 1 | 2              column-slab passes of the stream layout (auto: not for banded / block-local rows; 2: also there)
  *   PDHG_SLAB_MB         4                             slab size in MiB
  *   PDHG_TILE_COLS       auto | <columns>              tile width of the sweep
@@ -424,6 +427,15 @@ const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id);
  * LDS (csrc/small_lp_kernel.hpp; pdhg_trial_step itself is launched as [14] says); bit 3: it takes
  * them with the multi-step persistent kernel (several take_steps per launch: small grids). */
 int pdhg_layout_info(pdhg_handle *h, int64_t info[16]);
+/* The resident layouts of A, A' (and Q, Q') with every choice pdhg_create made for them, as one JSON
+ * object: the product kernels, row blocks / column slabs / long rows, the sweep's tile width, chunk
+ * variant and XCD dealing WITH the candidates pdhg_create timed on the matrix and their times
+ * ("chosen_by": "timing at create" | "static rule"), the sliced jagged copy's window, hub threshold,
+ * hub rows and fill.  A handle's dispatch -- hence its timing, never its bits -- can depend on a
+ * measurement taken at create (PDHG_TUNE=0 pins the static rules): a bench line or a profile quotes
+ * this text to say which variant it ran.  Writes at most cap - 1 characters + NUL into buf (buf may be
+ * NULL); returns the full length of the text, or < 0 on error.  (abi 11) */
+int pdhg_layout_describe(pdhg_handle *h, char *buf, int cap);
 /* Diagnostics: order-sensitive 64-bit checksums of every device array of the two layouts
  * (out[0..16) CSR(A): row pointers, columns, values, row blocks, the four long-row tables, the
  * sweep's pk / tv / wave rows / entry offsets / step offsets / step tiles / workgroup steps, the

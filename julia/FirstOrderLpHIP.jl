@@ -26,7 +26,7 @@ using SparseArrays
 import Random
 
 const LIB = get(ENV, "PDHG_HIP_LIB", "libpdhg_hip.so")
-const ABI_VERSION = 10
+const ABI_VERSION = 11
 const POINT_CURRENT = Cint(0)
 const POINT_AVERAGE = Cint(1)
 const POINT_RESTART = Cint(2)
@@ -494,6 +494,35 @@ function bound(s::HipSolverState, objective_constant, point, primal_w, dual_w, r
 end
 
 """
+Several `bound_optimal_objective` problems of one check at once: `requests = [(point, radius), ...]` gives one
+OptimalObjectiveBoundResult each -- the very numbers `bound` returns one by one.  Euclidean norm: up to three problems per
+`pdhg_trust_region_bounds` call (the average, the current iterate and the last restart point of a restart check,
+saddle_point.jl:432-496, 551-596: on medium single handles their searches share one persistent launch); MAX_NORM: the
+primal and the dual half of one point share a call.
+"""
+function bounds(s::HipSolverState, objective_constant, requests, primal_w, dual_w, norm, approximate = false)
+  out = FirstOrderLp.OptimalObjectiveBoundResult[]
+  if norm == FirstOrderLp.EUCLIDEAN_NORM
+    for i in 1:3:length(requests)
+      chunk = requests[i:min(i + 2, length(requests))]
+      rows = trust_region_bounds(s, Cint[p for (p, _) in chunk], primal_w, dual_w, Float64[r for (_, r) in chunk],
+                                 zeros(Cint, length(chunk)), approximate)
+      for k in 1:length(chunk)
+        lag = rows[1, k] + objective_constant
+        push!(out, FirstOrderLp.OptimalObjectiveBoundResult(lag, lag + rows[2, k], lag - rows[3, k], Float64[], Float64[]))
+      end
+    end
+    return out
+  end
+  for (point, radius) in requests
+    rows = trust_region_bounds(s, Cint[point, point], primal_w, dual_w, Float64[radius, radius], Cint[1, 2], approximate)
+    lag = rows[1, 1] + objective_constant
+    push!(out, FirstOrderLp.OptimalObjectiveBoundResult(lag, lag + rows[2, 1], lag - rows[3, 2], Float64[], Float64[]))
+  end
+  return out
+end
+
+"""
 compute_iteration_stats (iteration_stats_utils.jl:356-407) assembled from the raw
 sums / maxes of pdhg_eval_point on the UNSCALED point (evaluate_unscaled_iteration_stats,
 :413-451).  Index map: include/pdhg_hip.h, pdhg_eval_point.
@@ -586,18 +615,27 @@ function run_restart_scheme(s::HipSolverState, objective_constant, lri::HipResta
   average_distance_sq = nothing
   candidate_localized_gap = nothing
   candidate_distance_traveled = nothing
+  gap_at_last_restart = nothing
   reset_to_average = false
   if rp.restart_scheme != FirstOrderLp.NO_RESTARTS
-    # compute_localized_duality_gaps (:432-496): weighted_norm(v, w)^2 == w * sum(v.^2)
+    # compute_localized_duality_gaps (:432-496): weighted_norm(v, w)^2 == w * sum(v.^2).  The bounds at the average and at
+    # the current iterate -- and, for the adaptive-normalized test below (:551-596), the one at the last restart point --
+    # are ONE request (pdhg_trust_region_bounds): the same numbers as three `bound` calls, one persistent launch.
     dx2, dy2 = distance_sq_to_restart(s, POINT_AVERAGE)
     average_distance_sq = (dx2, dy2)
     distance_traveled_by_average = sqrt(primal_w * dx2 + dual_w * dy2)
-    gap_at_average = bound(s, objective_constant, POINT_AVERAGE, primal_w, dual_w,
-                           distance_traveled_by_average, FirstOrderLp.EUCLIDEAN_NORM, approx)
     cx2, cy2 = distance_sq_to_restart(s, POINT_CURRENT)
     distance_traveled_by_current = sqrt(primal_w * cx2 + dual_w * cy2)
-    gap_at_current = bound(s, objective_constant, POINT_CURRENT, primal_w, dual_w,
-                           distance_traveled_by_current, FirstOrderLp.EUCLIDEAN_NORM, approx)
+    requests = Tuple{Cint,Float64}[(POINT_AVERAGE, distance_traveled_by_average), (POINT_CURRENT, distance_traveled_by_current)]
+    if !do_restart && rp.restart_scheme == FirstOrderLp.ADAPTIVE_NORMALIZED
+      distance_traveled_last_restart = sqrt(
+        lri.primal_distance_moved_last_restart_period^2 * primal_weight +
+        lri.dual_distance_moved_last_restart_period^2 / primal_weight)
+      push!(requests, (POINT_RESTART, distance_traveled_last_restart))
+    end
+    gaps = bounds(s, objective_constant, requests, primal_w, dual_w, FirstOrderLp.EUCLIDEAN_NORM, approx)
+    gap_at_average, gap_at_current = gaps[1], gaps[2]
+    gap_at_last_restart = length(gaps) >= 3 ? gaps[3] : nothing
     reset_to_average = FirstOrderLp.should_reset_to_average(
       gap_at_current, distance_traveled_by_current, gap_at_average, distance_traveled_by_average,
       rp.restart_to_current_metric)
@@ -617,8 +655,7 @@ function run_restart_scheme(s::HipSolverState, objective_constant, lri::HipResta
       distance_traveled_last_restart = sqrt(
         lri.primal_distance_moved_last_restart_period^2 * primal_weight +
         lri.dual_distance_moved_last_restart_period^2 / primal_weight)
-      last_restart = bound(s, objective_constant, POINT_RESTART, primal_w, dual_w,
-                           distance_traveled_last_restart, FirstOrderLp.EUCLIDEAN_NORM, approx)
+      last_restart = gap_at_last_restart        # (requested with the two candidates above)
       normalized_candidate_gap = FirstOrderLp.get_gap(candidate_localized_gap) / candidate_distance_traveled
       normalized_last_restart_gap = FirstOrderLp.get_gap(last_restart) / distance_traveled_last_restart
       gap_reduction_ratio = normalized_candidate_gap / normalized_last_restart_gap
@@ -694,9 +731,10 @@ function update_objective_bound_estimates(method_specific_stats, s::HipSolverSta
   sx2, sy2 = point_sumsq(s, point)
   estimated_primal_distance_to_optimality = max(1e-8, sqrt(primal_w * sx2))
   estimated_dual_distance_to_optimality = max(1e-8, sqrt(dual_w * sy2))
-  gap = bound(s, objective_constant, point,
-              primal_w / estimated_primal_distance_to_optimality^2,
-              dual_w / estimated_dual_distance_to_optimality^2, 1.0, FirstOrderLp.MAX_NORM, false)
+  # (through `bounds`: the primal and the dual half of MAX_NORM are two trust-region problems, one launch on the device)
+  gap = bounds(s, objective_constant, Tuple{Cint,Float64}[(Cint(point), 1.0)],
+               primal_w / estimated_primal_distance_to_optimality^2,
+               dual_w / estimated_dual_distance_to_optimality^2, FirstOrderLp.MAX_NORM, false)[1]
   method_specific_stats["lagrangian_value"] = gap.lagrangian_value
   method_specific_stats["estimated_lower_bound"] = gap.lower_bound_value
   method_specific_stats["estimated_upper_bound"] = gap.upper_bound_value
@@ -900,6 +938,15 @@ function layout_info(s::HipSolverState)
   info = zeros(Int64, 16)
   check(ccall((:pdhg_layout_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), s.handle, info))
   return info
+end
+
+"The resident layouts and every choice `pdhg_create` made for them, timed ones included, as JSON text (`pdhg_layout_describe`)."
+function layout_describe(s::HipSolverState)
+  need = ccall((:pdhg_layout_describe, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint), s.handle, C_NULL, Cint(0))
+  need >= 0 || check(need)
+  buf = zeros(UInt8, need + 1)
+  ccall((:pdhg_layout_describe, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint), s.handle, buf, Cint(need + 1))
+  return unsafe_string(pointer(buf))
 end
 
 function measure_triad(s::HipSolverState, len::Int64 = 1 << 26, reps::Int = 5)

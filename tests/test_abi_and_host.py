@@ -27,7 +27,7 @@ def test_header_symbols_all_exported():
     L = ctypes.CDLL(_lib.LIB_PATH)       # loads without a GPU
     for name in declared:
         assert hasattr(L, name), f"{name} not exported by libpdhg_hip.so"
-    assert _lib.lib().pdhg_abi_version() == _lib.ABI_VERSION == 10
+    assert _lib.lib().pdhg_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_create_fails_loudly_without_gpu():

@@ -41,8 +41,12 @@ def _ragged_lp(m, n, seed):
     return linear_programming_problem(np.zeros(n), np.full(n, 5.0), rng.standard_normal(n), 0.0, A, rng.standard_normal(m), m // 3)
 
 
-def _engine(p, monkeypatch, sj, graph="1", slab_mb=None):
+def _engine(p, monkeypatch, sj, graph="1", slab_mb=None, wide=None):
     monkeypatch.setenv("PDHG_SPMV", "stream")
+    if wide is None:
+        monkeypatch.delenv("PDHG_SJ_WIDE", raising=False)
+    else:
+        monkeypatch.setenv("PDHG_SJ_WIDE", wide)         # dev: 0 = 256-row windows, 1 = 2 048-row windows (round 6)
     monkeypatch.setenv("PDHG_COOP", "0")                 # the products as their own kernels (graph nodes or plain launches)
     monkeypatch.setenv("PDHG_GRAPH", graph)
     monkeypatch.setenv("PDHG_SJ", sj)
@@ -66,19 +70,26 @@ def _run(e, p, steps=40):
                                    lambda: H.skewed_lp(3_000, 9_000, seed=7, dense_rows=2, dense_cols=2),
                                    lambda: random_lp(70, 50, 3, seed=1)],
                          ids=["random", "ragged", "skewed_long_rows", "tiny"])
-def test_products_are_bit_identical_to_the_oracle_in_every_row_order(gpu_required, monkeypatch, maker):
+@pytest.mark.parametrize("wide", ["0", "1"], ids=["narrow", "wide"])
+def test_products_are_bit_identical_to_the_oracle_in_every_row_order(gpu_required, monkeypatch, row_order_mode, maker, wide):
+    """Rows a lane walks (<= 128 entries) are the oracle's bits in BOTH row orders; hub rows (129 ... 2 048 entries: whole-workgroup
+    row blocks of the CSR arrays, round 6) follow the CSR kernel's rule -- bitwise up to 256 entries, and up to 2 048 in strict
+    order; relaxed order sums rows beyond 256 entries by their wave (1e-13 * sum |a x|)."""
     p = maker()
     A = p.constraint_matrix
     m, n = A.shape
-    eng = _engine(p, monkeypatch, "1")
+    eng = _engine(p, monkeypatch, "1", wide=wide)
     info = eng.layout_info()
-    assert info["A_sj"] == 1 and info["At_sj"] == 1, info
+    assert info["A_sj"] == 1 and info["At_sj"] == 1 and info["A_sj_wide"] == int(wide) and info["At_sj_wide"] == int(wide), info
+    hubs = int(((np.diff(A.tocsr().indptr) > 128) & (np.diff(A.tocsr().indptr) <= 2048)).sum())
+    assert info["A_sj_hub_rows"] == hubs, (info, hubs)
+    exact_to = 2048 if row_order_mode == "strict" else 256
     rng = np.random.default_rng(1)
     x, y = rng.standard_normal(n), rng.standard_normal(m)
     absA = abs(A).tocsr()
     for got, want, nnz_per, scale in ((eng.spmv(x), orc.spmv(m, n, A.indptr, A.indices, A.data, x), np.diff(A.tocsr().indptr), absA @ np.abs(x)),
                                       (eng.spmv_t(y), orc.spmv_t(m, n, A.indptr, A.indices, A.data, y), np.diff(A.indptr), absA.T @ np.abs(y))):
-        short = nnz_per <= 2048                           # every row of the layout, whatever PDHG_ROW_ORDER says
+        short = nnz_per <= exact_to
         assert np.array_equal(got[short], want[short])
         assert np.all(np.abs(got - want) <= 1e-13 * scale + 1e-300)      # the long-row kernels
     # the fused products: one trial against the oracle's trial
@@ -88,7 +99,7 @@ def test_products_are_bit_identical_to_the_oracle_in_every_row_order(gpu_require
     raw_o, xn, yn, an = st.trial_step(step, pw, 1.0)
     gx, gy, ga = eng.get_trial()
     assert np.array_equal(gx, xn)
-    short_r, short_c = np.diff(A.tocsr().indptr) <= 2048, np.diff(A.indptr) <= 2048
+    short_r, short_c = np.diff(A.tocsr().indptr) <= exact_to, np.diff(A.indptr) <= exact_to
     assert np.array_equal(gy[short_r], yn[short_r]) and np.allclose(gy, yn, rtol=1e-12, atol=1e-12)
     if short_r.all():
         assert np.array_equal(ga[short_c], an[short_c])
@@ -98,10 +109,11 @@ def test_products_are_bit_identical_to_the_oracle_in_every_row_order(gpu_require
 
 @pytest.mark.parametrize("maker", [lambda: random_lp(30_000, 20_000, 6, seed=21), lambda: _ragged_lp(5_000, 7_001, seed=2)],
                          ids=["random", "ragged"])
-def test_trajectories_equal_the_csr_row_block_layout(gpu_required, monkeypatch, row_order_mode, maker):
+@pytest.mark.parametrize("wide", ["0", "1"], ids=["narrow", "wide"])
+def test_trajectories_equal_the_csr_row_block_layout(gpu_required, monkeypatch, row_order_mode, maker, wide):
     p = maker()
-    r_sj = _run(_engine(p, monkeypatch, "1"), p)
-    r_sj_plain = _run(_engine(p, monkeypatch, "1", graph="0"), p)
+    r_sj = _run(_engine(p, monkeypatch, "1", wide=wide), p)
+    r_sj_plain = _run(_engine(p, monkeypatch, "1", graph="0", wide=wide), p)
     r_csr = _run(_engine(p, monkeypatch, "0"), p)
     for a, b, c in zip(r_sj, r_sj_plain, r_csr):
         assert np.array_equal(a, b)                       # graph nodes vs plain launches
@@ -113,18 +125,20 @@ def test_trajectories_equal_the_csr_row_block_layout(gpu_required, monkeypatch, 
 
 @pytest.mark.parametrize("maker,slab_mb", [(lambda: random_lp(200_000, 150_000, 8, seed=3), 0.5),
                                            (lambda: pagerank_lp(120_000, seed=4), 0.3)], ids=["random", "pagerank"])
-def test_slab_passes_on_the_sliced_jagged_copies(gpu_required, monkeypatch, row_order_mode, maker, slab_mb):
+@pytest.mark.parametrize("wide", ["0", "1"], ids=["narrow", "wide"])
+def test_slab_passes_on_the_sliced_jagged_copies(gpu_required, monkeypatch, row_order_mode, maker, slab_mb, wide):
     p = maker()
     A = p.constraint_matrix
     m, n = A.shape
-    eng = _engine(p, monkeypatch, "1", slab_mb=slab_mb)
+    eng = _engine(p, monkeypatch, "1", slab_mb=slab_mb, wide=wide)
     info = eng.layout_info()
     assert 2 <= info["A_slabs"] <= 4 and 2 <= info["At_slabs"] <= 4 and info["A_sj"] == 1 and info["At_sj"] == 1, info
     rng = np.random.default_rng(1)
     x, y = rng.standard_normal(n), rng.standard_normal(m)
     ref, ref_t = orc.spmv(m, n, A.indptr, A.indices, A.data, x), orc.spmv_t(m, n, A.indptr, A.indices, A.data, y)
     got, got_t = eng.spmv(x), eng.spmv_t(y)
-    short, short_t = np.diff(A.tocsr().indptr) <= 2048, np.diff(A.indptr) <= 2048
+    exact_to = 2048 if row_order_mode == "strict" else 256       # hub rows (> 128 entries inside a slab) follow the CSR kernel's rule
+    short, short_t = np.diff(A.tocsr().indptr) <= exact_to, np.diff(A.indptr) <= exact_to
     assert np.array_equal(got[short], ref[short]) and np.array_equal(got_t[short_t], ref_t[short_t])
     r_sj = _run(eng, p)
     r_csr = _run(_engine(p, monkeypatch, "0", slab_mb=slab_mb), p)
@@ -164,6 +178,8 @@ def test_the_builder_picks_the_layout_for_bandwidth_bound_stream_matrices(gpu_re
     eng = HipPdhgEngine.from_problem(p)
     info = eng.layout_info()
     assert info["A_tiled_waves"] == 0 and info["A_blocks"] > 1024 and info["A_sj"] == 1 and info["At_sj"] == 1, info
+    # rows of one length keep the 256-row windows; Poisson column counts fill 2 048-row windows better (round 6)
+    assert info["A_sj_wide"] == 0 and info["At_sj_wide"] == 1, (info, eng.layout_describe())
     assert "spmv_sj_kernel" in eng.kernel_name(1) and "spmv_sj_kernel" in eng.kernel_name(2)
     H.assert_products_match_oracle(eng, p.constraint_matrix, rng.standard_normal(n), rng.standard_normal(m), label="banded")
     r_auto = _run(eng, p, 20)
@@ -204,3 +220,52 @@ def test_device_rescaling_reaches_the_hessians_sliced_jagged_copies(gpu_required
     assert all(np.array_equal(u, v) for u, v in zip(sj.get_trial(), csr.get_trial()))
     for a, c in zip(_run(sj, p, 30), _run(csr, p, 30)):
         assert np.array_equal(a, c)
+
+
+def test_power_law_rows_with_hub_rows_split_off(gpu_required, monkeypatch, row_order_mode):
+    """PageRank LP (generate_pagerank_lp.jl:48-73), 300 000 nodes: rows of 5 ... ~2 000 entries by a power law and one
+    dense row.  Round 6 can RUN it on the layout -- rows beyond 128 entries are hub rows (whole-workgroup row blocks inside
+    the same kernel), the rest sorted inside 2 048-row windows -- and measured that it should not (0.22-0.37 ms per product
+    on PageRank-1M against 0.10 on the CSR row blocks: a third of the lane-levels sit in slices of 30 ... 128 levels, walked at
+    the latency of their batches), so the builder's rule declines it (`ragged_share`); forced, the products are the oracle's
+    and 25 free-running steps the CSR row blocks'."""
+    monkeypatch.delenv("PDHG_SJ", raising=False)
+    monkeypatch.delenv("PDHG_SJ_WIDE", raising=False)
+    p = pagerank_lp(300_000, seed=5)
+    auto = HipPdhgEngine.from_problem(p)
+    assert auto.layout_info()["A_sj"] == 0 and auto.layout_info()["At_sj"] == 0, auto.layout_describe()
+    monkeypatch.setenv("PDHG_SJ", "1")
+    eng = HipPdhgEngine.from_problem(p)
+    info, desc = eng.layout_info(), eng.layout_describe()
+    assert info["A_tiled_waves"] == 0 and info["A_sj"] == 1 and info["At_sj"] == 1, desc
+    assert info["A_sj_wide"] == 1 and info["At_sj_wide"] == 1 and info["A_sj_hub_rows"] > 0 and info["A_long_rows"] == 1, desc
+    sj = desc["A"]["sliced_jagged"]
+    assert sj["fill_wide"] > sj["fill_narrow"] + 0.08 and sj["hub_threshold"] == 128 and sj["ragged_share"] > 0.10, sj
+    assert "spmv_sj_kernel" in eng.kernel_name(1) and ", 8>" in eng.kernel_name(1)
+    rng = np.random.default_rng(3)
+    H.assert_products_match_oracle(eng, p.constraint_matrix, rng.standard_normal(eng.n), rng.standard_normal(eng.m), label="pagerank-300k")
+    r_sj = _run(eng, p, 25)
+    r_csr = _run(auto, p, 25)
+    for a, c in zip(r_sj, r_csr):
+        if row_order_mode == "strict":
+            assert np.array_equal(a, c)
+        else:
+            np.testing.assert_allclose(a, c, rtol=1e-9, atol=1e-9)
+
+
+def test_layout_describe_reports_the_timed_choices(gpu_required, monkeypatch):
+    """pdhg_layout_describe (abi 11): the sweep's chunk variant / XCD dealing with the candidates pdhg_create timed on the
+    matrix, and PDHG_TUNE=0 pinning the static rule (advisor r5: the dispatch of a handle must be reportable and pinnable)."""
+    monkeypatch.setenv("PDHG_SPMV", "tiled")
+    p = random_lp(400_000, 300_000, 10, seed=8)
+    d = HipPdhgEngine.from_problem(p).layout_describe()
+    for k in ("A", "At"):
+        sw = d[k]["sweep"]
+        assert d[k]["layout"] == "sweep" and sw["waves"] > 0 and sw["xcd_dealing"] in ("round robin", "contiguous eighths")
+        assert sw["chosen_by"] in ("timing at create (tune_tiled_variant)", "static rule")
+        if sw["chosen_by"].startswith("timing"):
+            assert len(sw["candidates"]) >= 2 and all(c["ms"] > 0 for c in sw["candidates"])
+    assert d["timing_at_create"] is True
+    monkeypatch.setenv("PDHG_TUNE", "0")
+    d0 = HipPdhgEngine.from_problem(p).layout_describe()
+    assert d0["timing_at_create"] is False and all(d0[k]["sweep"]["chosen_by"] == "static rule" and not d0[k]["sweep"]["candidates"] for k in ("A", "At"))

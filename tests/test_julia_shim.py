@@ -191,3 +191,20 @@ def test_ccall_checker_rejects_a_splatted_type_tuple():
                          "(Ptr{Cvoid}, Float64, Float64, Ptr{Float64}),\n    s.handle, step_size, primal_weight, theta, out))", 1)
     assert wrong != shim
     assert any("argument types, the prototype has" in p for p in check_ccalls(wrong, header))
+
+
+def test_the_restart_check_asks_for_its_bounds_in_one_request():
+    """VERDICT r5 #6a: the shim's run_restart_scheme (saddle_point.jl:688-846) must take the bounds at the average, the
+    current iterate and the last restart point through `bounds` -> pdhg_trust_region_bounds (one persistent launch on
+    medium handles), as evaluation.py / saddle_point.py do -- not through three single `bound` calls; likewise the two
+    halves of MAX_NORM in update_objective_bound_estimates (:1015-1047)."""
+    import os
+    import re
+    shim = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "julia", "FirstOrderLpHIP.jl")).read()
+    body = shim[shim.index("function run_restart_scheme("):shim.index("\"compute_new_primal_weight")]
+    assert len(re.findall(r"\bbounds\(s,", body)) == 1 and not re.findall(r"\bbound\(s,", body), "run_restart_scheme must batch its bounds"
+    assert "POINT_RESTART, distance_traveled_last_restart" in body and "gap_at_last_restart" in body
+    est = shim[shim.index("function update_objective_bound_estimates("):shim.index("\"estimate_maximum_singular_value")]
+    assert "bounds(s," in est and "FirstOrderLp.MAX_NORM" in est and not re.findall(r"\bbound\(s,", est)
+    helper = shim[shim.index("function bounds(s::HipSolverState"):shim.index("compute_iteration_stats (iteration_stats_utils.jl")]
+    assert helper.count("trust_region_bounds(s,") == 2 and ":pdhg_trust_region_bounds" in shim

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Drives the shard pool (csrc/dist.hpp: one issuing host thread per shard, peer-kernel back end, several shards on ONE
-GPU) through libpdhg_hip_tsan.so.  Run by tools/r4_tsan_shards.sh with the TSan runtime preloaded; prints TSAN_DRIVE_OK
+GPU) through libpdhg_hip_tsan.so.  Run by tools/archive/r4_tsan_shards.sh with the TSan runtime preloaded; prints TSAN_DRIVE_OK
 when the run itself worked -- ThreadSanitizer's reports, if any, go to stderr / the log file."""
 import os
 import sys
