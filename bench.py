@@ -112,6 +112,10 @@ def parse():
                          "roofline.kernel_ms_rocprof / roofline.traffic from THIS run (tools/selfprof.py); the committed "
                          "files under profiles/ are quoted instead")
     ap.add_argument("--no-vendor", action="store_true", help="skip the rocSPARSE comparator (roofline.vendor_spmv_ms)")
+    ap.add_argument("--dist-overlap", action="store_true",
+                    help="N > 1: run the exchange overlapped with the products -- xbar's all-gather in column chunks beside A_p xbar "
+                         "(PDHG_DIST_AG_OVERLAP=1) and per-slice reductions beside A_p'y' (PDHG_DIST_OVERLAP=1).  Off by default: "
+                         "both have only ever run over the test transport")
     ap.add_argument("--no-details", action="store_true",
                     help="do not write bench_details.json (the short child runs of tools/selfprof.py: the parent's record is the one kept)")
     ap.add_argument("--replay", metavar="DETAILS_JSON", default=None,
@@ -599,15 +603,20 @@ GATHER_RATE_G = 130.0             # nonzeros per ns the product kernels reach on
 STREAM_TBPS = 5.5                 # the box's streaming triad
 
 
-def scaling_model(m, n, nnz, world, trials_per_step=1.0):
+def scaling_model(m, n, nnz, world, trials_per_step=1.0, ag_chunks=4):
     """Strong scaling of one adaptive take_step on the 1-D row partition: per trial every GPU runs
     1/P of the kernels, receives (P-1) slices of xbar (all-gather) and sends (P-1) slices of A_p'y_p (reduce-scatter);
     on the fully connected xGMI node every slice has a link of its own, so a collective costs one slice over one link,
-    and all 7 links are only busy at P = 8."""
+    and all 7 links are only busy at P = 8.  Four forms of the same trial: nothing overlapped (the library's default on
+    RCCL), the all-gather cut into `ag_chunks` column chunks beside A_p xbar (PDHG_DIST_AG_OVERLAP=1, round 6), that and
+    the per-slice reductions beside A_p'y' (PDHG_DIST_OVERLAP=1), and the ideal (every byte hidden)."""
     S = max(16, ((n + world - 1) // world + 15) // 16 * 16)       # slice stride (init_group_geometry)
     slice_bytes = 8 * S
     links = min(world - 1, XGMI_LINKS)
-    kernel_ms = lambda p: 1e3 * (2 * (nnz / p) / (GATHER_RATE_G * 1e9) + 8 * (13 * n + 6 * m) / p / (STREAM_TBPS * 1e12))  # noqa: E731
+    prod_ms = lambda p: 1e3 * (nnz / p) / (GATHER_RATE_G * 1e9)                       # noqa: E731  one product's gathers
+    vec_n_ms = lambda p: 1e3 * 8 * 13 * n / p / (STREAM_TBPS * 1e12)                  # noqa: E731  primal step + interaction sums
+    vec_m_ms = lambda p: 1e3 * 8 * 6 * m / p / (STREAM_TBPS * 1e12)                   # noqa: E731  the dual step fused into A_p xbar
+    kernel_ms = lambda p: 2 * prod_ms(p) + vec_n_ms(p) + vec_m_ms(p)                  # noqa: E731
     one = kernel_ms(1)
     out = {"partition": f"1-D rows x{world}, owned column slices of {S}", "xgmi_bytes_per_trial_per_gpu": {
                "all_gather_xbar_received": (world - 1) * slice_bytes, "reduce_scatter_sent": (world - 1) * slice_bytes,
@@ -621,16 +630,29 @@ def scaling_model(m, n, nnz, world, trials_per_step=1.0):
                    predicted_speedup=1.0)
         return out
     floor = 2 * 1e3 * slice_bytes / (XGMI_LINK_GBPS_PEAK * 1e9)            # both collectives at the link's peak
-    coll = 2 * 1e3 * slice_bytes / (XGMI_LINK_GBPS_ASSUMED * 1e9) + 0.03   # + launch / synchronisation of 3 collectives
-    serial = kernel_ms(world) + coll                  # what csrc/dist.hpp does today for the all-gather; the RS overlaps
-    overlapped = max(kernel_ms(world), coll) + 0.02   # every byte hidden behind a kernel or vice versa
+    one_coll = 1e3 * slice_bytes / (XGMI_LINK_GBPS_ASSUMED * 1e9) + 0.015  # one collective: a slice over a link + launch / synchronisation
+    coll = 2 * one_coll
+    P = world
+    pipe = lambda a, b, k: (a + b) / k + (k - 1) / k * max(a, b)           # noqa: E731  two stages cut into k pieces, piece i+1 of one beside piece i of the other
+    dual = prod_ms(P) + vec_m_ms(P)
+    carry = 1e3 * 16 * (m / P) * (ag_chunks - 1) / (STREAM_TBPS * 1e12)    # the row sums written and read back between the passes
+    serial = kernel_ms(P) + coll                                           # csrc/dist.hpp's default on RCCL
+    ag_ov = vec_n_ms(P) + pipe(one_coll + 0.01 * (ag_chunks - 1), dual + carry, ag_chunks) + prod_ms(P) + one_coll
+    both_ov = vec_n_ms(P) + pipe(one_coll + 0.01 * (ag_chunks - 1), dual + carry, ag_chunks) + pipe(prod_ms(P), one_coll + 0.01 * (P - 1), P)
+    overlapped = max(kernel_ms(P), coll) + 0.02                            # every byte hidden behind a kernel or vice versa
+    forms = {"no_overlap": serial, "ag_overlap": ag_ov, "ag_and_rs_overlap": both_ov, "full_overlap": overlapped}
+    ag_on = os.environ.get("PDHG_DIST_AG_OVERLAP", "0") == "1"
+    rs_on = os.environ.get("PDHG_DIST_OVERLAP", "0") == "1"
+    as_built = "ag_and_rs_overlap" if ag_on and rs_on else "ag_overlap" if ag_on else "no_overlap"
     out.update(link_floor_ms_per_trial=round(floor, 4), collectives_ms_per_trial=round(coll, 4),
-               predicted_ms_per_step={"no_overlap": round(serial * trials_per_step, 4), "full_overlap": round(overlapped * trials_per_step, 4)},
-               predicted_it_per_s={"no_overlap": round(1e3 / (serial * trials_per_step), 1),
-                                   "full_overlap": round(1e3 / (overlapped * trials_per_step), 1)},
-               predicted_speedup={"no_overlap": round(one / serial, 2), "full_overlap": round(one / overlapped, 2),
-                                  "at_link_peak_full_overlap": round(one / (max(kernel_ms(world), floor) + 0.02), 2)},
-               efficiency={"no_overlap": round(one / serial / world, 3), "full_overlap": round(one / overlapped / world, 3)},
+               ag_chunks=ag_chunks, as_built=as_built,
+               as_built_note="the form THIS run's environment selects (PDHG_DIST_AG_OVERLAP / PDHG_DIST_OVERLAP; both default off on "
+                             "RCCL: the overlapped forms have only ever run over the test transport, bench.py --dist-overlap turns them on)",
+               predicted_ms_per_step={k: round(v * trials_per_step, 4) for k, v in forms.items()},
+               predicted_it_per_s={k: round(1e3 / (v * trials_per_step), 1) for k, v in forms.items()},
+               predicted_speedup=dict({k: round(one / v, 2) for k, v in forms.items()},
+                                      at_link_peak_full_overlap=round(one / (max(kernel_ms(P), floor) + 0.02), 2)),
+               efficiency={k: round(one / v / P, 3) for k, v in forms.items()},
                note="a 10-per-row LP moves as many bytes over xGMI per trial (16 n (P-1)/P) as through one GPU's HBM share "
                     "(24 nnz / P): the >= 6x target at P = 8 is above what the links allow for this partition (DESIGN.md section 5 "
                     "prices the 2-D alternative: same bytes per link, more phases)")
@@ -680,7 +702,7 @@ def _compact_model(sm):
     for key in ("predicted_it_per_s", "predicted_speedup"):
         if key in sm:
             out[key] = sm[key]
-    for key in ("kernel_ms_per_trial", "collectives_ms_per_trial", "link_floor_ms_per_trial", "as_built"):
+    for key in ("kernel_ms_per_trial", "collectives_ms_per_trial", "link_floor_ms_per_trial", "as_built", "ag_chunks"):
         if key in sm:
             out[key] = sm[key]
     if "at_2_4_8_gpus" in sm:
@@ -803,6 +825,9 @@ def multi_gpu_failure(args, world, rank, exc, real_stdout):
 
 def main():
     args = parse()
+    if args.dist_overlap:
+        os.environ["PDHG_DIST_AG_OVERLAP"] = "1"
+        os.environ["PDHG_DIST_OVERLAP"] = "1"
     if args.replay:
         with open(args.replay) as fh:
             full = json.load(fh)

@@ -355,6 +355,17 @@ int pdhg_layout_describe(pdhg_handle *h, char *buf, int cap) {
   if (!h) return fail(-1, "null handle");
   std::string out = "{\"A\": " + describe_matrix(h, h->A, MODE_DUAL, 0) + ", \"At\": " + describe_matrix(h, h->At, h->grp ? MODE_PLAIN : MODE_ATY, 1);
   if (h->has_q) out += ", \"Q\": " + describe_matrix(h, h->Q, MODE_PLAIN, 2) + ", \"Qt\": " + describe_matrix(h, h->Qt, MODE_PLAIN, 2);
+  if (h->grp && !h->Achunk.empty()) {
+    // the all-gather of xbar cut into column chunks, A_p xbar as one pass per chunk (dist.hpp: DistGroup::ag_chunks)
+    char b[256];
+    snprintf(b, sizeof b, ", \"all_gather\": {\"chunks\": %d, \"mode\": \"%s\", \"columns_per_rank_and_chunk\": %lld, \"passes\": [",
+             (int)h->Achunk.size(), (h->grp->ag_mode == 1 && h->grp->backend == COMM_RCCL) ? "overlapped with A_p xbar" : "passes behind one all-gather",
+             (long long)h->grp->ag_sub);
+    out += b;
+    for (size_t c = 0; c < h->Achunk.size(); ++c)
+      out += (c ? ", " : "") + describe_matrix(h, h->Achunk[c], c + 1 < h->Achunk.size() ? MODE_PLAIN : MODE_DUAL, 0);
+    out += "]}";
+  }
   const char *tv = getenv("PDHG_TUNE");
   out += std::string(", \"row_order\": \"") + (h->relaxed ? "relaxed" : "strict") + "\", \"timing_at_create\": " + ((tv && tv[0] == '0') ? "false" : "true") + "}";
   if (buf && cap > 0) {

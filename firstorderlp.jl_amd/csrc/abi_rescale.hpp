@@ -69,6 +69,7 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
   };
   scale_one(h->A, t.inv_e, t.inv_d, 0);
   scale_one(h->At, t.inv_e, t.inv_d, 1);
+  for (CsrDev &D : h->Achunk) scale_one(D, t.inv_e, t.inv_d, 0);       // the column-chunk layouts of a shard group (dist.hpp)
   if (h->has_q) {
     // objective_matrix = (D^-1 Q) D^-1 (preprocess.jl:562-564); Qt holds Q' entry by entry, so the
     // "transposed" order reproduces the same two roundings on it

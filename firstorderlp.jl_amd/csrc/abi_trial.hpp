@@ -38,10 +38,23 @@ static int trial_shard_mt(DistGroup &g, pdhg_handle *s, int i, const TrialArgs &
   int rc;
   if (a.primal) { if ((rc = launch_primal(s, a.step_size / a.primal_weight, a.theta, true))) return rc; }
   else if ((rc = launch_xbar(s, a.theta))) return rc;
-  if ((rc = mt_all_gather(g, s, i, [](pdhg_handle *q) { return q->xbar; }, g.S))) return rc;
-  if (s->has_q && (rc = mt_all_gather(g, s, i, [](pdhg_handle *q) { return q->x_next; }, g.S))) return rc;
   const double sigma = a.primal_weight * a.step_size;
-  if ((rc = launch_dual(s, sigma))) return rc;
+  if (g.ag_chunks > 1 && !s->has_q) {
+    // xbar chunk by chunk, A_p xbar as one pass per chunk (see trial_dual_group)
+    if (g.ag_mode == 1 && g.backend == COMM_RCCL) {
+      HIP_TRY(hipEventRecord(s->ev_xbar, s->stream));
+      for (int c = 0; c < g.ag_chunks; ++c)
+        if ((rc = mt_all_gather_chunk(g, s, i, [](pdhg_handle *q) { return q->xbar; }, c))) return rc;
+      if ((rc = launch_dual_chunked(s, sigma, true))) return rc;
+    } else {
+      if ((rc = mt_all_gather(g, s, i, [](pdhg_handle *q) { return q->xbar; }, g.S))) return rc;
+      if ((rc = launch_dual_chunked(s, sigma, false))) return rc;
+    }
+  } else {
+    if ((rc = mt_all_gather(g, s, i, [](pdhg_handle *q) { return q->xbar; }, g.S))) return rc;
+    if (s->has_q && (rc = mt_all_gather(g, s, i, [](pdhg_handle *q) { return q->x_next; }, g.S))) return rc;
+    if ((rc = launch_dual(s, sigma))) return rc;
+  }
   if (!g.overlap) {
     if ((rc = launch_aty_plain(s, s->y_next, s->aty_next))) return rc;
     if ((rc = mt_reduce_scatter(g, s, i, [](pdhg_handle *q) { return q->aty_next; }, g.S))) return rc;
@@ -80,7 +93,11 @@ static int trial_shard_mt(DistGroup &g, pdhg_handle *s, int i, const TrialArgs &
   }
   int qcount = 0;
   if ((rc = launch_q_interaction(s, &qcount))) return rc;
-  if ((rc = launch_final(s, s->pAt, ew_grid(s->cn), s->pAt_stride, s->pA, s->A.slots(), qcount))) return rc;
+  {
+    const bool chunked = g.ag_chunks > 1 && !s->has_q;
+    if ((rc = launch_final(s, s->pAt, ew_grid(s->cn), s->pAt_stride, s->pA, chunked ? dual_chunk_slots(s) : s->A.slots(), qcount, false,
+                           chunked ? dual_chunk_slots(s) : -1))) return rc;
+  }
   HIP_TRY(hipMemcpyAsync(s->scal_host, s->scal_dev, sizeof(double) * 5, hipMemcpyDeviceToHost, s->stream));
   *t_issued = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -223,7 +240,8 @@ static bool group_coop_eligible(const Shards &L) {
   if (g.coop_mode < 0) {
     const char *ev = getenv("PDHG_GROUP_COOP");
     bool on = g.all_local() && g.backend == COMM_P2P && L.count == g.world && g.world >= 2 && g.world <= P2P_MAX_WORLD &&
-              !(ev && ev[0] == '0') && !(getenv("PDHG_GRAPH") && getenv("PDHG_GRAPH")[0] == '0');
+              !(ev && ev[0] == '0') && !(getenv("PDHG_GRAPH") && getenv("PDHG_GRAPH")[0] == '0') &&
+              g.ag_chunks <= 1;      // (column-chunk passes fix another order of additions: the per-launch path runs them)
     bool one_device = true;
     for (int i = 0; i < L.count && on; ++i) {
       const pdhg_handle *s = L.p[i];
@@ -362,15 +380,28 @@ static int trial_dual_group(const Shards &L, double step_size, double primal_wei
   pdhg_handle *lead = L.p[0];
   int rc;
   const auto t_begin = std::chrono::steady_clock::now();
-  {
+  // The all-gather of xbar beside A_p xbar (DistGroup::ag_chunks; SURVEY 8e(ii), pdhg.jl:472-494): xbar travels in column
+  // chunks on the comm streams -- chunk c = sub-range c of every rank's slice, so that every link carries a part of every
+  // chunk -- and A_p xbar is one pass per chunk, pass c waiting for chunk c alone while chunk c + 1 is on the links.
+  // ag_mode 2 (and the peer back end): the same passes behind one all-gather -- the same bits, nothing overlapped.
+  const bool chunked = g.ag_chunks > 1 && !lead->has_q;
+  const bool chunks_on_comm = chunked && g.ag_mode == 1 && g.backend == COMM_RCCL;
+  if (chunks_on_comm) {
+    ProfScope ps(lead, PDHG_K_ALLGATHER);
+    FOR_SHARDS(L, s) { HIP_TRY(hipEventRecord(s->ev_xbar, s->stream)); }
+    for (int c = 0; c < g.ag_chunks; ++c)
+      if ((rc = dist_all_gather_chunk(g, [](pdhg_handle *s) { return s->xbar; }, c))) return rc;
+  } else {
     ProfScope ps(lead, PDHG_K_ALLGATHER);
     if ((rc = dist_all_gather(g, [](pdhg_handle *s) { return s->xbar; }, g.S))) return rc;
     // QP: Q acts on full vectors, so x' is kept full as well (x becomes x' at accept)
     if (lead->has_q && (rc = dist_all_gather(g, [](pdhg_handle *s) { return s->x_next; }, g.S))) return rc;
   }
+  auto dual_of = [&](pdhg_handle *s) { return chunked ? launch_dual_chunked(s, primal_weight * step_size, chunks_on_comm)
+                                                      : launch_dual(s, primal_weight * step_size); };
   if (!g.overlap) {
     FOR_SHARDS(L, s) {
-      if ((rc = launch_dual(s, primal_weight * step_size))) return rc;
+      if ((rc = dual_of(s))) return rc;
       if ((rc = launch_aty_plain(s, s->y_next, s->aty_next))) return rc;      // t_p = A_p' y'_p, all n columns
     }
     ProfScope ps(lead, PDHG_K_REDUCE_SCATTER);
@@ -381,7 +412,7 @@ static int trial_dual_group(const Shards &L, double step_size, double primal_wei
     // sweep); as soon as the rows of slice k are complete, slice k is reduced to rank k on
     // the comm stream while the next round computes.  The sequence of collectives (slice
     // 0, 1, ..., P-1) is the same on every rank however the local product is cut.
-    FOR_SHARDS(L, s) { if ((rc = launch_dual(s, primal_weight * step_size))) return rc; }
+    FOR_SHARDS(L, s) { if ((rc = dual_of(s))) return rc; }
     const char *rw_env = dev_env("PDHG_DIST_ROUND_WGS");            // tests use a finer granule on small problems
     const int round_wgs = rw_env ? std::max(1, atoi(rw_env)) : 256 * 2;
     std::vector<int> issued((size_t)L.count, 0), next_wg((size_t)L.count, 0);
@@ -429,7 +460,8 @@ static int trial_dual_group(const Shards &L, double step_size, double primal_wei
     }
     int qcount = 0;
     if ((rc = launch_q_interaction(s, &qcount))) return rc;   // replicated: identical on every shard
-    if ((rc = launch_final(s, s->pAt, ew_grid(s->cn), s->pAt_stride, s->pA, s->A.slots(), qcount))) return rc;
+    if ((rc = launch_final(s, s->pAt, ew_grid(s->cn), s->pAt_stride, s->pA, chunked ? dual_chunk_slots(s) : s->A.slots(), qcount, false,
+                           chunked ? dual_chunk_slots(s) : -1))) return rc;
   }
   double r[5];
   const auto t_issued = std::chrono::steady_clock::now();

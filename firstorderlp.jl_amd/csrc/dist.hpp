@@ -163,6 +163,19 @@ struct DistGroup {
   // overlapping the rest of the product).  Decided from (n, world, environment) only, so
   // that every rank issues the same sequence of collectives.
   bool overlap = false;
+  // The all-gather of xbar overlapped with A_p xbar (round 6; SURVEY 8e(ii), pdhg.jl:472-494).  On the fully connected node
+  // every slice has a link of its own and all of them arrive together, so the product can only run beside the transfer
+  // if it consumes PARTS of every slice: the column space is cut into `ag_chunks` chunks -- chunk c = sub-range c (ag_sub
+  // columns) of EVERY rank's slice -- xbar travels chunk by chunk (one grouped broadcast per rank and chunk on the comm
+  // streams) and A_p xbar runs as one pass per chunk (a complete layout of A_p restricted to the chunk's columns, the row
+  // sums carried through memory), pass c waiting only for chunk c.  0 / 1: off (one all-gather, one product).
+  // ag_mode 1: as described; 2: the same passes behind ONE all-gather (nothing overlapped: the reference the overlapped
+  // form must equal bit for bit, and what the peer back end inside one process runs).  A row's products are added chunk
+  // by chunk, ascending columns inside a chunk: not the single pass's order (rows within 1e-13 * sum |a x| of it), the
+  // same order in both modes and on every back end.  Decided from the environment only (PDHG_DIST_AG_OVERLAP, default
+  // off; PDHG_DIST_AG_CHUNKS, default 4): every rank makes the same sequence of collectives.
+  int ag_chunks = 0, ag_mode = 0;
+  int64_t ag_sub = 0;
   // true: every rank lives in this process (scalars and vectors can be collected shard by
   // shard).  false: one rank per process -- everything other ranks hold arrives through RCCL.
   // PDHG_DIST_FORCE_REMOTE=1 takes the second route even when all ranks are local, so that
@@ -402,6 +415,55 @@ int dist_join_comm(DistGroup &g) {
       for (pdhg_handle *q : g.sh) HIP_TRY(hipStreamWaitEvent(s->stream, q->ev_comm, 0));
     }
   }
+  return 0;
+}
+
+// ---- the all-gather of xbar, chunk by chunk (DistGroup::ag_chunks) -------------------------------------------------------
+// Chunk c of the vector `sel`: columns [q*S + c*ag_sub, q*S + min((c+1)*ag_sub, S)) of every rank q's slice, broadcast in
+// place by their owner (root q) -- world collectives in one group per local shard, on the COMM streams, which first wait
+// for "the owned slice is written" (ev_xbar, recorded by the caller on the compute streams); ev_ag[c] is recorded behind
+// them.  The buffers hold world * S doubles, so a sub-range is moved whole even where it runs past n.
+template <typename Sel>
+int dist_all_gather_chunk(DistGroup &g, Sel sel, int c) {
+  RCCL_API(R);
+  const int64_t off = (int64_t)c * g.ag_sub, len = std::min<int64_t>(g.ag_sub, g.S - off);
+  if (len <= 0) return fail(-1, "empty all-gather chunk");
+  if (c == 0)
+    for (pdhg_handle *s : g.sh) {
+      HIP_TRY(hipSetDevice(s->device));
+      HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_xbar, 0));
+    }
+  NCCL_TRY(R->GroupStart());
+  for (size_t i = 0; i < g.sh.size(); ++i) {
+    pdhg_handle *s = g.sh[i];
+    HIP_TRY(hipSetDevice(s->device));
+    double *b = sel(s);
+    for (int q = 0; q < g.world; ++q) {
+      double *p = b + (int64_t)q * g.S + off;
+      NCCL_TRY(R->Broadcast(p, p, (size_t)len, ncclDouble, q, g.comm[i], s->comm_stream));
+    }
+  }
+  NCCL_TRY(R->GroupEnd());
+  for (pdhg_handle *s : g.sh) {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventRecord(s->ev_ag[(size_t)c], s->comm_stream));
+  }
+  return 0;
+}
+// the same for ONE shard, issued by its own host thread (no group: one communicator per thread)
+int mt_all_gather_chunk(DistGroup &g, pdhg_handle *s, int i, BufSel sel, int c) {
+  RCCL_API(R);
+  const int64_t off = (int64_t)c * g.ag_sub, len = std::min<int64_t>(g.ag_sub, g.S - off);
+  if (len <= 0) return fail(-1, "empty all-gather chunk");
+  if (c == 0) HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_xbar, 0));
+  double *b = sel(s);
+  NCCL_TRY(R->GroupStart());
+  for (int q = 0; q < g.world; ++q) {
+    double *p = b + (int64_t)q * g.S + off;
+    NCCL_TRY(R->Broadcast(p, p, (size_t)len, ncclDouble, q, g.comm[(size_t)i], s->comm_stream));
+  }
+  NCCL_TRY(R->GroupEnd());
+  HIP_TRY(hipEventRecord(s->ev_ag[(size_t)c], s->comm_stream));
   return 0;
 }
 

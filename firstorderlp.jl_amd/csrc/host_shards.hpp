@@ -652,6 +652,10 @@ void destroy_shard(pdhg_handle *h) {
     }
   }
   free_csr_dev(h->A); free_csr_dev(h->At); free_csr_dev(h->Q); free_csr_dev(h->Qt);
+  for (CsrDev &D : h->Achunk) free_csr_dev(D);
+  if (h->chunk_carry) (void)hipFree(h->chunk_carry);
+  for (hipEvent_t ev : h->ev_ag) if (ev) (void)hipEventDestroy(ev);
+  if (h->ev_xbar) (void)hipEventDestroy(h->ev_xbar);
   double *bufs[] = {h->c, h->b, h->lb, h->ub, h->x, h->x_next, h->xbar, h->y, h->y_next,
                     h->aty, h->aty_next, h->sum_x, h->sum_y, h->qx, h->tmp_n, h->tmp_n2,
                     h->tmp_m, h->pA, h->pAt, h->pQ, h->scal_dev, h->scal_all, h->dn_buf, h->dm_buf,
@@ -713,6 +717,8 @@ void destroy_group(DistGroup *g) {
 int create_rank_shard_local(DistGroup *g, int rank, int64_t n, const int64_t *colptr, const int64_t *rowval,
                             const double *nzval, int base, const double *c, const double *b_local, const double *lb,
                             const double *ub, int device_id, void *stream, pdhg_handle **out);
+int build_column_chunks(DistGroup *g, pdhg_handle *s, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                        const double *nzval, int base);
 
 // Build rank `rank`'s shard of the GLOBAL problem: rows row_lo[rank]..row_lo[rank+1), all columns.
 int create_rank_shard(DistGroup *g, int rank, int64_t n, const int64_t *colptr, const int64_t *rowval,
@@ -758,8 +764,56 @@ int create_rank_shard_local(DistGroup *g, int rank, int64_t n, const int64_t *co
   s->cn = std::min<int64_t>(n, (int64_t)(rank + 1) * g->S) - s->clo;
   if ((rc = alloc_zero(&s->dn_buf, s->n_alloc))) { destroy_shard(s); return rc; }
   if ((rc = alloc_zero(&s->dm_buf, g->m_global))) { destroy_shard(s); return rc; }
+  if (g->ag_chunks > 1 && (rc = build_column_chunks(g, s, n, colptr, rowval, nzval, base))) { destroy_shard(s); return rc; }
   if ((rc = alloc_zero(&s->scal_all, (int64_t)SCAL_MAX * g->world))) { destroy_shard(s); return rc; }
   *out = s;
+  return 0;
+}
+
+// The column-chunk layouts of one shard (DistGroup::ag_chunks, dist.hpp): chunk c holds the entries of A_p whose column lies
+// in sub-range c of its owner's slice, as a complete layout of its own (rows x n, absolute column indices, no column slabs:
+// the passes carry the row sums themselves), built by the ordinary builder from the filtered CSC arrays.
+int build_column_chunks(DistGroup *g, pdhg_handle *s, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                        const double *nzval, int base) {
+  const int C = g->ag_chunks;
+  const int64_t m = s->m;
+  int rc = 0;
+  s->Achunk.resize((size_t)C);
+  std::vector<int64_t> cp((size_t)n + 1);
+  uvec<int64_t> rv;
+  dvec nv;
+  for (int c = 0; c < C && !rc; ++c) {
+    int64_t cnt = 0;
+    for (int64_t j = 0; j < n; ++j) {
+      cp[(size_t)j] = cnt;
+      if (((j % g->S) / g->ag_sub) == c) cnt += colptr[j + 1] - colptr[j];
+    }
+    cp[(size_t)n] = cnt;
+    rv.resize((size_t)std::max<int64_t>(cnt, 1));
+    nv.resize((size_t)std::max<int64_t>(cnt, 1));
+    parallel_ranges((int)std::min<int64_t>(n, INT32_MAX), 1 << 14, [&](int jb, int je) {
+      for (int64_t j = jb; j < je; ++j) {
+        if (((j % g->S) / g->ag_sub) != c) continue;
+        const int64_t k0 = colptr[j] - base, k1 = colptr[j + 1] - base, d0 = cp[(size_t)j];
+        for (int64_t k = k0; k < k1; ++k) { rv[(size_t)(d0 + k - k0)] = rowval[k] - base; nv[(size_t)(d0 + k - k0)] = nzval[k]; }
+      }
+    });
+    g_no_slabs = true;
+    rc = build_layout_pair(s->device, s->remap, s->relaxed, m, n, cnt, cp.data(), rv.data(), nv.data(), 0, &s->Achunk[(size_t)c], nullptr);
+    g_no_slabs = false;
+  }
+  if (rc) return rc;
+  if ((rc = alloc_zero(&s->chunk_carry, std::max<int64_t>(m, 1)))) return rc;
+  // the last pass's block partials: pA must hold its slots too
+  if (dual_chunk_slots(s) > s->A.slots()) {
+    (void)hipFree(s->pA);
+    s->pA = nullptr;
+    if ((rc = alloc_zero(&s->pA, 2 * (int64_t)dual_chunk_slots(s)))) return rc;
+  }
+  s->ev_ag.assign((size_t)C, nullptr);
+  for (int c = 0; c < C; ++c)
+    if (hipEventCreateWithFlags(&s->ev_ag[(size_t)c], hipEventDisableTiming) != hipSuccess) return fail(999, "event creation failed");
+  if (hipEventCreateWithFlags(&s->ev_xbar, hipEventDisableTiming) != hipSuccess) return fail(999, "event creation failed");
   return 0;
 }
 
@@ -769,9 +823,24 @@ int create_rank_shard_local(DistGroup *g, int rank, int64_t n, const int64_t *co
 // its owner); OFF for RCCL, where P reductions to P roots cost P collective latencies and
 // may not reach the bandwidth of one reduce-scatter over all links -- the product they
 // could hide behind is 0.1 ms at P = 8.  PDHG_DIST_OVERLAP=0/1 forces.
+// The all-gather side (DistGroup::ag_chunks): PDHG_DIST_AG_OVERLAP=1 cuts xbar's all-gather and A_p xbar into
+// PDHG_DIST_AG_CHUNKS (4) column chunks, pass c running beside the transfer of chunk c + 1; =2 runs the same passes behind
+// one all-gather (the bitwise reference of =1; what the peer back end does under either value).  Default OFF: RCCL's
+// kernels beside a sweep that fills every compute unit have never run on hardware.
 void choose_exchange_pattern(DistGroup *g) {
   const char *ov = getenv("PDHG_DIST_OVERLAP");
   g->overlap = ov ? (ov[0] != '0') : (g->backend == COMM_P2P && g->world > 1 && g->n * 8 > (4LL << 20));
+  const char *ag = getenv("PDHG_DIST_AG_OVERLAP");
+  g->ag_mode = (ag && (ag[0] == '1' || ag[0] == '2') && !ag[1]) ? ag[0] - '0' : 0;
+  g->ag_chunks = 0;
+  if (g->ag_mode && g->world > 1) {
+    const char *cv = dev_env("PDHG_DIST_AG_CHUNKS");
+    int C = cv ? std::max(2, std::min(16, atoi(cv))) : 4;
+    int64_t sub = ((g->S + C - 1) / C + 15) / 16 * 16;         // whole 128-byte lines
+    C = (int)((g->S + sub - 1) / sub);                        // (a short slice may give fewer chunks)
+    if (C > 1) { g->ag_chunks = C; g->ag_sub = sub; }
+  }
+  if (g->ag_chunks <= 1) { g->ag_chunks = 0; g->ag_mode = 0; }
 }
 
 // row_bounds != nullptr: the caller's partition ([world + 1], ascending, 0 .. m) instead of the

@@ -575,7 +575,9 @@ inline int slab_first_col(int cols, int P, int p) {
 // blocks: 0.099 / 0.100 ms per product with two slab passes against 0.05 without (the vendor's CSR kernel: 0.048),
 // profiles/r05_shape_table_1m.txt.  PDHG_SLABS=2 (dev use): slabs whatever the locality.
 // Returns the number of slabs (0: none) -- ONE rule for the host and the device construction.
+thread_local bool g_no_slabs = false;      // set around the builds of a group's column-chunk layouts (host_shards.hpp): they carry row sums themselves
 int slab_count(const CsrDev &D, int cols) {
+  if (g_no_slabs) return 0;
   const char *off = getenv("PDHG_SLABS");
   if (off && off[0] == '0') return 0;
   const char *mb = getenv("PDHG_SLAB_MB");

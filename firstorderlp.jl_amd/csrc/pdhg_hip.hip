@@ -150,6 +150,12 @@ struct pdhg_handle {
   hipStream_t comm_stream = nullptr;   // group: per-slice reductions run here, beside the product that feeds them
   std::vector<hipEvent_t> ev_part;     // [world] "slice k of A_p'y_p is complete" on `stream`
   hipEvent_t ev_comm = nullptr;        // "all of this shard's reductions are done" on `comm_stream`
+  // the all-gather of xbar overlapped with A_p xbar (DistGroup::ag_chunks > 1, dist.hpp): A_p cut by COLUMN CHUNK -- chunk c =
+  // sub-range c of every rank's slice -- one complete layout per chunk, the row sums carried from pass to pass
+  std::vector<CsrDev> Achunk;
+  double *chunk_carry = nullptr;       // [m] row sums between the passes
+  std::vector<hipEvent_t> ev_ag;       // [chunks] "chunk c of xbar has arrived" on `comm_stream`
+  hipEvent_t ev_xbar = nullptr;        // "the owned slice of xbar is written" on `stream`
   double *dn_buf = nullptr;        // [n_alloc] gather / partial buffer (group only)
   double *dm_buf = nullptr;        // [m_global] row-gather buffer (group only)
   // scalar results: scal_dev[SCAL_MAX] on the device, scal_all[world*SCAL_MAX] (RCCL gather), pinned scal_host
@@ -301,8 +307,13 @@ int launch_tiled(pdhg_handle *h, const CsrDev &D, const double *xin, const EpiAr
 }
 
 // TAG: 0 the constraint matrix, 1 its transpose, 2 the objective matrix (profiler names)
+// init != nullptr: the row sums start from init[row] -- a later COLUMN-CHUNK pass of a shard group's A_p xbar (the chunks of
+// xbar arrive one after the other, dist.hpp: every chunk's product runs while the next chunk is still on the links).  For
+// layouts without column slabs / row segments (the chunk matrices are built without them).
 template <int MODE, int TAG>
-int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
+int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e, const double *init = nullptr) {
+  if (init && (!D.segs.empty() || !D.slabs.empty())) return fail(-1, "a carried product needs a layout without segments / column slabs");
+  e.init = init;
   if (!D.segs.empty()) {
     // segments of whole rows (layout.hpp): the same product segment by segment, every row-indexed operand moved to the
     // segment's first row, its block partials behind those of the segments before it
@@ -382,13 +393,22 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e) {
       }
     }
   } else if (D.sj.on()) {
-    launch_sj<MODE, false, TAG>(h->stream, D.sj, xin, h->remap ? 1 : 0, rx, D.grid, e);
+    if (init) launch_sj<MODE, true, TAG>(h->stream, D.sj, xin, h->remap ? 1 : 0, rx, D.grid, e);
+    else launch_sj<MODE, false, TAG>(h->stream, D.sj, xin, h->remap ? 1 : 0, rx, D.grid, e);
   } else if (D.pipe_grid > 0) {
-    hipLaunchKernelGGL((spmv_stream_pipe_kernel<MODE, false, TAG>), dim3(D.pipe_grid), dim3(TPB), 0, h->stream, D.view(), xin,
-                       (const int4 *)D.ext, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, D.grid, e);
+    if (init)
+      hipLaunchKernelGGL((spmv_stream_pipe_kernel<MODE, true, TAG>), dim3(D.pipe_grid), dim3(TPB), 0, h->stream, D.view(), xin,
+                         (const int4 *)D.ext, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, D.grid, e);
+    else
+      hipLaunchKernelGGL((spmv_stream_pipe_kernel<MODE, false, TAG>), dim3(D.pipe_grid), dim3(TPB), 0, h->stream, D.view(), xin,
+                         (const int4 *)D.ext, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, D.grid, e);
   } else if (D.grid > 0) {
-    hipLaunchKernelGGL((spmv_stream_kernel<MODE, false, TAG>), dim3(D.grid), dim3(TPB), 0, h->stream,
-                       D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, e);
+    if (init)
+      hipLaunchKernelGGL((spmv_stream_kernel<MODE, true, TAG>), dim3(D.grid), dim3(TPB), 0, h->stream,
+                         D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, e);
+    else
+      hipLaunchKernelGGL((spmv_stream_kernel<MODE, false, TAG>), dim3(D.grid), dim3(TPB), 0, h->stream,
+                         D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, e);
   }
   if (D.nlong > 0) {
     hipLaunchKernelGGL(spmv_long_partial_kernel<TAG>, dim3(D.nchunks), dim3(TPB), 0, h->stream,
@@ -467,6 +487,34 @@ int launch_dual(pdhg_handle *h, double sigma) {
   return rc;
 }
 
+// The same product as column-chunk passes (DistGroup::ag_chunks, dist.hpp): chunk c's layout against the chunk's columns of
+// xbar, the row sums carried through chunk_carry, the dual step fused into the LAST pass, whose block partials go to the
+// front of pA (stride = that layout's slots: dual_chunk_slots).  wait_events: pass c first waits for "chunk c of xbar has
+// arrived" (ev_ag[c], recorded on the comm stream).
+int dual_chunk_slots(const pdhg_handle *h) { return std::max(h->Achunk.empty() ? 0 : h->Achunk.back().slots(), 1); }
+int launch_dual_chunked(pdhg_handle *h, double sigma, bool wait_events) {
+  ProfScope ps(h, PDHG_K_SPMV_DUAL);
+  const int C = (int)h->Achunk.size();
+  int rc = 0;
+  for (int c = 0; c < C && !rc; ++c) {
+    if (wait_events) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_ag[(size_t)c], 0));
+    const double *init = c > 0 ? h->chunk_carry : nullptr;
+    if (c + 1 < C) {
+      EpiArgs e{};
+      e.out = h->chunk_carry;
+      rc = launch_spmv<MODE_PLAIN, 0>(h, h->Achunk[(size_t)c], h->xbar, e, init);
+    } else {
+      EpiArgs e{};
+      e.y = h->y; e.b = h->b; e.y_next = h->y_next; e.sigma = sigma; e.num_eq = (int)h->num_eq;
+      e.partials = h->pA; e.stride = dual_chunk_slots(h); e.lo_offset = dual_chunk_slots(h);
+      if (h->pend_y) { e.sum_y = h->sum_y; e.avg_w = h->pend_w; }
+      rc = launch_spmv<MODE_DUAL, 0>(h, h->Achunk[(size_t)c], h->xbar, e, init);
+      if (!rc) h->pend_y = false;
+    }
+  }
+  return rc;
+}
+
 int launch_aty_fused(pdhg_handle *h) {
   ProfScope ps(h, PDHG_K_SPMV_ATY);
   EpiArgs e{};
@@ -516,8 +564,9 @@ __global__ __launch_bounds__(FINAL_TPB) void final_reduce_host_kernel(FinalSpec 
 }
 
 // second-stage reduction of the trial's block partials into scal_dev[0..5)
+// (dy_lo: where the low parts of the dy^2 partials start behind p_dy; < 0: the handle's own A.slots())
 int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int, const double *p_dy, int n_dy,
-                 int q_count, bool to_host = false) {
+                 int q_count, bool to_host = false, int dy_lo = -1) {
   ProfScope ps(h, PDHG_K_FINAL);
   FinalSpec sp{};
   sp.ptr[0] = p_int;                  sp.count[0] = n_int;
@@ -526,7 +575,7 @@ int launch_final(pdhg_handle *h, const double *p_int, int n_int, int stride_int,
   sp.ptr[3] = p_int + 2 * stride_int; sp.count[3] = n_int;
   sp.ptr[4] = h->pQ;                  sp.count[4] = q_count;
   for (int q : {0, 1, 3}) sp.ptr_lo[q] = sp.ptr[q] + 3 * stride_int;
-  sp.ptr_lo[2] = p_dy + h->A.slots();
+  sp.ptr_lo[2] = p_dy + (dy_lo >= 0 ? dy_lo : h->A.slots());
   sp.ptr_lo[4] = h->pQ + h->ew_grid_n;
   sp.out = h->scal_dev;
   if (to_host) {       // results straight into the pinned result word (the caller polls it: wait_result_word)

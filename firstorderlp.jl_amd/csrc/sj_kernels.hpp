@@ -308,7 +308,14 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
         epi_apply<MODE>(e, base + tid, row_sum[buf][tid], ops, acc3);
       }
       buf ^= 1;
-    } else if (cur.q == G - 1) {                          // the window's last slice of this wave (the same trip for all four waves)
+    } else if (cur.q != G - 1) {
+#ifndef PDHG_SJ_NOPACE
+      // pacing only (nothing is handed over): the four waves enter their next slices together, as the narrow form's
+      // barrier per 256 rows makes them -- without it they drift apart inside the window's eight slices and the part of
+      // the gathered vector in flight widens (A x on banded 10M: 0.70 ms against the narrow form's 0.61)
+      __syncthreads();
+#endif
+    } else {                                              // the window's last slice of this wave (the same trip for all four waves)
       __syncthreads();
 #pragma unroll
       for (int qq = 0; qq < G; ++qq) {

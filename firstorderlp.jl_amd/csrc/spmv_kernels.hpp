@@ -632,7 +632,13 @@ __global__ __launch_bounds__(TW_WPB * WAVE) void spmv_tiled_kernel(
   double *acc = tw_lds + wid * TW_ROWS;
   int2 rr = make_int2(0, 0);
   if (live) rr = wave_rows[w];
-  for (int r = lane; r < TW_ROWS; r += WAVE) acc[r] = 0.0;
+  // e.init (column-chunk passes of a shard group's A_p xbar, dist.hpp): the row sums of the chunks before this one
+  if (e.init) {
+    const int nr = live ? rr.y - rr.x : 0;
+    for (int r = lane; r < TW_ROWS; r += WAVE) acc[r] = r < nr ? e.init[rr.x + r] : 0.0;
+  } else {
+    for (int r = lane; r < TW_ROWS; r += WAVE) acc[r] = 0.0;
+  }
   // This workgroup's step list: one step = one column tile, or a slice of a
   // heavy tile (cells are cut on the host so that no wave has more than
   // TW_U*64 entries in a step); tiles in which none of the 8 waves has an entry
@@ -803,13 +809,15 @@ __global__ __launch_bounds__(TPB) void spmv_long_partial_kernel(
 // same bits.  Called by all 64 lanes of one wave.  AGENT: write-through stores (trial kernel).
 template <int MODE, bool AGENT, bool COH = false>
 __device__ __forceinline__ void long_final_row(int l, const int *long_row, const int *long_chunk_ptr,
-                                               const double *chunk_partial, const EpiArgs &e, int slot_base) {
+                                               const double *chunk_partial, const EpiArgs &e, int slot_base,
+                                               const double *init = nullptr) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int c0 = long_chunk_ptr[l], c1 = long_chunk_ptr[l + 1];
   double s = 0.0;
   for (int c = c0 + lane; c < c1; c += WAVE) s = s + chunk_partial[c];
   s = wave_sum(s);
   if (lane == 0) {
+    if (init) s = init[long_row[l]] + s;       // a later column-chunk pass: the row's sum so far
     Acc3 acc = acc3_zero();
     row_epilogue<MODE, COH>(e, long_row[l], s, acc);
     constexpr int NQ = ModeNQ<MODE>::value;
@@ -834,7 +842,7 @@ __global__ __launch_bounds__(TPB) void spmv_long_final_kernel(
     int nlong, const double *__restrict__ chunk_partial, EpiArgs e,
     int slot_base) {
   const int l = blockIdx.x * LONG_ROWS_PER_WG + threadIdx.x / WAVE;
-  if (l < nlong) long_final_row<MODE, false>(l, long_row, long_chunk_ptr, chunk_partial, e, slot_base);
+  if (l < nlong) long_final_row<MODE, false>(l, long_row, long_chunk_ptr, chunk_partial, e, slot_base, e.init);
 }
 
 }  // namespace

@@ -97,6 +97,77 @@ def traj(ingest, overlap, lp):
     finish(rc, eng)
 
 
+def agtraj(ingest, lp):
+    """The all-gather of xbar overlapped with A_p xbar (PDHG_DIST_AG_OVERLAP=1: xbar in column chunks on the comm stream, one
+    product pass per chunk) against the SAME passes behind one all-gather (=2): not a bit may differ, on any rank; rank 0
+    also runs the in-process group (peer back end: the passes behind its all-gather -> bitwise too), the group without
+    chunks and the single handle (another order of additions inside a row: decisions equal, iterates to 1e-9)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if lp == "tiled":
+        os.environ["PDHG_SPMV"] = "tiled"
+        p, steps, mp_steps = random_lp(300_000, 200_000, 6, seed=22), 30, 8
+    else:
+        p, steps, mp_steps = random_lp(30000, 20000, 6, seed=21), 60, 25
+    bounds = HipPdhgEngine.partition_rows(p.constraint_matrix, world)
+
+    def make():
+        if ingest == "rows":
+            return make_row_shard_hip_engine(row_shard_of(p, bounds, rank), device_id=DEVICE)
+        return make_row_partitioned_hip_engine(p, device_id=DEVICE)
+
+    def cat(g):
+        return np.concatenate([g["x"], g["y"], g["xa"], g["ya"], g["xm"], g["ym"], g["aty"], g["ax"],
+                               [g["step"], g["mp_step"], float(sum(g["decisions"]))]])
+    rc = 0
+    runs = {}
+    for mode in ("1", "2"):
+        os.environ["PDHG_DIST_AG_OVERLAP"] = mode
+        eng = make()
+        d = eng.layout_describe()
+        want = "overlapped with A_p xbar" if mode == "1" else "passes behind one all-gather"
+        assert d["all_gather"]["chunks"] >= 2 and d["all_gather"]["mode"] == want, d.get("all_gather")
+        runs[mode] = run(eng, p, steps, mp_steps)
+        layouts = [c["layout"] for c in d["all_gather"]["passes"]]
+        eng.close()
+        dist.barrier()
+    a, b = cat(runs["1"]), cat(runs["2"])
+    if not np.array_equal(a, b):
+        print(f"rank {rank}: the overlapped all-gather differs from the passes behind one all-gather", flush=True)
+        rc = 1
+    ref = torch.from_numpy(a.copy())
+    dist.broadcast(ref, src=0)
+    if not np.array_equal(ref.numpy(), a):
+        print(f"rank {rank} diverged from rank 0", flush=True)
+        rc = 1
+    if rank == 0:
+        try:
+            g = runs["1"]
+            os.environ["PDHG_DIST_AG_OVERLAP"] = "1"
+            geng = HipPdhgEngine.from_problem(p, device_ids=[DEVICE] * world)
+            assert geng.dist_info()["backend"] == 1 and geng.layout_describe()["all_gather"]["mode"] == "passes behind one all-gather"
+            inproc = run(geng, p, steps, mp_steps)
+            geng.close()
+            for k, v in g.items():
+                assert np.array_equal(np.asarray(v), np.asarray(inproc[k])), f"{k}: processes over the stand-in != in-process group"
+            os.environ.pop("PDHG_DIST_AG_OVERLAP")
+            plain = HipPdhgEngine.from_problem(p, device_ids=[DEVICE] * world)
+            assert "all_gather" not in plain.layout_describe()
+            s1 = run(plain, p, steps, mp_steps)
+            plain.close()
+            s2 = run(HipPdhgEngine.from_problem(p, device_id=DEVICE), p, steps, mp_steps)
+            for s in (s1, s2):
+                assert g["decisions"] == s["decisions"], "accept/reject decisions differ"
+                assert abs(g["step"] - s["step"]) <= 1e-9 * s["step"]
+                for k in ("x", "y", "xa", "ya", "xm", "ym"):
+                    np.testing.assert_allclose(g[k], s[k], rtol=1e-9, atol=1e-9, err_msg=k)
+            print(f"fake worker ok: agtraj world {world} ingest {ingest} lp {lp}, {sum(g['decisions'])} trials, pass layouts {layouts}", flush=True)
+        except AssertionError as exc:
+            print(f"fake worker FAILED: {exc}", flush=True)
+            rc = 1
+    os.environ.pop("PDHG_DIST_AG_OVERLAP", None)
+    finish(rc)
+
+
 def kat(names):
     from tests import kat_common
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -159,6 +230,8 @@ def main():
     mode = sys.argv[1]
     if mode == "traj":
         traj(*sys.argv[2:5])
+    elif mode == "agtraj":
+        agtraj(*sys.argv[2:4])
     elif mode == "kat":
         kat(sys.argv[2])
     else:
