@@ -116,6 +116,9 @@ def parse():
                     help="N > 1: run the exchange overlapped with the products -- xbar's all-gather in column chunks beside A_p xbar "
                          "(PDHG_DIST_AG_OVERLAP=1) and per-slice reductions beside A_p'y' (PDHG_DIST_OVERLAP=1).  Off by default: "
                          "both have only ever run over the test transport")
+    ap.add_argument("--full-line", action="store_true",
+                    help="tools (tools/rocprof_summary.py, tools/pmc_traffic.sh): print the WHOLE record as the stdout line instead of "
+                         "the compact one (never what the driver runs)")
     ap.add_argument("--no-details", action="store_true",
                     help="do not write bench_details.json (the short child runs of tools/selfprof.py: the parent's record is the one kept)")
     ap.add_argument("--replay", metavar="DETAILS_JSON", default=None,
@@ -358,8 +361,8 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         pass
     rocprof_ms, rocprof_source = None, None
     if dist is None and args.shards == 0:
-        fname = os.path.join("profiles", {"random": "r05_rocprof_summary.json", "pagerank": "r05_pagerank_rocprof_summary.json",
-                                          "l1svm": "r05_l1svm_rocprof_summary.json"}[workload])
+        fname = os.path.join("profiles", {"random": "r06_rocprof_summary.json", "pagerank": "r06_pagerank_rocprof_summary.json",
+                                          "l1svm": "r06_l1svm_rocprof_summary.json"}[workload])
         try:
             with open(os.path.join(ROOT, fname)) as fh:
                 for label, prod in json.load(fh).get("products", {}).items():
@@ -538,6 +541,7 @@ def measure(args, workload, ctx, steps, warmup, cpu_seconds, with_socket=True):
         "kernels": kernels,
         "layout": {k: v for k, v in eng.layout_info().items() if "tiled" in k or "tile_cols" in k or "slab" in k or "graph" in k},
         "layout_products": [eng.kernel_name(_lib.K_SPMV_DUAL), eng.kernel_name(_lib.K_SPMV_ATY)],
+        "layout_choices": eng.layout_describe(),      # incl. what pdhg_create settled by timing (pdhg_layout_describe)
         "launch_path": ("one workgroup for the whole batch of steps, vectors in LDS (small_lp_steps_kernel)"
                         if eng.layout_info().get("small_lp") and not args.per_step_calls else
                         "several take_steps per launch of one persistent kernel (steps_kernel)"
@@ -785,14 +789,14 @@ def write_details(full):
     return None
 
 
-def emit(full, real_stdout, details=True):
+def emit(full, real_stdout, details=True, full_line=False):
     """Details to the file and to stderr, then the compact line as the LAST line of stdout."""
     path = write_details(full) if details else None
     name = DETAILS_FILE if path == os.path.join(ROOT, DETAILS_FILE) else (path or "stderr")
     sys.stdout.flush()
     sys.stderr.write(json.dumps(full) + "\n")
     sys.stderr.flush()
-    line = compact_line(full, name)
+    line = json.dumps(full) if full_line else compact_line(full, name)
     if real_stdout is not None:
         os.dup2(real_stdout, 1)
     print(line, flush=True)
@@ -961,7 +965,7 @@ def main():
     if rank == 0:
         # the compact line is the LAST thing this script writes (the process then exits NORMALLY: rocprofv3 writes its
         # databases from exit handlers, so the child runs of tools/selfprof.py must not be cut short)
-        emit(out, real_stdout, details=not args.no_details)
+        emit(out, real_stdout, details=not args.no_details, full_line=args.full_line)
 
 
 if __name__ == "__main__":

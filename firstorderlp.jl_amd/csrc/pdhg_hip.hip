@@ -381,15 +381,15 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e, c
         pe.init = D.slab_partial;
         if (p == 0)
           hipLaunchKernelGGL((spmv_stream_kernel<MODE_PLAIN, false, TAG>), dim3(S.grid), dim3(TPB), 0, h->stream,
-                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx, pe);
+                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx | 2, pe);
         else
           hipLaunchKernelGGL((spmv_stream_kernel<MODE_PLAIN, true, TAG>), dim3(S.grid), dim3(TPB), 0, h->stream,
-                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx, pe);
+                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx | 2, pe);
       } else {
         EpiArgs le = e;
         le.init = D.slab_partial;
         hipLaunchKernelGGL((spmv_stream_kernel<MODE, true, TAG>), dim3(S.grid), dim3(TPB), 0, h->stream,
-                           S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx, le);
+                           S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx | 2, le);
       }
     }
   } else if (D.sj.on()) {

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TPB) void spmv_sj_kernel(SjView J, const double *__
 #pragma unroll
       for (int jj = 0; jj < SJ_U; ++jj) {
         xv[jj] = 0.0;
-        if (j0 + jj < L) xv[jj] = (j0 + jj < l) ? xin[B_n.c[jj]] : 0.0;      // (uniform branch: levels no lane of the slice has)
+        if (j0 + jj < L) xv[jj] = (j0 + jj < l) ? xin[(unsigned)B_n.c[jj]] : 0.0;      // (uniform branch: levels no lane of the slice has)
         vv[jj] = B_n.v[jj];
       }
       // behind these gathers: the batch that follows

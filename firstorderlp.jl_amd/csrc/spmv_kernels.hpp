@@ -125,6 +125,12 @@ struct ModeNQ { static constexpr int value = (MODE == MODE_PLAIN) ? 0 : (MODE ==
 // One row block of the stream layout, in two halves so that the one-launch trial kernel
 // (trial_kernel.hpp) can issue the first half -- which reads only the static matrix -- BEFORE
 // the grid barrier that delivers the gathered vector.
+// (dev A/B switches of the round-6 wait changes: -DPDHG_STREAM_SIGNED_OFFSETS, -DPDHG_STREAM_NO_GATHER_WAIT)
+#ifdef PDHG_STREAM_SIGNED_OFFSETS
+#define PDHG_COLOFF(c) (c)
+#else
+#define PDHG_COLOFF(c) ((unsigned)(c))
+#endif
 struct StreamRegs {
   int r0, r1, k0, k1;
   int cidx[UNROLL];
@@ -132,7 +138,17 @@ struct StreamRegs {
 };
 
 // first half: the block's extent and its (col, val) entries, UNROLL independent coalesced
-// non-temporal loads per lane
+// non-temporal loads per lane.
+// The column indices are used as UNSIGNED offsets further down (xin[(unsigned)cidx]).  With `int` offsets the compiler hoisted
+// the sign extension of every index into the conditional block right behind its load -- `s_waitcnt vmcnt(1)` after each (col,
+// val) pair: the eight "independent" load chains were eight DEPENDENT round trips to HBM per row block (round 6, found
+// in the ISA after the same accident in sj_kernels.hpp; profiles/r06_stream_waitcnt.txt).
+// THROTTLE (the column-slab passes): a lane waits for each index before it requests the next pair -- what rounds 1-5 did
+// everywhere by accident (see above).  The slab passes exist because the gathered window barely fits an XCD's L2; with
+// sixteen entry loads in flight per lane instead of two the streams crowd the window out: PageRank-1M 4 640 -> 4 470
+// it/s without the waits, while the latency-bound products (one resident wave of workgroups: the L1-SVM LP 17.8 / 27.8
+// -> 16.3 / 24.1 us per product) want them gone (profiles/r06_stream_waitcnt.txt).
+template <bool THROTTLE = false>
 __device__ __forceinline__ void stream_block_load(const CsrView &A, int2 rr, StreamRegs &g) {
   g.r0 = rr.x; g.r1 = rr.y;
   g.k0 = A.rowptr[g.r0];
@@ -144,6 +160,11 @@ __device__ __forceinline__ void stream_block_load(const CsrView &A, int2 rr, Str
     const bool ok = k < g.k1;
     g.cidx[i] = ok ? __builtin_nontemporal_load(A.col + k) : 0;
     g.v[i] = ok ? __builtin_nontemporal_load(A.val + k) : 0.0;
+#ifndef PDHG_THROTTLE_PAIRS
+#define PDHG_THROTTLE_PAIRS 1
+#endif
+    // (PDHG_THROTTLE_PAIRS, dev: wait after every k-th pair -- 1 is what rounds 1-5 did)
+    if (THROTTLE && (i + 1) % PDHG_THROTTLE_PAIRS == 0) __builtin_amdgcn_s_waitcnt(0x0F71);     // vmcnt(1): the index is here, its value may still be on the way
   }
 }
 
@@ -259,6 +280,12 @@ __device__ __forceinline__ void stream_block_finish(const CsrView &A, const doub
   const int lane = tid & (WAVE - 1);
   const int k0 = g.k0, k1 = g.k1;
   double xv[UNROLL];
+  // every column index must be here before its gather can go out, and loads return in order: one wait for all sixteen
+  // entry loads (requested together a round trip ago), then the eight gathers back to back -- the compiler, which cannot
+  // count conditionally issued loads, otherwise waits in front of the first three gathers one by one
+#ifndef PDHG_STREAM_NO_GATHER_WAIT
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+#endif
 #pragma unroll
   for (int i = 0; i < UNROLL; ++i) {
     const int k = k0 + tid + i * TPB;
@@ -266,10 +293,10 @@ __device__ __forceinline__ void stream_block_finish(const CsrView &A, const doub
       // unconditional: a lane without an entry holds column 0 (stream_block_load), a valid address -- an ATOMIC load
       // under a condition becomes a branch per load, and the waits the compiler puts in front of each serialise the
       // gathers.  (For plain loads the conditional form measured 1-2 % faster: kept.)
-      const double t = ldc<true>(xin + g.cidx[i]);
+      const double t = ldc<true>(xin + PDHG_COLOFF(g.cidx[i]));
       xv[i] = (k < k1) ? t : 0.0;
     } else {
-      xv[i] = (k < k1) ? xin[g.cidx[i]] : 0.0;
+      xv[i] = (k < k1) ? xin[PDHG_COLOFF(g.cidx[i])] : 0.0;
     }
   }
 #pragma unroll
@@ -296,8 +323,9 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
   const bool active = remap ? ((b >> 3) < per_xcd && blk < nblk) : (blk < nblk);
   if (active) {
     StreamRegs g;
-    stream_block_load(A, blks[blk], g);
-    stream_block_finish<MODE, INIT>(A, xin, g, e, relaxed, acc, prod);
+    if (relaxed & 2) stream_block_load<true>(A, blks[blk], g);      // bit 1 of `relaxed`: a column-slab pass (throttled entry loads)
+    else stream_block_load<false>(A, blks[blk], g);
+    stream_block_finish<MODE, INIT>(A, xin, g, e, relaxed & 1, acc, prod);
   }
   constexpr int NQ = ModeNQ<MODE>::value;
   if (NQ > 0) {
@@ -366,10 +394,13 @@ __global__ __launch_bounds__(TPB) void spmv_stream_pipe_kernel(
     const int4 cur = x_n;
     const RowPre pre = pre_n;
     double xv[UNROLL], vv[UNROLL];
+    // one wait for the block's entries (requested a trip ago), then the eight gathers back to back: the compiler's own
+    // waits sat in front of every gather (vmcnt(1): two gathers in flight per wave; round 6, as in sj_kernels.hpp)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
 #pragma unroll
     for (int i = 0; i < UNROLL; ++i) {
       const int k = cur.z + tid + i * TPB;
-      xv[i] = (k < cur.w) ? xin[c_n[i]] : 0.0;
+      xv[i] = (k < cur.w) ? xin[PDHG_COLOFF(c_n[i])] : 0.0;
       vv[i] = v_n[i];
     }
     // behind this block's gathers: the next block's entries and row data (its extent word came in a trip ago), and the
@@ -768,15 +799,20 @@ template <bool COH = false>
 __device__ __forceinline__ double long_chunk_finish(const double *xin, const StreamRegs &g, double (*red)[TPB / WAVE]) {
   double acc[3] = {0.0, 0.0, 0.0};
   double p[UNROLL];
+  // all eight gathers first, the products behind a scheduling barrier: left to itself the compiler, short of registers in
+  // the persistent kernels, reused ONE register pair for the eight gathered values -- load, wait, multiply, eight times
+  // over: eight dependent L2 round trips per chunk (round 6, seen in steps_kernel's ISA)
 #pragma unroll
   for (int i = 0; i < UNROLL; ++i) {
     const int k = g.k0 + threadIdx.x + i * TPB;
-    if (COH) {
-      const double t = ldc<true>(xin + g.cidx[i]);     // unconditional (column 0 for a lane without an entry): see stream_block_finish
-      p[i] = (k < g.k1) ? g.v[i] * t : 0.0;
-    } else {
-      p[i] = (k < g.k1) ? g.v[i] * xin[g.cidx[i]] : 0.0;
-    }
+    if (COH) p[i] = ldc<true>(xin + PDHG_COLOFF(g.cidx[i]));     // unconditional (column 0 for a lane without an entry): see stream_block_finish
+    else p[i] = (k < g.k1) ? xin[PDHG_COLOFF(g.cidx[i])] : 0.0;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < UNROLL; ++i) {
+    const int k = g.k0 + threadIdx.x + i * TPB;
+    p[i] = (k < g.k1) ? g.v[i] * p[i] : 0.0;
   }
   static_assert(UNROLL == 8 && LONG_CHUNK == UNROLL * TPB, "the chunk sum below is written for 8 products per lane");
   acc[0] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));

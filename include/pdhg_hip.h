@@ -20,7 +20,7 @@
  *  - fp64 throughout; kernels are built with -ffp-contract=off so elementwise
  *    updates round exactly like the reference's unfused Julia broadcasts.
  *
- * Environment variables (read when a handle is created unless noted).  These 26 are the
+ * Environment variables (read when a handle is created unless noted).  These 27 are the
  * library's run-time knobs; every other PDHG_* name in the sources is a development
  * variable (tuning constants, negative-result paths, fault injection) and is IGNORED unless
  * PDHG_DEV=1 is set as well (tests/conftest.py and tools/ set it).
@@ -50,6 +50,9 @@
  *   PDHG_RCCL_LIB        (unset) | <path>              the RCCL library to bind at run time
  *   PDHG_COMM            auto | p2p                    peer kernels instead of RCCL inside one process
  *   PDHG_DIST_OVERLAP    auto | 0 | 1                  per-slice reductions overlapped with the A_p' product
+ *   PDHG_DIST_AG_OVERLAP 0 | 1 | 2                     shard groups: xbar's all-gather in column chunks on the comm streams, A_p xbar as one
+ *                                                      carried pass per chunk beside it (2: the same passes behind ONE all-gather --
+ *                                                      the same bits, nothing overlapped; csrc/dist.hpp)
  *   PDHG_SHARD_THREADS   1 | 0                         one issuing host thread per local shard
  *   PDHG_GROUP_COOP      auto | 0 | 1                  persistent group kernels (1: also across devices)
  *   PDHG_ROCTX           0 | 1                         roctx ranges around entry points and products

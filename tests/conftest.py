@@ -23,6 +23,9 @@ def pytest_configure(config):
         "markers", "strict_rows: bit-exactness with the oracle on rows beyond 256 entries: strict row order only")
     config.addinivalue_line(
         "markers", "own_row_order: the test sets PDHG_ROW_ORDER itself (runs once)")
+    config.addinivalue_line(
+        "markers", "short_rows: no row of the test's matrices reaches 256 entries, so both row orders run the same code "
+                   "on the same data: once, in the shipped (relaxed) configuration")
 
 
 # Row order.  The library SHIPS with PDHG_ROW_ORDER=relaxed (rows of more than 256 entries are summed by their whole
@@ -35,6 +38,9 @@ def pytest_configure(config):
 ROW_ORDER_MODES = ("relaxed", "strict")
 OWN_ROW_ORDER_FILES = ("test_gpu_row_order.py", "test_gpu_small_lp.py", "test_gpu_device_loop.py", "test_gpu_exact_sums.py",
                        "test_gpu_native_take_step.py")
+# (round 6, review item 8) tests whose matrices have no row of 256 entries -- the reference's known-answer LPs have at most
+# six variables -- run ONCE, in the shipped order: @pytest.mark.short_rows, or a whole file listed here
+SHORT_ROWS_FILES = ("test_gpu_kat.py",)
 
 
 def pytest_generate_tests(metafunc):
@@ -45,6 +51,8 @@ def pytest_generate_tests(metafunc):
         modes = ("strict",)
     elif metafunc.definition.get_closest_marker("own_row_order") or fname in OWN_ROW_ORDER_FILES:
         modes = ("own",)
+    elif metafunc.definition.get_closest_marker("short_rows") or fname in SHORT_ROWS_FILES:
+        modes = ("relaxed",)
     else:
         modes = ROW_ORDER_MODES
     metafunc.parametrize("row_order_mode", modes, indirect=True)

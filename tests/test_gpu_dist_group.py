@@ -200,12 +200,14 @@ def _group_factory(device_ids):
     return factory
 
 
+@pytest.mark.short_rows
 @pytest.mark.parametrize("shards", [2, 3])
 @pytest.mark.parametrize("case", kat_common.CASES, ids=lambda c: c.__name__)
 def test_reference_kat_on_shard_group(gpu_required, case, shards):
     case(_group_factory([0] * shards))
 
 
+@pytest.mark.short_rows
 @pytest.mark.parametrize("case", kat_common.CASES, ids=lambda c: c.__name__)
 def test_reference_kat_on_tiled_shard_group(gpu_required, monkeypatch, case):
     monkeypatch.setenv("PDHG_SPMV", "tiled")
@@ -213,6 +215,7 @@ def test_reference_kat_on_tiled_shard_group(gpu_required, monkeypatch, case):
     case(_group_factory([0, 0]))
 
 
+@pytest.mark.short_rows
 @pytest.mark.parametrize("remote", ["0", "1"], ids=["local_route", "remote_route"])
 @pytest.mark.parametrize("case", kat_common.CASES[:6], ids=lambda c: c.__name__)
 def test_reference_kat_on_rccl_world_1(gpu_required, monkeypatch, case, remote):

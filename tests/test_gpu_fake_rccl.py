@@ -69,8 +69,7 @@ def test_optimize_with_device_evaluation_and_rescaling_between_processes(gpu_req
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,ingest,lp", [(2, "rows", "small"), (2, "global", "small"), (4, "rows", "small"), (8, "rows", "small"),
-                                             (2, "rows", "tiled"), (4, "rows", "tiled")])
+@pytest.mark.parametrize("world,ingest,lp", [(2, "global", "small"), (4, "rows", "small"), (8, "rows", "small"), (2, "rows", "tiled")])
 def test_all_gather_overlapped_with_the_product_is_bitwise_the_passes_behind_one_all_gather(gpu_required, world, ingest, lp):
     """VERDICT r5 #3 / SURVEY 8e(ii): xbar travels in column chunks on the comm stream (grouped ncclBroadcast per rank and
     chunk), A_p xbar runs as one pass per chunk (carried row sums), pass c waiting for chunk c only.  Bitwise the same

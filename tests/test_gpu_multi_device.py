@@ -39,11 +39,11 @@ needs2 = pytest.mark.skipif(device_count() < 2, reason=f"needs >= 2 GPUs, {devic
 needs4 = pytest.mark.skipif(device_count() < 4, reason=f"needs >= 4 GPUs, {device_count()} visible")
 
 
-def _spawn(world, ingest, overlap="0", timeout=540):
+def _spawn(world, ingest, overlap="0", timeout=540, ag="0"):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29600 + world),
-           os.path.join(ROOT, "tests", "workers", "dist_rank_worker.py"), ingest, "rank", overlap]
+           os.path.join(ROOT, "tests", "workers", "dist_rank_worker.py"), ingest, "rank", overlap, ag]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "dist worker ok" in r.stdout, r.stdout[-2000:]
@@ -157,3 +157,36 @@ def test_group_trial_kernels_across_two_gpus_are_bitwise_the_per_launch_path(gpu
     assert runs["1"].pop("trials") >= 60 and runs["0"].pop("trials") == 0
     for key, val in runs["1"].items():
         assert np.array_equal(np.asarray(val), np.asarray(runs["0"][key])), key
+
+
+# ---- round 6: the all-gather of xbar in column chunks beside A_p xbar (PDHG_DIST_AG_OVERLAP; csrc/dist.hpp) on real devices:
+# RCCL's broadcasts on the comm stream while the product passes run.  Over the test transport (one GPU) this is
+# tests/test_gpu_fake_rccl.py::test_all_gather_overlapped_with_the_product_is_bitwise_the_passes_behind_one_all_gather.
+@needs2
+@pytest.mark.parametrize("ag", ["1", "2"], ids=["overlapped", "passes_behind_one_all_gather"])
+@pytest.mark.parametrize("overlap", ["0", "1"], ids=["reduce_scatter", "per_slice_reduce"])
+def test_one_process_per_gpu_two_ranks_all_gather_in_column_chunks(gpu_required, ag, overlap):
+    _spawn(2, "rows", overlap, ag=ag)
+
+
+@needs2
+@pytest.mark.parametrize("threads", ["1", "0"], ids=["thread_per_shard", "single_thread_issue"])
+def test_create_multi_on_two_gpus_all_gather_overlap_is_bitwise_the_passes_behind_one_all_gather(gpu_required, monkeypatch, threads):
+    monkeypatch.setenv("PDHG_SHARD_THREADS", threads)
+    p = random_lp(30000, 20000, 6, seed=21)
+    runs = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("PDHG_DIST_AG_OVERLAP", mode)
+        geng = HipPdhgEngine.from_problem(p, device_ids=[0, 1])
+        assert geng.dist_info()["backend"] == 0 and geng.layout_describe()["all_gather"]["chunks"] >= 2
+        runs[mode] = _run(geng, p, 40, 10)
+        geng.close()
+    for k, v in runs["1"].items():
+        assert np.array_equal(np.asarray(v), np.asarray(runs["2"][k])), k
+    monkeypatch.delenv("PDHG_DIST_AG_OVERLAP")
+    _compare(runs["1"], _run(HipPdhgEngine.from_problem(p), p, 40, 10), p)
+
+
+@needs4
+def test_one_process_per_gpu_four_ranks_all_gather_in_column_chunks(gpu_required):
+    _spawn(4, "rows", "1", ag="1")

@@ -107,9 +107,8 @@ def test_products_are_bit_identical_to_the_oracle_in_every_row_order(gpu_require
     st.close()
 
 
-@pytest.mark.parametrize("maker", [lambda: random_lp(30_000, 20_000, 6, seed=21), lambda: _ragged_lp(5_000, 7_001, seed=2)],
-                         ids=["random", "ragged"])
-@pytest.mark.parametrize("wide", ["0", "1"], ids=["narrow", "wide"])
+@pytest.mark.parametrize("maker,wide", [(lambda: random_lp(30_000, 20_000, 6, seed=21), "1"), (lambda: _ragged_lp(5_000, 7_001, seed=2), "0"),
+                                        (lambda: _ragged_lp(5_000, 7_001, seed=2), "1")], ids=["random-wide", "ragged-narrow", "ragged-wide"])
 def test_trajectories_equal_the_csr_row_block_layout(gpu_required, monkeypatch, row_order_mode, maker, wide):
     p = maker()
     r_sj = _run(_engine(p, monkeypatch, "1", wide=wide), p)
@@ -126,6 +125,7 @@ def test_trajectories_equal_the_csr_row_block_layout(gpu_required, monkeypatch, 
 @pytest.mark.parametrize("maker,slab_mb", [(lambda: random_lp(200_000, 150_000, 8, seed=3), 0.5),
                                            (lambda: pagerank_lp(120_000, seed=4), 0.3)], ids=["random", "pagerank"])
 @pytest.mark.parametrize("wide", ["0", "1"], ids=["narrow", "wide"])
+@pytest.mark.strict_rows          # (the relaxed order only changes how hub rows beyond 256 entries are summed: covered by the products test)
 def test_slab_passes_on_the_sliced_jagged_copies(gpu_required, monkeypatch, row_order_mode, maker, slab_mb, wide):
     p = maker()
     A = p.constraint_matrix

@@ -5,7 +5,7 @@
 rank 0 also runs the single-handle engine and compares.  Exit code 0 = all checks passed.
 
 argv: <ingest: global|rows> <devices: 'rank' (rank r on GPU r) | int (every rank on that GPU)>
-      [overlap 0|1]
+      [overlap 0|1] [all-gather overlap 0|1|2: PDHG_DIST_AG_OVERLAP]
 """
 import os
 import sys
@@ -55,6 +55,8 @@ def main():
     ingest, devices = sys.argv[1], sys.argv[2]
     if len(sys.argv) > 3:
         os.environ["PDHG_DIST_OVERLAP"] = sys.argv[3]
+    if len(sys.argv) > 4 and sys.argv[4] != "0":
+        os.environ["PDHG_DIST_AG_OVERLAP"] = sys.argv[4]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     device = rank if devices == "rank" else int(devices)

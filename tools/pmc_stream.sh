@@ -21,7 +21,8 @@ for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
          "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum" \
          "TA_BUSY_sum TA_TA_BUSY_sum TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
          "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum" \
-         "TCC_EA0_RDREQ_sum TCC_BUSY_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum" ; do
+         "TCC_EA0_RDREQ_sum TCC_BUSY_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum" \
+         "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD" ; do
   i=$((i+1))
   eval timeout 400 rocprofv3 --kernel-trace --pmc $C -d $O/p$i -- $B > $O/p$i.log 2>&1 || echo "pass $i failed"
 done

@@ -17,7 +17,7 @@ LABEL="${1:-round 3}"; shift
 WLS="${@:-random pagerank l1svm}"
 rm -rf $O; mkdir -p $O
 for WL in $WLS; do
-  B="python $R/bench.py --workload $WL --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --profile-steps 0 --no-self-profile"
+  B="python $R/bench.py --workload $WL --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --profile-steps 0 --no-self-profile --full-line --no-details"
   PDHG_GRAPH=0 timeout 600 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum TCC_HIT_sum -d $O/$WL/p1 -- $B > $O/$WL.p1.log 2>&1 || echo "pass 1 failed"
   PDHG_GRAPH=0 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum -d $O/$WL/p2 -- $B > $O/$WL.p2.log 2>&1 || echo "pass 2 failed"
   PDHG_GRAPH=0 timeout 600 $B > $O/$WL.line.json 2> $O/$WL.line.err
