@@ -578,6 +578,15 @@ int pdhg_trust_region_bounds(pdhg_handle *h0, int count, const int *points, doub
       }
     }
     h->tr_epoch = (unsigned long long)r[8 * count + 1];
+#ifdef PDHG_TRB_TRACE
+    if ((h->trb_calls % 100) == 99) {
+      unsigned long long t[8];
+      if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_trb_trace), sizeof(t)) == hipSuccess && t[5] > 0 && t[7] > 0)
+        fprintf(stderr, "[pdhg_hip] batched searches: %llu launches, %.1f probe passes each; per pass (us): walk %.2f, block reductions %.2f, "
+                        "barrier %.2f, second stage %.2f, search step %.2f; set-up pass incl. barrier %.2f\n", t[7], (double)t[5] / t[7],
+                0.01 * t[0] / t[5], 0.01 * t[1] / t[5], 0.01 * t[2] / t[5], 0.01 * t[3] / t[5], 0.01 * t[4] / t[5], 0.01 * t[6] / t[7]);
+    }
+#endif
     if (r[8 * count] == 0.0) {
       for (int q = 0; q < 8 * count; ++q) out[q] = r[q];
       h->trb_calls += 1;

@@ -642,6 +642,13 @@ const char *pdhg_kernel_name(pdhg_handle *h, int kernel_id) {
     case PDHG_K_PRIMAL: return "primal_kernel";
     case PDHG_K_SPMV_DUAL:
       if (!h) return "spmv_stream_kernel<1, false, 0>";
+      if (h->grp && h->grp->ag_chunks > 1 && !h->has_q && !h->Achunk.empty()) {
+        // a shard group with the all-gather in column chunks: one carried pass per chunk (the stream kernels' later passes
+        // are their INIT instances, <.., true, ..>: a label for people, not for tools/rocprof_summary.py)
+        buf = std::to_string(h->Achunk.size()) + " column-chunk passes with carried row sums: " + product_kernels(h->Achunk.front(), MODE_PLAIN, 0) +
+              " ... " + product_kernels(h->Achunk.back(), MODE_DUAL, 0);
+        return buf.c_str();
+      }
       buf = product_kernels(h->A, MODE_DUAL, 0);
       return buf.c_str();
     case PDHG_K_SPMV_ATY:

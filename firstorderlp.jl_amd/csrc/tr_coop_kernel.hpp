@@ -232,6 +232,15 @@ struct TrBatchArgs {
   unsigned long long seq;
 };
 
+#ifdef PDHG_TRB_TRACE
+// dev: where a probe pass of the batched search spends its time (workgroup 0's wall clock, 100 MHz): sums over the passes
+// of [0] the element walk, [1] the block reductions, [2] the grid barrier, [3] the second stage, [4] the searches' step;
+// [5] passes, [6] the set-up pass up to its barrier's end, [7] launches
+__device__ unsigned long long g_trb_trace[8];
+#define TRB_STAMP(v) do { if (blockIdx.x == 0 && threadIdx.x == 0) v = wall_clock64(); } while (0)
+#else
+#define TRB_STAMP(v) do { } while (0)
+#endif
 __global__ __launch_bounds__(TPB) void tr_coop_batch_kernel(TrBatchArgs a) {
   __shared__ double res[TRB_MAX][EV_MAXQ];
   __shared__ TrProbes s_pr[TRB_MAX];
@@ -244,6 +253,9 @@ __global__ __launch_bounds__(TPB) void tr_coop_batch_kernel(TrBatchArgs a) {
   const size_t pstride = (size_t)EV_MAXQ * stride;          // one problem's partials of one pass
   unsigned long long epoch = a.epoch;
   int buf = 0;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+  (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)ts5;
+  TRB_STAMP(ts0);
   for (int p = 0; p < P; ++p) {
     // the set-up pass of problem p: tr_coop_kernel's statements
     const TrBatchProblem &q = a.pb[p];
@@ -290,6 +302,10 @@ __global__ __launch_bounds__(TPB) void tr_coop_batch_kernel(TrBatchArgs a) {
     block_reduce_store<TR_SETUP_NS, 1>(acc, a.partials + p * pstride, stride);
   }
   grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
+  TRB_STAMP(ts1);
+#ifdef PDHG_TRB_TRACE
+  if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&g_trb_trace[6], ts1 - ts0); atomicAdd(&g_trb_trace[7], 1ull); }
+#endif
   for (int p = 0; p < P; ++p) trc_reduce<TR_SETUP_NS, 1>(a.partials + p * pstride, stride, (int)gridDim.x, res[p]);
   buf ^= 1;
   if (threadIdx.x == 0) {
@@ -325,6 +341,7 @@ __global__ __launch_bounds__(TPB) void tr_coop_batch_kernel(TrBatchArgs a) {
     bool act[TRB_MAX];
 #pragma unroll
     for (int p = 0; p < TRB_MAX; ++p) act[p] = p < P && s_go[p] == 1;       // workgroup-uniform, and the same in every workgroup
+    TRB_STAMP(ts0);
     for (int k = gtid; k < total; k += gstride) {
       const bool primal = k < n;
       double wd2[TRB_MAX], t[TRB_MAX], gd[TRB_MAX];
@@ -349,14 +366,18 @@ __global__ __launch_bounds__(TPB) void tr_coop_batch_kernel(TrBatchArgs a) {
         }
       }
     }
+    TRB_STAMP(ts1);
 #pragma unroll
     for (int p = 0; p < TRB_MAX; ++p)
       if (act[p]) block_reduce_store<TRC_Q, 0>(acc[p], part + p * pstride, stride);
+    TRB_STAMP(ts2);
     grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
+    TRB_STAMP(ts3);
     for (int p = 0; p < P; ++p)
       if (s_go[p] == 1) trc_reduce<TRC_Q, 0>(part + p * pstride, stride, (int)gridDim.x, res[p]);
     buf ^= 1;
     __syncthreads();
+    TRB_STAMP(ts4);
     if (threadIdx.x == 0) {
       int any = 0;
       const bool broken = __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -370,6 +391,13 @@ __global__ __launch_bounds__(TPB) void tr_coop_batch_kernel(TrBatchArgs a) {
       s_any = any;
     }
     __syncthreads();
+#ifdef PDHG_TRB_TRACE
+    TRB_STAMP(ts5);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      atomicAdd(&g_trb_trace[0], ts1 - ts0); atomicAdd(&g_trb_trace[1], ts2 - ts1); atomicAdd(&g_trb_trace[2], ts3 - ts2);
+      atomicAdd(&g_trb_trace[3], ts4 - ts3); atomicAdd(&g_trb_trace[4], ts5 - ts4); atomicAdd(&g_trb_trace[5], 1ull);
+    }
+#endif
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const int k = 8 * P + 2;

@@ -195,13 +195,14 @@ def test_the_builder_picks_the_layout_for_bandwidth_bound_stream_matrices(gpu_re
     assert small["A_sj"] == 0 and small["At_sj"] == 0
 
 
+@pytest.mark.short_rows
 def test_device_rescaling_reaches_the_hessians_sliced_jagged_copies(gpu_required, monkeypatch):
     """A QP whose objective matrix runs `spmv_sj_kernel` (forced here; by itself for a sparse Hessian of n >~ 0.4M): after
     pdhg_rescale the sliced jagged copies of Q and Q' must hold (D^-1 Q) D^-1 (preprocess.jl:562-564) like the CSR
     arrays -- round 5 scaled only the CSR and slab arrays, so the products by Q used the UNSCALED Hessian (advisor r5,
     high).  Trial steps (x' = x - tau (c + Q x - A'y), pdhg.jl:462-477, and dx'Q dx) and 30 free-running steps bitwise the
     CSR layout's."""
-    n, m = 60_000, 40_000
+    n, m = 12_000, 8_000
     p = random_lp(m, n, 6, seed=31)
     rng = np.random.default_rng(4)
     B = sp.random(n, n, density=3.0 / n, random_state=9, format="csc")
