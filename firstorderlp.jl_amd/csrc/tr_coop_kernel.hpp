@@ -72,6 +72,47 @@ __device__ __forceinline__ void trc_reduce(const double *partials, int stride, i
   __syncthreads();
 }
 
+// The same for up to NP problems whose partials lie pstride apart, ALL their loads issued before the first tree and one
+// workgroup barrier at the end (round 6: problem by problem this stage was three times one problem's latency -- 6.3 us of a
+// 21 us pass on the L1-SVM LP, in-kernel trace).  Per problem and quantity the same lane grouping and the same tree as
+// trc_reduce: the same bits.  go[p] != 0: problem p takes part (workgroup-uniform).
+template <int NS, int NM, int NP>
+__device__ __forceinline__ void trc_reduce_multi(const double *partials, size_t pstride, int stride, int count, double (*res)[EV_MAXQ],
+                                                 const int *go, int P) {
+  constexpr int K = NS + NM, WAVES = TPB / WAVE, PER_WAVE = (K + WAVES - 1) / WAVES, PER_LANE = TRC_MAX_WGS / WAVE;
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+  double t[NP][PER_WAVE][PER_LANE];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const bool on = p < P && go[p];
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int q = wave + i * WAVES;
+#pragma unroll
+      for (int j = 0; j < PER_LANE; ++j) {
+        const int b = lane + j * WAVE;
+        t[p][i][j] = (on && q < K && b < count)
+                         ? __hip_atomic_load(partials + p * pstride + (size_t)q * stride + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if (!(p < P && go[p])) continue;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int q = wave + i * WAVES;
+      const bool is_max = q >= NS;
+      double v = 0.0;
+#pragma unroll
+      for (int j = 0; j < PER_LANE; ++j) v = is_max ? fmax(v, t[p][i][j]) : v + t[p][i][j];
+      v = is_max ? wave_max_nonneg_dpp(v) : wave_sum_dpp(v);
+      if (q < K && lane == WAVE - 1) res[p][q] = v;
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(TPB) void tr_coop_kernel(TrCoopArgs a) {
   __shared__ double res[EV_MAXQ];
   __shared__ TrProbes s_pr;
@@ -306,11 +347,18 @@ __global__ __launch_bounds__(TPB) void tr_coop_batch_kernel(TrBatchArgs a) {
 #ifdef PDHG_TRB_TRACE
   if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&g_trb_trace[6], ts1 - ts0); atomicAdd(&g_trb_trace[7], 1ull); }
 #endif
-  for (int p = 0; p < P; ++p) trc_reduce<TR_SETUP_NS, 1>(a.partials + p * pstride, stride, (int)gridDim.x, res[p]);
+  {
+    __shared__ int s_all[TRB_MAX];
+    if (threadIdx.x < TRB_MAX) s_all[threadIdx.x] = 1;
+    __syncthreads();
+    trc_reduce_multi<TR_SETUP_NS, 1, TRB_MAX>(a.partials, pstride, stride, (int)gridDim.x, res, s_all, P);
+  }
   buf ^= 1;
-  if (threadIdx.x == 0) {
-    int any = 0;
-    for (int p = 0; p < P; ++p) {
+  // one thread PER PROBLEM (each in a wave of its own) starts / advances its search: the problems are independent, and
+  // thread 0 doing them one after the other was 4.5 us of a 21 us pass
+  if ((threadIdx.x & (WAVE - 1)) == 0 && (int)(threadIdx.x / WAVE) < P) {
+    const int p = (int)(threadIdx.x / WAVE);
+    {
       const double *r = res[p];
       double *o = s_out[p];
       o[0] = 0.5 * r[10] + r[0] - r[1] + r[2];
@@ -328,8 +376,12 @@ __global__ __launch_bounds__(TPB) void tr_coop_batch_kernel(TrBatchArgs a) {
         tr_search_begin(S[p], r2, tmax, hinf, TrEnd{r[11], hinf, {r[12], r[14], r[13], r[15]}});
         s_go[p] = tr_search_next(S[p], s_pr[p]) ? 1 : 2;
       }
-      any |= s_go[p] == 1;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int any = 0;
+    for (int p = 0; p < P; ++p) any |= s_go[p] == 1;
     s_any = any;
   }
   __syncthreads();
@@ -373,21 +425,29 @@ __global__ __launch_bounds__(TPB) void tr_coop_batch_kernel(TrBatchArgs a) {
     TRB_STAMP(ts2);
     grid_barrier(a.sync, ++epoch, a.nxcd, a.xcd_cnt);
     TRB_STAMP(ts3);
-    for (int p = 0; p < P; ++p)
-      if (s_go[p] == 1) trc_reduce<TRC_Q, 0>(part + p * pstride, stride, (int)gridDim.x, res[p]);
+    {
+      __shared__ int s_act[TRB_MAX];
+      if (threadIdx.x < TRB_MAX) s_act[threadIdx.x] = (int)threadIdx.x < P && s_go[threadIdx.x] == 1;
+      __syncthreads();
+      trc_reduce_multi<TRC_Q, 0, TRB_MAX>(part, pstride, stride, (int)gridDim.x, res, s_act, P);
+    }
     buf ^= 1;
-    __syncthreads();
     TRB_STAMP(ts4);
-    if (threadIdx.x == 0) {
-      int any = 0;
-      const bool broken = __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-      for (int p = 0; p < P; ++p) {
-        if (s_go[p] != 1) continue;
+    if ((threadIdx.x & (WAVE - 1)) == 0 && (int)(threadIdx.x / WAVE) < P) {
+      const int p = (int)(threadIdx.x / WAVE);
+      if (s_go[p] == 1) {
+        const bool broken = __hip_atomic_load(&a.sync->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        // (state, probes and sums stay in LDS: copied into registers for the step the kernel spills 200 bytes per lane and the
+        //  step takes 5.8 us instead of 2.9)
         tr_search_feed(S[p], s_pr[p], res[p]);
         s_go[p] = tr_search_next(S[p], s_pr[p]) ? 1 : 2;
         if (broken) s_go[p] = 3;                               // a barrier timed out: the host repeats the calls one by one
-        any |= s_go[p] == 1;
       }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int any = 0;
+      for (int p = 0; p < P; ++p) any |= s_go[p] == 1;
       s_any = any;
     }
     __syncthreads();
