@@ -1054,9 +1054,17 @@ inline SjPlan sj_plan(int nblk, int rows, const std::vector<int> &rowptr, const 
 // hardware's dynamic dispatch of the plain kernel, not a fixed walk: PageRank-1M lost 6 % on the pipelined launch (0.105
 // against 0.099 ms per product) where banded / block-diagonal matrices with Poisson(10) rows gained 5-6 % (0.77 -> 0.73 ms;
 // profiles/r05_sj_layout.txt).  So: only matrices whose rows (the long-row path's apart) stay within SJ_MAX_LEN entries.
+// Round 6: ALSO every matrix of at most 1 024 row blocks, whatever its rows.  The persistent grid (4 workgroups per CU) then
+// holds one workgroup PER BLOCK -- no walk, the hardware still deals the blocks -- and what the kernel buys is its request
+// order: the extent word gives a block's entries, row extents and epilogue operands in ONE round trip, where the plain
+// kernel chains block table -> row pointers -> entries -> gathers -> row extents -> operands (six).  These launches are
+// one resident wave of workgroups, i.e. pure latency: the products of a termination / restart check, the event brackets
+// behind the roofline figures and the graph-path trials of such LPs (the persistent trial kernels walk the row blocks
+// themselves).  L1-SVM LP, products as separate kernels: profiles/r06_stream_waitcnt.txt.
 inline bool stream_pipe_wanted(int nblk, int64_t max_row_nnz, int long_thr) {
   if (const char *ev = dev_env("PDHG_STREAM_PIPE")) return ev[0] != '0';
-  return nblk > 1024 && std::min<int64_t>(max_row_nnz, long_thr) <= SJ_MAX_LEN;
+  if (nblk <= 1024) return nblk >= 2 * NUM_XCD;
+  return std::min<int64_t>(max_row_nnz, long_thr) <= SJ_MAX_LEN;
 }
 int build_block_extents(int4 **ext_out, int *grid_out, const int2 *d_blks, int nblk, int max_wgs, const std::vector<int> &rowptr, bool remap) {
   if (nblk <= 0) return 0;

@@ -3,7 +3,8 @@ lane-per-row sums in the same order as spmv_stream_kernel, so NOT A BIT may diff
 block partials (hence accept / reject decisions), in both row orders, with column-slab passes (INIT carry), long rows,
 blocks of more than 256 very short rows (whose later row trips are not pre-requested), empty rows, as graph nodes and as
 plain launches.  The builder picks it for stream-class matrices with more than 1 024 row blocks that did not get the
-sliced jagged copy (csrc/sj_kernels.hpp)."""
+sliced jagged copy (csrc/sj_kernels.hpp), and -- round 6 -- for every matrix of 16 ... 1 024 row blocks (one workgroup per block:
+its request order alone)."""
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -98,5 +99,9 @@ def test_the_builder_picks_the_pipelined_launch(gpu_required, monkeypatch):
     monkeypatch.delenv("PDHG_SPMV", raising=False)
     hub = HipPdhgEngine.from_problem(pagerank_lp(330_000, seed=4)).layout_info()
     assert hub["A_blocks"] > 1024 and hub["A_pipe"] == 0 and hub["A_sj"] == 0, hub
+    # round 6: at most 1 024 row blocks -> one workgroup per block in the pipelined kernel's request order (one round trip for
+    # entries, row extents and operands), whatever the rows; a handful of blocks: the plain kernel
     small = HipPdhgEngine.from_problem(random_lp(5000, 4000, 8, seed=7)).layout_info()
-    assert small["A_pipe"] == 0 and small["At_pipe"] == 0
+    assert 16 <= small["A_blocks"] <= 1024 and small["A_pipe"] == 1 and small["At_pipe"] == 1, small
+    tiny = HipPdhgEngine.from_problem(random_lp(700, 500, 6, seed=7)).layout_info()
+    assert tiny["A_blocks"] < 16 and tiny["A_pipe"] == 0, tiny
