@@ -18,16 +18,17 @@
 // and sorting a whole group (not one slice) makes the four slices nearly uniform inside.  Lane l adds its row's
 // products level by level, i.e. strictly left to right in a register: EVERY row of this layout has the reference's
 // order of additions (saddle_point.jl:1102-1107, pdhg.jl:492; bit-identical to the CPU loops), whatever its length --
-// there is no "relaxed" mode here.  The row sums then cross the workgroup through 2 KB of LDS so that thread t runs the
+// there is no "relaxed" mode for the rows a lane walks (hub rows, below, follow the CSR kernel's rule).  The row sums then cross the workgroup through 2 KB of LDS so that thread t runs the
 // fused epilogue of row (group base + t): y, b, x, A'y are read and y', A'y' written in ROW order, fully coalesced
 // (with the epilogue in slot order -- round 5's first cut, sorting windows of 2 048 rows -- every epilogue operand became a
 // 64-line gather and the A' product of a banded matrix ran at HALF the CSR kernel's speed).  Rows beyond
 // CsrDev::long_thr stay with the long-row kernels (slot row = -1, no epilogue here).
 // Column-slab passes (INIT) carry the row sums through e.init exactly as the CSR stream kernel does.
-// The builder uses the layout when no row of the matrix (slab) that is not "long" has more than SJ_MAX_LEN entries: a
-// lane walks its row in batches of SJ_U dependent load -> gather -> add trips, so a 2 000-entry hub row would hold its
-// workgroup for 250 memory round trips (PageRank-1M in the first cut: 1.19 ms against 0.10) -- such matrices keep the CSR
-// row blocks, whose lanes share a row block's entries whatever the row lengths.
+// Rows of more than SjDev::max_len (128) entries that are not "long" are HUB rows (round 6): a lane walks its row in batches of
+// SJ_U dependent load -> gather -> add trips, so a 2 000-entry hub row would hold its workgroup for 125 memory round trips
+// (PageRank-1M in round 5's first cut: 1.19 ms against 0.10) -- the kernel runs them as whole-workgroup row blocks of the CSR
+// arrays before its slices instead (see the kernel).  Which matrices get the layout, and in which of its two forms:
+// layout.hpp, sj_plan().
 //
 // Launch.  Persistent: SJ_WGS_PER_CU workgroups per compute unit (the skeleton is fastest at 1-4: more waves only
 // widen the window of the gathered vector in flight), one group of four slices per workgroup and trip, XCD x walking the
