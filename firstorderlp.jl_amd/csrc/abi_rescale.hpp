@@ -69,7 +69,15 @@ static int apply_scaling(pdhg_handle *h, RescaleTmp &t) {
   };
   scale_one(h->A, t.inv_e, t.inv_d, 0);
   scale_one(h->At, t.inv_e, t.inv_d, 1);
-  for (CsrDev &D : h->Achunk) scale_one(D, t.inv_e, t.inv_d, 0);       // the column-chunk layouts of a shard group (dist.hpp)
+  if (!h->Achunk.empty() && h->grp) {
+    // the column-chunk layouts of a shard group (dist.hpp) index their columns INTO THE CHUNK: the column factors in chunk
+    // layout (xchunk is free between trials: the next trial packs xbar into it again)
+    DistGroup &g = *h->grp;
+    int rc2 = launch_chunk_pack(g, h, t.inv_d, h->xchunk, 0, g.world, h->n, h->stream);
+    if (rc2) return rc2;
+    const int64_t W = (int64_t)g.world * g.ag_sub;
+    for (size_t c = 0; c < h->Achunk.size(); ++c) scale_one(h->Achunk[c], t.inv_e, h->xchunk + (int64_t)c * W, 0);
+  }
   if (h->has_q) {
     // objective_matrix = (D^-1 Q) D^-1 (preprocess.jl:562-564); Qt holds Q' entry by entry, so the
     // "transposed" order reproduces the same two roundings on it

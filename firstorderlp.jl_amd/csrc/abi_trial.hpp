@@ -41,13 +41,19 @@ static int trial_shard_mt(DistGroup &g, pdhg_handle *s, int i, const TrialArgs &
   const double sigma = a.primal_weight * a.step_size;
   if (g.ag_chunks > 1 && !s->has_q) {
     // xbar chunk by chunk, A_p xbar as one pass per chunk (see trial_dual_group)
-    if (g.ag_mode == 1 && g.backend == COMM_RCCL) {
+    if (g.backend == COMM_RCCL) {
+      // the owned slice into the chunk layout, then one all-gather per chunk on the comm stream; ag_mode 2: the passes wait
+      // for the LAST chunk (one all-gather's worth of waiting: nothing overlapped, the same bits)
+      if ((rc = launch_chunk_pack(g, s, s->xbar, s->xchunk, s->rank, s->rank + 1, s->n_alloc, s->stream))) return rc;
       HIP_TRY(hipEventRecord(s->ev_xbar, s->stream));
       for (int c = 0; c < g.ag_chunks; ++c)
-        if ((rc = mt_all_gather_chunk(g, s, i, [](pdhg_handle *q) { return q->xbar; }, c))) return rc;
-      if ((rc = launch_dual_chunked(s, sigma, true))) return rc;
+        if ((rc = mt_all_gather_chunk(g, s, i, c))) return rc;
+      if (g.ag_mode != 1) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_ag[(size_t)g.ag_chunks - 1], 0));
+      if ((rc = launch_dual_chunked(s, sigma, g.ag_mode == 1))) return rc;
     } else {
+      // peer back end: the ordinary all-gather, then the whole vector into the chunk layout
       if ((rc = mt_all_gather(g, s, i, [](pdhg_handle *q) { return q->xbar; }, g.S))) return rc;
+      if ((rc = launch_chunk_pack(g, s, s->xbar, s->xchunk, 0, g.world, s->n_alloc, s->stream))) return rc;
       if ((rc = launch_dual_chunked(s, sigma, false))) return rc;
     }
   } else {
@@ -386,11 +392,22 @@ static int trial_dual_group(const Shards &L, double step_size, double primal_wei
   // ag_mode 2 (and the peer back end): the same passes behind one all-gather -- the same bits, nothing overlapped.
   const bool chunked = g.ag_chunks > 1 && !lead->has_q;
   const bool chunks_on_comm = chunked && g.ag_mode == 1 && g.backend == COMM_RCCL;
-  if (chunks_on_comm) {
+  if (chunked && g.backend == COMM_RCCL) {
+    // the owned slices into the chunk layout (dist.hpp), then ONE ncclAllGather per chunk on the comm streams
     ProfScope ps(lead, PDHG_K_ALLGATHER);
-    FOR_SHARDS(L, s) { HIP_TRY(hipEventRecord(s->ev_xbar, s->stream)); }
+    FOR_SHARDS(L, s) {
+      if ((rc = launch_chunk_pack(g, s, s->xbar, s->xchunk, s->rank, s->rank + 1, s->n_alloc, s->stream))) return rc;
+      HIP_TRY(hipEventRecord(s->ev_xbar, s->stream));
+    }
     for (int c = 0; c < g.ag_chunks; ++c)
-      if ((rc = dist_all_gather_chunk(g, [](pdhg_handle *s) { return s->xbar; }, c))) return rc;
+      if ((rc = dist_all_gather_chunk(g, c))) return rc;
+    if (!chunks_on_comm)       // ag_mode 2: every pass behind the whole all-gather
+      FOR_SHARDS(L, s) { HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_ag[(size_t)g.ag_chunks - 1], 0)); }
+  } else if (chunked) {
+    // peer back end: the ordinary all-gather, then the whole vector into the chunk layout
+    ProfScope ps(lead, PDHG_K_ALLGATHER);
+    if ((rc = dist_all_gather(g, [](pdhg_handle *s) { return s->xbar; }, g.S))) return rc;
+    FOR_SHARDS(L, s) { if ((rc = launch_chunk_pack(g, s, s->xbar, s->xchunk, 0, g.world, s->n_alloc, s->stream))) return rc; }
   } else {
     ProfScope ps(lead, PDHG_K_ALLGATHER);
     if ((rc = dist_all_gather(g, [](pdhg_handle *s) { return s->xbar; }, g.S))) return rc;

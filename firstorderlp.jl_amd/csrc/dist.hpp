@@ -166,8 +166,8 @@ struct DistGroup {
   // The all-gather of xbar overlapped with A_p xbar (round 6; SURVEY 8e(ii), pdhg.jl:472-494).  On the fully connected node
   // every slice has a link of its own and all of them arrive together, so the product can only run beside the transfer
   // if it consumes PARTS of every slice: the column space is cut into `ag_chunks` chunks -- chunk c = sub-range c (ag_sub
-  // columns) of EVERY rank's slice -- xbar travels chunk by chunk (one grouped broadcast per rank and chunk on the comm
-  // streams) and A_p xbar runs as one pass per chunk (a complete layout of A_p restricted to the chunk's columns, the row
+  // columns) of EVERY rank's slice -- xbar travels chunk by chunk (one ncclAllGather per chunk on the comm streams, into a
+  // chunk-major copy of xbar: pdhg_handle::xchunk) and A_p xbar runs as one pass per chunk (a complete layout of A_p restricted to the chunk's columns, the row
   // sums carried through memory), pass c waiting only for chunk c.  0 / 1: off (one all-gather, one product).
   // ag_mode 1: as described; 2: the same passes behind ONE all-gather (nothing overlapped: the reference the overlapped
   // form must equal bit for bit, and what the peer back end inside one process runs).  A row's products are added chunk
@@ -419,15 +419,33 @@ int dist_join_comm(DistGroup &g) {
 }
 
 // ---- the all-gather of xbar, chunk by chunk (DistGroup::ag_chunks) -------------------------------------------------------
-// Chunk c of the vector `sel`: columns [q*S + c*ag_sub, q*S + min((c+1)*ag_sub, S)) of every rank q's slice, broadcast in
-// place by their owner (root q) -- world collectives in one group per local shard, on the COMM streams, which first wait
-// for "the owned slice is written" (ev_xbar, recorded by the caller on the compute streams); ev_ag[c] is recorded behind
-// them.  The buffers hold world * S doubles, so a sub-range is moved whole even where it runs past n.
-template <typename Sel>
-int dist_all_gather_chunk(DistGroup &g, Sel sel, int c) {
+// CHUNK layout of an n-vector: chunk c = [world][ag_sub] doubles, rank q's part being columns q*S + c*ag_sub ... of the
+// natural vector (its sub-range c).  One ncclAllGather per chunk fills it in place -- every rank contributes ag_sub doubles at
+// its own offset -- so a chunk is ONE standard collective (not a broadcast per rank), and the chunk layouts of A_p
+// (host_shards.hpp: build_column_chunks) carry column indices into their chunk.
+// rows of `src` [q*S, q*S + S) for q in [q0, q1) into the chunk layout `dst` ([C][world * sub])
+__global__ __launch_bounds__(TPB) void chunk_pack_kernel(const double *__restrict__ src, double *__restrict__ dst, int64_t S, int64_t sub,
+                                                         int C, int world, int q0, int q1, int64_t src_len) {
+  const int64_t stride = (int64_t)gridDim.x * TPB, W = (int64_t)world * sub;
+  for (int q = q0; q < q1; ++q)
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < S; i += stride) {
+      const int64_t j = (int64_t)q * S + i;
+      const int64_t c = i / sub, off = i - c * sub;
+      dst[c * W + (int64_t)q * sub + off] = j < src_len ? src[j] : 0.0;
+    }
+}
+inline int launch_chunk_pack(DistGroup &g, pdhg_handle *s, const double *src, double *dst, int q0, int q1, int64_t src_len, hipStream_t stream) {
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((g.S + TPB - 1) / TPB, EW_MAX_BLOCKS));
+  hipLaunchKernelGGL(chunk_pack_kernel, dim3(grid), dim3(TPB), 0, stream, src, dst, g.S, g.ag_sub, g.ag_chunks, g.world, q0, q1, src_len);
+  HIP_TRY(hipGetLastError());
+  (void)s;
+  return 0;
+}
+// Chunk c of every local shard's xchunk, on the COMM streams (which first wait for "the owned slice is packed": ev_xbar,
+// recorded by the caller on the compute streams); ev_ag[c] is recorded behind it.
+int dist_all_gather_chunk(DistGroup &g, int c) {
   RCCL_API(R);
-  const int64_t off = (int64_t)c * g.ag_sub, len = std::min<int64_t>(g.ag_sub, g.S - off);
-  if (len <= 0) return fail(-1, "empty all-gather chunk");
+  const int64_t W = (int64_t)g.world * g.ag_sub;
   if (c == 0)
     for (pdhg_handle *s : g.sh) {
       HIP_TRY(hipSetDevice(s->device));
@@ -437,11 +455,8 @@ int dist_all_gather_chunk(DistGroup &g, Sel sel, int c) {
   for (size_t i = 0; i < g.sh.size(); ++i) {
     pdhg_handle *s = g.sh[i];
     HIP_TRY(hipSetDevice(s->device));
-    double *b = sel(s);
-    for (int q = 0; q < g.world; ++q) {
-      double *p = b + (int64_t)q * g.S + off;
-      NCCL_TRY(R->Broadcast(p, p, (size_t)len, ncclDouble, q, g.comm[i], s->comm_stream));
-    }
+    double *b = s->xchunk + (int64_t)c * W;
+    NCCL_TRY(R->AllGather(b + (int64_t)s->rank * g.ag_sub, b, (size_t)g.ag_sub, ncclDouble, g.comm[i], s->comm_stream));
   }
   NCCL_TRY(R->GroupEnd());
   for (pdhg_handle *s : g.sh) {
@@ -450,19 +465,13 @@ int dist_all_gather_chunk(DistGroup &g, Sel sel, int c) {
   }
   return 0;
 }
-// the same for ONE shard, issued by its own host thread (no group: one communicator per thread)
-int mt_all_gather_chunk(DistGroup &g, pdhg_handle *s, int i, BufSel sel, int c) {
+// the same for ONE shard, issued by its own host thread
+int mt_all_gather_chunk(DistGroup &g, pdhg_handle *s, int i, int c) {
   RCCL_API(R);
-  const int64_t off = (int64_t)c * g.ag_sub, len = std::min<int64_t>(g.ag_sub, g.S - off);
-  if (len <= 0) return fail(-1, "empty all-gather chunk");
+  const int64_t W = (int64_t)g.world * g.ag_sub;
   if (c == 0) HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->ev_xbar, 0));
-  double *b = sel(s);
-  NCCL_TRY(R->GroupStart());
-  for (int q = 0; q < g.world; ++q) {
-    double *p = b + (int64_t)q * g.S + off;
-    NCCL_TRY(R->Broadcast(p, p, (size_t)len, ncclDouble, q, g.comm[(size_t)i], s->comm_stream));
-  }
-  NCCL_TRY(R->GroupEnd());
+  double *b = s->xchunk + (int64_t)c * W;
+  NCCL_TRY(R->AllGather(b + (int64_t)s->rank * g.ag_sub, b, (size_t)g.ag_sub, ncclDouble, g.comm[(size_t)i], s->comm_stream));
   HIP_TRY(hipEventRecord(s->ev_ag[(size_t)c], s->comm_stream));
   return 0;
 }

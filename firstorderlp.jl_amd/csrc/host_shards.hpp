@@ -654,6 +654,7 @@ void destroy_shard(pdhg_handle *h) {
   free_csr_dev(h->A); free_csr_dev(h->At); free_csr_dev(h->Q); free_csr_dev(h->Qt);
   for (CsrDev &D : h->Achunk) free_csr_dev(D);
   if (h->chunk_carry) (void)hipFree(h->chunk_carry);
+  if (h->xchunk) (void)hipFree(h->xchunk);
   for (hipEvent_t ev : h->ev_ag) if (ev) (void)hipEventDestroy(ev);
   if (h->ev_xbar) (void)hipEventDestroy(h->ev_xbar);
   double *bufs[] = {h->c, h->b, h->lb, h->ub, h->x, h->x_next, h->xbar, h->y, h->y_next,
@@ -771,37 +772,44 @@ int create_rank_shard_local(DistGroup *g, int rank, int64_t n, const int64_t *co
 }
 
 // The column-chunk layouts of one shard (DistGroup::ag_chunks, dist.hpp): chunk c holds the entries of A_p whose column lies
-// in sub-range c of its owner's slice, as a complete layout of its own (rows x n, absolute column indices, no column slabs:
-// the passes carry the row sums themselves), built by the ordinary builder from the filtered CSC arrays.
+// in sub-range c of its owner's slice, as a complete layout of its own -- rows x (world * ag_sub) with column indices INTO
+// THE CHUNK (rank after rank, what one all-gather of the chunk delivers: pdhg_handle::xchunk), no column slabs (the
+// passes carry the row sums themselves) -- built by the ordinary builder from the filtered, re-indexed CSC arrays.
 int build_column_chunks(DistGroup *g, pdhg_handle *s, int64_t n, const int64_t *colptr, const int64_t *rowval,
                         const double *nzval, int base) {
   const int C = g->ag_chunks;
-  const int64_t m = s->m;
+  const int64_t m = s->m, sub = g->ag_sub, W = (int64_t)g->world * sub;       // W: columns of a chunk (chunk layout, dist.hpp)
   int rc = 0;
   s->Achunk.resize((size_t)C);
-  std::vector<int64_t> cp((size_t)n + 1);
+  std::vector<int64_t> cp((size_t)W + 1);
   uvec<int64_t> rv;
   dvec nv;
+  // chunk column jc = q * sub + off  <->  natural column j = q * S + c * sub + off (ascending jc = ascending j inside a chunk:
+  // the passes add a row's products of one chunk in ascending column order)
+  auto natural = [&](int c, int64_t jc) { const int64_t q = jc / sub, off = jc - q * sub; const int64_t i = (int64_t)c * sub + off; return i < g->S ? q * g->S + i : (int64_t)-1; };
   for (int c = 0; c < C && !rc; ++c) {
     int64_t cnt = 0;
-    for (int64_t j = 0; j < n; ++j) {
-      cp[(size_t)j] = cnt;
-      if (((j % g->S) / g->ag_sub) == c) cnt += colptr[j + 1] - colptr[j];
+    for (int64_t jc = 0; jc < W; ++jc) {
+      cp[(size_t)jc] = cnt;
+      const int64_t j = natural(c, jc);
+      if (j >= 0 && j < n) cnt += colptr[j + 1] - colptr[j];
     }
-    cp[(size_t)n] = cnt;
+    cp[(size_t)W] = cnt;
     rv.resize((size_t)std::max<int64_t>(cnt, 1));
     nv.resize((size_t)std::max<int64_t>(cnt, 1));
-    parallel_ranges((int)std::min<int64_t>(n, INT32_MAX), 1 << 14, [&](int jb, int je) {
-      for (int64_t j = jb; j < je; ++j) {
-        if (((j % g->S) / g->ag_sub) != c) continue;
-        const int64_t k0 = colptr[j] - base, k1 = colptr[j + 1] - base, d0 = cp[(size_t)j];
+    parallel_ranges((int)std::min<int64_t>(W, INT32_MAX), 1 << 14, [&](int jb, int je) {
+      for (int64_t jc = jb; jc < je; ++jc) {
+        const int64_t j = natural(c, jc);
+        if (j < 0 || j >= n) continue;
+        const int64_t k0 = colptr[j] - base, k1 = colptr[j + 1] - base, d0 = cp[(size_t)jc];
         for (int64_t k = k0; k < k1; ++k) { rv[(size_t)(d0 + k - k0)] = rowval[k] - base; nv[(size_t)(d0 + k - k0)] = nzval[k]; }
       }
     });
     g_no_slabs = true;
-    rc = build_layout_pair(s->device, s->remap, s->relaxed, m, n, cnt, cp.data(), rv.data(), nv.data(), 0, &s->Achunk[(size_t)c], nullptr);
+    rc = build_layout_pair(s->device, s->remap, s->relaxed, m, W, cnt, cp.data(), rv.data(), nv.data(), 0, &s->Achunk[(size_t)c], nullptr);
     g_no_slabs = false;
   }
+  if (!rc) rc = alloc_zero(&s->xchunk, (int64_t)C * W);
   if (rc) return rc;
   if ((rc = alloc_zero(&s->chunk_carry, std::max<int64_t>(m, 1)))) return rc;
   // the last pass's block partials: pA must hold its slots too

@@ -154,6 +154,8 @@ struct pdhg_handle {
   // sub-range c of every rank's slice -- one complete layout per chunk, the row sums carried from pass to pass
   std::vector<CsrDev> Achunk;
   double *chunk_carry = nullptr;       // [m] row sums between the passes
+  double *xchunk = nullptr;            // [chunks][world * ag_sub] xbar in CHUNK layout: chunk c holds, rank after rank, sub-range c of every slice
+                                       // (what one ncclAllGather per chunk delivers; the chunk layouts' column indices point into it)
   std::vector<hipEvent_t> ev_ag;       // [chunks] "chunk c of xbar has arrived" on `comm_stream`
   hipEvent_t ev_xbar = nullptr;        // "the owned slice of xbar is written" on `stream`
   double *dn_buf = nullptr;        // [n_alloc] gather / partial buffer (group only)
@@ -487,8 +489,8 @@ int launch_dual(pdhg_handle *h, double sigma) {
   return rc;
 }
 
-// The same product as column-chunk passes (DistGroup::ag_chunks, dist.hpp): chunk c's layout against the chunk's columns of
-// xbar, the row sums carried through chunk_carry, the dual step fused into the LAST pass, whose block partials go to the
+// The same product as column-chunk passes (DistGroup::ag_chunks, dist.hpp): chunk c's layout against chunk c of xbar (xchunk:
+// the chunk's columns side by side, rank after rank), the row sums carried through chunk_carry, the dual step fused into the LAST pass, whose block partials go to the
 // front of pA (stride = that layout's slots: dual_chunk_slots).  wait_events: pass c first waits for "chunk c of xbar has
 // arrived" (ev_ag[c], recorded on the comm stream).
 int dual_chunk_slots(const pdhg_handle *h) { return std::max(h->Achunk.empty() ? 0 : h->Achunk.back().slots(), 1); }
@@ -502,13 +504,13 @@ int launch_dual_chunked(pdhg_handle *h, double sigma, bool wait_events) {
     if (c + 1 < C) {
       EpiArgs e{};
       e.out = h->chunk_carry;
-      rc = launch_spmv<MODE_PLAIN, 0>(h, h->Achunk[(size_t)c], h->xbar, e, init);
+      rc = launch_spmv<MODE_PLAIN, 0>(h, h->Achunk[(size_t)c], h->xchunk + (size_t)c * h->Achunk[(size_t)c].cols, e, init);
     } else {
       EpiArgs e{};
       e.y = h->y; e.b = h->b; e.y_next = h->y_next; e.sigma = sigma; e.num_eq = (int)h->num_eq;
       e.partials = h->pA; e.stride = dual_chunk_slots(h); e.lo_offset = dual_chunk_slots(h);
       if (h->pend_y) { e.sum_y = h->sum_y; e.avg_w = h->pend_w; }
-      rc = launch_spmv<MODE_DUAL, 0>(h, h->Achunk[(size_t)c], h->xbar, e, init);
+      rc = launch_spmv<MODE_DUAL, 0>(h, h->Achunk[(size_t)c], h->xchunk + (size_t)c * h->Achunk[(size_t)c].cols, e, init);
       if (!rc) h->pend_y = false;
     }
   }

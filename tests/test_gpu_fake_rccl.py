@@ -72,8 +72,8 @@ def test_optimize_with_device_evaluation_and_rescaling_between_processes(gpu_req
 @pytest.mark.parametrize("world,ingest,lp", [(2, "global", "small"), (4, "rows", "small"), (2, "rows", "tiled")])     # (world 8: `bench.py --gpus 8 --dist-overlap` over the
                          # same transport, profiles/r06_bench_fake_rccl_8ranks_overlap.json; the eight-process case took 100 s here)
 def test_all_gather_overlapped_with_the_product_is_bitwise_the_passes_behind_one_all_gather(gpu_required, world, ingest, lp):
-    """VERDICT r5 #3 / SURVEY 8e(ii): xbar travels in column chunks on the comm stream (grouped ncclBroadcast per rank and
-    chunk), A_p xbar runs as one pass per chunk (carried row sums), pass c waiting for chunk c only.  Bitwise the same
+    """VERDICT r5 #3 / SURVEY 8e(ii): xbar travels in column chunks on the comm stream (one ncclAllGather per chunk into a
+    chunk-major copy), A_p xbar runs as one pass per chunk (carried row sums), pass c waiting for chunk c only.  Bitwise the same
     passes behind one all-gather, on every rank; bitwise the in-process group; decisions of the unchunked group and of the
     single handle, iterates to 1e-9 (pdhg.jl:472-494)."""
     out = _spawn(world, "agtraj", ingest, lp)
