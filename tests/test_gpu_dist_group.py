@@ -292,6 +292,27 @@ def test_group_rescale_matches_single_engine(gpu_required, qp):
     np.testing.assert_allclose(single.spmv(x), group.spmv(x), rtol=1e-11, atol=1e-11)
 
 
+@pytest.mark.parametrize("shards", [2, 3])
+def test_group_with_column_chunk_passes_matches_the_plain_group(gpu_required, monkeypatch, shards):
+    """Round 6 (csrc/dist.hpp: DistGroup::ag_chunks): with PDHG_DIST_AG_OVERLAP set, A_p xbar runs as one carried pass per
+    column chunk against a chunk-major copy of xbar (on the peer back end: behind the ordinary all-gather).  A row's
+    products are added chunk by chunk -- decisions of the plain group, iterates to 1e-9 -- and DEVICE RESCALING must reach
+    the chunk layouts (their column factors travel in chunk layout): the same trajectory after Ruiz + Pock-Chambolle."""
+    p = random_lp(30000, 20000, 6, seed=21)
+    plain = HipPdhgEngine.from_problem(p, device_ids=[0] * shards)
+    monkeypatch.setenv("PDHG_DIST_AG_OVERLAP", "1")
+    chunked = HipPdhgEngine.from_problem(p, device_ids=[0] * shards)
+    d = chunked.layout_describe()
+    assert d["all_gather"]["chunks"] >= 2 and len(d["all_gather"]["passes"]) == d["all_gather"]["chunks"], d.get("all_gather")
+    assert "all_gather" not in plain.layout_describe()
+    for e in (plain, chunked):
+        e.rescale(10, False, 1.0)
+    g, s = _run(chunked, p, 40, 10), _run(plain, p, 40, 10)
+    assert g["decisions"] == s["decisions"] and g["mp_iters"] == s["mp_iters"]
+    for k in ("x", "y", "xa", "ya", "xm", "ym", "aty", "ax"):
+        np.testing.assert_allclose(g[k], s[k], rtol=1e-9, atol=1e-9, err_msg=k)
+
+
 @pytest.mark.timeout(900)
 def test_group_solve_matches_single_engine_solve(gpu_required):
     """optimize() with solve_qp.jl's defaults, all on the device: three shards vs one handle."""
