@@ -297,7 +297,7 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
     // register window (with a quarter's margin for the spread): a cell beyond it costs the whole workgroup a second step
     // on that tile.  When they would not (rows of very different lengths: many waves sit at the cap), the extra
     // residency round is taken and the waves are BALANCED instead -- cap 1.3 x the average.  Column-skewed 10M, A'y'
-    // (tools/r5_colskew_sweep.sh): cap grown to 2.9 to fit two rounds 1.64 ms (257 steps for the heavy workgroups, at 4.9 us
+    // (tools/archive/r5_colskew_sweep.sh): cap grown to 2.9 to fit two rounds 1.64 ms (257 steps for the heavy workgroups, at 4.9 us
     // each: long same-row runs); cap 1.0 / 1.3 / 1.6, three rounds of 129 steps, 1.13 / 1.11 / 1.11 ms.
     const double avg_cell = (double)D.nnz / (double)est_waves / (double)std::max(1, ntiles_planned);
     const bool near_miss = (double)wave_rows.size() <= 1.03 * (double)planned && cap_factor < 4.0;

@@ -1,9 +1,9 @@
 #!/bin/bash
 export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
-# round 5's final measurement set: bench lines + rocprofv3 summaries + PMC traffic (tools/r5_profile.sh), the shape table with
+# round 5's final measurement set: bench lines + rocprofv3 summaries + PMC traffic (tools/archive/r5_profile.sh), the shape table with
 # the vendor's kernel beside every product, counter passes of the sliced jagged kernel on the banded matrix
 cd "$GRAFT_REPO_ROOT"
-bash tools/r5_profile.sh > gpurun_out/r5prof.log 2>&1
+bash tools/archive/r5_profile.sh > gpurun_out/r5prof.log 2>&1
 export SHAPE_CACHE_DIR=/tmp/shape_cache
 mkdir -p gpurun_out/r5f
 python tools/shape_table.py > gpurun_out/r5f/r05_shape_table.txt 2> gpurun_out/r5f/shape.err

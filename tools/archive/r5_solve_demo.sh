@@ -6,7 +6,7 @@ export PDHG_DEV=1   # development variables on (csrc/common.hpp: dev_env)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r5solve
 O=gpurun_out/r5solve/r05_solve_demo.txt
 {
-echo "# optimize() end to end, solve_qp.jl defaults, 1e-4 (tools/r5_solve_demo.sh; one fresh process per solve: each total includes ~0.15-0.25 s of first-launch costs)"
+echo "# optimize() end to end, solve_qp.jl defaults, 1e-4 (tools/archive/r5_solve_demo.sh; one fresh process per solve: each total includes ~0.15-0.25 s of first-launch costs)"
 echo "# stages: wall clock around the host's calls (tools/solve_demo.py --breakdown)"
 for args in "--workload random --n 1000000" "--workload pagerank --n 1000000" "--workload l1svm --iteration_limit 40000"; do
   echo "## $args"

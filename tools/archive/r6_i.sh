@@ -1,6 +1,6 @@
 export PDHG_DEV=1
 mkdir -p gpurun_out/r6prof
-timeout 600 python tools/r6_qp_sj_time.py 2>&1 | tail -12
+timeout 600 python tools/archive/r6_qp_sj_time.py 2>&1 | tail -12
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 bash tools/r6_bench_check.sh --steps 20 --warmup 5 | tail -3 | cut -c1-300
 cp gpurun_out/r6/bench_stdout.txt gpurun_out/r6prof/r06_bench_default_line.json
