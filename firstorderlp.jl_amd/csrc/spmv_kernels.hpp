@@ -182,6 +182,20 @@ struct RowPre {
   double init;
 };
 
+// the row data of the trip that starts at row `base` (this thread: row base + tid), requested in one go
+template <int MODE, bool INIT, bool COH>
+__device__ __forceinline__ RowPre stream_row_request(const CsrView &A, const EpiArgs &e, int base, int r1) {
+  RowPre p{0, 0, EpiOps{0.0, 0.0, 0.0}, 0.0};
+  const int r = base + (int)threadIdx.x;
+  if (r < r1) {
+    p.rs = A.rowptr[r];
+    p.re = A.rowptr[r + 1];
+    p.ops = epi_load<MODE, COH>(e, r);
+    if (INIT) p.init = e.init[r];
+  }
+  return p;
+}
+
 // The row phase of a stream block whose products lie in prod[]: one lane per row adds them left to right (rows beyond
 // RELAXED_MIN_ROW entries by their wave in relaxed order) and runs the fused epilogue.  pre != nullptr: the data of the
 // rows r0 .. r0 + TPB - 1 is in *pre (spmv_stream_pipe_kernel); further row trips of a block of very short rows read theirs here.
@@ -190,13 +204,31 @@ __device__ __forceinline__ void stream_rows_phase(const CsrView &A, int r0, int 
                                                   const double *prod, const RowPre *pre) {
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
+  // A trip's row data -- extent, epilogue operands, carried sum -- is requested a trip AHEAD (round 6): the first trip's by the
+  // caller (`pre`: behind the block's gathers, or a block ahead in the pipelined kernel), every further trip's before the
+  // current trip is summed.  Trip by trip a block of very short rows (1 024 rows of 2-3 entries: four trips) paid two
+  // dependent round trips per trip -- row pointers, then operands -- with nothing to hide them.
+  // (Not in the persistent trial kernels -- COH: at their register limit the ten more live registers become spills, the
+  //  multi-step kernel's scratch grows from 20 to 88 bytes per lane and the L1-SVM leg loses 2 %; there a trip requests its
+  //  own data.  PageRank-1M's slab passes: 0.099 -> 0.093 ms per product, profiles/r06_stream_waitcnt.txt.)
+  RowPre cur{0, 0, EpiOps{0.0, 0.0, 0.0}, 0.0}, nxt = cur;
+  if (!COH) cur = pre ? *pre : stream_row_request<MODE, INIT, COH>(A, e, r0, r1);
   for (int base = r0; base < r1; base += TPB) {     // workgroup-uniform trip count (the wave sums below need all lanes)
     const int r = base + tid;
     const bool have = r < r1;
-    const bool first = pre && base == r0;                 // this trip's row data came in ahead of time (workgroup-uniform)
-    const int ks = have ? (first ? pre->rs : A.rowptr[r]) - k0 : 0;
-    const int ke = have ? (first ? pre->re : A.rowptr[r + 1]) - k0 : 0;
-    double s = (INIT && have) ? (first ? pre->init : e.init[r]) : 0.0;
+    const bool first = COH && pre && base == r0;          // (COH) this trip's row data came in ahead of time (workgroup-uniform)
+    int ks, ke;
+    double s;
+    if (COH) {
+      ks = have ? (first ? pre->rs : A.rowptr[r]) - k0 : 0;
+      ke = have ? (first ? pre->re : A.rowptr[r + 1]) - k0 : 0;
+      s = (INIT && have) ? (first ? pre->init : e.init[r]) : 0.0;
+    } else {
+      if (base + TPB < r1) nxt = stream_row_request<MODE, INIT, COH>(A, e, base + TPB, r1);      // (workgroup-uniform)
+      ks = have ? cur.rs - k0 : 0;
+      ke = have ? cur.re - k0 : 0;
+      s = (INIT && have) ? cur.init : 0.0;
+    }
     const bool wide = relaxed && (ke - ks > RELAXED_MIN_ROW);
     if (have && !wide) {
       int k = ks;
@@ -256,9 +288,11 @@ __device__ __forceinline__ void stream_rows_phase(const CsrView &A, int r0, int 
       }
     }
     if (have) {
-      if (first) epi_apply<MODE, COH>(e, r, s, pre->ops, acc);
+      if (!COH) epi_apply<MODE, COH>(e, r, s, cur.ops, acc);
+      else if (first) epi_apply<MODE, COH>(e, r, s, pre->ops, acc);
       else row_epilogue<MODE, COH>(e, r, s, acc);
     }
+    if (!COH) cur = nxt;
   }
 }
 
@@ -299,13 +333,16 @@ __device__ __forceinline__ void stream_block_finish(const CsrView &A, const doub
       xv[i] = (k < k1) ? xin[PDHG_COLOFF(g.cidx[i])] : 0.0;
     }
   }
+  // behind the gathers: the first row trip's extents, operands and carried sums (nothing of it depends on the products)
+  RowPre pre0{0, 0, EpiOps{0.0, 0.0, 0.0}, 0.0};
+  if (!COH) pre0 = stream_row_request<MODE, INIT, COH>(A, e, g.r0, g.r1);
 #pragma unroll
   for (int i = 0; i < UNROLL; ++i) {
     const int k = tid + i * TPB;
     if (k0 + k < k1) prod[k] = g.v[i] * xv[i];
   }
   __syncthreads();
-  stream_rows_phase<MODE, INIT, PIPE, COH>(A, g.r0, g.r1, g.k0, e, relaxed, acc, prod, nullptr);
+  stream_rows_phase<MODE, INIT, PIPE, COH>(A, g.r0, g.r1, g.k0, e, relaxed, acc, prod, COH ? nullptr : &pre0);
 }
 
 // TAG names the product in profiler output (0: the constraint matrix A, 1: its transpose,
