@@ -117,13 +117,13 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
         pe.out = D.slab_partial;
         pe.init = D.slab_partial;
         const void *fn = p == 0 ? (const void *)spmv_stream_kernel<MODE_PLAIN, false, TAG> : (const void *)spmv_stream_kernel<MODE_PLAIN, true, TAG>;
-        HIP_TRY(graph_add_kernel(graph, &nd, prev, fn, dim3(S.grid), dim3(TPB), S.view(D.rows), xin, (const int2 *)S.blks,
+        HIP_TRY(graph_add_kernel(graph, &nd, prev, fn, dim3(S.grid), dim3(TPB), S.view(D.rows), xin, (const int2 *)S.blks, (const int4 *)S.ext,
                                  S.nblk, S.per_xcd, rm, rx | 2, pe));
       } else {
         EpiArgs le = e;
         le.init = D.slab_partial;
         HIP_TRY(graph_add_kernel(graph, &nd, prev, (const void *)spmv_stream_kernel<MODE, true, TAG>, dim3(S.grid), dim3(TPB),
-                                 S.view(D.rows), xin, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, rx | 2, le));
+                                 S.view(D.rows), xin, (const int2 *)S.blks, (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx | 2, le));
         if (main_node) *main_node = nd;
       }
       prev.assign(1, nd);
@@ -144,7 +144,7 @@ int graph_add_spmv(pdhg_handle *h, hipGraph_t graph, const CsrDev &D, const doub
   } else if (D.grid > 0) {
     hipGraphNode_t nd = nullptr;
     HIP_TRY(graph_add_kernel(graph, &nd, deps, (const void *)spmv_stream_kernel<MODE, false, TAG>, dim3(D.grid), dim3(TPB),
-                             D.view(), xin, (const int2 *)D.blks, D.nblk, D.per_xcd, rm, rx, e));
+                             D.view(), xin, (const int2 *)D.blks, (const int4 *)D.ext, D.nblk, D.per_xcd, rm, rx, e));
     if (main_node) *main_node = nd;
     done.push_back(nd);
   }
@@ -188,7 +188,7 @@ int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &du
                                  S.view(A.rows), (const double *)h->xbar, (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx, S.grid, le));
       else
         HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, true, 0>, dim3(S.grid), dim3(TPB),
-                                 S.view(A.rows), (const double *)h->xbar, (const int2 *)S.blks, S.nblk, S.per_xcd, rm, rx | 2, le));
+                                 S.view(A.rows), (const double *)h->xbar, (const int2 *)S.blks, (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx | 2, le));
     } else if (A.sj.on()) {
       HIP_TRY(graph_set_kernel(G.exec, G.n_dual, sj_kernel_fn<MODE_DUAL, false, 0>(A.sj), dim3(A.sj.grid), dim3(TPB),
                                sj_view(A.sj, rx), (const double *)h->xbar, rm, A.grid, dual_epi));
@@ -197,7 +197,7 @@ int graph_set_dual(pdhg_handle *h, pdhg_handle::TrialGraph &G, const EpiArgs &du
                                A.view(), (const double *)h->xbar, (const int4 *)A.ext, A.nblk, A.per_xcd, rm, rx, A.grid, dual_epi));
     } else {
       HIP_TRY(graph_set_kernel(G.exec, G.n_dual, (const void *)spmv_stream_kernel<MODE_DUAL, false, 0>, dim3(A.grid), dim3(TPB),
-                               A.view(), (const double *)h->xbar, (const int2 *)A.blks, A.nblk, A.per_xcd, rm, rx, dual_epi));
+                               A.view(), (const double *)h->xbar, (const int2 *)A.blks, (const int4 *)A.ext, A.nblk, A.per_xcd, rm, rx, dual_epi));
     }
   }
   if (G.n_dual_long)

@@ -1066,7 +1066,10 @@ inline bool stream_pipe_wanted(int nblk, int64_t max_row_nnz, int long_thr) {
   if (nblk <= 1024) return nblk >= 2 * NUM_XCD;
   return std::min<int64_t>(max_row_nnz, long_thr) <= SJ_MAX_LEN;
 }
-int build_block_extents(int4 **ext_out, int *grid_out, const int2 *d_blks, int nblk, int max_wgs, const std::vector<int> &rowptr, bool remap) {
+// want_pipe == false: the extent words alone (round 6: the plain kernel reads a block's rows AND entry range from one word
+// instead of the block table, then two row pointers), the persistent kernel's grid stays 0.
+int build_block_extents(int4 **ext_out, int *grid_out, const int2 *d_blks, int nblk, int max_wgs, const std::vector<int> &rowptr, bool remap,
+                        bool want_pipe = true) {
   if (nblk <= 0) return 0;
   std::vector<int2> blks((size_t)nblk);
   HIP_TRY(hipMemcpy(blks.data(), d_blks, sizeof(int2) * (size_t)nblk, hipMemcpyDeviceToHost));
@@ -1082,7 +1085,7 @@ int build_block_extents(int4 **ext_out, int *grid_out, const int2 *d_blks, int n
   // never more workgroups than the plain kernel's grid: every workgroup owns a block-partial slot of that grid
   int grid = std::max(1, std::min(std::min(STREAM_PIPE_WGS_PER_CU * cus, nblk), std::max(1, max_wgs)));
   if (remap) grid = std::max(NUM_XCD, (grid + NUM_XCD - 1) / NUM_XCD * NUM_XCD > max_wgs ? grid / NUM_XCD * NUM_XCD : (grid + NUM_XCD - 1) / NUM_XCD * NUM_XCD);
-  *grid_out = grid;
+  if (want_pipe) *grid_out = grid;
   return upload(ext_out, ext);
 }
 
@@ -1092,20 +1095,21 @@ int build_sj_copies(CsrDev &D, int rows, const std::vector<int> &rowptr, bool re
   int rc = build_sj_copies_only(D, rows, rowptr, remap);
   if (rc || D.tiled || !D.segs.empty()) return rc;
   // products that did not get the sliced jagged copy: the pipelined launch of the row blocks
+  // (every row-block layout gets its extent words: the plain kernel reads them too; the persistent grid only where wanted)
   if (!D.slabs.empty()) {
     if (D.slabs.front().sj.on()) return 0;
     int nblk_max = 0;
     for (const SlabDev &S : D.slabs) nblk_max = std::max(nblk_max, S.nblk);
-    if (!stream_pipe_wanted(nblk_max, D.max_row_nnz, D.long_thr)) return 0;
+    const bool pipe = stream_pipe_wanted(nblk_max, D.max_row_nnz, D.long_thr);
     for (SlabDev &S : D.slabs) {
       std::vector<int> rp((size_t)rows + 1);
       HIP_TRY(hipMemcpy(rp.data(), S.rowptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost));
-      if ((rc = build_block_extents(&S.ext, &S.pipe_grid, S.blks, S.nblk, S.grid, rp, remap))) return rc;
+      if ((rc = build_block_extents(&S.ext, &S.pipe_grid, S.blks, S.nblk, S.grid, rp, remap, pipe))) return rc;
     }
     return 0;
   }
-  if (D.sj.on() || D.grid <= 0 || !stream_pipe_wanted(D.nblk, D.max_row_nnz, D.long_thr)) return 0;
-  return build_block_extents(&D.ext, &D.pipe_grid, D.blks, D.nblk, D.grid, rowptr, remap);
+  if (D.sj.on() || D.grid <= 0) return 0;
+  return build_block_extents(&D.ext, &D.pipe_grid, D.blks, D.nblk, D.grid, rowptr, remap, stream_pipe_wanted(D.nblk, D.max_row_nnz, D.long_thr));
 }
 int build_sj_copies_only(CsrDev &D, int rows, const std::vector<int> &rowptr, bool remap) {
   if (D.tiled || !D.segs.empty()) return 0;

@@ -383,15 +383,15 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e, c
         pe.init = D.slab_partial;
         if (p == 0)
           hipLaunchKernelGGL((spmv_stream_kernel<MODE_PLAIN, false, TAG>), dim3(S.grid), dim3(TPB), 0, h->stream,
-                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx | 2, pe);
+                             S.view(D.rows), xin, S.blks, (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx | 2, pe);
         else
           hipLaunchKernelGGL((spmv_stream_kernel<MODE_PLAIN, true, TAG>), dim3(S.grid), dim3(TPB), 0, h->stream,
-                             S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx | 2, pe);
+                             S.view(D.rows), xin, S.blks, (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx | 2, pe);
       } else {
         EpiArgs le = e;
         le.init = D.slab_partial;
         hipLaunchKernelGGL((spmv_stream_kernel<MODE, true, TAG>), dim3(S.grid), dim3(TPB), 0, h->stream,
-                           S.view(D.rows), xin, S.blks, S.nblk, S.per_xcd, rm, rx | 2, le);
+                           S.view(D.rows), xin, S.blks, (const int4 *)S.ext, S.nblk, S.per_xcd, rm, rx | 2, le);
       }
     }
   } else if (D.sj.on()) {
@@ -407,10 +407,10 @@ int launch_spmv(pdhg_handle *h, const CsrDev &D, const double *xin, EpiArgs e, c
   } else if (D.grid > 0) {
     if (init)
       hipLaunchKernelGGL((spmv_stream_kernel<MODE, true, TAG>), dim3(D.grid), dim3(TPB), 0, h->stream,
-                         D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, e);
+                         D.view(), xin, D.blks, (const int4 *)D.ext, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, e);
     else
       hipLaunchKernelGGL((spmv_stream_kernel<MODE, false, TAG>), dim3(D.grid), dim3(TPB), 0, h->stream,
-                         D.view(), xin, D.blks, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, e);
+                         D.view(), xin, D.blks, (const int4 *)D.ext, D.nblk, D.per_xcd, h->remap ? 1 : 0, rx, e);
   }
   if (D.nlong > 0) {
     hipLaunchKernelGGL(spmv_long_partial_kernel<TAG>, dim3(D.nchunks), dim3(TPB), 0, h->stream,

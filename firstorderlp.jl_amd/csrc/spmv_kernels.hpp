@@ -149,10 +149,7 @@ struct StreamRegs {
 // it/s without the waits, while the latency-bound products (one resident wave of workgroups: the L1-SVM LP 17.8 / 27.8
 // -> 16.3 / 24.1 us per product) want them gone (profiles/r06_stream_waitcnt.txt).
 template <bool THROTTLE = false>
-__device__ __forceinline__ void stream_block_load(const CsrView &A, int2 rr, StreamRegs &g) {
-  g.r0 = rr.x; g.r1 = rr.y;
-  g.k0 = A.rowptr[g.r0];
-  g.k1 = A.rowptr[g.r1];
+__device__ __forceinline__ void stream_block_entries(const CsrView &A, StreamRegs &g) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < UNROLL; ++i) {
@@ -166,6 +163,19 @@ __device__ __forceinline__ void stream_block_load(const CsrView &A, int2 rr, Str
     // (PDHG_THROTTLE_PAIRS, dev: wait after every k-th pair -- 1 is what rounds 1-5 did)
     if (THROTTLE && (i + 1) % PDHG_THROTTLE_PAIRS == 0) __builtin_amdgcn_s_waitcnt(0x0F71);     // vmcnt(1): the index is here, its value may still be on the way
   }
+}
+template <bool THROTTLE = false>
+__device__ __forceinline__ void stream_block_load(const CsrView &A, int2 rr, StreamRegs &g) {
+  g.r0 = rr.x; g.r1 = rr.y;
+  g.k0 = A.rowptr[g.r0];
+  g.k1 = A.rowptr[g.r1];
+  stream_block_entries<THROTTLE>(A, g);
+}
+// the same from the block's extent word (r0, r1, k0, k1)
+template <bool THROTTLE = false>
+__device__ __forceinline__ void stream_block_load_ext(const CsrView &A, int4 x, StreamRegs &g) {
+  g.r0 = x.x; g.r1 = x.y; g.k0 = x.z; g.k1 = x.w;
+  stream_block_entries<THROTTLE>(A, g);
 }
 
 // Rows of more than this many entries are summed by a whole wave in relaxed-order mode.  Measured on the
@@ -350,7 +360,7 @@ __device__ __forceinline__ void stream_block_finish(const CsrView &A, const doub
 // products would otherwise share one kernel name for both products.
 template <int MODE, bool INIT = false, int TAG = 0>
 __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
-    CsrView A, const double *__restrict__ xin, const int2 *__restrict__ blks,
+    CsrView A, const double *__restrict__ xin, const int2 *__restrict__ blks, const int4 *__restrict__ ext,
     int nblk, int per_xcd, int remap, int relaxed, EpiArgs e) {
   __shared__ double prod[BLOCK_NNZ];
   __shared__ double red[6][TPB / WAVE];
@@ -360,7 +370,13 @@ __global__ __launch_bounds__(TPB) void spmv_stream_kernel(
   const bool active = remap ? ((b >> 3) < per_xcd && blk < nblk) : (blk < nblk);
   if (active) {
     StreamRegs g;
-    if (relaxed & 2) stream_block_load<true>(A, blks[blk], g);      // bit 1 of `relaxed`: a column-slab pass (throttled entry loads)
+    // ext (round 6): (r0, r1, k0, k1) of the block in ONE word -- the entry loads no longer wait for the block table AND two
+    // row pointers (layouts built before it / callers without the table pass nullptr)
+    if (ext) {
+      const int4 x = ext[blk];
+      if (relaxed & 2) stream_block_load_ext<true>(A, x, g);        // bit 1 of `relaxed`: a column-slab pass (throttled entry loads)
+      else stream_block_load_ext<false>(A, x, g);
+    } else if (relaxed & 2) stream_block_load<true>(A, blks[blk], g);
     else stream_block_load<false>(A, blks[blk], g);
     stream_block_finish<MODE, INIT>(A, xin, g, e, relaxed & 1, acc, prod);
   }
