@@ -8,7 +8,10 @@ constexpr int TPB = 256;             // 4 waves of 64
 constexpr int WAVE = 64;
 constexpr int BLOCK_NNZ = 2048;      // products staged in LDS per workgroup (16 KiB)
 constexpr int UNROLL = BLOCK_NNZ / TPB;
-constexpr int MAX_ROWS_PER_BLOCK = 4 * TPB;
+#ifndef PDHG_MAX_ROWS_PER_BLOCK
+#define PDHG_MAX_ROWS_PER_BLOCK (4 * TPB)
+#endif
+constexpr int MAX_ROWS_PER_BLOCK = PDHG_MAX_ROWS_PER_BLOCK;      // (dev: -DPDHG_MAX_ROWS_PER_BLOCK=512 -- fewer row trips per block of very short rows)
 // Environment variables.  The documented run-time knobs (include/pdhg_hip.h has the table) are read with getenv as they
 // are; everything else -- tuning constants, negative-result paths kept for the measurements that settled them, fault
 // injection for tests -- is a DEVELOPMENT variable and is only honoured when PDHG_DEV=1 is set as well (tests/conftest.py

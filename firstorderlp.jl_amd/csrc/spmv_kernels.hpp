@@ -220,7 +220,8 @@ __device__ __forceinline__ void stream_rows_phase(const CsrView &A, int r0, int 
   // dependent round trips per trip -- row pointers, then operands -- with nothing to hide them.
   // (Not in the persistent trial kernels -- COH: at their register limit the ten more live registers become spills, the
   //  multi-step kernel's scratch grows from 20 to 88 bytes per lane and the L1-SVM leg loses 2 %; there a trip requests its
-  //  own data.  PageRank-1M's slab passes: 0.099 -> 0.093 ms per product, profiles/r06_stream_waitcnt.txt.)
+  //  own data; even the operands alone requested beside the row pointers spill 60 bytes and cost 4 %.  PageRank-1M's slab
+  //  passes: 0.099 -> 0.093 ms per product, profiles/r06_stream_waitcnt.txt.)
   RowPre cur{0, 0, EpiOps{0.0, 0.0, 0.0}, 0.0}, nxt = cur;
   if (!COH) cur = pre ? *pre : stream_row_request<MODE, INIT, COH>(A, e, r0, r1);
   for (int base = r0; base < r1; base += TPB) {     // workgroup-uniform trip count (the wave sums below need all lanes)
