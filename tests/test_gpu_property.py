@@ -274,3 +274,53 @@ def test_medium_shapes_match_the_oracle_in_every_layout(gpu_required, case, layo
     finally:
         eng.close()
         oracle.close()
+
+
+@st.composite
+def rescale_cases(draw):
+    p, seed = draw(medium_lps())
+    n = p.constraint_matrix.shape[1]
+    if draw(st.booleans()):      # a QP: sparse PSD objective matrix (its copies are rescaled with the column factors)
+        B = sp.random(n, n, density=min(1.0, 3.0 / n), random_state=np.random.RandomState(seed % (2 ** 31)), format="csc")
+        p.objective_matrix = sp.csc_matrix(2.0 * (B.T @ B) + sp.diags(np.random.default_rng(seed).uniform(0.0, 2.0, n)))
+    how = draw(st.sampled_from([(10, False, None), (3, False, 1.0), (0, True, None), (2, True, 0.0), (0, False, 2.0)]))
+    return p, seed, how
+
+
+RESCALE_LAYOUTS = ["default", "stream_nograph", "slabs", "sj_narrow", "sj_wide", "sj_hub", "pipe", "tiled8", "tiled_var",
+                   "shards2", "shards3", "shards2_ag", "shards3_ag2"]
+
+
+@settings(max_examples=150 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
+@given(case=rescale_cases(), layout=st.sampled_from(RESCALE_LAYOUTS))
+def test_device_rescaling_reaches_every_copy_of_the_matrices(gpu_required, case, layout):
+    """pdhg_rescale on an engine in any layout, then the products and a trial step, against an engine BUILT from the
+    host-rescaled problem (preprocess.py, pinned by the reference's test_qp_processing.jl values): a copy of A, A', Q or
+    Q' that the device rescaling forgot to refill shows up as an O(1) difference."""
+    from firstorderlp_jl_amd.preprocess import rescale_problem
+    p, seed, (ruiz, l2, alpha) = case
+    host = rescale_problem(ruiz, l2, alpha, 0, p)
+    eng = _engine(p, layout)
+    ref = None
+    try:
+        E, D = eng.rescale(ruiz, l2, alpha)
+        np.testing.assert_allclose(E, host.constraint_rescaling, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(D, host.variable_rescaling, rtol=1e-12, atol=0)
+        ref = HipPdhgEngine.from_problem(host.scaled_qp)
+        rng = np.random.default_rng(seed + 2)
+        x, y = rng.standard_normal(eng.n), rng.standard_normal(eng.m)
+        S = abs(host.scaled_qp.constraint_matrix).tocsr()
+        np.testing.assert_allclose(eng.spmv(x), ref.spmv(x), rtol=0, atol=1e-11 * (S @ np.abs(x)).max(initial=0) + 1e-300,
+                                   err_msg=f"{layout} A x")
+        np.testing.assert_allclose(eng.spmv_t(y), ref.spmv_t(y), rtol=0, atol=1e-11 * (S.T @ np.abs(y)).max(initial=0) + 1e-300,
+                                   err_msg=f"{layout} A'y")
+        for e in (eng, ref):
+            e.set_current(x, y)
+        ra, rb = eng.trial_step(0.05, 1.3), ref.trial_step(0.05, 1.3)
+        for q, (u, v) in enumerate(zip(eng.get_trial(), ref.get_trial())):
+            np.testing.assert_allclose(u, v, rtol=1e-9, atol=1e-10 * (1.0 + np.abs(v).max(initial=0)), err_msg=f"{layout} trial vector {q}")
+        np.testing.assert_allclose(ra[1:4], rb[1:4], rtol=1e-8, err_msg=layout)
+    finally:
+        eng.close()
+        if ref is not None:
+            ref.close()
