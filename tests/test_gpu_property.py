@@ -324,3 +324,46 @@ def test_device_rescaling_reaches_every_copy_of_the_matrices(gpu_required, case,
         eng.close()
         if ref is not None:
             ref.close()
+
+
+TRAJECTORY_LAYOUTS = ["default", "stream_nograph", "slabs", "sj_narrow", "sj_wide", "sj_hub", "pipe", "tiled8",
+                      "shards2", "shards3", "shards2_ag", "shards3_ag2"]
+
+
+@settings(max_examples=150 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
+@given(case=rescale_cases(), layout=st.sampled_from(TRAJECTORY_LAYOUTS), batch=st.sampled_from([1, 3, 24]))
+def test_adaptive_trajectories_follow_the_oracle_in_every_layout(gpu_required, case, layout, batch):
+    """24 take_steps of the adaptive rule (pdhg.jl:657-737) from the origin, in calls of 1, 3 or 24 steps (the persistent
+    multi-step kernels take whole batches), on LPs and QPs: the same number of trials as the oracle's loop, the step size
+    and the iterates within 1e-8 (a 1-ulp difference in a step scalar moves the step size, not the decisions)."""
+    p, seed, _ = case
+    A = p.constraint_matrix
+    if A.nnz == 0:
+        return
+    eng = _engine(p, layout)
+    oracle = H.oracle_from_problem(p)
+    try:
+        step, pw = H.initial_step_and_weight(p)
+        oracle.step_size, oracle.primal_weight, oracle.ratio_step_sizes = step, pw, 1.0
+        total, it, kkt, err = 0, 0, 0.0, False
+        while total < 24 and not err:
+            step, it, kkt, err, done = eng.take_steps_adaptive(min(batch, 24 - total), 0.3, 0.6, step, pw, it, kkt)
+            assert done >= 1, (layout, err, done)
+            total += done
+        taken = 0      # movement == 0.0 ends the loop with numerical_error set (pdhg.jl:694-698): the same step on both sides
+        while taken < 24 and not oracle.numerical_error:
+            oracle.take_step_adaptive(0.3, 0.6)
+            taken += 1
+        assert (total, bool(err)) == (taken, bool(oracle.numerical_error)), (layout, total, err, taken)
+        assert it == oracle.total_number_iterations, (layout, it, oracle.total_number_iterations)
+        assert step == pytest.approx(oracle.step_size, rel=1e-8), layout
+        x, y = eng.get_current()
+        np.testing.assert_allclose(x, oracle.x, rtol=1e-8, atol=1e-8 * (1e-300 + np.abs(oracle.x).max()), err_msg=layout)
+        np.testing.assert_allclose(y, oracle.y, rtol=1e-8, atol=1e-8 * (1e-300 + np.abs(oracle.y).max()), err_msg=layout)
+        xa, ya = eng.get_average()
+        xo, yo = oracle.compute_average()
+        np.testing.assert_allclose(xa, xo, rtol=1e-8, atol=1e-8 * (1e-300 + np.abs(xo).max()), err_msg=layout)
+        np.testing.assert_allclose(ya, yo, rtol=1e-8, atol=1e-8 * (1e-300 + np.abs(yo).max()), err_msg=layout)
+    finally:
+        eng.close()
+        oracle.close()
