@@ -367,3 +367,85 @@ def test_adaptive_trajectories_follow_the_oracle_in_every_layout(gpu_required, c
     finally:
         eng.close()
         oracle.close()
+
+
+EVAL_LAYOUTS = ["default", "slabs", "sj_narrow", "sj_wide", "sj_hub", "pipe", "tiled8", "shards2", "shards3", "shards2_ag"]
+
+
+@settings(max_examples=100 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
+@given(case=rescale_cases(), layout=st.sampled_from(EVAL_LAYOUTS))
+def test_device_checks_match_the_host_evaluation_in_every_layout(gpu_required, case, layout):
+    """What a termination check asks of the device -- convergence and infeasibility statistics (iteration_stats_utils.jl),
+    restart distances and the trust-region bounds (trust_region_utils.jl:353-455) of the average and the current iterate --
+    against the numpy evaluation of the same engine state, after 12 adaptive steps on a rescaled LP or QP."""
+    import dataclasses
+    from hypothesis import event
+    from firstorderlp_jl_amd.evaluation import POINT_AVERAGE, POINT_CURRENT, POINT_RESTART, DeviceEvaluator, HostEvaluator
+    from firstorderlp_jl_amd.preprocess import rescale_problem
+    from firstorderlp_jl_amd.primal_dual_hybrid_gradient import (AdaptiveStepsizeParams, EngineOps, PdhgSolverState,
+                                                                 UnscaledEngineOps, take_step)
+    from firstorderlp_jl_amd.solve_log import PointType
+    from firstorderlp_jl_amd.termination import cached_quadratic_program_info, construct_termination_criteria
+    from firstorderlp_jl_amd.trust_region_utils import EUCLIDEAN_NORM, MAX_NORM
+    p, seed, (ruiz, l2, alpha) = case
+    if p.constraint_matrix.nnz == 0:
+        return
+    sp_ = rescale_problem(ruiz, l2, alpha, 0, p)
+    eng = _engine(sp_.scaled_qp, layout)
+    try:
+        qp_cache = cached_quadratic_program_info(p)
+        ev_h = HostEvaluator(eng, sp_, qp_cache, EngineOps(eng, sp_.scaled_qp), UnscaledEngineOps(eng, sp_))
+        ev_d = DeviceEvaluator(eng, sp_, qp_cache)
+        step, pw = H.initial_step_and_weight(sp_.scaled_qp)
+        st_ = PdhgSolverState(eng, step_size=step, primal_weight=pw)
+        for k in range(12):
+            if k == 6:      # a restart point that is neither the origin nor the iterate (the host evaluator keeps its own copy)
+                eng.save_restart_point()
+                ev_h.x_r, ev_h.y_r = (v.copy() for v in eng.get_current())
+            take_step(AdaptiveStepsizeParams(0.3, 0.6), st_)
+            if st_.numerical_error:
+                event("stopped: zero movement")
+                return
+        event("checked")
+
+        def close(a, b, rel=1e-9, scale=1.0, what=""):
+            if np.isinf(a) or np.isinf(b) or np.isnan(a) or np.isnan(b):
+                assert a == b or (np.isnan(a) and np.isnan(b)), (layout, what, a, b)
+            else:
+                assert abs(a - b) <= rel * max(abs(a), abs(b), scale), (layout, what, a, b)
+
+        tc = construct_termination_criteria()
+        for point in (POINT_AVERAGE, POINT_CURRENT):
+            a = ev_h.iteration_stats(point, tc, True, 12, 0.0, 24.0, st_.step_size, st_.primal_weight,
+                                     PointType.POINT_TYPE_AVERAGE_ITERATE)
+            b = ev_d.iteration_stats(point, tc, True, 12, 0.0, 24.0, st_.step_size, st_.primal_weight,
+                                     PointType.POINT_TYPE_AVERAGE_ITERATE)
+            ca, cb = a.convergence_information[0], b.convergence_information[0]
+            obj_scale = abs(ca.primal_objective) + abs(ca.dual_objective) + 1.0
+            for f in dataclasses.fields(ca):
+                va, vb = getattr(ca, f.name), getattr(cb, f.name)
+                if isinstance(va, float):
+                    close(va, vb, scale=obj_scale if "objective" in f.name else 1e-6, what=f.name)
+            ia, ib = a.infeasibility_information[0], b.infeasibility_information[0]
+            for f in dataclasses.fields(ia):
+                va, vb = getattr(ia, f.name), getattr(ib, f.name)
+                if isinstance(va, float):
+                    close(va, vb, scale=1e-6, what=f.name)
+        wp = st_.primal_weight / st_.step_size
+        wd = 1.0 / st_.step_size / st_.primal_weight
+        for point in (POINT_AVERAGE, POINT_CURRENT, POINT_RESTART):
+            dh, dd = ev_h.distance_sq_to_restart(point), ev_d.distance_sq_to_restart(point)
+            close(dh[0], dd[0], what="dx2"); close(dh[1], dd[1], what="dy2")
+        dx2, dy2 = ev_h.distance_sq_to_restart(POINT_AVERAGE)
+        radius = float(np.sqrt(wp * dx2 + wd * dy2))
+        for point in (POINT_AVERAGE, POINT_CURRENT):
+            for norm in (EUCLIDEAN_NORM, MAX_NORM):
+                for rad in (radius, 0.05 * radius, 30.0 * radius):
+                    gh = ev_h.bound(point, wp, wd, rad, norm, False)
+                    gd = ev_d.bound(point, wp, wd, rad, norm, False)
+                    sc = abs(gh.lagrangian_value) + abs(gh.upper_bound_value - gh.lower_bound_value) + 1e-9
+                    close(gh.lagrangian_value, gd.lagrangian_value, scale=sc, what="lagrangian")
+                    close(gh.lower_bound_value, gd.lower_bound_value, rel=1e-8, scale=sc, what=("lower", point, norm, rad))
+                    close(gh.upper_bound_value, gd.upper_bound_value, rel=1e-8, scale=sc, what=("upper", point, norm, rad))
+    finally:
+        eng.close()
