@@ -538,8 +538,17 @@ int build_tiled(CsrDev &D, int rows, const std::vector<int> &rowptr, const ivec 
 // Row blocks of one column slab: runs of consecutive rows with <= BLOCK_NNZ slab entries and
 // <= MAX_ROWS_PER_BLOCK rows.  Rows that are LONG in the full matrix belong to the long-row
 // path: no block may contain them (their epilogue must run exactly once, there).
+// (dev) PDHG_BLOCK_CAP: a row block is closed once it holds this many entries (a single row may still bring it up to
+// BLOCK_NNZ): smaller blocks = more workgroups with shorter phases.  Default: BLOCK_NNZ.
+inline int block_cap() {
+  const char *e = dev_env("PDHG_BLOCK_CAP");
+  const int v = e ? atoi(e) : BLOCK_NNZ;
+  return v < 64 ? 64 : (v > BLOCK_NNZ ? BLOCK_NNZ : v);
+}
+
 void make_row_blocks(int rows, const std::vector<int> &slab_rowptr, const std::vector<int> &full_rowptr,
                      std::vector<int2> &blks, int long_thr) {
+  const int cap = block_cap();
   int r = 0;
   while (r < rows) {
     if (full_rowptr[r + 1] - full_rowptr[r] > long_thr) { ++r; continue; }
@@ -547,7 +556,7 @@ void make_row_blocks(int rows, const std::vector<int> &slab_rowptr, const std::v
     int nn = 0;
     while (r < rows && (r - r0) < MAX_ROWS_PER_BLOCK && full_rowptr[r + 1] - full_rowptr[r] <= long_thr) {
       const int len = slab_rowptr[r + 1] - slab_rowptr[r];
-      if (len > BLOCK_NNZ - nn) break;
+      if (len > BLOCK_NNZ - nn || (nn > 0 && len > cap - nn)) break;
       nn += len;
       ++r;
     }
@@ -710,6 +719,7 @@ int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &r
   D.long_thr = long_row_threshold_from_env();
   std::vector<int2> blks;
   std::vector<int> long_row, long_chunk_ptr(1, 0), chunk_row, chunk_off, chunk_lidx;
+  const int cap = block_cap();
   int r = 0;
   while (r < rows) {
     int len = rowptr[r + 1] - rowptr[r];
@@ -730,7 +740,7 @@ int build_stream_tables(CsrDev &D, int rows, int cols, const std::vector<int> &r
     int nn = 0;
     while (r < rows && (r - r0) < MAX_ROWS_PER_BLOCK) {
       len = rowptr[r + 1] - rowptr[r];
-      if (len > D.long_thr || len > BLOCK_NNZ - nn) break;
+      if (len > D.long_thr || len > BLOCK_NNZ - nn || (nn > 0 && len > cap - nn)) break;
       D.max_row_nnz = std::max<int64_t>(D.max_row_nnz, len);
       nn += len;
       ++r;
