@@ -292,6 +292,10 @@ int graph_trial(pdhg_handle *h, double step_size, double primal_weight, double t
   h->seq_expected += 1;
   const auto c1 = std::chrono::steady_clock::now();
   HIP_TRY(hipGraphLaunch(G->exec, h->stream));
+#ifdef PDHG_PROBE_GRAPH_TWICE      // latency probe only (the deferred sums are applied twice): the boundary between two queued graphs, tools/archive/r6_w.sh
+  HIP_TRY(hipGraphLaunch(G->exec, h->stream));
+  h->seq_expected += 1;
+#endif
   const auto c2 = std::chrono::steady_clock::now();
   h->t_launch += std::chrono::duration<double>(c2 - c1).count();
   h->n_graph_trials += 1;

@@ -1,4 +1,5 @@
 # round 6 probe: the boundary between two trial graphs queued back to back (would a speculatively queued next trial start sooner?)
+# (build the probe first: bash tools/variants.sh twice "-DPDHG_PROBE_GRAPH_TWICE")
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 rm -rf gpurun_out/prtl; mkdir -p gpurun_out/prtl
 PDHG_HIP_LIB=$PWD/firstorderlp.jl_amd/csrc/variants/libpdhg_twice.so rocprofv3 --kernel-trace -d gpurun_out/prtl/kt -- python bench.py --workload pagerank --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs --no-self-profile --no-ceiling --no-vendor --no-details --profile-steps 0 > /dev/null 2>&1

@@ -1,4 +1,5 @@
 # round 6: kernel trace of PageRank-1M trials with the next trial queued behind the current one
+# (these two scripts measured a build that is no longer in the tree: NOTEBOOK section 10.5)
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 rm -rf gpurun_out/prtl; mkdir -p gpurun_out/prtl
 rocprofv3 --kernel-trace -d gpurun_out/prtl/kt -- python bench.py --workload pagerank --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs --no-self-profile --no-ceiling --no-vendor --no-details --profile-steps 0 > /dev/null 2>&1
