@@ -27,14 +27,64 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// Wave sums of N quantities at once (N a power of two, 8 ... 64), round 6.  One tree per quantity (wave_sum_dpp) is six
+// dependent steps of two DPP moves and an add EACH: 30 quantities x 3 problems were 4.8 us of a 21 us probe pass of the
+// batched trust-region search (NOTEBOOK 10.4).  Here the lanes SHARE the work: at the level that pairs lanes l and l ^ m,
+// a lane keeps half of the quantities it still holds (bit m of l clear: the lower half) and hands the other half to its
+// partner, so the six levels cost N/2 + N/4 + ... exchanges instead of 6 N.  Every quantity is still summed over the same
+// balanced tree of adjacent lanes as wave_sum_dpp builds (pairs, fours, ..., rows, row pairs, halves), each node the sum of
+// the same two operands -- floating-point addition commutes, so THE BITS are those of the one-tree-per-quantity form.
+// Afterwards lane l holds the wave's total of quantity wave_split_index<N>(l) in v[0].
+template <int N>
+__device__ __forceinline__ int wave_split_index(int lane) {
+  int q = 0, h = N >> 1;
+#pragma unroll
+  for (int m = 1; h >= 1; m <<= 1, h >>= 1) q += (lane & m) ? h : 0;
+  return q;
+}
+template <int N, int H, int M>
+struct WaveSplit {
+  static __device__ __forceinline__ void run(double (&v)[N], int lane) {
+    const bool up = (lane & M) != 0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const double give = up ? v[j] : v[j + H];
+      const double keep = up ? v[j + H] : v[j];
+      v[j] = keep + __shfl_xor(give, M, WAVE);
+    }
+    WaveSplit<N, H / 2, M * 2>::run(v, lane);
+  }
+};
+template <int N, int M>
+struct WaveSplit<N, 0, M> {       // one quantity left per lane: plain butterflies over the remaining levels
+  static __device__ __forceinline__ void run(double (&v)[N], int) {
+#pragma unroll
+    for (int m = M; m < WAVE; m <<= 1) v[0] = v[0] + __shfl_xor(v[0], m, WAVE);
+  }
+};
+constexpr int pow2_at_least(int n) { return n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 32 ? 32 : 64)); }
+
 // partials[q*stride + blockIdx.x]: q < NS sums, then NM maxes (all maxes are of non-negative values)
 template <int NS, int NM>
 __device__ __forceinline__ void block_reduce_store(const RedAcc<NS, NM> &a, double *partials, int stride) {
   __shared__ double red[NS + NM][TPB / WAVE];
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+#ifndef PDHG_NO_WAVE_SPLIT
+  if constexpr (NS >= 8 && NS <= 64) {
+    constexpr int N = pow2_at_least(NS);
+    double v[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = q < NS ? a.s[q] : 0.0;
+    WaveSplit<N, N / 2, 1>::run(v, lane);
+    const int q = wave_split_index<N>(lane);
+    if (lane < N && q < NS) red[q][wid] = v[0];
+  } else
+#endif
+  {
   // DPP trees (common.hpp): the wave's total ends in lane 63
 #pragma unroll
   for (int q = 0; q < NS; ++q) { const double w = wave_sum_dpp(a.s[q]); if (lane == WAVE - 1) red[q][wid] = w; }
+  }
 #pragma unroll
   for (int q = 0; q < NM; ++q) { const double w = wave_max_nonneg_dpp(a.m[q]); if (lane == WAVE - 1) red[NS + q][wid] = w; }
   __syncthreads();
