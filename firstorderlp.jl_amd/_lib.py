@@ -36,7 +36,7 @@ EXPORTS = [
     "pdhg_distance_to_restart", "pdhg_get_point", "pdhg_trust_region_bound", "pdhg_trust_region_bounds",
     "pdhg_point_sumsq", "pdhg_rescale", "pdhg_get_problem_vectors", "pdhg_matrix_max_abs",
     "pdhg_partition_rows", "pdhg_create_dist_rows", "pdhg_rccl_info", "pdhg_host_issue_stats",
-    "pdhg_measure_launch_overhead", "pdhg_layout_checksums",
+    "pdhg_measure_launch_overhead", "pdhg_selftest_wave_sums", "pdhg_layout_checksums",
 ]
 
 ABI_VERSION = 11
@@ -178,6 +178,8 @@ def lib():
     L.pdhg_layout_checksums.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64)]
     L.pdhg_measure_launch_overhead.restype = i32
     L.pdhg_measure_launch_overhead.argtypes = [_vp, i32, _dp]
+    L.pdhg_selftest_wave_sums.restype = i32
+    L.pdhg_selftest_wave_sums.argtypes = [_vp, ctypes.c_int64, _ip]
     L.pdhg_dist_get_unique_id.restype = i32
     L.pdhg_dist_get_unique_id.argtypes = [_vp]
     L.pdhg_create_dist.restype = i32

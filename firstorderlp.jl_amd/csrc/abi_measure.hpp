@@ -247,6 +247,29 @@ int pdhg_trial_timeline(pdhg_handle *h, double out[14]) {
   return trial_timeline(h, out) ? fail(1, "no one-launch trial has been traced (PDHG_COOP_TRACE=1, stream-layout LP on one handle)") : 0;
 }
 
+int pdhg_selftest_wave_sums(pdhg_handle *h, int64_t seed, int64_t out[2]) {
+  int rc = check_handle(h);
+  if (rc) return rc;
+  if (!out) return fail(-1, "out == NULL");
+  unsigned long long *bad = nullptr;
+  HIP_TRY(hipMalloc((void **)&bad, sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(bad, 0, sizeof(unsigned long long), h->stream));
+  constexpr int GRID = 256;
+  hipLaunchKernelGGL(wave_sums_selftest_kernel<8>, dim3(GRID), dim3(TPB), 0, h->stream, (unsigned long long)seed, bad);
+  hipLaunchKernelGGL(wave_sums_selftest_kernel<TR_SETUP_NS>, dim3(GRID), dim3(TPB), 0, h->stream, (unsigned long long)seed + 1, bad);
+  hipLaunchKernelGGL(wave_sums_selftest_kernel<22>, dim3(GRID), dim3(TPB), 0, h->stream, (unsigned long long)seed + 2, bad);
+  hipLaunchKernelGGL((wave_sums_selftest_kernel<TR_Q * TR_K>), dim3(GRID), dim3(TPB), 0, h->stream, (unsigned long long)seed + 3, bad);
+  hipLaunchKernelGGL(wave_sums_selftest_kernel<64>, dim3(GRID), dim3(TPB), 0, h->stream, (unsigned long long)seed + 4, bad);
+  unsigned long long host_bad = 0;
+  hipError_t e = hipMemcpyAsync(&host_bad, bad, sizeof host_bad, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(bad);
+  if (e != hipSuccess) return fail_hip(e, "pdhg_selftest_wave_sums");
+  out[0] = (int64_t)GRID * (TPB / WAVE) * (8 + TR_SETUP_NS + 22 + TR_Q * TR_K + 64);
+  out[1] = (int64_t)host_bad;
+  return 0;
+}
+
 int pdhg_measure_launch_overhead(pdhg_handle *h, int reps, double out[2]) {
   int rc = check_handle(h);
   if (rc) return rc;

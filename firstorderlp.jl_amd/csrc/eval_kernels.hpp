@@ -98,6 +98,39 @@ __device__ __forceinline__ void block_reduce_store(const RedAcc<NS, NM> &a, doub
   }
 }
 
+// Self-test of the check kernels' block reduction (eval_kernels.hpp: WaveSplit): NS quantities per lane, pseudo-random
+// magnitudes over 80 binades, both signs, signed zeros -- every wave total through the shared form and through one DPP tree
+// per quantity (wave_sum_dpp, the form of rounds 1-5) must have the SAME BITS.
+template <int NS>
+__global__ __launch_bounds__(TPB) void wave_sums_selftest_kernel(unsigned long long seed, unsigned long long *mismatches) {
+  __shared__ unsigned long long ref[NS][TPB / WAVE], got[NS][TPB / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  constexpr int N = pow2_at_least(NS);
+  double v[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    unsigned long long x = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(((size_t)blockIdx.x * TPB + threadIdx.x) * 64 + q + 1);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;      // splitmix64
+    const double mant = 1.0 + (double)(x >> 12) * (1.0 / 4503599627370496.0);
+    const int ex = (int)((x >> 3) % 80u) - 40;
+    double val = ldexp(mant, ex);
+    if (x & 1ull) val = -val;
+    if ((x & 0xF0ull) == 0) val = (x & 2ull) ? -0.0 : 0.0;
+    v[q] = q < NS ? val : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < NS; ++q) { const double w = wave_sum_dpp(v[q]); if (lane == WAVE - 1) ref[q][wid] = (unsigned long long)__double_as_longlong(w); }
+  WaveSplit<N, N / 2, 1>::run(v, lane);
+  const int q = wave_split_index<N>(lane);
+  if (lane < N && q < NS) got[q][wid] = (unsigned long long)__double_as_longlong(v[0]);
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    unsigned long long bad = 0;
+    for (int w = 0; w < TPB / WAVE; ++w) bad += ref[threadIdx.x][w] != got[threadIdx.x][w];
+    if (bad) atomicAdd(mismatches, bad);
+  }
+}
+
 // Second stage of the evaluation kernels' block partials: quantity q (ns sums, then nm maxes) belongs to
 // wave q mod 16, which adds / maxes its `count` partials in a fixed order (lane i takes i, i + 64, ..., eight
 // loads in flight at a time; then the shuffle tree) -- no workgroup barrier between quantities, so 16 of them

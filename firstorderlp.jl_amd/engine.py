@@ -397,6 +397,13 @@ class HipPdhgEngine:
         _lib.check(self._L.pdhg_measure_launch_overhead(self._h, int(reps), _pd(out)))
         return float(out[0]), float(out[1])
 
+    def selftest_wave_sums(self, seed=0):
+        """pdhg_selftest_wave_sums: (wave totals compared, totals whose bits differ between the shared wave reduction of the
+        check kernels and one DPP tree per quantity) -- the second must be 0."""
+        out = np.zeros(2, dtype=np.int64)
+        _lib.check(self._L.pdhg_selftest_wave_sums(self._h, int(seed), _pi(out)))
+        return int(out[0]), int(out[1])
+
     # ---- measurement -------------------------------------------------------------
     def profile_enable(self, enable=True):
         _lib.check(self._L.pdhg_profile_enable(self._h, int(bool(enable))))

@@ -474,6 +474,13 @@ int pdhg_trial_timeline(pdhg_handle *h, double out[14]);
  * the kernels themselves, is shorter by that amount). */
 int pdhg_measure_launch_overhead(pdhg_handle *h, int reps, double out[2]);
 
+/* Self-test (abi 11, round 6): the block reduction of the evaluation / trust-region kernels shares the wave sums of a
+ * workgroup's quantities between the lanes (csrc/eval_kernels.hpp: WaveSplit) instead of running one tree per quantity;
+ * both forms sum every quantity over the same balanced tree, so their results must agree BIT FOR BIT.  Runs both on
+ * pseudo-random data (seed) for 8, 16, 22, 30 and 64 quantities per lane: out[0] = wave totals compared, out[1] = totals
+ * whose bits differ (0 expected).  No reference counterpart: a property of this implementation. */
+int pdhg_selftest_wave_sums(pdhg_handle *h, int64_t seed, int64_t out[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,6 +183,13 @@ function measure_launch_overhead(s::HipSolverState, reps::Integer = 20)
   return out[1], out[2]
 end
 
+"Self-test of the check kernels' shared wave reduction: (totals compared, totals whose bits differ: 0 expected) (`pdhg_selftest_wave_sums`)."
+function selftest_wave_sums(s::HipSolverState, seed::Integer = 0)
+  out = zeros(Int64, 2)
+  check(ccall((:pdhg_selftest_wave_sums, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}), s.handle, seed, out))
+  return out[1], out[2]
+end
+
 "Host-side cost of the trial steps so far: (trials, seconds issuing, seconds waiting) (`pdhg_host_issue_stats`)."
 function host_issue_stats(s::HipSolverState)
   trials = Ref{Int64}(0); issue = Ref{Float64}(0.0); wait = Ref{Float64}(0.0)

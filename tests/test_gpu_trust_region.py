@@ -186,3 +186,16 @@ def test_a_solve_takes_the_same_restart_decisions_with_and_without_the_batch(gpu
                        out.iteration_stats[-1].convergence_information[0].dual_objective)
     assert runs["1"] == runs["0"], (runs["1"][:2], runs["0"][:2])
     assert runs["1"][0] == "OPTIMAL"
+
+
+@pytest.mark.own_row_order
+def test_shared_wave_sums_have_the_bits_of_one_tree_per_quantity(gpu_required):
+    """The check kernels' block reduction (csrc/eval_kernels.hpp: WaveSplit, round 6) against the form of rounds 1-5 on
+    pseudo-random data of 80 binades, both signs and signed zeros: 8 / 16 / 22 / 30 / 64 quantities per lane, every wave
+    total bit for bit (pdhg_selftest_wave_sums)."""
+    from tests import helpers as H
+    eng = HipPdhgEngine.from_problem(H.example_lp())
+    for seed in (0, 1, 20260929):
+        compared, differing = eng.selftest_wave_sums(seed)
+        assert compared == 256 * 4 * (8 + 16 + 22 + 30 + 64) and differing == 0, (seed, compared, differing)
+    eng.close()
