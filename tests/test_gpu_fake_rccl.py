@@ -84,3 +84,17 @@ def test_all_gather_overlapped_with_the_product_is_bitwise_the_passes_behind_one
 @pytest.mark.timeout(900)
 def test_reference_kats_with_the_overlapped_all_gather(gpu_required):
     _spawn(2, "kat", _KATS, PDHG_DIST_AG_OVERLAP="1")
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,mode,ingest,seed", [(3, "traj1", "global", 1180834645),      # 2 x 1: fewer rows than ranks, nothing averaged
+                                                     (3, "agtraj", "rows", 1413644620),       # 6 x 1: a slice too short to cut into chunks
+                                                     (4, "agtraj", "rows", 544083118),
+                                                     (2, "traj0", "rows", 2037209174)])
+def test_random_shapes_between_processes(gpu_required, world, mode, ingest, seed):
+    """Four cases of tools/dist_shape_hunt.py (random LP shapes through the one-process-per-GPU routes; 330 cases in the
+    round's hunts, profiles/r06_dist_shape_hunt.txt), among them the degenerate shapes its checker first tripped over."""
+    if mode == "agtraj":
+        _spawn(world, "agtraj", ingest, f"rand:{seed}", PDHG_DEV="1", PDHG_DIST_AG_CHUNKS="3")
+    else:
+        _spawn(world, "traj", ingest, mode[-1], f"rand:{seed}")

@@ -39,7 +39,8 @@ def run(eng, p, steps=60, mp_steps=25):
     out = dict(decisions=decisions, step=st.step_size)
     out["x"], out["y"] = eng.get_current()
     out["xa"], out["ya"] = eng.get_average()
-    eng.restart_to_average()
+    if eng.average_info()[0] > 0:       # (a degenerate random LP can stop at its first trial: zero movement, nothing averaged)
+        eng.restart_to_average()
     out["aty"] = eng.get_dual_product()
     out["ax"] = eng.spmv(out["x"])
     ms = PdhgSolverState(eng, step_size=st.step_size, primal_weight=pw, ratio_step_sizes=1.0)
