@@ -205,7 +205,7 @@ def test_device_rescaling_reaches_the_hessians_sliced_jagged_copies(gpu_required
     n, m = 12_000, 8_000
     p = random_lp(m, n, 6, seed=31)
     rng = np.random.default_rng(4)
-    B = sp.random(n, n, density=3.0 / n, random_state=9, format="csc")
+    B = H.sparse_uniform(n, n, 3.0 / n, 9)
     p.objective_matrix = sp.csc_matrix(B.T @ B + sp.diags(rng.uniform(0.5, 3.0, n)))
     p.objective_matrix.sum_duplicates()
     p.objective_matrix.sort_indices()

@@ -87,7 +87,7 @@ def test_one_launch_search_matches_pass_by_pass(gpu_required, monkeypatch, name)
         import scipy.sparse as sp
         from dataclasses import replace
         p = random_lp(9000, 12000, 5, seed=8)
-        q = sp.random(12000, 12000, density=2e-4, random_state=1, format="csc")
+        q = H.sparse_uniform(12000, 12000, 2e-4, 1)
         p = replace(p, objective_matrix=(q @ q.T + sp.identity(12000) * 0.1).tocsc())
     want, i0 = _bounds(p, monkeypatch, "0")
     got, i1 = _bounds(p, monkeypatch, "1")
@@ -126,6 +126,7 @@ def test_batched_searches_return_the_single_calls_bits(gpu_required, monkeypatch
     for in one call: each row must be bit for bit what pdhg_trust_region_bound returns for that problem -- on medium single
     handles the batch shares one persistent launch (same statements, same grouping of the sums), elsewhere it is a loop."""
     from firstorderlp_jl_amd.generators import pagerank_lp, random_lp
+    from tests import helpers as H
     if name == "random":
         p = random_lp(40000, 30000, 6, seed=5)
     elif name == "pagerank":
@@ -136,7 +137,7 @@ def test_batched_searches_return_the_single_calls_bits(gpu_required, monkeypatch
         import scipy.sparse as sp
         from dataclasses import replace
         p = random_lp(9000, 12000, 5, seed=8)
-        q = sp.random(12000, 12000, density=2e-4, random_state=1, format="csc")
+        q = H.sparse_uniform(12000, 12000, 2e-4, 1)
         p = replace(p, objective_matrix=(q @ q.T + sp.identity(12000) * 0.1).tocsc())
     eng = _state_with_restart_point(p)
     requests = [([1, 0, 2], [0.3, 5.0, 0.7], [0, 0, 0]),       # average, current, restart point: the restart check
