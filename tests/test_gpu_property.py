@@ -96,7 +96,7 @@ def _engine(p, layout):
                 os.environ[k] = v
 
 
-@settings(max_examples=600 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=1000 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
 @given(case=small_lps(), layout=st.sampled_from(LAYOUTS))
 def test_products_and_one_trial_are_bit_identical_to_the_oracle(gpu_required, case, layout):
     p, seed, step, pw, theta = case
@@ -223,7 +223,7 @@ MEDIUM_LAYOUTS = ["default", "stream_nograph", "slabs", "sj_narrow", "sj_wide", 
                   "shards3_ag2", "tiled8"]
 
 
-@settings(max_examples=400 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=800 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
 @given(case=medium_lps(), layout=st.sampled_from(MEDIUM_LAYOUTS))
 def test_medium_shapes_match_the_oracle_in_every_layout(gpu_required, case, layout):
     """Products and two trials (accept between them) on shapes of several row blocks and sorting windows.  Row sums of more
@@ -292,7 +292,7 @@ RESCALE_LAYOUTS = ["default", "stream_nograph", "slabs", "sj_narrow", "sj_wide",
                    "shards2", "shards3", "shards2_ag", "shards3_ag2"]
 
 
-@settings(max_examples=200 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=300 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
 @given(case=rescale_cases(), layout=st.sampled_from(RESCALE_LAYOUTS))
 def test_device_rescaling_reaches_every_copy_of_the_matrices(gpu_required, case, layout):
     """pdhg_rescale on an engine in any layout, then the products and a trial step, against an engine BUILT from the
@@ -331,7 +331,7 @@ TRAJECTORY_LAYOUTS = ["default", "stream_nograph", "slabs", "sj_narrow", "sj_wid
                       "shards2", "shards3", "shards2_ag", "shards3_ag2"]
 
 
-@settings(max_examples=200 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=300 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
 @given(case=rescale_cases(), layout=st.sampled_from(TRAJECTORY_LAYOUTS), batch=st.sampled_from([1, 3, 24]))
 def test_adaptive_trajectories_follow_the_oracle_in_every_layout(gpu_required, case, layout, batch):
     """24 take_steps of the adaptive rule (pdhg.jl:657-737) from the origin, in calls of 1, 3 or 24 steps (the persistent
@@ -373,7 +373,7 @@ def test_adaptive_trajectories_follow_the_oracle_in_every_layout(gpu_required, c
 EVAL_LAYOUTS = ["default", "slabs", "sj_narrow", "sj_wide", "sj_hub", "pipe", "tiled8", "shards2", "shards3", "shards2_ag"]
 
 
-@settings(max_examples=200 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=300 * FUZZ_SCALE, deadline=None, suppress_health_check=list(HealthCheck))
 @given(case=rescale_cases(), layout=st.sampled_from(EVAL_LAYOUTS))
 def test_device_checks_match_the_host_evaluation_in_every_layout(gpu_required, case, layout):
     """What a termination check asks of the device -- convergence and infeasibility statistics (iteration_stats_utils.jl),
